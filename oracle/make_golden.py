@@ -1,0 +1,434 @@
+"""Golden-vector generator + oracle pinning (BUILD CONTAINER ONLY -- needs /root/reference).
+
+Imports the real reference (model/vid2seq.py, model/modeling_t5.py, model/vit.py, dvc.py) through a
+runtime shim (no reference file is modified or copied), runs it on seeded
+synthetic inputs and
+  (1) asserts that oracle/vid2seq_ref.py reproduces it (<=1e-5 abs on logits, <=1e-6 rel on loss),
+  (2) writes the input/expected-output vectors to tests/golden/*.npz / *.json.
+The fixtures are data only (inputs + expected outputs); nothing from the reference travels.
+
+Run:  python oracle/make_golden.py [--skip-full]
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import types
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import vid2seq_ref as R          # noqa: E402
+from vidchapters_amd import synth            # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+warnings.filterwarnings("ignore")
+
+
+# ------------------------------------------------------------------------------------------- shim
+def load_reference():
+    import transformers.pytorch_utils as pu
+    if not hasattr(pu, "find_pruneable_heads_and_indices"):
+        pu.find_pruneable_heads_and_indices = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+    mp = types.ModuleType("transformers.utils.model_parallel_utils")
+    mp.assert_device_map = mp.get_device_map = lambda *a, **k: None
+    sys.modules["transformers.utils.model_parallel_utils"] = mp
+    pkg = types.ModuleType("model"); pkg.__path__ = [REF + "/model"]; sys.modules["model"] = pkg
+    mt5 = importlib.import_module("model.modeling_t5")
+    v2s = importlib.import_module("model.vid2seq")
+    vit = importlib.import_module("model.vit")
+    mt5.T5PreTrainedModel.get_head_mask = lambda self, hm, n, *_: [None] * n
+    pkg.build_vid2seq_model = None
+    pkg._get_tokenizer = v2s._get_tokenizer
+    return mt5, v2s, vit
+
+
+def load_reference_dvc():
+    """Import the reference's dvc.py (for train_one_epoch) with stub modules for absent deps."""
+    for name in ("hostlist",):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    ds = types.ModuleType("dataset")
+    for n in ("densevideocaptioning_collate_fn", "build_densevideocaptioning_dataset", "build_yt_dataset", "yt_collate_fn"):
+        setattr(ds, n, None)
+    sys.modules["dataset"] = ds
+    ev = types.ModuleType("dvc_eval"); ev.eval_dvc = ev.eval_soda = None
+    sys.modules["dvc_eval"] = ev
+    sys.path.insert(0, REF)
+    try:
+        return importlib.import_module("dvc")
+    finally:
+        sys.path.remove(REF)
+
+
+class StubTokenizer:
+    pad_token_id = 0
+    eos_token_id = 1
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def batch_decode(self, seqs, skip_special_tokens=True):
+        return [" ".join(str(int(t)) for t in s) for s in seqs]
+
+
+def build_ref_model(v2s, cfg: R.RefConfig, params):
+    """Construct the reference Vid2Seq at ``cfg`` shapes and load ``params`` (oracle key names)."""
+    import transformers
+    t5cfg = transformers.T5Config(
+        vocab_size=cfg.vocab - cfg.num_bins + 28, d_model=cfg.d_model, d_kv=cfg.d_kv, d_ff=cfg.d_ff,
+        num_layers=cfg.n_enc, num_decoder_layers=cfg.n_dec, num_heads=cfg.heads,
+        relative_attention_num_buckets=cfg.buckets, relative_attention_max_distance=cfg.max_distance,
+        dropout_rate=0.1, layer_norm_epsilon=cfg.rms_eps, feed_forward_proj="relu",
+        tie_word_embeddings=True, pad_token_id=0, eos_token_id=1, decoder_start_token_id=0)
+    tmp = tempfile.mkdtemp(prefix="t5cfg_")
+    transformers.T5ForConditionalGeneration(t5cfg).save_pretrained(tmp)
+    m = v2s.Vid2Seq(t5_path=tmp, num_features=cfg.num_features, embed_dim=cfg.vit_dim, depth=cfg.vit_depth,
+                    heads=cfg.vit_heads, mlp_dim=cfg.vit_mlp, vis_drop=0., tokenizer=StubTokenizer(cfg.vocab),
+                    enc_drop=0., dec_drop=0., num_bins=cfg.num_bins, label_smoothing=cfg.label_smoothing)
+    # The reference hard-codes "proj_v2t = Linear(768, d_model) iff d_model != 768" (vid2seq.py:54-56).  For
+    # reduced test shapes the harness re-creates that layer with the same rule expressed on embed_dim
+    # (identical whenever embed_dim == 768, i.e. for every real configuration); forward code is untouched.
+    m.proj_v2t = torch.nn.Linear(cfg.vit_dim, cfg.d_model) if cfg.d_model != cfg.vit_dim else None
+    m.t5_model.lm_head.weight = m.t5_model.shared.weight          # 4.28 tie semantics
+    m.t5_model.encoder.embed_tokens = m.t5_model.shared
+    m.t5_model.decoder.embed_tokens = m.t5_model.shared
+    sd = {k: v.clone() for k, v in params.items()}
+    for a in R.TIED_ALIASES:
+        sd[a] = sd["t5_model.shared.weight"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert not [k for k in missing if "relative_attention_bias" not in k], missing
+    if getattr(m, "proj_v2t", None) is not None:
+        assert "proj_v2t.weight" in params
+    m.eval()
+    return m
+
+
+def oracle_params(cfg: R.RefConfig, seed: int, grad=False):
+    P = synth.init_params(R.param_shapes(cfg), seed, cfg.d_model, cfg.inner, cfg.d_ff)
+    if grad:
+        for v in P.values():
+            v.requires_grad_(True)
+    return P
+
+
+def ref_forward(m, batch, want_logits=True):
+    inp = {"input_ids": batch["input_ids"], "attention_mask": batch["input_ids"] != 0}
+    out = {"input_ids": batch["output_ids"], "attention_mask": batch["output_ids"] != 0}
+    loss_dict, vd = m(batch["video"], inp, out)
+    return loss_dict["loss"], vd
+
+
+def ref_logits(m, batch):
+    """Logits through the reference's own T5ForConditionalGeneration.forward (same call as vid2seq.py:89)."""
+    from transformers.modeling_outputs import BaseModelOutput
+    vis = m.visual_encoder(batch["video"])
+    if m.proj_v2t is not None:
+        vis = m.proj_v2t(vis)
+    mask = batch["input_ids"] != 0
+    enc = m.t5_model.encoder(attention_mask=mask, inputs_embeds=m.t5_model.encoder.embed_tokens(batch["input_ids"]))
+    mem = torch.cat([vis, enc.last_hidden_state], 1)
+    atts = torch.cat([torch.ones(vis.shape[:2], dtype=torch.long), mask.long()], 1)
+    tgt = batch["output_ids"].masked_fill(batch["output_ids"] == 0, -100)
+    o = m.t5_model(encoder_outputs=BaseModelOutput(last_hidden_state=mem), attention_mask=atts,
+                   decoder_attention_mask=batch["output_ids"] != 0, return_dict=True, labels=tgt)
+    return o.logits, o.loss, mem, atts
+
+
+def ref_greedy(m, batch, max_new):
+    """Hand-rolled HF-4.28 greedy loop over the REFERENCE forward with its own cache."""
+    from transformers.modeling_outputs import BaseModelOutput
+    with torch.no_grad():
+        _, _, mem, atts = ref_logits(m, batch)
+        B = mem.shape[0]
+        seq = torch.zeros(B, 1, dtype=torch.long)
+        unfinished = torch.ones(B, dtype=torch.long)
+        past = None
+        for _ in range(max_new):
+            step = seq if past is None else seq[:, -1:]
+            o = m.t5_model(encoder_outputs=BaseModelOutput(last_hidden_state=mem), attention_mask=atts,
+                           decoder_input_ids=step, past_key_values=past, use_cache=True, return_dict=True)
+            past = o.past_key_values
+            nxt = o.logits[:, -1].argmax(-1)
+            nxt = nxt * unfinished
+            seq = torch.cat([seq, nxt[:, None]], 1)
+            unfinished = unfinished * (nxt != 1).long()
+            if unfinished.max() == 0:
+                break
+        return seq
+
+
+def npz(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name), **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                                    for k, v in arrs.items()})
+    print(f"  wrote tests/golden/{name}  ({os.path.getsize(os.path.join(OUT, name)) / 1e3:.1f} kB)")
+
+
+def check(name, a, b, atol=1e-5, rtol=0.0):
+    a, b = a.detach().double(), b.detach().double()
+    err = (a - b).abs().max().item()
+    ok = err <= atol + rtol * b.abs().max().item()
+    print(f"  {'OK ' if ok else 'BAD'} {name}: max|diff|={err:.3e} (max|ref|={b.abs().max().item():.3e})")
+    assert ok, name
+    return err
+
+
+# ------------------------------------------------------------------------------------------- cases
+def case_functions(mt5):
+    print("[functions]")
+    A = mt5.T5Attention
+    rel = torch.arange(-1200, 1201)
+    bi = A._relative_position_bucket(rel, True, 32, 128)
+    uni = A._relative_position_bucket(rel, False, 32, 128)
+    assert torch.equal(bi, R.relative_position_bucket(rel, True, 32, 128))
+    assert torch.equal(uni, R.relative_position_bucket(rel, False, 32, 128))
+    # SURVEY T2 probes
+    d = torch.arange(-130, 131, 10)
+    assert A._relative_position_bucket(d, True).tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 8, 0, 24, 26, 27, 28, 29, 29, 30, 30, 30, 31, 31, 31, 31]
+    labels = torch.tensor([[5, 9, -100, 3, 1, -100, -100], [7, -100, -100, -100, -100, -100, -100]])
+    cfg = R.RefConfig.tiny()
+    t5 = mt5.T5ForConditionalGeneration.__new__(mt5.T5ForConditionalGeneration)
+    t5.config = types.SimpleNamespace(decoder_start_token_id=0, pad_token_id=0)
+    sr = mt5.T5PreTrainedModel._shift_right(t5, labels)
+    assert torch.equal(sr, R.shift_right(labels, cfg))
+    x = synth.normal((5, 9, 64), 11) * 3
+    w = synth.normal((64,), 12, 0.2, 1.0)
+    ln = mt5.T5LayerNorm(64, eps=1e-6); ln.weight.data.copy_(w)
+    rn = ln(x)
+    check("rmsnorm", R.rms_norm(x, w, 1e-6), rn, 1e-6)
+    logits = synth.normal((14, 612), 13) * 4
+    y = labels.view(-1)
+    ce = torch.nn.functional.cross_entropy(logits, y, ignore_index=-100, label_smoothing=0.1)
+    check("smoothed_ce", R.smoothed_ce(logits, y, 0.1), ce, 1e-6)
+    npz("functions.npz", rel=rel, bucket_bi=bi, bucket_uni=uni, labels=labels, shift_right=sr,
+        rms_x=x, rms_w=w, rms_out=rn, ce_logits=logits, ce_labels=y, ce_loss=ce)
+
+
+def case_tiny(v2s, tag, cfg, B, T, L, Lo, seed):
+    print(f"[{tag}] B={B} T={T} L={L} Lo={Lo}")
+    P = oracle_params(cfg, seed, grad=True)
+    m = build_ref_model(v2s, cfg, {k: v.detach() for k, v in P.items()})
+    batch = synth.make_batch(B, T, L, Lo, cfg.vocab, seed, cfg.vit_dim)
+    if tag == "tiny":                                   # exercise ragged edge cases: a 1-token row, a full row
+        batch["input_ids"][0, 1:] = 0; batch["input_ids"][0, 0] = 1
+        batch["output_ids"][1, 1:] = 0; batch["output_ids"][1, 0] = 1
+    for p in m.parameters():
+        p.requires_grad_(True)
+    lg_ref, loss_ref2, mem_ref, _ = ref_logits(m, batch)
+    loss_ref, vd = ref_forward(m, batch)
+    check("loss(forward) vs loss(t5 call)", loss_ref, loss_ref2, 1e-6)
+    lg, tgt, vd_o = R.vid2seq_logits(P, cfg, batch["video"], batch["input_ids"], batch["input_ids"] != 0,
+                                     batch["output_ids"], batch["output_ids"] != 0)
+    loss = R.smoothed_ce(lg, tgt, cfg.label_smoothing)
+    check("vit/video_dict", vd_o["video"], vd["video"], 1e-5)
+    check("logits", lg, lg_ref, 1e-5, 1e-6)
+    assert abs(loss.item() - loss_ref.item()) <= 1e-6 * abs(loss_ref.item()) + 1e-7, (loss.item(), loss_ref.item())
+    print(f"  OK  loss oracle={loss.item():.8f} ref={loss_ref.item():.8f}")
+    m.zero_grad()
+    loss_ref.backward()
+    names = list(P.keys())
+    g = torch.autograd.grad(loss, [P[k] for k in names], allow_unused=True)
+    ref_named = dict(m.named_parameters())
+    gref = {}
+    worst = 0.0
+    for k, gi in zip(names, g):
+        rk = k if k in ref_named else None
+        if rk is None:
+            # tied alias: shared is registered under one of its names
+            rk = next(n for n in ref_named if ref_named[n] is m.t5_model.shared.weight)
+        gr = ref_named[rk].grad
+        gi = gi if gi is not None else torch.zeros_like(P[k])
+        gr = gr if gr is not None else torch.zeros_like(P[k])
+        err = (gi - gr).abs().max().item() / (gr.abs().max().item() + 1e-12)
+        worst = max(worst, err)
+        gref[k] = gr.clone()
+    print(f"  OK  grads: worst rel-to-max err over {len(names)} tensors = {worst:.2e}")
+    assert worst < 2e-4, worst
+    arrs = {"video": batch["video"], "input_ids": batch["input_ids"], "output_ids": batch["output_ids"],
+            "loss": loss_ref.detach(), "logits": lg_ref.detach(), "memory": mem_ref.detach()}
+    for k, v in gref.items():
+        arrs["grad:" + k] = v
+    npz(f"{tag}_forward_backward.npz", **arrs)
+    return m, P, batch
+
+
+def case_decode(m, P, cfg, batch, tag, max_new=24):
+    print(f"[{tag} greedy decode]")
+    seq_ref = ref_greedy(m, batch, max_new)
+    Pd = {k: v.detach() for k, v in P.items()}
+    seq = R.greedy_generate(Pd, cfg, batch["video"], batch["input_ids"], batch["input_ids"] != 0, max_new)
+    assert torch.equal(seq, seq_ref), (seq, seq_ref)
+    print(f"  OK  tokens identical, shape {tuple(seq.shape)}; sample row: {seq[0].tolist()[:12]}")
+    # incremental (cached) logits == full-sequence logits, on the reference itself
+    # cross-check with the installed transformers' own generate (labelled: installed-HF, not 4.28)
+    try:
+        import transformers
+        from transformers.modeling_outputs import BaseModelOutput
+        hf = transformers.T5ForConditionalGeneration(transformers.T5Config(
+            vocab_size=cfg.vocab, d_model=cfg.d_model, d_kv=cfg.d_kv, d_ff=cfg.d_ff, num_layers=cfg.n_enc,
+            num_decoder_layers=cfg.n_dec, num_heads=cfg.heads, feed_forward_proj="relu", dropout_rate=0.0,
+            tie_word_embeddings=True, pad_token_id=0, eos_token_id=1, decoder_start_token_id=0))
+        sd = {k[len("t5_model."):]: v for k, v in Pd.items() if k.startswith("t5_model.")}
+        for a in ("encoder.embed_tokens.weight", "decoder.embed_tokens.weight", "lm_head.weight"):
+            sd[a] = sd["shared.weight"]
+        hf.load_state_dict(sd, strict=False); hf.eval()
+        mem, mm, _ = R.encode(Pd, cfg, batch["video"], batch["input_ids"], batch["input_ids"] != 0)
+        with torch.no_grad():
+            out = hf.generate(encoder_outputs=BaseModelOutput(last_hidden_state=mem), attention_mask=mm,
+                              num_beams=1, do_sample=False, max_new_tokens=max_new, min_length=1)
+        n = min(out.shape[1], seq.shape[1])
+        same = torch.equal(out[:, :n], seq[:, :n])
+        print(f"  {'OK ' if same else 'DIFF'} installed-HF generate(num_beams=1) agrees on the first {n} positions")
+    except Exception as e:  # pragma: no cover
+        print("  (installed-HF cross-check skipped:", type(e).__name__, str(e)[:80], ")")
+    npz(f"{tag}_greedy.npz", video=batch["video"], input_ids=batch["input_ids"], tokens=seq_ref, max_new=max_new)
+
+
+def case_train_recipe(v2s, cfg, seed=5):
+    """dvc.py:train_one_epoch (the real one) for 2 steps on a fake loader vs oracle train_step."""
+    print("[train recipe: reference dvc.train_one_epoch x2 steps]")
+    dvc = load_reference_dvc()
+    P = oracle_params(cfg, seed, grad=True)
+    m = build_ref_model(v2s, cfg, {k: v.detach() for k, v in P.items()})
+    for p in m.parameters():
+        p.requires_grad_(True)
+    batches = [synth.make_batch(3, cfg.num_features, 20, 12, cfg.vocab, seed + i, cfg.vit_dim, denoising=True) for i in range(2)]
+    loader = [{"video": b["video"], "input_tokens": b["input_ids"], "output_tokens": b["output_ids"],
+               "denoising_input_tokens": b["den_input_ids"], "denoising_output_tokens": b["den_output_ids"]} for b in batches]
+    args = types.SimpleNamespace(epochs=1, print_freq=100, use_speech=True, genasr=False, generative=1.0, denoising=1.0,
+                                 clip_max_norm=0.1, num_bins=cfg.num_bins, lr=3e-4, schedule="", fraction_warmup_steps=0.1)
+    params_all = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params_all, lr=args.lr, betas=(0.9, 0.999), weight_decay=0)
+    torch.distributed.is_available  # noqa
+    dvc.dist.reduce_dict = lambda d: d                      # single process: all_reduce is identity
+    m.train()                                                # dropout rates are 0 in this model
+    dvc.train_one_epoch(m, loader, opt, torch.device("cpu"), 0, args)
+    state = {}
+    recs = []
+    for b in batches:
+        recs.append(R.train_step(P, state, cfg, b, lr=args.lr, clip=args.clip_max_norm))
+    ref_named = dict(m.named_parameters())
+    worst = 0.0
+    post = {}
+    for k, v in P.items():
+        rk = k if k in ref_named else next(n for n in ref_named if ref_named[n] is m.t5_model.shared.weight)
+        r = ref_named[rk].detach()
+        worst = max(worst, (v.detach() - r).abs().max().item())
+        post[k] = r
+    print(f"  OK  post-2-step weights: max|diff| = {worst:.2e};  oracle records: {recs}")
+    assert worst < 5e-6, worst
+    arrs = {}
+    for i, b in enumerate(batches):
+        for k, v in b.items():
+            arrs[f"b{i}:{k}"] = v
+    sel = ["t5_model.shared.weight", "t5_model.encoder.block.0.layer.0.SelfAttention.q.weight",
+           "t5_model.decoder.block.1.layer.1.EncDecAttention.k.weight", "visual_encoder.blocks.0.attn.qkv.weight",
+           "visual_encoder.blocks.1.mlp.fc2.bias", "t5_model.decoder.final_layer_norm.weight",
+           "t5_model.encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"]
+    for k in sel:
+        arrs["post:" + k] = post[k]
+    arrs["loss0"] = recs[0]["losses"]["loss"]; arrs["den0"] = recs[0]["losses"]["denoising_loss"]
+    arrs["gnorm0"] = recs[0]["grad_norm"]; arrs["gnorm1"] = recs[1]["grad_norm"]
+    npz("tiny_train_recipe.npz", **arrs)
+
+
+def case_parse():
+    print("[parse_chapters]")
+    cases = [
+        ("<time=5> <time=7> Blablabla <time=7> <time=9> Blobloblo <time=2>", 120.0, 100),
+        ("<time=0> <time=99> intro to the video", 60.0, 100),
+        ("<time=10> <time=5> backwards <time=20> <time=30> fine", 99.0, 100),
+        ("<time=1> <time=2> <time=3> three in a row then text <time=4> <time=8> ok", 50.0, 100),
+        ("no time tokens at all", 10.0, 100),
+        ("<time=3> <time=4>", 10.0, 100),
+        ("<time=3> <time=4> a  b   c <time=", 10.0, 100),
+        ("", 10.0, 100),
+    ]
+    # the reference has no function for this (inline loop dvc.py:186-212); run that loop body verbatim-in-spirit by
+    # exec'ing it from the reference source so expected values come from reference code, not from the restatement
+    src = open(REF + "/dvc.py").read().splitlines()
+    body = src[186:212]                                         # lines 187-212 (body of the per-video loop)
+    import re, textwrap
+    code = textwrap.dedent("\n".join(body))
+    out = []
+    for text, dur, nb in cases:
+        env = {"re": re, "output": [text], "i": 0, "vid": "v", "res": {}, "duration": [dur],
+               "args": types.SimpleNamespace(num_bins=nb)}
+        exec(code, env)
+        exp = env["res"]["v"]
+        got = R.parse_chapters(text, dur, nb)
+        assert got == exp, (text, got, exp)
+        out.append({"text": text, "duration": dur, "num_bins": nb, "expected": exp})
+    os.makedirs(OUT, exist_ok=True)
+    json.dump(out, open(os.path.join(OUT, "parse_chapters.json"), "w"), indent=1)
+    print(f"  OK  {len(cases)} cases; wrote tests/golden/parse_chapters.json")
+
+
+def case_full(v2s, B=2, L=256, Lo=256, seed=1234):
+    print(f"[full-size cfg-1] t5-base, B={B} T=100 L={L} Lo={Lo}  (reference fp32 CPU)")
+    cfg = R.RefConfig()
+    P = oracle_params(cfg, seed, grad=False)
+    m = build_ref_model(v2s, cfg, P)
+    batch = synth.make_batch(B, 100, L, Lo, cfg.vocab, seed, 768)
+    with torch.no_grad():
+        lg_ref, loss_ref, mem_ref, _ = ref_logits(m, batch)
+        lg, tgt, _ = R.vid2seq_logits(P, cfg, batch["video"], batch["input_ids"], batch["input_ids"] != 0,
+                                      batch["output_ids"], batch["output_ids"] != 0)
+        loss = R.smoothed_ce(lg, tgt, cfg.label_smoothing)
+    check("full logits", lg, lg_ref, 2e-5, 2e-6)
+    print(f"  loss oracle={loss.item():.7f} ref={loss_ref.item():.7f}")
+    assert abs(loss.item() - loss_ref.item()) <= 2e-6 * abs(loss_ref.item())
+    for p in m.parameters():
+        p.requires_grad_(True)
+    loss2, _ = ref_forward(m, batch)
+    loss2.backward()
+    named = dict(m.named_parameters())
+    gn = {}
+    tot = 0.0
+    for k in P:
+        rk = k if k in named else next(n for n in named if named[n] is m.t5_model.shared.weight)
+        g = named[rk].grad
+        gn[k] = float(g.norm()) if g is not None else 0.0
+        tot += gn[k] ** 2
+    print(f"  total grad norm = {tot ** 0.5:.6f}")
+    npz("full_cfg1_scalars.npz", seed=seed, B=B, L=L, Lo=Lo, loss=loss_ref.detach(), grad_norm=tot ** 0.5,
+        logits_slice=lg_ref[:, :4, :64].detach(), logits_rowmax=lg_ref.max(-1).values.detach(),
+        logits_argmax=lg_ref.argmax(-1), memory_slice=mem_ref[:, ::37, :32].detach(),
+        grad_norm_keys=np.array(list(gn.keys())), grad_norm_vals=np.array(list(gn.values())))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-full", action="store_true")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    mt5, v2s, vit = load_reference()
+    case_functions(mt5)
+    case_parse()
+    cfg = R.RefConfig.tiny()
+    m, P, batch = case_tiny(v2s, "tiny", cfg, B=3, T=10, L=24, Lo=12, seed=7)
+    case_decode(m, P, cfg, batch, "tiny")
+    # ViT nearest-neighbour pos-embed resize branch (vit.py:119-123): T != num_features, and d_model != vit_dim => proj_v2t
+    cfg2 = R.RefConfig.tiny(vit_dim=48, vit_heads=3, num_features=10)
+    case_tiny(v2s, "tiny_resize_proj", cfg2, B=2, T=7, L=16, Lo=9, seed=9)
+    case_train_recipe(v2s, cfg)
+    if not a.skip_full:
+        case_full(v2s)
+    print("ALL GOLDEN CASES OK")
+
+
+if __name__ == "__main__":
+    main()

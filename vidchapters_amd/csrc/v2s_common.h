@@ -1,0 +1,98 @@
+// Shared device/host helpers for libvid2seq_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vid2seq_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define V2S_LDS __attribute__((address_space(3)))
+
+// ---------------------------------------------------------------- error plumbing (host)
+void v2s_set_error(const char* fmt, ...);
+#define V2S_CHECK(cond, code, ...)            \
+  do {                                        \
+    if (!(cond)) {                            \
+      v2s_set_error(__VA_ARGS__);             \
+      return (code);                          \
+    }                                         \
+  } while (0)
+#define V2S_LAUNCH_CHECK()                                                    \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) {                                                  \
+      v2s_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,            \
+                    hipGetErrorString(e__));                                  \
+      return V2S_ERR_LAUNCH;                                                  \
+    }                                                                         \
+  } while (0)
+
+int v2s_opt_tr_read();  // 1 = use ds_read_b64_tr_b16 for transposed operand fragments
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+  v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// counter-based dropout RNG: one 32-bit hash per PAIR of elements, 16 bits each.
+__device__ __forceinline__ uint32_t v2s_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+// keep-decision for element index e (64-bit) under (seed, p16): drop iff r16 < p16
+__device__ __forceinline__ bool v2s_keep(unsigned long long e, uint32_t seed, uint32_t p16) {
+  unsigned long long pair = e >> 1;
+  uint32_t h = v2s_hash32((uint32_t)pair ^ seed) ^ v2s_hash32((uint32_t)(pair >> 32) + 0x9e3779b9u * (seed | 1u));
+  uint32_t r16 = (e & 1) ? (h >> 16) : (h & 0xffffu);
+  return r16 >= p16;
+}
+
+// exact-erf GELU and its derivative (torch nn.GELU default, vit.py:9)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// XCD-aware bijective block remap: consecutive logical ids land on the same XCD (8 XCDs, bid%8 -> XCD)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + loc;
+}
