@@ -1,0 +1,238 @@
+/*
+ * libvid2seq_hip.so -- C ABI of the MI355X-native (gfx950) Vid2Seq hot path.
+ *
+ * The reference (antoyang/VidChapters) has no FFI for this path: its boundary is the Python module
+ * surface Vid2Seq.forward()/generate() (model/vid2seq.py:58-167).  This header is the C-ABI that a
+ * maintainer would bind underneath that surface (INTEGRATION.md shows the ctypes stubs).  Each entry
+ * point names the reference arithmetic it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory unless noted "host".
+ *   - the caller owns every buffer (inputs, outputs, saved-for-backward, workspace); the library
+ *     allocates nothing and never synchronises the device.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - activations are bf16 (raw uint16 bits), accumulators/statistics/gradients-of-parameters fp32.
+ *   - return value: 0 = ok, negative = V2S_ERR_*; message via v2s_last_error() (thread local).
+ */
+#ifndef VID2SEQ_HIP_H
+#define VID2SEQ_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V2S_OK 0
+#define V2S_ERR_SHAPE (-1)
+#define V2S_ERR_DTYPE (-2)
+#define V2S_ERR_ALIGN (-3)
+#define V2S_ERR_LAUNCH (-4)
+#define V2S_ERR_ARG (-5)
+
+#define V2S_BF16 0
+#define V2S_F32 1
+
+#define V2S_ABI_VERSION 1
+
+int v2s_version(void);
+const char* v2s_last_error(void);
+/* runtime switches: "tr_read" (1: ds_read_b64_tr_b16 operand transposes, 0: scalar LDS gathers) */
+int v2s_set_option(const char* name, int value);
+int v2s_get_option(const char* name);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM:  C[M,N] (+)= epilogue( alpha * sum_k A(m,k) * B(n,k) )
+ * replaces every nn.Linear on the path: vit.py:41,53,17,20; modeling_t5.py:304-311,528-536,581,1714
+ * (forward), and their autograd dgrad/wgrad.
+ *   transA = 0: A stored [M][K] (row stride lda, K contiguous);  1: stored [K][M] (row stride lda)
+ *   transB = 0: B stored [N][K] (row stride ldb, K contiguous);  1: stored [K][N] (row stride ldb)
+ *     forward  y = x W^T        : transA=0, transB=0 (W is [out,in] like nn.Linear.weight)
+ *     dgrad    dx = dy W        : transA=0, transB=1
+ *     wgrad    dW = dy^T x      : transA=1, transB=1
+ *   epilogue order: v = alpha*acc; v += bias[n]; (pre-activation optionally stored to `pre`);
+ *     v = act(v); v *= dact(z[m,n]) ; dropout(v) ; v += residual[m,n]; C = (accumulate ? C + v : v)
+ *   M, N arbitrary; K, N, lda, ldb, ldc multiples of 8 elements; pointers 16-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+#define V2S_ACT_NONE 0
+#define V2S_ACT_RELU 1
+#define V2S_ACT_GELU 2 /* exact erf GELU (torch nn.GELU default) */
+
+typedef struct v2s_gemm_args {
+  int32_t M, N, K;
+  int32_t transA, transB;
+  const void* A; /* bf16 */
+  const void* B; /* bf16 */
+  int64_t lda, ldb;
+  void* C;
+  int64_t ldc;
+  int32_t c_dtype;    /* V2S_BF16 or V2S_F32 */
+  int32_t accumulate; /* C += result (f32 output only) */
+  float alpha;
+  const float* bias;    /* [N] fp32 or NULL */
+  int32_t act;          /* V2S_ACT_* applied in the forward direction */
+  void* pre;            /* bf16 [M][ldc] or NULL: pre-activation copy (needed by GELU backward) */
+  int32_t dact;         /* V2S_ACT_*: multiply by act'(z) (RELU: z>0 ? 1:0 with z = forward output;
+                           GELU: gelu'(z) with z = saved pre-activation) */
+  const void* z;        /* bf16 [M][ldz] */
+  int64_t ldz;
+  const void* residual; /* bf16 [M][ldr] or NULL */
+  int64_t ldr;
+  float dropout_p;      /* 0 = off */
+  uint32_t dropout_seed;
+} v2s_gemm_args;
+
+int v2s_gemm(const v2s_gemm_args* args, void* stream);
+
+/* column sums of a bf16 matrix (bias gradients of the ViT linears: autograd of vit.py:41,53,17,20)
+ * out[n] (+)= sum_m X[m][n];  out fp32 */
+int v2s_colsum(const void* X, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation
+ *   rmsnorm: modeling_t5.py:263-277 (T5LayerNorm): y = w * x * rsqrt(mean(x^2)+eps)
+ *   layernorm: torch nn.LayerNorm used at vit.py:64,69,99 (eps 1e-5, affine)
+ *   x,y bf16 [rows][cols]; w,b fp32 [cols]; rstd/mean fp32 [rows] (saved for backward)
+ *   backward: dx bf16; dw/db fp32 [cols], accumulated (+=) into the caller's gradient buffers;
+ *   `partial` = fp32 workspace of v2s_norm_partial_floats(rows, cols) elements.
+ *   `dx_add` (bf16, may be NULL) is added to dx: the residual-stream gradient that bypasses the norm.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t v2s_norm_partial_floats(int32_t rows, int32_t cols);
+int v2s_rmsnorm_fwd(const void* x, const float* w, void* y, float* rstd, int32_t rows, int32_t cols,
+                    float eps, void* stream);
+int v2s_rmsnorm_bwd(const void* x, const float* w, const float* rstd, const void* dy, void* dx,
+                    const void* dx_add, float* dw, float* partial, int32_t rows, int32_t cols, void* stream);
+int v2s_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                      int32_t rows, int32_t cols, float eps, void* stream);
+int v2s_layernorm_bwd(const void* x, const float* w, const float* mean, const float* rstd, const void* dy,
+                      void* dx, const void* dx_add, float* dw, float* db, float* partial, int32_t rows,
+                      int32_t cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused attention (flash-style, scores never materialised)
+ *   replaces vit.py:47-51 and modeling_t5.py:539-580 (+ compute_bias :445-460, masks :996,1005,559)
+ *   S[b,h,q,k] = scale * <Q[b,q,h,:], K[b,k,h,:]> + bias[h][k-q+(Nq-1)]   (bias optional)
+ *   masked (key_mask[b,k]==0, or causal && k>q+causal_off) scores are REPLACED by finfo(float32).min,
+ *   which reproduces the reference's additive (1-m)*finfo.min exactly in fp32 (fully masked rows
+ *   become uniform over all keys, like the reference).
+ *   P = softmax_k(S); dropout(P); O[b,q,h,:] = P V.   head_dim must be 64.
+ *   Q/K/V/O are bf16 with element strides (batch stride, row stride); head h sits at column h*64.
+ *   `ml` fp32 [B][H][Nq][2] = (row max, row sum) saved for backward.
+ *   backward needs `delta` fp32 [B][H][Nq] = sum_d dO*O (v2s_attn_delta) and produces dQ,dK,dV
+ *   (same strides as q/k/v via dq_*, dk_*, dv_*) and, if bias != NULL, dbias_diag fp32
+ *   [H][Nq+Nk-1] accumulated (+=) per relative position (bucket-reduced by v2s_bias_bucket_bwd).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct v2s_attn_args {
+  int32_t B, H, Nq, Nk;
+  const void *q, *k, *v;
+  int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs; /* batch / row strides in elements */
+  void* o;
+  int64_t o_bs, o_rs;
+  float* ml;              /* [B][H][Nq][2] */
+  float scale;            /* 1.0 for T5 (modeling_t5.py:539-541), head_dim^-0.5 for ViT (vit.py:30) */
+  const float* bias_diag; /* fp32 [H][Nq+Nk-1] or NULL; index (k - q) + (Nq-1) */
+  const uint8_t* key_mask; /* [B][Nk] 1=keep, or NULL */
+  int32_t causal;         /* 1: key k visible iff k <= q + causal_off */
+  int32_t causal_off;     /* Nk - Nq for cached decoding, else 0 */
+  float dropout_p;
+  uint32_t dropout_seed;
+  /* backward only */
+  const void* d_o;
+  int64_t do_bs, do_rs;
+  const float* delta;     /* [B][H][Nq] */
+  void *dq, *dk, *dv;
+  int64_t dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+  float* dbias_diag;      /* fp32 [H][Nq+Nk-1], += ; or NULL */
+} v2s_attn_args;
+
+int v2s_attn_fwd(const v2s_attn_args* a, void* stream);
+int v2s_attn_delta(const v2s_attn_args* a, float* delta, void* stream); /* delta = rowsum(dO * O) */
+int v2s_attn_bwd(const v2s_attn_args* a, void* stream);
+
+/* relative-position bias (modeling_t5.py:397-460): host passes the bucket LUT lut[i] = bucket(i-(Nq-1)),
+ * i in [0, Nq+Nk-1) (int32, computed on the host exactly as the reference does in fp32).
+ *   fwd: bias_diag[h][i] = table[lut[i]][h]          (table fp32 [num_buckets][H])
+ *   bwd: dtable[lut[i]][h] += dbias_diag[h][i]       */
+int v2s_bias_diag_fwd(const float* table, const int32_t* lut, float* bias_diag, int32_t H, int32_t n,
+                      int32_t num_buckets, void* stream);
+int v2s_bias_bucket_bwd(const float* dbias_diag, const int32_t* lut, float* dtable, int32_t H, int32_t n,
+                        int32_t num_buckets, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embedding (modeling_t5.py:972, vid2seq.py:71): out[i,:] = table[ids[i],:]  (bf16 table -> bf16)
+ * optional dropout; backward scatter-adds bf16 dy rows into the fp32 gradient of the tied table.
+ * ---------------------------------------------------------------------------------------------- */
+int v2s_embed_fwd(const int64_t* ids, const void* table, void* out, int64_t n, int32_t d, int32_t vocab,
+                  float dropout_p, uint32_t dropout_seed, void* stream);
+int v2s_embed_bwd(const int64_t* ids, const void* dy, float* dtable, int64_t n, int32_t d, int32_t vocab,
+                  float dropout_p, uint32_t dropout_seed, void* stream);
+
+/* elementwise helpers on bf16 [n] : y = x + add[(i mod add_n)] ; dropout ; grad-of-dropout */
+int v2s_add_bcast(const void* x, const void* add, void* y, int64_t n, int64_t add_n, void* stream);
+int v2s_dropout(const void* x, void* y, int64_t n, float p, uint32_t seed, void* stream);
+int v2s_add(const void* a, const void* b, void* y, int64_t n, void* stream);
+/* out_f32[i mod add_n] += sum over broadcast copies of dy (pos_embed gradient) */
+int v2s_bcast_grad(const void* dy, float* out, int64_t n, int64_t add_n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Label-smoothed cross entropy over fp32 logits (modeling_t5.py:1721 == F.cross_entropy(ignore_index
+ * =-100, label_smoothing=eps)), forward + gradient in one pass:
+ *   per row i with label y != -100: l_i = (1-eps)*(lse - z_y) + eps*(lse - mean_c z_c)
+ *   row_lse: fp32 [rows][2] = (logsumexp, l_i) saved for backward;
+ *   loss_sum += sum l_i ; count += #rows kept   (fp32 device scalars, deterministic single-block
+ *   reduction; caller zeroes them);  dlogits (bf16, same shape) = (softmax - (1-eps)*onehot - eps/V) * gscale[0]
+ *   for kept rows and 0 for ignored rows, where gscale is a device scalar (= upstream grad / count).
+ *   Two entry points so that count is known before gradients are scaled.
+ * ---------------------------------------------------------------------------------------------- */
+int v2s_ce_fwd(const float* logits, int64_t ld, const int64_t* labels, int32_t rows, int32_t V, float eps,
+               float* row_lse, float* loss_sum, float* count, void* stream);
+int v2s_ce_bwd(const float* logits, int64_t ld, const int64_t* labels, const float* row_lse, int32_t rows,
+               int32_t V, float eps, const float* gscale, void* dlogits, int64_t ldd, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser over the flat parameter arena (dvc.py:112-126: clip_grad_norm_, torch.optim.Adam step,
+ * time-token renorm) + bf16 shadow refresh.
+ * ---------------------------------------------------------------------------------------------- */
+/* out_sum[0] += sum(g^2), deterministic two-stage reduction; partial_ws: >= 1024 floats */
+int v2s_sqnorm(const float* g, int64_t n, float* partial_ws, float* out_sum, void* stream);
+typedef struct v2s_adam_args {
+  float* p; float* m; float* v; const float* g; void* p_bf16; /* bf16 shadow or NULL */
+  int64_t n;
+  float lr, beta1, beta2, eps, weight_decay;
+  int32_t step;            /* 1-based */
+  const float* gnorm_sq;   /* device scalar: sum of squared grads (for clipping) or NULL */
+  float max_norm;          /* <=0: no clipping */
+  float grad_scale;        /* extra multiplier applied to g before everything (e.g. 1/world) */
+} v2s_adam_args;
+int v2s_adam_step(const v2s_adam_args* a, void* stream);
+int v2s_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dvc.py:118-126: rows [V-num_bins, V) of emb (fp32 [V][d]) are divided by
+ * mean(row-norm of those rows)/mean(row-norm of rows [0,V-num_bins)); shadow refreshed. ws: V+2 floats */
+int v2s_timetoken_renorm(float* emb, void* emb_bf16, int32_t V, int32_t d, int32_t num_bins, float* ws,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Greedy decoding helpers (HF 4.28 greedy_search, call site vid2seq.py:150-162)
+ *   decode attention: one query row per (b,h) against a KV cache [B][Nk_max][H*64]-strided
+ *   argmax over fp32 logits rows with the finished-row rule (finished rows emit pad)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct v2s_decode_attn_args {
+  int32_t B, H, Nk;
+  const void* q; int64_t q_bs;            /* bf16 [B][H*64] */
+  const void* k; const void* v; int64_t kv_bs, kv_rs;
+  void* o; int64_t o_bs;
+  const float* bias_row;                  /* fp32 [H][Nk] or NULL */
+  const uint8_t* key_mask;                /* [B][mask_ld] or NULL */
+  int64_t mask_ld;
+  float scale;
+} v2s_decode_attn_args;
+int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream);
+int v2s_argmax_step(const float* logits, int64_t ld, int32_t rows, int32_t V, int64_t* next_tok,
+                    int32_t* unfinished, int32_t eos_id, int32_t pad_id, void* stream);
+/* append new K/V rows ([B][H*64], strided) into the cache at position pos */
+int v2s_kv_append(const void* src, int64_t src_bs, void* cache, int64_t cache_bs, int64_t cache_rs,
+                  int32_t B, int32_t width, int32_t pos, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

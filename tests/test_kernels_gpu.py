@@ -1,0 +1,394 @@
+"""Per-kernel parity tests: every C-ABI entry point vs an fp32 torch statement of the same op, on the GPU.
+
+Inputs are bf16-representable so the only differences are accumulation order and bf16 rounding of outputs.
+Tolerances are written next to each check.  (The end-to-end parity against the CPU oracle / reference
+goldens is in test_model_gpu.py.)
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from vidchapters_amd import lib as L  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.bfloat16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def cos(a, b):
+    a, b = a.float().flatten(), b.float().flatten()
+    return (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+
+
+@pytest.fixture(params=[1, 0], ids=["tr_read", "scalar_lds"])
+def tr_mode(request):
+    L.set_option("tr_read", request.param)
+    yield request.param
+    L.set_option("tr_read", 1)
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (200, 136, 72), (77, 200, 328), (3200, 768, 768), (1024, 32200, 768)])
+def test_gemm_nt(M, N, K):
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    Cb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L.gemm(A, B, Cb, M, N, K)
+    ref = A.float() @ B.float().T
+    e = relerr(Cb, ref)
+    print(f"gemm_nt {M}x{N}x{K}: relerr {e:.2e}")
+    assert e < 1e-2          # bf16 output rounding: 2^-8 relative on the largest element
+    Cf = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    L.gemm(A, B, Cf, M, N, K, alpha=0.5)
+    e = relerr(Cf, 0.5 * ref)
+    print(f"  fp32 out: relerr {e:.2e}")
+    assert e < 2e-5          # fp32 accumulate of exact bf16 products; only summation order differs
+
+
+def test_gemm_ragged_vocab():
+    """LM-head shapes with a vocabulary that is not a multiple of 8 (612 tiny, 32100 for num_bins=0)."""
+    M, V, d = 72, 612, 64
+    ldv = (V + 7) // 8 * 8
+    H, E = rnd(M, d, seed=1), rnd(V, d, seed=2)
+    logits = torch.full((M, ldv), float("nan"), dtype=torch.float32, device=DEV)
+    L.gemm(H, E, logits, M, V, d, ldc=ldv)
+    assert relerr(logits[:, :V], H.float() @ E.float().T) < 2e-5
+    dl = torch.zeros(M, ldv, dtype=torch.bfloat16, device=DEV); dl[:, :V] = rnd(M, V, seed=3)
+    dH = torch.empty(M, d, dtype=torch.float32, device=DEV)
+    L.gemm(dl, E, dH, M, d, V, transB=True, lda=ldv)                       # dgrad, ragged K
+    assert relerr(dH, dl[:, :V].float() @ E.float()) < 2e-5
+    dE = torch.zeros(V, d, dtype=torch.float32, device=DEV)
+    L.gemm(dl, H, dE, V, d, M, transA=True, transB=True, lda=ldv, accumulate=True)   # wgrad, ragged M
+    assert relerr(dE, dl[:, :V].float().T @ H.float()) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (264, 768, 3072), (1000, 64, 200)])
+def test_gemm_dgrad_wgrad(M, N, K, tr_mode):
+    # dgrad: dx[M, N] = dy[M, K] @ W[K, N]   (W stored [K][N] -> transB)
+    dy, W = rnd(M, K, seed=3), rnd(K, N, seed=4)
+    dx = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    L.gemm(dy, W, dx, M, N, K, transB=True)
+    e = relerr(dx, dy.float() @ W.float())
+    print(f"dgrad {M}x{N}x{K} tr={tr_mode}: relerr {e:.2e}")
+    assert e < 2e-5
+    # wgrad: dW[M', N'] = dY[Kc, M']^T @ X[Kc, N']  (both stored [K][*] -> transA, transB), accumulate into fp32
+    Mp, Np, Kc = (N // 8) * 8, (K // 8) * 8, M
+    dY, X = rnd(Kc, Mp, seed=5), rnd(Kc, Np, seed=6)
+    dW = torch.ones(Mp, Np, dtype=torch.float32, device=DEV)
+    L.gemm(dY, X, dW, Mp, Np, Kc, transA=True, transB=True, accumulate=True)
+    ref = 1.0 + dY.float().T @ X.float()
+    e = relerr(dW, ref)
+    print(f"wgrad {Mp}x{Np}x{Kc} tr={tr_mode}: relerr {e:.2e}")
+    assert e < 2e-5
+
+
+def test_gemm_epilogues():
+    M, N, K = 264, 256, 128
+    A, B = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.1)
+    bias = rnd(N, seed=9, dtype=torch.float32)
+    res = rnd(M, N, seed=10)
+    acc = A.float() @ B.float().T
+    # bias + gelu (+ saved pre-activation) + residual
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L.gemm(A, B, out, M, N, K, bias=bias, act=L.ACT_GELU, pre=pre, residual=res)
+    ref_pre = acc + bias
+    ref = torch.nn.functional.gelu(ref_pre) + res.float()
+    assert relerr(pre, ref_pre) < 1e-2 and relerr(out, ref) < 1e-2
+    # relu
+    L.gemm(A, B, out, M, N, K, act=L.ACT_RELU)
+    assert relerr(out, torch.relu(acc)) < 1e-2
+    # dact relu / gelu against saved z
+    z = rnd(M, N, seed=11)
+    o32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    L.gemm(A, B, o32, M, N, K, dact=L.ACT_RELU, z=z)
+    assert relerr(o32, acc * (z.float() > 0)) < 2e-5
+    L.gemm(A, B, o32, M, N, K, dact=L.ACT_GELU, z=z)
+    zf = z.float().requires_grad_(True)
+    torch.nn.functional.gelu(zf).sum().backward()
+    assert relerr(o32, acc * zf.grad) < 1e-4
+    # dropout: keep-rate and scaling; same seed -> same mask; mask reproduced by v2s_dropout at equal indices
+    p = 0.1
+    L.gemm(A, B, o32, M, N, K, dropout_p=p, dropout_seed=1234)
+    kept = o32 != 0
+    rate = 1.0 - kept.float().mean().item()
+    assert abs(rate - p) < 0.01, rate
+    inv = 1.0 / (1.0 - round(p * 65536) / 65536)
+    assert relerr(o32[kept], (acc * inv)[kept]) < 2e-5
+    ones = torch.ones(M * N, dtype=torch.bfloat16, device=DEV)
+    dm = torch.empty_like(ones)
+    L.dropout(ones, dm, M * N, p, 1234)
+    assert torch.equal(dm.view(M, N) != 0, kept | (acc == 0))
+
+
+def test_colsum():
+    X = rnd(1000, 136, seed=12)
+    out = torch.zeros(136, dtype=torch.float32, device=DEV)
+    L.colsum(X, 1000, 136, out, accumulate=False)
+    assert relerr(out, X.float().sum(0)) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,cols", [(37, 64), (1000, 768), (515, 1024), (64, 48)])
+def test_rmsnorm(rows, cols):
+    x, w, dy, addg = rnd(rows, cols, seed=1, scale=3), 1 + 0.1 * rnd(cols, seed=2, dtype=torch.float32), rnd(rows, cols, seed=3), rnd(rows, cols, seed=4)
+    y = torch.empty_like(x); rstd = torch.empty(rows, dtype=torch.float32, device=DEV)
+    L.rmsnorm_fwd(x, w, y, rstd, rows, cols, 1e-6)
+    xf = x.float().requires_grad_(True); wf = w.clone().requires_grad_(True)
+    ref = wf * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert relerr(y, ref) < 1e-2
+    ref.backward(dy.float())
+    dx = torch.empty_like(x); dw = torch.zeros(cols, dtype=torch.float32, device=DEV)
+    part = torch.empty(L.norm_partial_floats(rows, cols), dtype=torch.float32, device=DEV)
+    L.rmsnorm_bwd(x, w, rstd, dy, dx, addg, dw, part, rows, cols)
+    assert relerr(dx, xf.grad + addg.float()) < 1e-2
+    assert relerr(dw, wf.grad) < 1e-4
+
+
+@pytest.mark.parametrize("rows,cols", [(37, 64), (300, 768), (64, 48)])
+def test_layernorm(rows, cols):
+    x, dy = rnd(rows, cols, seed=1, scale=2), rnd(rows, cols, seed=3)
+    w, b = 1 + 0.1 * rnd(cols, seed=2, dtype=torch.float32), 0.1 * rnd(cols, seed=5, dtype=torch.float32)
+    y = torch.empty_like(x); mean = torch.empty(rows, dtype=torch.float32, device=DEV); rstd = torch.empty_like(mean)
+    L.layernorm_fwd(x, w, b, y, mean, rstd, rows, cols, 1e-5)
+    xf = x.float().requires_grad_(True); wf = w.clone().requires_grad_(True); bf = b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xf, (cols,), wf, bf, 1e-5)
+    assert relerr(y, ref) < 1e-2
+    ref.backward(dy.float())
+    dx = torch.empty_like(x); dw = torch.zeros(cols, dtype=torch.float32, device=DEV); db = torch.zeros_like(dw)
+    part = torch.empty(L.norm_partial_floats(rows, cols), dtype=torch.float32, device=DEV)
+    L.layernorm_bwd(x, w, mean, rstd, dy, dx, None, dw, db, part, rows, cols)
+    assert relerr(dx, xf.grad) < 1e-2
+    assert relerr(dw, wf.grad) < 1e-4 and relerr(db, bf.grad) < 1e-4
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, scale, bias, mask, causal, causal_off):
+    """fp32 reference: q [B,Nq,H,64] etc.  bias [H,Nq,Nk] or None, mask [B,Nk] bool or None (additive finfo.min)."""
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * scale
+    fmin = torch.finfo(torch.float32).min
+    Nq, Nk = q.shape[1], k.shape[1]
+    if bias is not None:
+        s = s + bias[None]
+    keep = torch.ones(q.shape[0], 1, Nq, Nk, dtype=torch.bool, device=q.device)
+    if mask is not None:
+        keep = keep & mask[:, None, None, :]
+    if causal:
+        qi = torch.arange(Nq, device=q.device)[:, None]; ki = torch.arange(Nk, device=q.device)[None, :]
+        keep = keep & (ki <= qi + causal_off)[None, None]
+    s = s + (~keep).float() * fmin
+    p = torch.softmax(s, -1)
+    return torch.einsum("bhqk,bkhd->bqhd", p, v)
+
+
+def bias_from_diag(diag, Nq, Nk):
+    qi = torch.arange(Nq, device=diag.device)[:, None]; ki = torch.arange(Nk, device=diag.device)[None, :]
+    return diag[:, (ki - qi) + Nq - 1]
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,scale,use_bias,use_mask,causal", [
+    (2, 2, 100, 100, 0.125, False, False, False),     # ViT shape
+    (2, 3, 200, 200, 1.0, True, True, False),         # encoder self-attention (ragged tiles)
+    (2, 2, 72, 72, 1.0, True, True, True),            # decoder self-attention
+    (2, 2, 40, 300, 1.0, False, True, False),         # cross-attention
+    (1, 1, 7, 9, 1.0, True, True, False),             # tiny ragged
+    (3, 4, 256, 1100, 1.0, False, True, False),       # cfg-2 cross-attention shape
+    (2, 12, 1000, 1000, 1.0, True, True, False),      # cfg-2 encoder shape
+])
+def test_attention_fwd_bwd(B, H, Nq, Nk, scale, use_bias, use_mask, causal, tr_mode):
+    W = H * 64
+    qkv_q = rnd(B, Nq, 3 * W, seed=1, scale=0.5)           # fused [q|k|v] rows like the QKV GEMM writes them
+    qkv_k = qkv_q if Nq == Nk else rnd(B, Nk, 3 * W, seed=2, scale=0.5)
+    q = qkv_q[..., :W]; k = qkv_k[..., W:2 * W]; v = qkv_k[..., 2 * W:]
+    mask = None
+    if use_mask:
+        lens = torch.tensor([max(1, Nk - 3 - 17 * i) for i in range(B)], device=DEV)
+        mask = torch.arange(Nk, device=DEV)[None, :] < lens[:, None]
+        if B > 1 and not causal:
+            mask[1, :] = mask[1, :] & (torch.arange(Nk, device=DEV) != 0)      # a hole at key 0
+    diag = rnd(H, Nq + Nk - 1, seed=3, dtype=torch.float32) if use_bias else None
+    o = torch.empty(B, Nq, W, dtype=torch.bfloat16, device=DEV)
+    ml = torch.empty(B, H, Nq, 2, dtype=torch.float32, device=DEV)
+    mk = mask.to(torch.uint8).contiguous() if mask is not None else None
+    a = L.attn_args(B, H, Nq, Nk, q, k, v, o, (Nq * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), (Nq * W, W),
+                    ml=ml, scale=scale, bias_diag=diag, key_mask=mk, causal=causal)
+    L.attn_fwd(a)
+    qf = q.float().reshape(B, Nq, H, 64).requires_grad_(True)
+    kf = k.float().reshape(B, Nk, H, 64).requires_grad_(True)
+    vf = v.float().reshape(B, Nk, H, 64).requires_grad_(True)
+    df = diag.clone().requires_grad_(True) if use_bias else None
+    ref = attn_ref(qf, kf, vf, scale, bias_from_diag(df, Nq, Nk) if use_bias else None, mask, causal, 0)
+    e = relerr(o.view(B, Nq, H, 64), ref)
+    print(f"attn fwd B{B} H{H} {Nq}x{Nk} tr={tr_mode}: relerr {e:.2e}")
+    assert e < 2e-2          # P and O are rounded to bf16 (2^-8) once each
+    d_o = rnd(B, Nq, W, seed=5)
+    ref.backward(d_o.float().view(B, Nq, H, 64))
+    dqkv_q = torch.zeros(B, Nq, 3 * W, dtype=torch.bfloat16, device=DEV)
+    dqkv_k = dqkv_q if Nq == Nk else torch.zeros(B, Nk, 3 * W, dtype=torch.bfloat16, device=DEV)
+    delta = torch.empty(B, H, Nq, dtype=torch.float32, device=DEV)
+    ddiag = torch.zeros(H, Nq + Nk - 1, dtype=torch.float32, device=DEV) if use_bias else None
+    L.attn_bwd(a, d_o, (Nq * W, W), delta, dqkv_q[..., :W], dqkv_k[..., W:2 * W], dqkv_k[..., 2 * W:],
+               (Nq * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), dbias_diag=ddiag)
+    dq, dk, dv = dqkv_q[..., :W], dqkv_k[..., W:2 * W], dqkv_k[..., 2 * W:]
+    for name, got, want in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
+        c = cos(got, want.reshape(B, -1, W)); e = relerr(got, want.reshape(B, -1, W))
+        print(f"  {name}: cos {c:.5f} relerr {e:.2e}")
+        assert c > 0.999 and e < 4e-2
+    if use_bias:
+        c = cos(ddiag, df.grad); e = relerr(ddiag, df.grad)
+        print(f"  dbias_diag: cos {c:.5f} relerr {e:.2e}")
+        assert c > 0.999 and e < 3e-2
+
+
+def test_attention_fully_masked_row_is_uniform():
+    B, H, N = 1, 1, 70
+    W = 64
+    q, k, v = rnd(B, N, W, seed=1), rnd(B, N, W, seed=2), rnd(B, N, W, seed=3)
+    mk = torch.zeros(B, N, dtype=torch.uint8, device=DEV)          # every key masked -> reference gives uniform weights
+    o = torch.empty(B, N, W, dtype=torch.bfloat16, device=DEV)
+    a = L.attn_args(B, H, N, N, q, k, v, o, (N * W, W), (N * W, W), (N * W, W), (N * W, W), key_mask=mk)
+    L.attn_fwd(a)
+    want = v.float().mean(1, keepdim=True).expand(B, N, W)
+    assert relerr(o, want) < 2e-2
+
+
+def test_attention_dropout_consistency():
+    B, H, Nq, Nk, W = 2, 2, 128, 192, 128
+    q, k, v = rnd(B, Nq, W, seed=1, scale=0.3), rnd(B, Nk, W, seed=2, scale=0.3), rnd(B, Nk, W, seed=3)
+    o0 = torch.empty(B, Nq, W, dtype=torch.bfloat16, device=DEV); o1 = torch.empty_like(o0); o2 = torch.empty_like(o0)
+    ml = torch.empty(B, H, Nq, 2, dtype=torch.float32, device=DEV)
+    st = ((Nq * W, W), (Nk * W, W), (Nk * W, W), (Nq * W, W))
+    L.attn_fwd(L.attn_args(B, H, Nq, Nk, q, k, v, o0, *st, ml=ml))
+    a = L.attn_args(B, H, Nq, Nk, q, k, v, o1, *st, ml=ml, dropout_p=0.1, dropout_seed=77)
+    L.attn_fwd(a)
+    L.attn_fwd(L.attn_args(B, H, Nq, Nk, q, k, v, o2, *st, ml=ml, dropout_p=0.1, dropout_seed=77))
+    assert torch.equal(o1, o2) and not torch.equal(o0, o1)
+    # O is linear in V for a fixed mask: <dO, O(V=D)> == <dV, D>  ties the forward mask to the dK/dV kernel's mask
+    d_o = rnd(B, Nq, W, seed=5)
+    dq, dk, dv = (torch.zeros(B, n, W, dtype=torch.bfloat16, device=DEV) for n in (Nq, Nk, Nk))
+    delta = torch.empty(B, H, Nq, dtype=torch.float32, device=DEV)
+    L.attn_bwd(a, d_o, (Nq * W, W), delta, dq, dk, dv, (Nq * W, W), (Nk * W, W), (Nk * W, W))
+    D = rnd(B, Nk, W, seed=6)
+    oD = torch.empty_like(o0)
+    L.attn_fwd(L.attn_args(B, H, Nq, Nk, q, k, D, oD, *st, dropout_p=0.1, dropout_seed=77))
+    lhs = (d_o.float() * oD.float()).sum().item(); rhs = (dv.float() * D.float()).sum().item()
+    print(f"dropout linearity: {lhs:.4f} vs {rhs:.4f}")
+    assert abs(lhs - rhs) < 2e-2 * (abs(lhs) + abs(rhs) + 1.0)
+
+
+def test_bias_diag_roundtrip():
+    H, n, nb = 12, 1999, 32
+    table = rnd(nb, H, seed=1, dtype=torch.float32)
+    lut = (torch.arange(n, device=DEV) % nb).to(torch.int32)
+    diag = torch.empty(H, n, dtype=torch.float32, device=DEV)
+    L.bias_diag_fwd(table, lut, diag, H, n, nb)
+    assert torch.equal(diag, table[lut.long()].T.contiguous())
+    dd = rnd(H, n, seed=2, dtype=torch.float32)
+    dt = torch.zeros(nb, H, dtype=torch.float32, device=DEV)
+    L.bias_bucket_bwd(dd, lut, dt, H, n, nb)
+    ref = torch.zeros(nb, H, device=DEV).index_add_(0, lut.long(), dd.T.contiguous())
+    assert relerr(dt, ref) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- misc
+def test_embedding_and_elementwise():
+    V, d, n = 612, 64, 300
+    table = rnd(V, d, seed=1)
+    ids = torch.randint(0, V, (n,), device=DEV)
+    out = torch.empty(n, d, dtype=torch.bfloat16, device=DEV)
+    L.embed_fwd(ids, table, out, n, d, V)
+    assert torch.equal(out, table[ids])
+    dy = rnd(n, d, seed=2)
+    dt = torch.zeros(V, d, dtype=torch.float32, device=DEV)
+    L.embed_bwd(ids, dy, dt, n, d, V)
+    ref = torch.zeros(V, d, device=DEV).index_add_(0, ids, dy.float())
+    assert relerr(dt, ref) < 1e-5
+    x, pos = rnd(6, 10, 64, seed=3), rnd(10, 64, seed=4)
+    y = torch.empty_like(x)
+    L.add_bcast(x, pos, y, x.numel(), pos.numel())
+    assert relerr(y, x.float() + pos.float()) < 1e-2
+    g = torch.zeros(10, 64, dtype=torch.float32, device=DEV)
+    L.bcast_grad(x, g, x.numel(), pos.numel())
+    assert relerr(g, x.float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("rows,V", [(24, 612), (512, 32200)])
+def test_cross_entropy(rows, V):
+    logits = rnd(rows, V, seed=1, scale=3, dtype=torch.float32)
+    labels = torch.randint(0, V, (rows,), device=DEV)
+    labels[::5] = -100
+    row = torch.empty(rows, 2, dtype=torch.float32, device=DEV)
+    ls = torch.zeros(1, dtype=torch.float32, device=DEV); cnt = torch.zeros(1, dtype=torch.float32, device=DEV)
+    L.ce_fwd(logits, V, labels, rows, V, 0.1, row, ls, cnt)
+    lf = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lf, labels, ignore_index=-100, label_smoothing=0.1)
+    got = (ls / cnt).item()
+    print(f"CE {rows}x{V}: {got:.6f} vs {ref.item():.6f}")
+    assert abs(got - ref.item()) < 2e-5 * abs(ref.item())      # fp32 both sides
+    ref.backward()
+    gs = (1.0 / cnt).contiguous()
+    ldd = (V + 7) // 8 * 8
+    dl = torch.full((rows, ldd), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L.ce_bwd(logits, V, labels, row, rows, V, 0.1, gs, dl, ldd)
+    assert relerr(dl[:, :V], lf.grad) < 1e-2 and cos(dl[:, :V], lf.grad) > 0.9999
+    assert (dl[:, V:] == 0).all()
+
+
+def test_optimizer_kernels():
+    n = 100003 * 4
+    p = rnd(n, seed=1, dtype=torch.float32); g = rnd(n, seed=2, dtype=torch.float32, scale=0.01)
+    m = torch.zeros_like(p); v = torch.zeros_like(p); pb = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(1024, dtype=torch.float32, device=DEV); sq = torch.zeros(1, dtype=torch.float32, device=DEV)
+    L.sqnorm(g, n, ws, sq)
+    assert abs(sq.item() - (g.double() ** 2).sum().item()) < 1e-5 * sq.item()
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=3e-4)
+    for step in (1, 2):
+        pr.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 0.1)
+        opt.step()
+        sq.zero_(); L.sqnorm(g, n, ws, sq)
+        L.adam_step(p, m, v, g, pb, n, 3e-4, 0.9, 0.999, 1e-8, 0.0, step, gnorm_sq=sq, max_norm=0.1)
+    assert (p - pr.detach()).abs().max().item() < 1e-6        # <= 2 ulp of fp32 at |p| ~ 4
+    assert torch.equal(pb, p.to(torch.bfloat16))
+    # time-token renorm (dvc.py:118-126)
+    V, d, nb = 612, 64, 100
+    emb = rnd(V, d, seed=3, dtype=torch.float32); embb = torch.empty(V, d, dtype=torch.bfloat16, device=DEV)
+    ref = emb.clone()
+    ref[-nb:] /= (ref[-nb:].norm(dim=1).mean() / ref[:-nb].norm(dim=1).mean())
+    wsr = torch.empty(V + 2, dtype=torch.float32, device=DEV)
+    L.cast_bf16(emb, embb, V * d)
+    L.timetoken_renorm(emb, embb, V, d, nb, wsr)
+    assert relerr(emb, ref) < 1e-6 and torch.equal(embb, emb.to(torch.bfloat16))
+
+
+def test_decode_kernels():
+    B, H, Nk = 3, 4, 333
+    W = H * 64
+    q = rnd(B, W, seed=1, scale=0.5); kc = rnd(B, 400, W, seed=2, scale=0.5); vc = rnd(B, 400, W, seed=3)
+    bias = rnd(H, Nk, seed=4, dtype=torch.float32)
+    mask = (torch.arange(Nk, device=DEV)[None, :] < torch.tensor([333, 200, 5], device=DEV)[:, None])
+    o = torch.empty(B, W, dtype=torch.bfloat16, device=DEV)
+    L.decode_attn(B, H, Nk, q, W, kc, vc, 400 * W, W, o, W, bias_row=bias, key_mask=mask.to(torch.uint8).contiguous(), mask_ld=Nk)
+    s = torch.einsum("bhd,bkhd->bhk", q.float().view(B, H, 64), kc[:, :Nk].float().view(B, Nk, H, 64)) + bias[None]
+    s = s + (~mask)[:, None, :].float() * torch.finfo(torch.float32).min
+    ref = torch.einsum("bhk,bkhd->bhd", torch.softmax(s, -1), vc[:, :Nk].float().view(B, Nk, H, 64)).reshape(B, W)
+    assert relerr(o, ref) < 1e-2
+    logits = rnd(B, 32200, seed=5, dtype=torch.float32)
+    nxt = torch.empty(B, dtype=torch.int64, device=DEV); unf = torch.tensor([1, 0, 1], dtype=torch.int32, device=DEV)
+    logits[2, 1] = 100.0                                          # row 2 emits EOS
+    L.argmax_step(logits, 32200, B, 32200, nxt, unf, 1, 0)
+    assert nxt.tolist() == [logits[0].argmax().item(), 0, 1] and unf.tolist() == [1, 0, 0]
+    src = rnd(B, W, seed=6)
+    L.kv_append(src, W, kc, 400 * W, W, B, W, 399)
+    assert torch.equal(kc[:, 399], src)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libvid2seq_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [-j N]
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+SRCS="v2s_api v2s_gemm v2s_norm v2s_attn v2s_misc v2s_optim v2s_decode"
+mkdir -p build
+pids=()
+for s in $SRCS; do
+  if [ ! -f build/$s.o ] || [ $s.hip -nt build/$s.o ] || [ v2s_common.h -nt build/$s.o ] || [ ../../include/vid2seq_hip.h -nt build/$s.o ]; then
+    ( $HIPCC $FLAGS -c $s.hip -o build/$s.o ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+OBJS=""; for s in $SRCS; do OBJS="$OBJS build/$s.o"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libvid2seq_hip.so $OBJS
+echo "built $(realpath ../libvid2seq_hip.so)"

@@ -1,0 +1,32 @@
+// Library plumbing: version, thread-local error text, runtime options.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <atomic>
+#include "v2s_common.h"
+
+static thread_local char g_err[512] = "";
+static std::atomic<int> g_tr_read{1};
+
+void v2s_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int v2s_opt_tr_read() { return g_tr_read.load(std::memory_order_relaxed); }
+
+extern "C" int v2s_version(void) { return V2S_ABI_VERSION; }
+extern "C" const char* v2s_last_error(void) { return g_err; }
+
+extern "C" int v2s_set_option(const char* name, int value) {
+  if (name && strcmp(name, "tr_read") == 0) { g_tr_read.store(value ? 1 : 0); return V2S_OK; }
+  v2s_set_error("v2s_set_option: unknown option '%s'", name ? name : "(null)");
+  return V2S_ERR_ARG;
+}
+extern "C" int v2s_get_option(const char* name) {
+  if (name && strcmp(name, "tr_read") == 0) return g_tr_read.load();
+  v2s_set_error("v2s_get_option: unknown option '%s'", name ? name : "(null)");
+  return V2S_ERR_ARG;
+}

@@ -1,0 +1,754 @@
+// Fused (flash-style) attention for gfx950: forward, dQ and dK/dV kernels, head_dim = 64, bf16 I/O,
+// fp32 softmax statistics, scores never written to HBM.
+//
+// Replaces model/vit.py:47-51 and model/modeling_t5.py:539-580 (incl. compute_bias :445-460 and the
+// additive masks built at :996,1005,559) plus their autograd.
+//
+// Layout idea (all three kernels): the score tile is computed TRANSPOSED with respect to the operand that a
+// wave owns, so that (a) the softmax statistics of a row live in one lane (+2 xor-shuffles), and (b) the
+// accumulator registers of the first GEMM are *already* the MFMA operand registers of the second GEMM:
+// the contraction index is simply enumerated in the order (16*(j>>2) + 4*(lane>>4) + (j&3)), which the
+// other operand reproduces with two ds_read_b64_tr_b16 transpose reads from a row-major LDS tile.
+// One LDS image (32-byte column chunks XOR-swizzled by (row>>1)&3) serves both the ds_read_b128 row
+// fragments and the transpose reads without bank conflicts.
+#include <math.h>
+#include "v2s_common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float MASKED2 = -3.0e38f;  // finite stand-in for finfo(float32).min in the log2 domain
+constexpr int HD = 64;
+
+struct AttnP {
+  int B, H, Nq, Nk;
+  const bf16_t *q, *k, *v;
+  long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs;
+  bf16_t* o; long o_bs, o_rs;
+  float* ml;
+  float scale;
+  const float* bias_diag;
+  const uint8_t* key_mask;
+  int causal, causal_off;
+  uint32_t p16; float inv_keep; uint32_t seed;
+  const bf16_t* d_o; long do_bs, do_rs;
+  const float* delta;
+  bf16_t *dq, *dk, *dv;
+  long dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+  float* dbias_diag;
+};
+
+// byte offset of element (row, d) inside a [rows][64] bf16 LDS tile
+__device__ __forceinline__ int tile_off(int row, int d) {
+  return row * 128 + ((((d >> 4) ^ ((row >> 1) & 3))) << 5) + ((d & 15) << 1);
+}
+
+// row fragment (A or B operand with the contraction over d): lane -> row (lane&15), d = ks*32+(lane>>4)*8+j
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int rowbase, int ks, int lane) {
+  const int row = rowbase + (lane & 15);
+  const int d = ks * 32 + (lane >> 4) * 8;
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tile + tile_off(row, d)));
+}
+
+// transposed fragment: lane -> column d = dbase+(lane&15); contraction rows enumerated as
+// slot j of lane group g=(lane>>4):  row = rbase + 16*(j>>2) + 4*g + (j&3)
+template <bool TR>
+__device__ __forceinline__ bf16x8 col_frag(const char* tile, int rbase, int dbase, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  if (TR) {
+    const int r0 = rbase + 4 * g + (i >> 2);
+    const int d = dbase + (i & 3) * 4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((V2S_LDS s16x4*)(tile + tile_off(r0, d)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((V2S_LDS s16x4*)(tile + tile_off(r0 + 16, d)));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  } else {
+    s16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = rbase + 16 * (j >> 2) + 4 * g + (j & 3);
+      v[j] = *reinterpret_cast<const short*>(tile + tile_off(r, dbase + i));
+    }
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+// cooperative 64x64 tile load: thread -> (row = tid>>3 (+32), 16-byte chunk = tid&7)
+__device__ __forceinline__ void tile_load(const bf16_t* base, long rs, int row0, int nrows, int tid, uint4 (&r)[2]) {
+  const int chunk = tid & 7, rr = tid >> 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = row0 + rr + i * 32;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < nrows) v = *reinterpret_cast<const uint4*>(base + (long)row * rs + chunk * 8);
+    r[i] = v;
+  }
+}
+__device__ __forceinline__ void tile_store(char* tile, int tid, const uint4 (&r)[2]) {
+  const int chunk = tid & 7, rr = tid >> 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(tile + tile_off(rr + i * 32, chunk * 8)) = r[i];
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
+  bf16x8 f;
+  f[0] = (__bf16)a[0]; f[1] = (__bf16)a[1]; f[2] = (__bf16)a[2]; f[3] = (__bf16)a[3];
+  f[4] = (__bf16)b[0]; f[5] = (__bf16)b[1]; f[6] = (__bf16)b[2]; f[7] = (__bf16)b[3];
+  return f;
+}
+
+constexpr int KV_TILE = 8192;                   // one [64][64] bf16 tile
+constexpr int STAGE = 2 * KV_TILE + 192 * 4 + 64 + 64 * 16;  // K,V (or Q,dO) + bias window + flags + (m,l,delta,pad)
+
+// ====================================================================================== forward
+// block = 4 waves x 32 query rows; loop over 64-key tiles.
+template <bool TR>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nqb = (p.Nq + 127) >> 7;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int qblk = id % nqb, bh = id / nqb, h = bh % p.H, b = bh / p.H;
+  const int Q0 = qblk * 128, wq0 = wave * 32;
+
+  const bf16_t* qp = p.q + (long)b * p.q_bs + h * HD;
+  const bf16_t* kp = p.k + (long)b * p.k_bs + h * HD;
+  const bf16_t* vp = p.v + (long)b * p.v_bs + h * HD;
+
+  bf16x8 qf[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int q = Q0 + wq0 + qb * 16 + li;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < p.Nq) v = *reinterpret_cast<const uint4*>(qp + (long)q * p.q_rs + ks * 32 + g * 8);
+      qf[qb][ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+  f32x4 ot[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int db = 0; db < 4; ++db) ot[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (p.Nk + 63) >> 6;
+  const float sc2 = p.scale * LOG2E;
+  uint4 rk[2], rv[2];
+  float rbias = 0.f;
+  uint8_t rflag = 0;
+
+  auto prefetch = [&](int t) {
+    const int k0 = t * 64;
+    tile_load(kp, p.k_rs, k0, p.Nk, tid, rk);
+    tile_load(vp, p.v_rs, k0, p.Nk, tid, rv);
+    if (p.bias_diag && tid < 192) {
+      const int idx = k0 - Q0 - 127 + tid + p.Nq - 1;
+      rbias = (idx >= 0 && idx < p.Nq + p.Nk - 1) ? p.bias_diag[(long)h * (p.Nq + p.Nk - 1) + idx] * LOG2E : 0.f;
+    }
+    if (tid < 64) {
+      const int k = k0 + tid;
+      rflag = (k >= p.Nk) ? 2 : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1 : 0);
+    }
+  };
+  auto commit = [&](int s) {
+    char* st = smem + s * STAGE;
+    tile_store(st, tid, rk);
+    tile_store(st + KV_TILE, tid, rv);
+    if (tid < 192) reinterpret_cast<float*>(st + 2 * KV_TILE)[tid] = rbias;
+    if (tid < 64) reinterpret_cast<uint8_t*>(st + 2 * KV_TILE + 768)[tid] = rflag;
+  };
+
+  prefetch(0);
+  commit(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const char* sK = smem + (t & 1) * STAGE;
+    const char* sV = sK + KV_TILE;
+    const float* bw = reinterpret_cast<const float*>(sK + 2 * KV_TILE);
+    const uint8_t* fl = reinterpret_cast<const uint8_t*>(sK + 2 * KV_TILE + 768);
+    const int k0 = t * 64;
+    if (t + 1 < ntiles) prefetch(t + 1);
+
+    f32x4 st[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) st[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 kf = row_frag(sK, kb * 16, ks, lane);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], st[qb][kb], 0, 0, 0);
+      }
+
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qq = wq0 + qb * 16 + li, q = Q0 + qq;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const uint32_t f4 = *reinterpret_cast<const uint32_t*>(fl + kb * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = kb * 16 + 4 * g + r;
+          float s = st[qb][kb][r] * sc2;
+          if (p.bias_diag) s += bw[kk + 127 - qq];
+          uint32_t f = (f4 >> (8 * r)) & 0xffu;
+          if (p.causal && (k0 + kk) > q + p.causal_off) f |= 1u;
+          s = (f & 2u) ? -INFINITY : ((f & 1u) ? MASKED2 : s);
+          st[qb][kb][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m[qb], mx);
+      const float alpha = exp2f(m[qb] - mn);
+      m[qb] = mn;
+      float rs = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pv = exp2f(st[qb][kb][r] - mn);
+          rs += pv;
+          if (p.p16) {
+            const unsigned long long e = (((unsigned long long)(b * p.H + h) * p.Nq + q) * p.Nk) + (k0 + kb * 16 + 4 * g + r);
+            pv = v2s_keep(e, p.seed, p.p16) ? pv * p.inv_keep : 0.f;
+          }
+          st[qb][kb][r] = pv;
+        }
+      lsum[qb] = lsum[qb] * alpha + rs;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) ot[qb][db] *= alpha;
+      pf[qb][0] = pack_frag(st[qb][0], st[qb][1]);
+      pf[qb][1] = pack_frag(st[qb][2], st[qb][3]);
+    }
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 vf = col_frag<TR>(sV, kh * 32, db * 16, lane);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) ot[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][kh], ot[qb][db], 0, 0, 0);
+      }
+    if (t + 1 < ntiles) commit((t + 1) & 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int q = Q0 + wq0 + qb * 16 + li;
+    float l = lsum[qb];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (q < p.Nq) {
+      const float inv = 1.0f / l;
+      bf16_t* op = p.o + (long)b * p.o_bs + (long)q * p.o_rs + h * HD;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        uint2 w;
+        w.x = pack2bf(ot[qb][db][0] * inv, ot[qb][db][1] * inv);
+        w.y = pack2bf(ot[qb][db][2] * inv, ot[qb][db][3] * inv);
+        *reinterpret_cast<uint2*>(op + db * 16 + 4 * g) = w;
+      }
+      if (g == 0 && p.ml) {
+        float* mp = p.ml + (((long)(b * p.H + h)) * p.Nq + q) * 2;
+        mp[0] = m[qb];
+        mp[1] = l;
+      }
+    }
+  }
+}
+
+// ====================================================================================== delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p, float* __restrict__ delta) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per 8 elements of a (b,q,h) row
+  const long total = (long)p.B * p.Nq * p.H * 8;
+  float s = 0.f;
+  int b = 0, q = 0, h = 0;
+  if (t < total) {
+    const int c = (int)(t & 7);
+    long r = t >> 3;
+    h = (int)(r % p.H); r /= p.H;
+    q = (int)(r % p.Nq); b = (int)(r / p.Nq);
+    float a[8], d[8];
+    unpack8(*reinterpret_cast<const uint4*>(p.o + (long)b * p.o_bs + (long)q * p.o_rs + h * HD + c * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(p.d_o + (long)b * p.do_bs + (long)q * p.do_rs + h * HD + c * 8), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += a[j] * d[j];
+  }
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  if (t < total && (t & 7) == 0) delta[((long)(b * p.H + h)) * p.Nq + q] = s;
+}
+
+// ====================================================================================== backward: dQ (+ dbias)
+// same decomposition as the forward: wave = 32 query rows, loop over key tiles.
+template <bool TR>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2*STAGE + (Nk+128)*4 (dbias window) bytes
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nqb = (p.Nq + 127) >> 7;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int qblk = id % nqb, bh = id / nqb, h = bh % p.H, b = bh / p.H;
+  const int Q0 = qblk * 128, wq0 = wave * 32;
+  float* dbw = reinterpret_cast<float*>(smem + 2 * STAGE);   // index: (k - q) + (Q0 + 127)  in [0, Nk+127)
+  const int ndb = p.Nk + 127;
+  if (p.dbias_diag) {
+    for (int i = tid; i < ndb; i += 256) dbw[i] = 0.f;
+  }
+
+  const bf16_t* qp = p.q + (long)b * p.q_bs + h * HD;
+  const bf16_t* dop = p.d_o + (long)b * p.do_bs + h * HD;
+  const bf16_t* kp = p.k + (long)b * p.k_bs + h * HD;
+  const bf16_t* vp = p.v + (long)b * p.v_bs + h * HD;
+
+  bf16x8 qf[2][2], dof[2][2];
+  float m2[2], linv[2], dl[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int q = Q0 + wq0 + qb * 16 + li;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+      if (q < p.Nq) {
+        v = *reinterpret_cast<const uint4*>(qp + (long)q * p.q_rs + ks * 32 + g * 8);
+        w = *reinterpret_cast<const uint4*>(dop + (long)q * p.do_rs + ks * 32 + g * 8);
+      }
+      qf[qb][ks] = __builtin_bit_cast(bf16x8, v);
+      dof[qb][ks] = __builtin_bit_cast(bf16x8, w);
+    }
+    m2[qb] = 0.f; linv[qb] = 1.f; dl[qb] = 0.f;
+    if (q < p.Nq) {
+      const long r = ((long)(b * p.H + h)) * p.Nq + q;
+      m2[qb] = p.ml[r * 2];
+      linv[qb] = 1.0f / p.ml[r * 2 + 1];
+      dl[qb] = p.delta[r];
+    }
+  }
+  f32x4 dqt[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dqt[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (p.Nk + 63) >> 6;
+  const float sc2 = p.scale * LOG2E;
+  uint4 rk[2], rv[2];
+  float rbias = 0.f;
+  uint8_t rflag = 0;
+  auto prefetch = [&](int t) {
+    const int k0 = t * 64;
+    tile_load(kp, p.k_rs, k0, p.Nk, tid, rk);
+    tile_load(vp, p.v_rs, k0, p.Nk, tid, rv);
+    if (p.bias_diag && tid < 192) {
+      const int idx = k0 - Q0 - 127 + tid + p.Nq - 1;
+      rbias = (idx >= 0 && idx < p.Nq + p.Nk - 1) ? p.bias_diag[(long)h * (p.Nq + p.Nk - 1) + idx] * LOG2E : 0.f;
+    }
+    if (tid < 64) {
+      const int k = k0 + tid;
+      rflag = (k >= p.Nk) ? 2 : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1 : 0);
+    }
+  };
+  auto commit = [&](int s) {
+    char* st = smem + s * STAGE;
+    tile_store(st, tid, rk);
+    tile_store(st + KV_TILE, tid, rv);
+    if (tid < 192) reinterpret_cast<float*>(st + 2 * KV_TILE)[tid] = rbias;
+    if (tid < 64) reinterpret_cast<uint8_t*>(st + 2 * KV_TILE + 768)[tid] = rflag;
+  };
+  prefetch(0);
+  commit(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const char* sK = smem + (t & 1) * STAGE;
+    const char* sV = sK + KV_TILE;
+    const float* bw = reinterpret_cast<const float*>(sK + 2 * KV_TILE);
+    const uint8_t* fl = reinterpret_cast<const uint8_t*>(sK + 2 * KV_TILE + 768);
+    const int k0 = t * 64;
+    if (t + 1 < ntiles) prefetch(t + 1);
+
+    f32x4 st[2][4], dp[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) { st[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 kf = row_frag(sK, kb * 16, ks, lane);
+        const bf16x8 vf = row_frag(sV, kb * 16, ks, lane);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], st[qb][kb], 0, 0, 0);
+          dp[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qb][ks], dp[qb][kb], 0, 0, 0);
+        }
+      }
+    bf16x8 dsf[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qq = wq0 + qb * 16 + li, q = Q0 + qq;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const uint32_t f4 = *reinterpret_cast<const uint32_t*>(fl + kb * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = kb * 16 + 4 * g + r;
+          float s = st[qb][kb][r] * sc2;
+          if (p.bias_diag) s += bw[kk + 127 - qq];
+          uint32_t f = (f4 >> (8 * r)) & 0xffu;
+          if (p.causal && (k0 + kk) > q + p.causal_off) f |= 1u;
+          s = (f & 2u) ? -INFINITY : ((f & 1u) ? MASKED2 : s);
+          const float pr = exp2f(s - m2[qb]) * linv[qb];
+          float dpv = dp[qb][kb][r];
+          if (p.p16) {
+            const unsigned long long e = (((unsigned long long)(b * p.H + h) * p.Nq + q) * p.Nk) + (k0 + kk);
+            dpv = v2s_keep(e, p.seed, p.p16) ? dpv * p.inv_keep : 0.f;
+          }
+          const float ds = (q < p.Nq) ? pr * (dpv - dl[qb]) : 0.f;
+          st[qb][kb][r] = ds;
+          if (p.dbias_diag && ds != 0.f) atomicAdd(&dbw[(k0 + kk) + 127 - qq], ds);
+        }
+      }
+      dsf[qb][0] = pack_frag(st[qb][0], st[qb][1]);
+      dsf[qb][1] = pack_frag(st[qb][2], st[qb][3]);
+    }
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 ktf = col_frag<TR>(sK, kh * 32, db * 16, lane);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) dqt[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qb][kh], dqt[qb][db], 0, 0, 0);
+      }
+    if (t + 1 < ntiles) commit((t + 1) & 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int q = Q0 + wq0 + qb * 16 + li;
+    if (q < p.Nq) {
+      bf16_t* op = p.dq + (long)b * p.dq_bs + (long)q * p.dq_rs + h * HD;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        uint2 w;
+        w.x = pack2bf(dqt[qb][db][0] * p.scale, dqt[qb][db][1] * p.scale);
+        w.y = pack2bf(dqt[qb][db][2] * p.scale, dqt[qb][db][3] * p.scale);
+        *reinterpret_cast<uint2*>(op + db * 16 + 4 * g) = w;
+      }
+    }
+  }
+  if (p.dbias_diag) {
+    // dbw index i <-> (k - q) = i - (Q0 + 127);  global index = (k - q) + Nq - 1
+    float* dst = p.dbias_diag + (long)h * (p.Nq + p.Nk - 1);
+    for (int i = tid; i < ndb; i += 256) {
+      const int gi = i - (Q0 + 127) + p.Nq - 1;
+      const float v = dbw[i];
+      if (gi >= 0 && gi < p.Nq + p.Nk - 1 && v != 0.f) atomicAdd(dst + gi, v);
+    }
+  }
+}
+
+// ====================================================================================== backward: dK, dV
+// wave = 32 keys (2 key blocks), block = 128 keys, loop over 64-query tiles (Q and dO tiles in LDS).
+template <bool TR>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nkb = (p.Nk + 127) >> 7;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int kblk = id % nkb, bh = id / nkb, h = bh % p.H, b = bh / p.H;
+  const int K0 = kblk * 128, wk0 = wave * 32;
+
+  const bf16_t* qp = p.q + (long)b * p.q_bs + h * HD;
+  const bf16_t* dop = p.d_o + (long)b * p.do_bs + h * HD;
+  const bf16_t* kp = p.k + (long)b * p.k_bs + h * HD;
+  const bf16_t* vp = p.v + (long)b * p.v_bs + h * HD;
+
+  bf16x8 kf[2][2], vf[2][2];
+  uint32_t kflag[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int k = K0 + wk0 + kb * 16 + li;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 a = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
+      if (k < p.Nk) {
+        a = *reinterpret_cast<const uint4*>(kp + (long)k * p.k_rs + ks * 32 + g * 8);
+        c = *reinterpret_cast<const uint4*>(vp + (long)k * p.v_rs + ks * 32 + g * 8);
+      }
+      kf[kb][ks] = __builtin_bit_cast(bf16x8, a);
+      vf[kb][ks] = __builtin_bit_cast(bf16x8, c);
+    }
+    kflag[kb] = (k >= p.Nk) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
+  }
+  f32x4 dkt[2][4], dvt[2][4];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { dkt[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int ntiles = (p.Nq + 63) >> 6;
+  const float sc2 = p.scale * LOG2E;
+  uint4 rq[2], rdo[2];
+  float rbias = 0.f;
+  float rm = 0.f, rl = 1.f, rd = 0.f;
+  // bias window for this (128-key block, 64-query tile): index (k - q) - dmin, dmin = K0 - (q0 + 63); 191 entries
+  auto prefetch = [&](int t) {
+    const int q0 = t * 64;
+    tile_load(qp, p.q_rs, q0, p.Nq, tid, rq);
+    tile_load(dop, p.do_rs, q0, p.Nq, tid, rdo);
+    if (p.bias_diag && tid < 192) {
+      const int idx = K0 - q0 - 63 + tid + p.Nq - 1;
+      rbias = (idx >= 0 && idx < p.Nq + p.Nk - 1) ? p.bias_diag[(long)h * (p.Nq + p.Nk - 1) + idx] * LOG2E : 0.f;
+    }
+    if (tid < 64) {
+      const int q = q0 + tid;
+      rm = 0.f; rl = 1.f; rd = 0.f;
+      if (q < p.Nq) {
+        const long r = ((long)(b * p.H + h)) * p.Nq + q;
+        rm = p.ml[r * 2]; rl = 1.0f / p.ml[r * 2 + 1]; rd = p.delta[r];
+      }
+    }
+  };
+  auto commit = [&](int s) {
+    char* st = smem + s * STAGE;
+    tile_store(st, tid, rq);
+    tile_store(st + KV_TILE, tid, rdo);
+    if (tid < 192) reinterpret_cast<float*>(st + 2 * KV_TILE)[tid] = rbias;
+    if (tid < 64) {
+      float* ms = reinterpret_cast<float*>(st + 2 * KV_TILE + 768 + 64);
+      ms[tid] = rm; ms[64 + tid] = rl; ms[128 + tid] = rd;
+    }
+  };
+  prefetch(0);
+  commit(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const char* sQ = smem + (t & 1) * STAGE;
+    const char* sDO = sQ + KV_TILE;
+    const float* bw = reinterpret_cast<const float*>(sQ + 2 * KV_TILE);
+    const float* ms = reinterpret_cast<const float*>(sQ + 2 * KV_TILE + 768 + 64);
+    const int q0 = t * 64;
+    if (t + 1 < ntiles) prefetch(t + 1);
+
+    // two halves of 32 query rows each (keeps the live score registers at 2x2 fragments)
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+      // S[q][key] and dP[q][key]:  D[row = q = qb*16 + 4g + r][col = key = kb*16 + li]
+      f32x4 st[2][2], dp[2][2];
+#pragma unroll
+      for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { st[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+          const bf16x8 qfr = row_frag(sQ, (2 * qh + qi) * 16, ks, lane);
+          const bf16x8 dfr = row_frag(sDO, (2 * qh + qi) * 16, ks, lane);
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            st[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kb][ks], st[qi][kb], 0, 0, 0);
+            dp[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[kb][ks], dp[qi][kb], 0, 0, 0);
+          }
+        }
+      // P (dropped) -> dp registers become Pd ; st registers become dS
+#pragma unroll
+      for (int qi = 0; qi < 2; ++qi) {
+        const int qb = 2 * qh + qi;
+        const float4 mv = *reinterpret_cast<const float4*>(ms + qb * 16 + 4 * g);
+        const float4 lv = *reinterpret_cast<const float4*>(ms + 64 + qb * 16 + 4 * g);
+        const float4 dv4 = *reinterpret_cast<const float4*>(ms + 128 + qb * 16 + 4 * g);
+        const float mr[4] = {mv.x, mv.y, mv.z, mv.w}, lr[4] = {lv.x, lv.y, lv.z, lv.w}, dr[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int kk = wk0 + kb * 16 + li, k = K0 + kk;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qq = qb * 16 + 4 * g + r, q = q0 + qq;
+            float s = st[qi][kb][r] * sc2;
+            if (p.bias_diag) s += bw[kk + 63 - qq];
+            uint32_t f = kflag[kb];
+            if (p.causal && k > q + p.causal_off) f |= 1u;
+            s = (f & 2u) ? -INFINITY : ((f & 1u) ? MASKED2 : s);
+            const float pr = (q < p.Nq) ? exp2f(s - mr[r]) * lr[r] : 0.f;
+            float dpv = dp[qi][kb][r];
+            float pd = pr;
+            if (p.p16) {
+              const unsigned long long e = (((unsigned long long)(b * p.H + h) * p.Nq + q) * p.Nk) + k;
+              const bool keep = v2s_keep(e, p.seed, p.p16);
+              dpv = keep ? dpv * p.inv_keep : 0.f;
+              pd = keep ? pr * p.inv_keep : 0.f;
+            }
+            st[qi][kb][r] = pr * (dpv - dr[r]);
+            dp[qi][kb][r] = pd;
+          }
+        }
+      }
+      // dV^T[d][key] += dO^T[d][q] * Pd[q][key] ; dK^T[d][key] += Q^T[d][q] * dS[q][key]
+      bf16x8 pdf[2], dsf[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        pdf[kb] = pack_frag(dp[0][kb], dp[1][kb]);
+        dsf[kb] = pack_frag(st[0][kb], st[1][kb]);
+      }
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 dot = col_frag<TR>(sDO, qh * 32, db * 16, lane);
+        const bf16x8 qt = col_frag<TR>(sQ, qh * 32, db * 16, lane);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          dvt[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pdf[kb], dvt[kb][db], 0, 0, 0);
+          dkt[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb], dkt[kb][db], 0, 0, 0);
+        }
+      }
+    }
+    if (t + 1 < ntiles) commit((t + 1) & 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int k = K0 + wk0 + kb * 16 + li;
+    if (k < p.Nk) {
+      bf16_t* dkp = p.dk + (long)b * p.dk_bs + (long)k * p.dk_rs + h * HD;
+      bf16_t* dvp = p.dv + (long)b * p.dv_bs + (long)k * p.dv_rs + h * HD;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        uint2 w;
+        w.x = pack2bf(dkt[kb][db][0] * p.scale, dkt[kb][db][1] * p.scale);
+        w.y = pack2bf(dkt[kb][db][2] * p.scale, dkt[kb][db][3] * p.scale);
+        *reinterpret_cast<uint2*>(dkp + db * 16 + 4 * g) = w;
+        uint2 u;
+        u.x = pack2bf(dvt[kb][db][0], dvt[kb][db][1]);
+        u.y = pack2bf(dvt[kb][db][2], dvt[kb][db][3]);
+        *reinterpret_cast<uint2*>(dvp + db * 16 + 4 * g) = u;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- bias table <-> diagonal
+__global__ void bias_diag_fwd_kernel(const float* __restrict__ table, const int* __restrict__ lut, float* __restrict__ out,
+                                     int H, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * H) return;
+  const int h = i / n, d = i - h * n;
+  out[i] = table[lut[d] * H + h];
+}
+// one block per (bucket, head): deterministic reduction over the diagonals mapping to that bucket
+__global__ __launch_bounds__(256) void bias_bucket_bwd_kernel(const float* __restrict__ dd, const int* __restrict__ lut,
+                                                              float* __restrict__ dtable, int H, int n) {
+  __shared__ float red[256];
+  const int bucket = blockIdx.x, h = blockIdx.y;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256)
+    if (lut[i] == bucket) s += dd[(long)h * n + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dtable[bucket * H + h] += red[0];
+}
+
+int fill(AttnP& p, const v2s_attn_args* a, const char* who, bool bwd) {
+  V2S_CHECK(a != nullptr, V2S_ERR_ARG, "%s: null args", who);
+  V2S_CHECK(a->B > 0 && a->H > 0 && a->Nq > 0 && a->Nk > 0, V2S_ERR_SHAPE, "%s: bad shape B=%d H=%d Nq=%d Nk=%d", who, a->B, a->H, a->Nq, a->Nk);
+  V2S_CHECK(((a->q_rs | a->k_rs | a->v_rs | a->o_rs | a->q_bs | a->k_bs | a->v_bs | a->o_bs) % 8) == 0, V2S_ERR_ALIGN, "%s: strides must be multiples of 8 elements", who);
+  V2S_CHECK((((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->o) & 15) == 0, V2S_ERR_ALIGN, "%s: pointers must be 16-byte aligned", who);
+  V2S_CHECK(a->dropout_p >= 0.f && a->dropout_p < 1.f, V2S_ERR_ARG, "%s: dropout_p out of range", who);
+  p.B = a->B; p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk;
+  p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v;
+  p.q_bs = a->q_bs; p.q_rs = a->q_rs; p.k_bs = a->k_bs; p.k_rs = a->k_rs; p.v_bs = a->v_bs; p.v_rs = a->v_rs;
+  p.o = (bf16_t*)a->o; p.o_bs = a->o_bs; p.o_rs = a->o_rs;
+  p.ml = a->ml; p.scale = a->scale; p.bias_diag = a->bias_diag; p.key_mask = a->key_mask;
+  p.causal = a->causal; p.causal_off = a->causal_off;
+  p.p16 = (uint32_t)(a->dropout_p * 65536.0f + 0.5f);
+  p.inv_keep = p.p16 ? 1.0f / (1.0f - (float)p.p16 / 65536.0f) : 1.0f;
+  p.seed = a->dropout_seed;
+  p.d_o = (const bf16_t*)a->d_o; p.do_bs = a->do_bs; p.do_rs = a->do_rs; p.delta = a->delta;
+  p.dq = (bf16_t*)a->dq; p.dk = (bf16_t*)a->dk; p.dv = (bf16_t*)a->dv;
+  p.dq_bs = a->dq_bs; p.dq_rs = a->dq_rs; p.dk_bs = a->dk_bs; p.dk_rs = a->dk_rs; p.dv_bs = a->dv_bs; p.dv_rs = a->dv_rs;
+  p.dbias_diag = a->dbias_diag;
+  if (bwd) {
+    V2S_CHECK(a->d_o && a->ml && a->dq && a->dk && a->dv, V2S_ERR_ARG, "%s: backward needs d_o, ml, dq, dk, dv", who);
+    V2S_CHECK(((a->do_rs | a->do_bs | a->dq_rs | a->dk_rs | a->dv_rs | a->dq_bs | a->dk_bs | a->dv_bs) % 8) == 0, V2S_ERR_ALIGN, "%s: grad strides must be multiples of 8", who);
+  }
+  return V2S_OK;
+}
+
+}  // namespace
+
+extern "C" int v2s_attn_fwd(const v2s_attn_args* a, void* stream) {
+  AttnP p;
+  if (int e = fill(p, a, "v2s_attn_fwd", false)) return e;
+  const int grid = ((p.Nq + 127) / 128) * p.H * p.B;
+  if (v2s_opt_tr_read()) hipLaunchKernelGGL((attn_fwd_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_attn_delta(const v2s_attn_args* a, float* delta, void* stream) {
+  AttnP p;
+  if (int e = fill(p, a, "v2s_attn_delta", false)) return e;
+  V2S_CHECK(a->d_o && delta, V2S_ERR_ARG, "v2s_attn_delta: needs d_o and delta");
+  const long total = (long)p.B * p.Nq * p.H * 8;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, delta);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_attn_bwd(const v2s_attn_args* a, void* stream) {
+  AttnP p;
+  if (int e = fill(p, a, "v2s_attn_bwd", true)) return e;
+  V2S_CHECK(a->delta != nullptr, V2S_ERR_ARG, "v2s_attn_bwd: delta missing (call v2s_attn_delta first)");
+  hipStream_t s = (hipStream_t)stream;
+  const bool tr = v2s_opt_tr_read() != 0;
+  const int gq = ((p.Nq + 127) / 128) * p.H * p.B;
+  const size_t dyn = 2 * (size_t)STAGE + (size_t)(p.Nk + 128) * 4;
+  V2S_CHECK(dyn <= 160 * 1024, V2S_ERR_SHAPE, "v2s_attn_bwd: Nk=%d too large for the LDS dbias window", p.Nk);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (tr) hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), dim3(gq), dim3(256), dyn, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), dim3(gq), dim3(256), dyn, s, p);
+  V2S_LAUNCH_CHECK();
+  const int gk = ((p.Nk + 127) / 128) * p.H * p.B;
+  if (tr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), dim3(gk), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), dim3(gk), dim3(256), 0, s, p);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_bias_diag_fwd(const float* table, const int32_t* lut, float* bias_diag, int32_t H, int32_t n,
+                                 int32_t num_buckets, void* stream) {
+  V2S_CHECK(table && lut && bias_diag && H > 0 && n > 0 && num_buckets > 0, V2S_ERR_ARG, "v2s_bias_diag_fwd: bad args");
+  hipLaunchKernelGGL(bias_diag_fwd_kernel, dim3((n * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, lut, bias_diag, H, n);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_bias_bucket_bwd(const float* dbias_diag, const int32_t* lut, float* dtable, int32_t H, int32_t n,
+                                   int32_t num_buckets, void* stream) {
+  V2S_CHECK(dbias_diag && lut && dtable && H > 0 && n > 0 && num_buckets > 0, V2S_ERR_ARG, "v2s_bias_bucket_bwd: bad args");
+  hipLaunchKernelGGL(bias_bucket_bwd_kernel, dim3(num_buckets, H), dim3(256), 0, (hipStream_t)stream, dbias_diag, lut, dtable, H, n);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}

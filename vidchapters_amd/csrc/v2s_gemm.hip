@@ -1,0 +1,343 @@
+// MFMA bf16 GEMM family for gfx950 (CDNA4): 128x128x64 block tile, 4 waves (2x2), each wave a 64x64
+// sub-tile of 4x4 mfma_f32_16x16x32_bf16 fragments, fp32 accumulation.
+//
+// Replaces every nn.Linear on the Vid2Seq path and its autograd dgrad/wgrad
+// (reference: model/vit.py:41,53,17,20; model/modeling_t5.py:304-311,528-536,581,1714).
+//
+// Data movement: global -> registers (16 B/lane, issued one K-tile ahead) -> LDS (XOR-swizzled so
+// that the ds_read_b128 / ds_read_b64_tr_b16 fragment reads are bank-conflict free) -> MFMA.
+// Operands stored with the contraction index NOT contiguous (dgrad's W, wgrad's dY and X) are kept
+// in their natural [k][row] order in LDS and transposed on the way to the matrix core with the
+// gfx950 LDS transpose read, so no operand is ever re-laid-out in HBM.
+// The epilogue goes through LDS so that bias / activation / activation-derivative / dropout /
+// residual / accumulate all run on 8-wide row-contiguous vectors with 16-byte global accesses.
+#include "v2s_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;  // 32 KiB
+constexpr int A_BYTES = BM * BK * 2;                  // 16 KiB
+
+struct GemmP {
+  int M, N, K;
+  const bf16_t* A; const bf16_t* B;
+  long lda, ldb;
+  void* C; long ldc;
+  int c_f32, accumulate;
+  float alpha;
+  const float* bias;
+  int act;
+  bf16_t* pre;
+  int dact;
+  const bf16_t* z; long ldz;
+  const bf16_t* residual; long ldr;
+  uint32_t p16; float inv_keep; uint32_t seed;
+  int tilesM, tilesN;
+};
+
+// swizzle of the [k][row] (transposed-operand) LDS image: XOR the 32-byte column chunk with bits of k
+__device__ __forceinline__ int tr_g(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+// ---- global -> register staging -------------------------------------------------------------------
+template <bool T>
+__device__ __forceinline__ void load_tile(const bf16_t* __restrict__ base, long ld, int row0, int R, int k0,
+                                          int K, int tid, uint4 (&r)[4]) {
+  if (!T) {  // memory is [row][k]
+    const int chunk = tid & 7, rr = tid >> 3;
+    const int k = k0 + chunk * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + rr + i * 32;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < R && k < K) v = *reinterpret_cast<const uint4*>(base + (long)row * ld + k);
+      r[i] = v;
+    }
+  } else {  // memory is [k][row]
+    const int c16 = tid & 15, kk = tid >> 4;
+    const int row = row0 + c16 * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + kk + i * 16;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (k < K && row < R) v = *reinterpret_cast<const uint4*>(base + (long)k * ld + row);
+      r[i] = v;
+    }
+  }
+}
+
+template <bool T>
+__device__ __forceinline__ void store_tile(char* lds, int tid, const uint4 (&r)[4]) {
+  if (!T) {
+    const int chunk = tid & 7, rr = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rr + i * 32;
+      *reinterpret_cast<uint4*>(lds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = r[i];
+    }
+  } else {
+    const int c16 = tid & 15, kk = tid >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kk + i * 16;
+      *reinterpret_cast<uint4*>(lds + k * 256 + (((c16 >> 1) ^ tr_g(k)) << 5) + ((c16 & 1) << 4)) = r[i];
+    }
+  }
+}
+
+// ---- LDS -> MFMA fragment ------------------------------------------------------------------------------
+// fragment of 16 rows x 32 k: lane l holds row (l&15), k = ks*32 + (l>>4)*8 + j, j=0..7
+template <bool T, bool TR>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowbase, int ks, int lane) {
+  if (!T) {
+    const int row = rowbase + (lane & 15);
+    const int chunk = ks * 4 + (lane >> 4);
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+    return __builtin_bit_cast(bf16x8, v);
+  } else if (TR) {
+    // ds_read_b64_tr_b16: within a 16-lane group, lane i supplies the address of 4 contiguous bf16 of
+    // k-row (i>>2) at columns (i&3)*4.., and receives column i of that 4x16 block (4 consecutive k).
+    const int i = lane & 15;
+    const int k = ks * 32 + (lane >> 4) * 8 + (i >> 2);
+    const int m = rowbase + (i & 3) * 4;
+    const char* p0 = lds + k * 256 + (((m >> 4) ^ tr_g(k)) << 5) + ((m & 15) << 1);
+    const int k1 = k + 4;
+    const char* p1 = lds + k1 * 256 + (((m >> 4) ^ tr_g(k1)) << 5) + ((m & 15) << 1);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((V2S_LDS s16x4*)(p0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((V2S_LDS s16x4*)(p1));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  } else {
+    const int m = rowbase + (lane & 15);
+    s16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = ks * 32 + (lane >> 4) * 8 + j;
+      v[j] = *reinterpret_cast<const short*>(lds + k * 256 + (((m >> 4) ^ tr_g(k)) << 5) + ((m & 15) << 1));
+    }
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <bool TA, bool TB, bool TR>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = p.tilesM * p.tilesN;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tm = id / p.tilesN, tn = id - tm * p.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  const int nk = (p.K + BK - 1) / BK;
+  load_tile<TA>(p.A, p.lda, m0, p.M, 0, p.K, tid, ra);
+  load_tile<TB>(p.B, p.ldb, n0, p.N, 0, p.K, tid, rb);
+  store_tile<TA>(smem, tid, ra);
+  store_tile<TB>(smem + A_BYTES, tid, rb);
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const char* sa = smem + (t & 1) * STAGE_BYTES;
+    const char* sb = sa + A_BYTES;
+    const bool more = (t + 1 < nk);
+    if (more) {
+      load_tile<TA>(p.A, p.lda, m0, p.M, (t + 1) * BK, p.K, tid, ra);
+      load_tile<TB>(p.B, p.ldb, n0, p.N, (t + 1) * BK, p.K, tid, rb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = read_frag<TA, TR>(sa, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB, TR>(sb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      char* da = smem + ((t + 1) & 1) * STAGE_BYTES;
+      store_tile<TA>(da, tid, ra);
+      store_tile<TB>(da + A_BYTES, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---------------- epilogue: accumulators -> LDS (fp32 [128][128]) -> vector post-ops -> global
+  float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        cs[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * BN + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+  __syncthreads();
+
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    const int c = tid + it * NTHREADS;
+    const int row = c >> 4, cc = (c & 15) * 8;
+    const int gm = m0 + row, gn = n0 + cc;
+    if (gm >= p.M || gn >= p.N) continue;
+    float v[8];
+    {
+      const float4 x0 = *reinterpret_cast<const float4*>(cs + row * BN + cc);
+      const float4 x1 = *reinterpret_cast<const float4*>(cs + row * BN + cc + 4);
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+    if (p.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gn);
+      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + gn + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (p.pre) *reinterpret_cast<uint4*>(p.pre + (long)gm * p.ldc + gn) = pack8(v);
+    if (p.act == V2S_ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    } else if (p.act == V2S_ACT_GELU) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+    }
+    if (p.dact != V2S_ACT_NONE) {
+      float zf[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.z + (long)gm * p.ldz + gn), zf);
+      if (p.dact == V2S_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = zf[j] > 0.f ? v[j] : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= dgelu_f(zf[j]);
+      }
+    }
+    if (p.p16) {
+      const unsigned long long e0 = (unsigned long long)gm * (unsigned long long)p.N + gn;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v2s_keep(e0 + j, p.seed, p.p16) ? v[j] * p.inv_keep : 0.f;
+    }
+    if (p.residual) {
+      float rf[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.residual + (long)gm * p.ldr + gn), rf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += rf[j];
+    }
+    if (p.c_f32) {
+      float* cp = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
+      float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+      if (p.accumulate) {
+        const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+        o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w;
+        o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
+      }
+      *reinterpret_cast<float4*>(cp) = o0;
+      *reinterpret_cast<float4*>(cp + 4) = o1;
+    } else {
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
+    }
+  }
+}
+
+// ---- column sums (bias gradients) ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, long ldx, int M, int N,
+                                                     float* __restrict__ out, int rows_per_block) {
+  // block handles 64 columns x rows_per_block rows; thread (c8 = tid&7 -> 8 columns, r = tid>>3)
+  __shared__ float red[32][65];
+  const int tid = threadIdx.x;
+  const int c8 = tid & 7, rr = tid >> 3;
+  const int n0 = blockIdx.x * 64 + c8 * 8;
+  const int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (n0 < N) {
+    for (int m = mbeg + rr; m < mend; m += 32) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(X + (long)m * ldx + n0), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += f[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rr][c8 * 8 + j] = s[j];
+  __syncthreads();
+  if (tid < 64) {
+    float t = 0.f;
+    for (int r = 0; r < 32; ++r) t += red[r][tid];
+    const int n = blockIdx.x * 64 + tid;
+    if (n < N) atomicAdd(out + n, t);
+  }
+}
+
+}  // namespace
+
+extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
+  V2S_CHECK(a != nullptr, V2S_ERR_ARG, "v2s_gemm: null args");
+  V2S_CHECK(a->M > 0 && a->N > 0 && a->K > 0, V2S_ERR_SHAPE, "v2s_gemm: non-positive shape %d %d %d", a->M, a->N, a->K);
+  // Ragged sizes (e.g. vocab 32100 or 612): rows are always exact (predicated); a dimension that is walked in
+  // 8-element chunks may be ragged only if the caller padded the row pitch to a multiple of 8 (pad content of
+  // A must be finite/zero when K is ragged: it is multiplied by zero-filled B rows).
+  const long N8 = (a->N + 7) / 8 * 8, K8 = (a->K + 7) / 8 * 8, M8 = (a->M + 7) / 8 * 8;
+  V2S_CHECK((a->lda % 8) == 0 && (a->ldb % 8) == 0 && (a->ldc % 8) == 0, V2S_ERR_ALIGN, "v2s_gemm: leading dims must be multiples of 8");
+  V2S_CHECK(a->ldc >= N8, V2S_ERR_SHAPE, "v2s_gemm: ldc (%ld) must cover N rounded up to 8 (%ld)", (long)a->ldc, N8);
+  V2S_CHECK((a->K % 8) == 0 || (!a->transA && a->transB && a->lda >= K8), V2S_ERR_SHAPE,
+            "v2s_gemm: ragged K (%d) only for transA=0,transB=1 with lda >= %ld", a->K, K8);
+  V2S_CHECK(!a->transA || a->lda >= M8, V2S_ERR_SHAPE, "v2s_gemm: transA needs lda >= M rounded up to 8");
+  V2S_CHECK(!a->transB || a->ldb >= N8, V2S_ERR_SHAPE, "v2s_gemm: transB needs ldb >= N rounded up to 8");
+  V2S_CHECK((a->N % 8) == 0 || (!a->bias && !a->residual && !a->z && !a->pre), V2S_ERR_SHAPE,
+            "v2s_gemm: ragged N (%d) is supported for plain epilogues only", a->N);
+  V2S_CHECK((((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) == 0, V2S_ERR_ALIGN, "v2s_gemm: pointers must be 16-byte aligned");
+  V2S_CHECK(a->c_dtype == V2S_BF16 || a->c_dtype == V2S_F32, V2S_ERR_DTYPE, "v2s_gemm: bad c_dtype %d", a->c_dtype);
+  V2S_CHECK(!(a->accumulate && a->c_dtype != V2S_F32), V2S_ERR_DTYPE, "v2s_gemm: accumulate needs fp32 C");
+  V2S_CHECK(!(a->dact != V2S_ACT_NONE && a->z == nullptr), V2S_ERR_ARG, "v2s_gemm: dact needs z");
+  V2S_CHECK(a->dropout_p >= 0.f && a->dropout_p < 1.f, V2S_ERR_ARG, "v2s_gemm: dropout_p out of range");
+  V2S_CHECK(!(a->transA && !a->transB), V2S_ERR_ARG, "v2s_gemm: (transA=1, transB=0) is not instantiated");
+
+  GemmP p;
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.A = (const bf16_t*)a->A; p.B = (const bf16_t*)a->B; p.lda = a->lda; p.ldb = a->ldb;
+  p.C = a->C; p.ldc = a->ldc; p.c_f32 = (a->c_dtype == V2S_F32); p.accumulate = a->accumulate;
+  p.alpha = a->alpha; p.bias = a->bias; p.act = a->act; p.pre = (bf16_t*)a->pre; p.dact = a->dact;
+  p.z = (const bf16_t*)a->z; p.ldz = a->ldz; p.residual = (const bf16_t*)a->residual; p.ldr = a->ldr;
+  p.p16 = (uint32_t)(a->dropout_p * 65536.0f + 0.5f);
+  p.inv_keep = p.p16 ? 1.0f / (1.0f - (float)p.p16 / 65536.0f) : 1.0f;
+  p.seed = a->dropout_seed;
+  p.tilesM = (a->M + BM - 1) / BM; p.tilesN = (a->N + BN - 1) / BN;
+  const dim3 grid(p.tilesM * p.tilesN), block(NTHREADS);
+  hipStream_t s = (hipStream_t)stream;
+  const bool tr = v2s_opt_tr_read() != 0;
+  if (!a->transA && !a->transB) {
+    hipLaunchKernelGGL((gemm_kernel<false, false, true>), grid, block, 0, s, p);
+  } else if (!a->transA && a->transB) {
+    if (tr) hipLaunchKernelGGL((gemm_kernel<false, true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<false, true, false>), grid, block, 0, s, p);
+  } else {
+    if (tr) hipLaunchKernelGGL((gemm_kernel<true, true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<true, true, false>), grid, block, 0, s, p);
+  }
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_colsum(const void* X, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
+                          void* stream) {
+  V2S_CHECK(M > 0 && N > 0 && (N % 8) == 0 && (ldx % 8) == 0, V2S_ERR_SHAPE, "v2s_colsum: bad shape M=%d N=%d", M, N);
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) != hipSuccess) { v2s_set_error("v2s_colsum: memset failed"); return V2S_ERR_LAUNCH; }
+  }
+  const int rows_per_block = 1024;
+  const dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block), block(256);
+  hipLaunchKernelGGL(colsum_kernel, grid, block, 0, s, (const bf16_t*)X, (long)ldx, M, N, out, rows_per_block);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}

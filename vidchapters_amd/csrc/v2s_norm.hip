@@ -1,0 +1,227 @@
+// Row normalisations for gfx950: one 64-lane wavefront per row, 16-byte bf16 loads, shuffle reductions,
+// fp32 statistics.  HBM-bound (reads x once, writes y once).
+//   RMSNorm  : model/modeling_t5.py:263-277 (T5LayerNorm.forward)
+//   LayerNorm: torch nn.LayerNorm as used at model/vit.py:64,69,99 (eps 1e-5, affine)
+// Backward produces dx (+ fused residual-gradient add) and per-block partial dw/db that a second
+// kernel reduces deterministically into the caller's fp32 gradient (+=).
+#include "v2s_common.h"
+
+namespace {
+
+constexpr int MAXC = 4;  // chunks of 8 columns per lane -> cols <= 2048
+constexpr int BWD_BLOCKS = 512;
+
+template <bool LN>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, bf16_t* __restrict__ y,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                       int rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = cols >> 3;
+  const bf16_t* xr = x + (long)row * cols;
+  float v[MAXC][8];
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+      unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s += v[i][j]; ss += v[i][j] * v[i][j]; }
+    }
+  }
+  float mean = 0.f, rstd;
+  if (LN) {
+    mean = wave_sum(s) / cols;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; var += d * d; }
+      }
+    }
+    rstd = rsqrtf(wave_sum(var) / cols + eps);
+  } else {
+    rstd = rsqrtf(wave_sum(ss) / cols + eps);
+  }
+  if (lane == 0) {
+    rstd_out[row] = rstd;
+    if (LN) mean_out[row] = mean;
+  }
+  bf16_t* yr = y + (long)row * cols;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+      float o[8];
+      const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8), w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      if (LN) {
+        const float4 b0 = *reinterpret_cast<const float4*>(b + c * 8), b1 = *reinterpret_cast<const float4*>(b + c * 8 + 4);
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = wv[j] * (v[i][j] * rstd);
+      }
+      *reinterpret_cast<uint4*>(yr + c * 8) = pack8(o);
+    }
+  }
+}
+
+template <bool LN>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                       const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+                                                       const bf16_t* __restrict__ dx_add, float* __restrict__ partial,
+                                                       int rows, int cols) {
+  __shared__ float red[4][2048];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = cols >> 3;
+  float dwacc[MAXC][8], dbacc[MAXC][8];
+  float wv[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + i * 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dwacc[i][j] = 0.f; dbacc[i][j] = 0.f; wv[i][j] = 0.f; }
+    if (c < nch) {
+      const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8), w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
+      wv[i][0] = w0.x; wv[i][1] = w0.y; wv[i][2] = w0.z; wv[i][3] = w0.w;
+      wv[i][4] = w1.x; wv[i][5] = w1.y; wv[i][6] = w1.z; wv[i][7] = w1.w;
+    }
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float rstd = rstd_in[row];
+    const float mean = LN ? mean_in[row] : 0.f;
+    float xh[MAXC][8], g[MAXC][8];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        float xv[8], dv[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + (long)row * cols + c * 8), xv);
+        unpack8(*reinterpret_cast<const uint4*>(dy + (long)row * cols + c * 8), dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xh[i][j] = (xv[j] - mean) * rstd;
+          g[i][j] = dv[j] * wv[i][j];
+          sg += g[i][j];
+          sgx += g[i][j] * xh[i][j];
+          dwacc[i][j] += dv[j] * xh[i][j];
+          dbacc[i][j] += dv[j];
+        }
+      }
+    }
+    sgx = wave_sum(sgx) / cols;
+    sg = LN ? wave_sum(sg) / cols : 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - sg - xh[i][j] * sgx);
+        if (dx_add) {
+          float a[8];
+          unpack8(*reinterpret_cast<const uint4*>(dx_add + (long)row * cols + c * 8), a);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += a[j];
+        }
+        *reinterpret_cast<uint4*>(dx + (long)row * cols + c * 8) = pack8(o);
+      }
+    }
+  }
+  // block reduction of dw (and db) over the 4 waves, then one partial row per block
+  for (int pass = 0; pass < (LN ? 2 : 1); ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][c * 8 + j] = pass ? dbacc[i][j] : dwacc[i][j];
+      }
+    }
+    __syncthreads();
+    float* dst = partial + ((long)pass * gridDim.x + blockIdx.x) * cols;
+    for (int c = threadIdx.x; c < cols; c += 256) dst[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  }
+}
+
+// out[c] += sum_b partial[b][c]
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                             int nblocks, int cols) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * cols + c];
+  out[c] += s;
+}
+
+int bwd_blocks(int rows) { return (rows + 3) / 4 < BWD_BLOCKS ? (rows + 3) / 4 : BWD_BLOCKS; }
+
+int check_shape(const char* who, int rows, int cols) {
+  if (rows <= 0 || cols <= 0 || (cols % 8) != 0 || cols > 8 * 64 * MAXC) {
+    v2s_set_error("%s: unsupported shape rows=%d cols=%d (cols must be a multiple of 8, <= %d)", who, rows, cols, 8 * 64 * MAXC);
+    return V2S_ERR_SHAPE;
+  }
+  return V2S_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t v2s_norm_partial_floats(int32_t rows, int32_t cols) { return 2LL * bwd_blocks(rows) * cols; }
+
+extern "C" int v2s_rmsnorm_fwd(const void* x, const float* w, void* y, float* rstd, int32_t rows, int32_t cols,
+                               float eps, void* stream) {
+  if (int e = check_shape("v2s_rmsnorm_fwd", rows, cols)) return e;
+  hipLaunchKernelGGL((norm_fwd_kernel<false>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w,
+                     (const float*)nullptr, (bf16_t*)y, (float*)nullptr, rstd, rows, cols, eps);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                 int32_t rows, int32_t cols, float eps, void* stream) {
+  if (int e = check_shape("v2s_layernorm_fwd", rows, cols)) return e;
+  hipLaunchKernelGGL((norm_fwd_kernel<true>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, b,
+                     (bf16_t*)y, mean, rstd, rows, cols, eps);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_rmsnorm_bwd(const void* x, const float* w, const float* rstd, const void* dy, void* dx,
+                               const void* dx_add, float* dw, float* partial, int32_t rows, int32_t cols, void* stream) {
+  if (int e = check_shape("v2s_rmsnorm_bwd", rows, cols)) return e;
+  const int nb = bwd_blocks(rows);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((norm_bwd_kernel<false>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, (const float*)nullptr, rstd,
+                     (const bf16_t*)dy, (bf16_t*)dx, (const bf16_t*)dx_add, partial, rows, cols);
+  V2S_LAUNCH_CHECK();
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial, dw, nb, cols);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_layernorm_bwd(const void* x, const float* w, const float* mean, const float* rstd, const void* dy,
+                                 void* dx, const void* dx_add, float* dw, float* db, float* partial, int32_t rows,
+                                 int32_t cols, void* stream) {
+  if (int e = check_shape("v2s_layernorm_bwd", rows, cols)) return e;
+  const int nb = bwd_blocks(rows);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((norm_bwd_kernel<true>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy,
+                     (bf16_t*)dx, (const bf16_t*)dx_add, partial, rows, cols);
+  V2S_LAUNCH_CHECK();
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial, dw, nb, cols);
+  V2S_LAUNCH_CHECK();
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial + (long)nb * cols, db, nb, cols);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}

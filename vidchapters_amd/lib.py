@@ -1,0 +1,318 @@
+"""ctypes binding of libvid2seq_hip.so (the C-ABI declared in include/vid2seq_hip.h).
+
+PyTorch is used only for device memory and streams: every wrapper below takes torch tensors, passes raw
+device pointers + sizes + the current HIP stream to the library, and raises ``RuntimeError`` with
+``v2s_last_error()`` on a non-zero return.  There is NO fallback: if the shared library is missing the
+import of :func:`lib` fails loudly (product path never routes through the CPU oracle).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvid2seq_hip.so")
+
+V2S_BF16, V2S_F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+_vp = C.c_void_p
+_i32, _i64, _f32, _u32 = C.c_int32, C.c_int64, C.c_float, C.c_uint32
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("M", _i32), ("N", _i32), ("K", _i32), ("transA", _i32), ("transB", _i32),
+                ("A", _vp), ("B", _vp), ("lda", _i64), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
+                ("c_dtype", _i32), ("accumulate", _i32), ("alpha", _f32), ("bias", _vp), ("act", _i32),
+                ("pre", _vp), ("dact", _i32), ("z", _vp), ("ldz", _i64), ("residual", _vp), ("ldr", _i64),
+                ("dropout_p", _f32), ("dropout_seed", _u32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("B", _i32), ("H", _i32), ("Nq", _i32), ("Nk", _i32),
+                ("q", _vp), ("k", _vp), ("v", _vp),
+                ("q_bs", _i64), ("q_rs", _i64), ("k_bs", _i64), ("k_rs", _i64), ("v_bs", _i64), ("v_rs", _i64),
+                ("o", _vp), ("o_bs", _i64), ("o_rs", _i64), ("ml", _vp), ("scale", _f32),
+                ("bias_diag", _vp), ("key_mask", _vp), ("causal", _i32), ("causal_off", _i32),
+                ("dropout_p", _f32), ("dropout_seed", _u32),
+                ("d_o", _vp), ("do_bs", _i64), ("do_rs", _i64), ("delta", _vp),
+                ("dq", _vp), ("dk", _vp), ("dv", _vp),
+                ("dq_bs", _i64), ("dq_rs", _i64), ("dk_bs", _i64), ("dk_rs", _i64), ("dv_bs", _i64), ("dv_rs", _i64),
+                ("dbias_diag", _vp)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("p", _vp), ("m", _vp), ("v", _vp), ("g", _vp), ("p_bf16", _vp), ("n", _i64),
+                ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32),
+                ("step", _i32), ("gnorm_sq", _vp), ("max_norm", _f32), ("grad_scale", _f32)]
+
+
+class DecodeAttnArgs(C.Structure):
+    _fields_ = [("B", _i32), ("H", _i32), ("Nk", _i32), ("q", _vp), ("q_bs", _i64), ("k", _vp), ("v", _vp),
+                ("kv_bs", _i64), ("kv_rs", _i64), ("o", _vp), ("o_bs", _i64), ("bias_row", _vp),
+                ("key_mask", _vp), ("mask_ld", _i64), ("scale", _f32)]
+
+
+#: every symbol include/vid2seq_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = {
+    "v2s_version": (C.c_int, []),
+    "v2s_last_error": (C.c_char_p, []),
+    "v2s_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "v2s_get_option": (C.c_int, [C.c_char_p]),
+    "v2s_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "v2s_colsum": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
+    "v2s_norm_partial_floats": (_i64, [_i32, _i32]),
+    "v2s_rmsnorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
+    "v2s_rmsnorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "v2s_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
+    "v2s_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "v2s_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
+    "v2s_attn_delta": (C.c_int, [C.POINTER(AttnArgs), _vp, _vp]),
+    "v2s_attn_bwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
+    "v2s_bias_diag_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "v2s_bias_bucket_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "v2s_embed_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _u32, _vp]),
+    "v2s_embed_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _u32, _vp]),
+    "v2s_add_bcast": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "v2s_dropout": (C.c_int, [_vp, _vp, _i64, _f32, _u32, _vp]),
+    "v2s_add": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "v2s_bcast_grad": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    "v2s_ce_fwd": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "v2s_ce_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _i64, _vp]),
+    "v2s_sqnorm": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "v2s_adam_step": (C.c_int, [C.POINTER(AdamArgs), _vp]),
+    "v2s_cast_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "v2s_timetoken_renorm": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "v2s_decode_attn": (C.c_int, [C.POINTER(DecodeAttnArgs), _vp]),
+    "v2s_argmax_step": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "v2s_kv_append": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+}
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built -- there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with vidchapters_amd/csrc/build.sh (or __graft_entry__.build()). "
+                "The Vid2Seq hot path has no non-HIP fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = l
+    return _LIB
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib().v2s_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def set_option(name: str, value: int) -> None:
+    _check(lib().v2s_set_option(name.encode(), int(value)), "v2s_set_option")
+
+
+def _need(t: torch.Tensor, dtype, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor must live on the GPU (HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{what}: expected dtype {dtype}, got {t.dtype}")
+
+
+# --------------------------------------------------------------------------------------------- GEMM
+def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, K: int, *, transA=False, transB=False,
+         lda=None, ldb=None, ldc=None, accumulate=False, alpha=1.0, bias=None, act=ACT_NONE, pre=None, dact=ACT_NONE,
+         z=None, ldz=None, residual=None, ldr=None, dropout_p=0.0, dropout_seed=0) -> None:
+    """C[M,N] (+)= epilogue(alpha * A(m,k) B(n,k)); see include/vid2seq_hip.h for layouts."""
+    _need(A, torch.bfloat16, "gemm A"); _need(B, torch.bfloat16, "gemm B")
+    a = GemmArgs()
+    a.M, a.N, a.K = M, N, K
+    a.transA, a.transB = int(transA), int(transB)
+    a.A, a.B = A.data_ptr(), B.data_ptr()
+    a.lda = lda if lda is not None else (M if transA else K)
+    a.ldb = ldb if ldb is not None else (N if transB else K)
+    a.C = C_out.data_ptr()
+    a.ldc = ldc if ldc is not None else N
+    a.c_dtype = V2S_F32 if C_out.dtype == torch.float32 else V2S_BF16
+    a.accumulate = int(accumulate)
+    a.alpha = alpha
+    a.bias = ptr(bias)
+    a.act = act
+    a.pre = ptr(pre)
+    a.dact = dact
+    a.z = ptr(z)
+    a.ldz = ldz if ldz is not None else N
+    a.residual = ptr(residual)
+    a.ldr = ldr if ldr is not None else N
+    a.dropout_p = dropout_p
+    a.dropout_seed = dropout_seed & 0xFFFFFFFF
+    _check(lib().v2s_gemm(C.byref(a), stream_ptr()), "v2s_gemm")
+
+
+def colsum(X: torch.Tensor, M: int, N: int, out: torch.Tensor, accumulate=True, ldx=None) -> None:
+    _need(X, torch.bfloat16, "colsum X"); _need(out, torch.float32, "colsum out")
+    _check(lib().v2s_colsum(X.data_ptr(), ldx if ldx is not None else N, M, N, out.data_ptr(), int(accumulate), stream_ptr()),
+           "v2s_colsum")
+
+
+# --------------------------------------------------------------------------------------------- norms
+def norm_partial_floats(rows: int, cols: int) -> int:
+    return int(lib().v2s_norm_partial_floats(rows, cols))
+
+
+def rmsnorm_fwd(x, w, y, rstd, rows, cols, eps):
+    _need(x, torch.bfloat16, "rmsnorm x"); _need(w, torch.float32, "rmsnorm w")
+    _check(lib().v2s_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows, cols, eps, stream_ptr()),
+           "v2s_rmsnorm_fwd")
+
+
+def rmsnorm_bwd(x, w, rstd, dy, dx, dx_add, dw, partial, rows, cols):
+    _check(lib().v2s_rmsnorm_bwd(x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(), ptr(dx_add),
+                                 dw.data_ptr(), partial.data_ptr(), rows, cols, stream_ptr()), "v2s_rmsnorm_bwd")
+
+
+def layernorm_fwd(x, w, b, y, mean, rstd, rows, cols, eps):
+    _need(x, torch.bfloat16, "layernorm x")
+    _check(lib().v2s_layernorm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                   rows, cols, eps, stream_ptr()), "v2s_layernorm_fwd")
+
+
+def layernorm_bwd(x, w, mean, rstd, dy, dx, dx_add, dw, db, partial, rows, cols):
+    _check(lib().v2s_layernorm_bwd(x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(),
+                                   ptr(dx_add), dw.data_ptr(), db.data_ptr(), partial.data_ptr(), rows, cols, stream_ptr()),
+           "v2s_layernorm_bwd")
+
+
+# --------------------------------------------------------------------------------------------- attention
+def attn_args(B, H, Nq, Nk, q, k, v, o, q_st, k_st, v_st, o_st, *, ml=None, scale=1.0, bias_diag=None, key_mask=None,
+              causal=False, causal_off=0, dropout_p=0.0, dropout_seed=0) -> AttnArgs:
+    """q_st etc. are (batch_stride, row_stride) in elements; q/k/v/o are tensors whose data_ptr() already
+    points at column 0 of head 0."""
+    a = AttnArgs()
+    a.B, a.H, a.Nq, a.Nk = B, H, Nq, Nk
+    a.q, a.k, a.v, a.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+    a.q_bs, a.q_rs = q_st; a.k_bs, a.k_rs = k_st; a.v_bs, a.v_rs = v_st; a.o_bs, a.o_rs = o_st
+    a.ml = ptr(ml); a.scale = scale; a.bias_diag = ptr(bias_diag); a.key_mask = ptr(key_mask)
+    a.causal, a.causal_off = int(causal), causal_off
+    a.dropout_p, a.dropout_seed = dropout_p, dropout_seed & 0xFFFFFFFF
+    return a
+
+
+def attn_fwd(a: AttnArgs) -> None:
+    _check(lib().v2s_attn_fwd(C.byref(a), stream_ptr()), "v2s_attn_fwd")
+
+
+def attn_bwd(a: AttnArgs, d_o, do_st, delta, dq, dk, dv, dq_st, dk_st, dv_st, dbias_diag=None) -> None:
+    a.d_o = d_o.data_ptr(); a.do_bs, a.do_rs = do_st
+    a.delta = delta.data_ptr()
+    a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    a.dq_bs, a.dq_rs = dq_st; a.dk_bs, a.dk_rs = dk_st; a.dv_bs, a.dv_rs = dv_st
+    a.dbias_diag = ptr(dbias_diag)
+    _check(lib().v2s_attn_delta(C.byref(a), delta.data_ptr(), stream_ptr()), "v2s_attn_delta")
+    _check(lib().v2s_attn_bwd(C.byref(a), stream_ptr()), "v2s_attn_bwd")
+
+
+def bias_diag_fwd(table, lut, out, H, n, num_buckets):
+    _check(lib().v2s_bias_diag_fwd(table.data_ptr(), lut.data_ptr(), out.data_ptr(), H, n, num_buckets, stream_ptr()),
+           "v2s_bias_diag_fwd")
+
+
+def bias_bucket_bwd(dd, lut, dtable, H, n, num_buckets):
+    _check(lib().v2s_bias_bucket_bwd(dd.data_ptr(), lut.data_ptr(), dtable.data_ptr(), H, n, num_buckets, stream_ptr()),
+           "v2s_bias_bucket_bwd")
+
+
+# --------------------------------------------------------------------------------------------- misc
+def embed_fwd(ids, table, out, n, d, vocab, p=0.0, seed=0):
+    _need(ids, torch.int64, "embed ids"); _need(table, torch.bfloat16, "embed table")
+    _check(lib().v2s_embed_fwd(ids.data_ptr(), table.data_ptr(), out.data_ptr(), n, d, vocab, p, seed & 0xFFFFFFFF, stream_ptr()),
+           "v2s_embed_fwd")
+
+
+def embed_bwd(ids, dy, dtable, n, d, vocab, p=0.0, seed=0):
+    _need(dtable, torch.float32, "embed dtable")
+    _check(lib().v2s_embed_bwd(ids.data_ptr(), dy.data_ptr(), dtable.data_ptr(), n, d, vocab, p, seed & 0xFFFFFFFF, stream_ptr()),
+           "v2s_embed_bwd")
+
+
+def add_bcast(x, add, y, n, add_n):
+    _check(lib().v2s_add_bcast(x.data_ptr(), add.data_ptr(), y.data_ptr(), n, add_n, stream_ptr()), "v2s_add_bcast")
+
+
+def add(a, b, y, n):
+    _check(lib().v2s_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), n, stream_ptr()), "v2s_add")
+
+
+def dropout(x, y, n, p, seed):
+    _check(lib().v2s_dropout(x.data_ptr(), y.data_ptr(), n, p, seed & 0xFFFFFFFF, stream_ptr()), "v2s_dropout")
+
+
+def bcast_grad(dy, out, n, add_n):
+    _check(lib().v2s_bcast_grad(dy.data_ptr(), out.data_ptr(), n, add_n, stream_ptr()), "v2s_bcast_grad")
+
+
+def ce_fwd(logits, ld, labels, rows, V, eps, row_lse, loss_sum, count):
+    _need(logits, torch.float32, "ce logits"); _need(labels, torch.int64, "ce labels")
+    _check(lib().v2s_ce_fwd(logits.data_ptr(), ld, labels.data_ptr(), rows, V, eps, row_lse.data_ptr(), loss_sum.data_ptr(),
+                            count.data_ptr(), stream_ptr()), "v2s_ce_fwd")
+
+
+def ce_bwd(logits, ld, labels, row_lse, rows, V, eps, gscale, dlogits, ldd):
+    _check(lib().v2s_ce_bwd(logits.data_ptr(), ld, labels.data_ptr(), row_lse.data_ptr(), rows, V, eps, gscale.data_ptr(),
+                            dlogits.data_ptr(), ldd, stream_ptr()), "v2s_ce_bwd")
+
+
+def sqnorm(g, n, ws, out):
+    _check(lib().v2s_sqnorm(g.data_ptr(), n, ws.data_ptr(), out.data_ptr(), stream_ptr()), "v2s_sqnorm")
+
+
+def adam_step(p, m, v, g, p_bf16, n, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+    a = AdamArgs()
+    a.p, a.m, a.v, a.g, a.p_bf16, a.n = p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), ptr(p_bf16), n
+    a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.step = lr, beta1, beta2, eps, wd, step
+    a.gnorm_sq, a.max_norm, a.grad_scale = ptr(gnorm_sq), max_norm, grad_scale
+    _check(lib().v2s_adam_step(C.byref(a), stream_ptr()), "v2s_adam_step")
+
+
+def cast_bf16(src, dst, n):
+    _need(src, torch.float32, "cast src")
+    _check(lib().v2s_cast_bf16(src.data_ptr(), dst.data_ptr(), n, stream_ptr()), "v2s_cast_bf16")
+
+
+def timetoken_renorm(emb, emb_bf16, V, d, num_bins, ws):
+    _check(lib().v2s_timetoken_renorm(emb.data_ptr(), ptr(emb_bf16), V, d, num_bins, ws.data_ptr(), stream_ptr()),
+           "v2s_timetoken_renorm")
+
+
+def decode_attn(B, H, Nk, q, q_bs, k, v, kv_bs, kv_rs, o, o_bs, bias_row=None, key_mask=None, mask_ld=0, scale=1.0):
+    a = DecodeAttnArgs()
+    a.B, a.H, a.Nk = B, H, Nk
+    a.q, a.q_bs, a.k, a.v, a.kv_bs, a.kv_rs = q.data_ptr(), q_bs, k.data_ptr(), v.data_ptr(), kv_bs, kv_rs
+    a.o, a.o_bs, a.bias_row, a.key_mask, a.mask_ld, a.scale = o.data_ptr(), o_bs, ptr(bias_row), ptr(key_mask), mask_ld, scale
+    _check(lib().v2s_decode_attn(C.byref(a), stream_ptr()), "v2s_decode_attn")
+
+
+def argmax_step(logits, ld, rows, V, next_tok, unfinished, eos_id, pad_id):
+    _check(lib().v2s_argmax_step(logits.data_ptr(), ld, rows, V, next_tok.data_ptr(), unfinished.data_ptr(), eos_id, pad_id,
+                                 stream_ptr()), "v2s_argmax_step")
+
+
+def kv_append(src, src_bs, cache, cache_bs, cache_rs, B, width, pos):
+    _check(lib().v2s_kv_append(src.data_ptr(), src_bs, cache.data_ptr(), cache_bs, cache_rs, B, width, pos, stream_ptr()),
+           "v2s_kv_append")
