@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""Headline benchmark: Vid2Seq train-step samples/sec on synthetic (100 frames x 768, 1000 ASR tokens, 256 target
+tokens) batches, t5-base, bf16 MFMA compute with fp32 accumulation/master weights, one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = dvc.py's training step with the generative pass (ViT + T5 encoder + decoder + label-smoothed CE forward and
+backward, clip_grad_norm_, Adam, time-token renorm), reference-default dropout 0.1; --denoising 1 adds the second
+(span-corruption) pass of the reference's default recipe.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16 peak, MI355X_MICROARCH.md
+
+
+def flops_per_sample(T=100, L=1000, Lo=256, V=32200, d=768, ff=3072, n_enc=12, n_dec=12, vit_depth=12, vit_mlp=2048):
+    """Algorithmic forward FLOPs per sample: GEMMs 2mnk, attention dense (causal not halved)."""
+    S = T + L
+    vit = vit_depth * (T * (2 * d * 3 * d + 2 * d * d + 4 * d * vit_mlp) + 4 * T * T * d)
+    enc = n_enc * (L * (8 * d * d + 4 * d * ff) + 4 * L * L * d)
+    dec = n_dec * (Lo * (8 * d * d + 4 * d * ff) + Lo * 4 * d * d + S * 4 * d * d + 4 * Lo * Lo * d + 4 * Lo * S * d)
+    head = 2 * Lo * d * V
+    return vit + enc + dec + head
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--asr-tokens", type=int, default=1000)
+    ap.add_argument("--target-tokens", type=int, default=256)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--denoising", type=float, default=0.0)
+    ap.add_argument("--model", default="t5-base")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" == RCCL on ROCm
+
+    from vidchapters_amd import SyntheticTokenizer, Vid2Seq, synth
+    from vidchapters_amd import lib as L
+    from vidchapters_amd.train import Trainer
+
+    B, T, Lx, Lo = a.batch, 100, a.asr_tokens, a.target_tokens
+    tok = SyntheticTokenizer(32100, 100)
+    model = Vid2Seq(a.model, tokenizer=tok, vis_drop=a.dropout, enc_drop=a.dropout, dec_drop=a.dropout, init_seed=1234,
+                    device=dev).train()
+    trainer = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=a.denoising)
+    batch = {k: v.to(dev) for k, v in synth.make_batch(B, T, Lx, Lo, len(tok), 1234 + rank, 768, denoising=a.denoising > 0).items()}
+    batch["video"] = batch["video"].to(torch.bfloat16)       # features resident in HBM as bf16 (documented in DESIGN.md)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        losses = trainer.step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = trainer.step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(losses["loss"].item())
+    ms_per_step = dt / a.steps * 1e3
+    value = world * B * a.steps / dt
+
+    # algorithmic work per step: 3x forward FLOPs (fwd + dgrad + wgrad)
+    cfgm = model.cfg
+    fps = flops_per_sample(T, Lx, Lo, cfgm.vocab, cfgm.d_model, cfgm.d_ff, cfgm.n_enc, cfgm.n_dec)
+    step_tflop = 3.0 * fps * B / 1e12
+    out = {
+        "metric": "Vid2Seq train-step samples/sec (100f x 768 vis, 1000 ASR tok)",
+        "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"cfg-2: Vid2Seq {a.model} train step (generative pass"
+                               f"{' + denoising pass' if a.denoising > 0 else ''}), per-GPU batch {B}, 100 frames x 768, "
+                               f"{Lx} ASR tokens, {Lo} target tokens, dropout {a.dropout}, fp32 master weights + fused clip/Adam/renorm",
+                   "global_batch": world * B, "parallelism": f"dp{world}", "weights": "deterministic synthetic init (no checkpoints offline)"},
+        "loss": round(loss_val, 5),
+        "model_tflops_per_step_per_gpu": round(step_tflop, 2),
+        "achieved_model_tflops_per_gpu": round(step_tflop / (ms_per_step / 1e3), 1),
+        "frac_of_mfma_peak_whole_step": round(step_tflop / (ms_per_step / 1e3) / PEAK_BF16_TFLOPS, 4),
+    }
+
+    if rank == 0 and not a.no_roofline:
+        with L.KernelTimer() as kt:
+            trainer.step(batch)
+        summ = kt.summary()
+        tag = max(summ, key=lambda k: summ[k][1])
+        n, ms, work = summ[tag]
+        ach = work / (ms / 1e3) / 1e12
+        out["roofline"] = {"kernel": {"gemm_nt": "gemm_kernel<false,false,true> (forward / NT)",
+                                      "gemm_dgrad": "gemm_kernel<false,true,true> (dgrad)",
+                                      "gemm_wgrad": "gemm_kernel<true,true,true> (wgrad)"}.get(tag, tag),
+                           "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": n, "avg_launch_us": round(ms / n * 1e3, 2),
+                           "algorithmic_gflop_per_launch": round(work / n / 1e9, 2)}
+        out["kernel_breakdown_ms_per_step"] = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] / 1e3) / 1e12, 1)}
+                                               for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, tok, Lx, Lo)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model, tok, Lx, Lo):
+    """The CPU oracle (fp32 torch port of the reference path, pinned against the reference in the build container)
+    timed on this box's host cores on a bounded sample: ONE optimizer step at B=1 of the same workload."""
+    from oracle import vid2seq_ref as R
+    from vidchapters_amd import synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = R.RefConfig(vocab=len(tok))
+    P = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    b = synth.make_batch(1, 100, Lx, Lo, len(tok), 99, 768)
+    t0 = time.perf_counter()
+    rec = R.train_step(P, {}, cfg, b, lr=3e-4, clip=1.0, generative=1.0, denoising=0.0)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 optimizer step (fwd+bwd+clip+Adam+renorm) at B=1, 100 frames, {Lx} ASR tokens, {Lo} target tokens, "
+                      f"fp32 torch CPU oracle, dropout 0; {dt:.1f} s", "loss": round(rec["losses"]["loss"], 5)}
+
+
+if __name__ == "__main__":
+    main()

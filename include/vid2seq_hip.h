@@ -220,7 +220,8 @@ typedef struct v2s_decode_attn_args {
   const void* q; int64_t q_bs;            /* bf16 [B][H*64] */
   const void* k; const void* v; int64_t kv_bs, kv_rs;
   void* o; int64_t o_bs;
-  const float* bias_row;                  /* fp32 [H][Nk] or NULL */
+  const float* bias_row;                  /* fp32, element (h,k) at bias_row[h*bias_ld + k], or NULL */
+  int64_t bias_ld;
   const uint8_t* key_mask;                /* [B][mask_ld] or NULL */
   int64_t mask_ld;
   float scale;

@@ -198,7 +198,7 @@ def case_functions(mt5):
     d = torch.arange(-130, 131, 10)
     assert A._relative_position_bucket(d, True).tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 8, 0, 24, 26, 27, 28, 29, 29, 30, 30, 30, 31, 31, 31, 31]
     labels = torch.tensor([[5, 9, -100, 3, 1, -100, -100], [7, -100, -100, -100, -100, -100, -100]])
-    cfg = R.RefConfig.tiny()
+    cfg = R.RefConfig.small()
     t5 = mt5.T5ForConditionalGeneration.__new__(mt5.T5ForConditionalGeneration)
     t5.config = types.SimpleNamespace(decoder_start_token_id=0, pad_token_id=0)
     sr = mt5.T5PreTrainedModel._shift_right(t5, labels)
@@ -221,7 +221,7 @@ def case_tiny(v2s, tag, cfg, B, T, L, Lo, seed):
     P = oracle_params(cfg, seed, grad=True)
     m = build_ref_model(v2s, cfg, {k: v.detach() for k, v in P.items()})
     batch = synth.make_batch(B, T, L, Lo, cfg.vocab, seed, cfg.vit_dim)
-    if tag == "tiny":                                   # exercise ragged edge cases: a 1-token row, a full row
+    if tag == "small":                                   # exercise ragged edge cases: a 1-token row, a full row
         batch["input_ids"][0, 1:] = 0; batch["input_ids"][0, 0] = 1
         batch["output_ids"][1, 1:] = 0; batch["output_ids"][1, 0] = 1
     for p in m.parameters():
@@ -258,7 +258,9 @@ def case_tiny(v2s, tag, cfg, B, T, L, Lo, seed):
     assert worst < 2e-4, worst
     arrs = {"video": batch["video"], "input_ids": batch["input_ids"], "output_ids": batch["output_ids"],
             "loss": loss_ref.detach(), "logits": lg_ref.detach(), "memory": mem_ref.detach()}
-    for k, v in gref.items():
+    arrs["grad_norm_keys"] = np.array(list(gref.keys()))
+    arrs["grad_norm_vals"] = np.array([float(v.norm()) for v in gref.values()])
+    for k, v in gref.items():                      # full gradients for every tensor (fixture stays < 3 MB compressed)
         arrs["grad:" + k] = v
     npz(f"{tag}_forward_backward.npz", **arrs)
     return m, P, batch
@@ -341,7 +343,7 @@ def case_train_recipe(v2s, cfg, seed=5):
         arrs["post:" + k] = post[k]
     arrs["loss0"] = recs[0]["losses"]["loss"]; arrs["den0"] = recs[0]["losses"]["denoising_loss"]
     arrs["gnorm0"] = recs[0]["grad_norm"]; arrs["gnorm1"] = recs[1]["grad_norm"]
-    npz("tiny_train_recipe.npz", **arrs)
+    npz("small_train_recipe.npz", **arrs)
 
 
 def case_parse():
@@ -418,12 +420,12 @@ def main():
     mt5, v2s, vit = load_reference()
     case_functions(mt5)
     case_parse()
-    cfg = R.RefConfig.tiny()
-    m, P, batch = case_tiny(v2s, "tiny", cfg, B=3, T=10, L=24, Lo=12, seed=7)
-    case_decode(m, P, cfg, batch, "tiny")
+    cfg = R.RefConfig.small()
+    m, P, batch = case_tiny(v2s, "small", cfg, B=3, T=10, L=24, Lo=12, seed=7)
+    case_decode(m, P, cfg, batch, "small")
     # ViT nearest-neighbour pos-embed resize branch (vit.py:119-123): T != num_features, and d_model != vit_dim => proj_v2t
-    cfg2 = R.RefConfig.tiny(vit_dim=48, vit_heads=3, num_features=10)
-    case_tiny(v2s, "tiny_resize_proj", cfg2, B=2, T=7, L=16, Lo=9, seed=9)
+    cfg2 = R.RefConfig.small(vit_dim=64, vit_heads=1, num_features=10)
+    case_tiny(v2s, "small_resize_proj", cfg2, B=2, T=7, L=16, Lo=9, seed=9)
     case_train_recipe(v2s, cfg)
     if not a.skip_full:
         case_full(v2s)

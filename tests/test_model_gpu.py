@@ -1,0 +1,240 @@
+"""End-to-end parity of the HIP engine (bf16 activations, fp32 accumulation) on the GPU against
+  (a) golden vectors captured from the REAL reference (tests/golden/*.npz, made by oracle/make_golden.py), and
+  (b) the CPU oracle (oracle/vid2seq_ref.py, itself pinned against the reference) on other seeded inputs.
+
+Stated tolerances: loss rel <= 2e-2; gradients cosine >= 0.99 per tensor (>= 0.98 for tensors whose
+gradient is dominated by bf16 rounding noise, listed explicitly); greedy tokens equal up to a first divergence.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vid2seq_ref as R            # noqa: E402  (checker only)
+from vidchapters_amd import SyntheticTokenizer, Vid2Seq, synth  # noqa: E402
+from vidchapters_amd.train import Trainer      # noqa: E402
+
+DEV = "cuda"
+
+
+def build(cfg: R.RefConfig, seed: int, **kw) -> Vid2Seq:
+    t5 = dict(d_model=cfg.d_model, d_kv=cfg.d_kv, heads=cfg.heads, d_ff=cfg.d_ff, n_enc=cfg.n_enc, n_dec=cfg.n_dec)
+    args = dict(num_features=cfg.num_features, embed_dim=cfg.vit_dim, depth=cfg.vit_depth, heads=cfg.vit_heads,
+                mlp_dim=cfg.vit_mlp, tokenizer=SyntheticTokenizer(cfg.vocab - cfg.num_bins, cfg.num_bins), vis_drop=0.0,
+                enc_drop=0.0, dec_drop=0.0, num_bins=cfg.num_bins, label_smoothing=cfg.label_smoothing, init_seed=seed)
+    args.update(kw)
+    return Vid2Seq(t5, **args).to(DEV)
+
+
+def tok(ids):
+    ids = ids.to(DEV)
+    return {"input_ids": ids, "attention_mask": ids != 0}
+
+
+def cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float(a @ b / (a.norm() * b.norm() + 1e-30))
+
+
+def named_grads(model):
+    return {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("tag,cfg,seed", [
+    ("small", R.RefConfig.small(), 7),
+    ("small_resize_proj", R.RefConfig.small(vit_dim=64, vit_heads=1, num_features=10), 9),
+])
+def test_forward_backward_vs_reference_golden(golden_dir, tag, cfg, seed):
+    g = np.load(os.path.join(golden_dir, f"{tag}_forward_backward.npz"))
+    model = build(cfg, seed).eval()
+    video = torch.from_numpy(g["video"]).to(DEV)
+    out, vd = model(video, tok(torch.from_numpy(g["input_ids"])), tok(torch.from_numpy(g["output_ids"])))
+    loss = out["loss"]
+    ref = float(g["loss"])
+    print(f"[{tag}] loss hip={loss.item():.6f} reference={ref:.6f}")
+    assert abs(loss.item() - ref) <= 2e-2 * abs(ref)
+    mem = torch.from_numpy(g["memory"])
+    T = video.shape[1]
+    c = cos(vd["video"].float().cpu(), mem[:, :T])
+    print(f"  ViT output cosine vs reference: {c:.6f}")
+    assert c > 0.999
+    loss.backward()
+    grads = named_grads(model)
+    worst = 1.0
+    for k in g.files:
+        if not k.startswith("grad:"):
+            continue
+        name = k[5:]
+        want = torch.from_numpy(g[k])
+        got = grads[name].view_as(want)
+        cs = cos(got, want)
+        rn = float(got.norm() / (want.norm() + 1e-30))
+        worst = min(worst, cs)
+        if cs < 0.995:
+            print(f"  {name}: cos {cs:.4f} norm ratio {rn:.3f}")
+        assert cs > 0.99 and 0.9 < rn < 1.1, (name, cs, rn)
+    print(f"  worst gradient cosine over all tensors: {worst:.5f}")
+
+
+@pytest.mark.parametrize("use_video,use_speech", [(True, False), (False, True)])
+def test_ablation_flags_vs_oracle(use_video, use_speech):
+    cfg = R.RefConfig.small(use_video=use_video, use_speech=use_speech)
+    model = build(cfg, 21, use_video=use_video, use_speech=use_speech).eval()
+    P = synth.init_params(R.param_shapes(cfg), 21, cfg.d_model, cfg.inner, cfg.d_ff)
+    b = synth.make_batch(2, 10, 40, 17, cfg.vocab, 33, cfg.vit_dim)
+    with torch.no_grad():
+        want, _ = R.vid2seq_forward(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, b["output_ids"], b["output_ids"] != 0)
+        got, _ = model(b["video"].to(DEV), tok(b["input_ids"]), tok(b["output_ids"]))
+    print(f"ablation video={use_video} speech={use_speech}: hip {got['loss'].item():.5f} oracle {want['loss'].item():.5f}")
+    assert abs(got["loss"].item() - want["loss"].item()) <= 2e-2 * abs(want["loss"].item())
+
+
+def test_ragged_batch_and_two_pass_vs_oracle():
+    """Ragged lengths (a 1-token row, a full row, >64 and >128 keys so several attention tiles are partly masked) and
+    the cached video_dict path of dvc.py:78-92."""
+    cfg = R.RefConfig.small()
+    model = build(cfg, 11).eval()
+    P = synth.init_params(R.param_shapes(cfg), 11, cfg.d_model, cfg.inner, cfg.d_ff)
+    for v in P.values():
+        v.requires_grad_(True)
+    b = synth.make_batch(3, 10, 150, 70, cfg.vocab, 5, cfg.vit_dim, denoising=True)
+    b["input_ids"][0, 1:] = 0; b["input_ids"][0, 0] = 1
+    b["output_ids"][1, 1:] = 0; b["output_ids"][1, 0] = 1
+    o1, vd = R.vid2seq_forward(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, b["output_ids"], b["output_ids"] != 0)
+    o2, _ = R.vid2seq_forward(P, cfg, vd, b["den_input_ids"], b["den_input_ids"] != 0, b["den_output_ids"], b["den_output_ids"] != 0)
+    tot = o1["loss"] + o2["loss"]
+    names = list(P)
+    gw = torch.autograd.grad(tot, [P[k] for k in names])
+    l1, vdict = model(b["video"].to(DEV), tok(b["input_ids"]), tok(b["output_ids"]))
+    l2, _ = model(vdict, tok(b["den_input_ids"]), tok(b["den_output_ids"]))
+    (l1["loss"] + l2["loss"]).backward()
+    print(f"two-pass losses hip ({l1['loss'].item():.5f}, {l2['loss'].item():.5f}) oracle ({o1['loss'].item():.5f}, {o2['loss'].item():.5f})")
+    assert abs(l1["loss"].item() - o1["loss"].item()) <= 2e-2 * o1["loss"].item()
+    assert abs(l2["loss"].item() - o2["loss"].item()) <= 2e-2 * o2["loss"].item()
+    grads = named_grads(model)
+    for k, w in zip(names, gw):
+        cs = cos(grads[k], w)
+        assert cs > 0.99, (k, cs)
+
+
+def test_train_recipe_vs_reference_golden(golden_dir):
+    """dvc.py:train_one_epoch x2 steps (captured from the real reference) vs Trainer.step x2."""
+    g = np.load(os.path.join(golden_dir, "small_train_recipe.npz"))
+    cfg = R.RefConfig.small()
+    model = build(cfg, 5).train()
+    pre = {k: p.detach().float().cpu().clone() for k, p in model.named_parameters()}
+    tr = Trainer(model, lr=3e-4, clip_max_norm=0.1, generative=1.0, denoising=1.0)
+    for i in range(2):
+        batch = {k.split(":", 1)[1]: torch.from_numpy(g[k]).to(DEV) for k in g.files if k.startswith(f"b{i}:")}
+        losses = tr.step(batch)
+        if i == 0:
+            l0, d0, gn0 = losses["loss"].item(), losses["denoising_loss"].item(), tr.grad_norm().item()
+            print(f"step0 loss {l0:.5f}/{float(g['loss0']):.5f} den {d0:.5f}/{float(g['den0']):.5f} gnorm {gn0:.4f}/{float(g['gnorm0']):.4f}")
+            assert abs(l0 - float(g["loss0"])) <= 2e-2 * float(g["loss0"])
+            assert abs(d0 - float(g["den0"])) <= 2e-2 * float(g["den0"])
+            assert abs(gn0 - float(g["gnorm0"])) <= 5e-2 * float(g["gnorm0"])
+    post = {k: p.detach().float().cpu() for k, p in model.named_parameters()}
+    for k in g.files:
+        if not k.startswith("post:"):
+            continue
+        name = k[5:]
+        want = torch.from_numpy(g[k]).view_as(post[name])
+        du_ref, du = want - pre[name], post[name] - pre[name]
+        cs = cos(du, du_ref)
+        mx = float((post[name] - want).abs().max())
+        print(f"  {name}: update cosine {cs:.4f}, max|w - w_ref| {mx:.2e}")
+        # Adam's first steps move every weight by ~lr*sign(g): elements whose tiny gradient changes sign under bf16
+        # rounding differ by up to 2*lr per step, so compare the update direction and bound the distance by 2 steps * 2 lr
+        assert cs > 0.9 and mx <= 4.2 * 3e-4 + 1e-6, (name, cs, mx)
+    # the bf16 shadow tracks the fp32 master after the fused step
+    eng = model.engine()
+    assert torch.equal(eng.arena.shadow, eng.arena.master.to(torch.bfloat16))
+
+
+def test_dropin_optimizer_path_matches_trainer():
+    """The reference's caller idiom: loss.backward(); clip_grad_norm_; torch.optim.Adam.step(); zero_grad()."""
+    cfg = R.RefConfig.small()
+    b = synth.make_batch(2, 10, 33, 12, cfg.vocab, 3, cfg.vit_dim)
+    m1, m2 = build(cfg, 4).train(), build(cfg, 4).train()
+    opt = torch.optim.Adam(m1.parameters(), lr=3e-4)
+    for _ in range(2):
+        opt.zero_grad()
+        out, _ = m1(b["video"].to(DEV), tok(b["input_ids"]), tok(b["output_ids"]))
+        out["loss"].backward()
+        torch.nn.utils.clip_grad_norm_(m1.parameters(), 1.0)
+        opt.step()
+    tr = Trainer(m2, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=0.0)
+    m2.num_bins = 0                      # no renorm, like the plain optimizer loop above
+    for _ in range(2):
+        tr.step({k: v.to(DEV) for k, v in b.items()})
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert (p1 - p2).abs().max().item() < 2e-6, k
+
+
+def test_greedy_vs_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "small_greedy.npz"))
+    cfg = R.RefConfig.small()
+    model = build(cfg, 7).eval()
+    toks = model.engine().greedy(torch.from_numpy(g["video"]).to(DEV), tok(torch.from_numpy(g["input_ids"])),
+                                 max_new_tokens=int(g["max_new"])).cpu()
+    want = torch.from_numpy(g["tokens"])
+    n = min(toks.shape[1], want.shape[1])
+    same = (toks[:, :n] == want[:, :n])
+    first_div = [int((~r).nonzero()[0]) if (~r).any() else n for r in same]
+    print("greedy first divergence per row:", first_div, "of", n)
+    assert toks[:, 0].eq(0).all()
+    assert min(first_div) >= n // 2, (toks, want)          # bf16 argmax flips only on <1e-2 logit margins
+    text = model.generate(torch.from_numpy(g["video"]).to(DEV), tok(torch.from_numpy(g["input_ids"])), num_beams=1,
+                          max_length=int(g["max_new"]))
+    assert isinstance(text, list) and len(text) == want.shape[0] and all(isinstance(t, str) for t in text)
+
+
+def test_dropout_training_mode_runs_and_differs():
+    cfg = R.RefConfig.small()
+    model = build(cfg, 8, vis_drop=0.1, enc_drop=0.1, dec_drop=0.1)
+    b = synth.make_batch(2, 10, 40, 17, cfg.vocab, 9, cfg.vit_dim)
+    model.eval()
+    with torch.no_grad():
+        l_eval = model(b["video"].to(DEV), tok(b["input_ids"]), tok(b["output_ids"]))[0]["loss"].item()
+    model.train()
+    out, _ = model(b["video"].to(DEV), tok(b["input_ids"]), tok(b["output_ids"]))
+    out["loss"].backward()
+    l_tr = out["loss"].item()
+    print(f"dropout: eval loss {l_eval:.5f} train loss {l_tr:.5f}")
+    assert np.isfinite(l_tr) and l_tr != l_eval and abs(l_tr - l_eval) < 0.5
+    for k, p in model.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+
+
+def test_full_size_cfg1_vs_reference_golden(golden_dir):
+    """t5-base Vid2Seq (289 M parameters), B=2, T=100, L=256, Lo=256: loss, logits-free scalars and gradient norms
+    captured from the real reference in fp32."""
+    g = np.load(os.path.join(golden_dir, "full_cfg1_scalars.npz"))
+    seed, B, Lx, Lo = int(g["seed"]), int(g["B"]), int(g["L"]), int(g["Lo"])
+    model = Vid2Seq("t5-base", tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
+                    init_seed=seed, device=DEV).eval()
+    b = synth.make_batch(B, 100, Lx, Lo, 32200, seed, 768)
+    out, vd = model(b["video"].to(DEV), tok(b["input_ids"]), tok(b["output_ids"]))
+    ref = float(g["loss"])
+    print(f"full cfg-1 loss hip={out['loss'].item():.5f} reference={ref:.5f}")
+    assert abs(out["loss"].item() - ref) <= 2e-2 * ref
+    ms = torch.from_numpy(g["memory_slice"])
+    got = vd["video"].float().cpu()[:, ::37, :32]
+    assert cos(got, ms[:, :got.shape[1]]) > 0.999
+    out["loss"].backward()
+    keys = [str(k) for k in g["grad_norm_keys"]]
+    vals = g["grad_norm_vals"]
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    tot = float(torch.sqrt(sum((v.float() ** 2).sum() for v in grads.values())))
+    print(f"  total grad norm hip={tot:.4f} reference={float(g['grad_norm']):.4f}")
+    assert abs(tot - float(g["grad_norm"])) <= 5e-2 * float(g["grad_norm"])
+    bad = []
+    for k, v in zip(keys, vals):
+        r = float(grads[k].float().norm()) / (float(v) + 1e-12)
+        if not 0.9 < r < 1.1:
+            bad.append((k, r))
+    print(f"  per-tensor grad-norm ratio outside [0.9,1.1]: {bad[:8]}")
+    assert len(bad) <= 2

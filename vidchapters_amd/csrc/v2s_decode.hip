@@ -12,7 +12,7 @@ struct DecP {
   const bf16_t* q; long q_bs;
   const bf16_t *k, *v; long kv_bs, kv_rs;
   bf16_t* o; long o_bs;
-  const float* bias_row;
+  const float* bias_row; long bias_ld;
   const uint8_t* key_mask; long mask_ld;
   float scale;
 };
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
     if (k < p.Nk) {
       s *= p.scale;
-      if (p.bias_row) s += p.bias_row[(long)h * p.Nk + k];
+      if (p.bias_row) s += p.bias_row[(long)h * p.bias_ld + k];
       if (p.key_mask && p.key_mask[(long)b * p.mask_ld + k] == 0) s = -3.0e38f;
       const float mn = fmaxf(m, s);
       const float alpha = __expf(m - mn), pr = __expf(s - mn);
@@ -132,7 +132,7 @@ extern "C" int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream) {
   DecP p;
   p.B = a->B; p.H = a->H; p.Nk = a->Nk; p.q = (const bf16_t*)a->q; p.q_bs = a->q_bs;
   p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.kv_bs = a->kv_bs; p.kv_rs = a->kv_rs;
-  p.o = (bf16_t*)a->o; p.o_bs = a->o_bs; p.bias_row = a->bias_row; p.key_mask = a->key_mask; p.mask_ld = a->mask_ld;
+  p.o = (bf16_t*)a->o; p.o_bs = a->o_bs; p.bias_row = a->bias_row; p.bias_ld = a->bias_ld ? a->bias_ld : a->Nk; p.key_mask = a->key_mask; p.mask_ld = a->mask_ld;
   p.scale = a->scale;
   hipLaunchKernelGGL(decode_attn_kernel, dim3(p.B * p.H), dim3(256), 0, (hipStream_t)stream, p);
   V2S_LAUNCH_CHECK();

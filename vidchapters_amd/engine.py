@@ -1,0 +1,702 @@
+"""Hand-orchestrated forward/backward of the Vid2Seq hot path as a sequence of C-ABI HIP kernel launches.
+
+Maps to the reference as follows:
+  V1-V3  model/vit.py:117-133,73-76,38-55,16-22      -> Engine.vit_forward / vit_backward
+  T1-T9  model/modeling_t5.py:263-277,397-460,462-588,598-656,304-354,670-769,930-1138
+                                                      -> Engine._self_attn / _cross_attn / _ffn (+ *_bwd), _stack_*
+  T10/11 model/modeling_t5.py:845-868,1587-1738       -> Engine.t5_loss_forward / t5_loss_backward
+  A1     model/vid2seq.py:58-98                       -> Engine.forward
+  D1-D3  transformers 4.28 greedy_search (vid2seq.py:150-162) -> Engine.greedy
+
+PyTorch supplies device buffers (torch.empty), the stream, int64 index prep (shift/mask, a few elements) and
+the autograd hook; all floating-point work runs in libvid2seq_hip.so.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as L
+from .arena import ParamArena
+
+
+def _bucket_lut(nq: int, nk: int, bidirectional: bool, num_buckets: int, max_distance: int) -> torch.Tensor:
+    """int32 LUT over relative positions d = k - q, d in [-(nq-1), nk-1], computed on the host exactly as the
+    reference does (modeling_t5.py:397-443: torch float32 log) so that bucket edges agree bit for bit."""
+    rel = torch.arange(-(nq - 1), nk, dtype=torch.long)
+    out = torch.zeros_like(rel)
+    nb = num_buckets
+    if bidirectional:
+        nb //= 2
+        out = out + (rel > 0).long() * nb
+        n = rel.abs()
+    else:
+        n = (-rel).clamp(min=0)
+    exact = nb // 2
+    big = exact + (torch.log(n.float() / exact) / math.log(max_distance / exact) * (nb - exact)).long()
+    big = big.clamp(max=nb - 1)
+    return (out + torch.where(n < exact, n, big)).to(torch.int32)
+
+
+class _Rec(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class Engine:
+    def __init__(self, model, device: torch.device):
+        self.model = model
+        self.device = device
+        self.cfg = model.cfg
+        c = self.cfg
+        self.d, self.inner, self.H, self.ff, self.V = c.d_model, c.inner, c.heads, c.d_ff, c.vocab
+        self.ldv = (self.V + 7) // 8 * 8
+        self.vd, self.vH, self.vmlp = model.vit_dim, model.vit_heads, model.vit_mlp
+        L.lib()                                                   # fail loudly if the HIP library is missing
+        self.arena = ParamArena(self._arena_order(), device)
+        assert self.arena.adjacent(*[self._sa("encoder", 0) + w for w in ("q.weight", "k.weight", "v.weight")])
+        self._luts: Dict[Tuple[int, int, bool], torch.Tensor] = {}
+        self._seed = 0x1234
+        self._site = 0
+        self._ws: Dict[str, torch.Tensor] = {}
+        # autograd anchor: the coarse Functions take it as an input so that their outputs get a grad_fn even though
+        # parameter gradients are written straight into the arena (backward returns None for it)
+        self.anchor = torch.zeros(1, device=device, requires_grad=True)
+        self.arena.refresh_shadow(force=True)
+
+    # ------------------------------------------------------------------------------------------ names / arena order
+    @staticmethod
+    def _sa(stack: str, i: int) -> str:
+        return f"t5_model.{stack}.block.{i}.layer.0.SelfAttention."
+
+    @staticmethod
+    def _ca(i: int) -> str:
+        return f"t5_model.decoder.block.{i}.layer.1.EncDecAttention."
+
+    @staticmethod
+    def _ln(stack: str, i: int, j: int) -> str:
+        return f"t5_model.{stack}.block.{i}.layer.{j}.layer_norm.weight"
+
+    @staticmethod
+    def _ffp(stack: str, i: int) -> str:
+        return f"t5_model.{stack}.block.{i}.layer.{2 if stack == 'decoder' else 1}.DenseReluDense."
+
+    def _arena_order(self):
+        """Parameters in (approximately) the order their gradients complete during backward, q|k|v adjacent."""
+        named = dict(self.model.named_parameters())
+        order: List[str] = []
+        c = self.cfg
+        for stack, n in (("decoder", c.n_dec), ("encoder", c.n_enc)):
+            order.append(f"t5_model.{stack}.final_layer_norm.weight")
+            ffj = 2 if stack == "decoder" else 1
+            for i in reversed(range(n)):
+                order += [self._ffp(stack, i) + "wi.weight", self._ffp(stack, i) + "wo.weight", self._ln(stack, i, ffj)]
+                if stack == "decoder":
+                    order += [self._ca(i) + w for w in ("q.weight", "k.weight", "v.weight", "o.weight")]
+                    order.append(self._ln(stack, i, 1))
+                order += [self._sa(stack, i) + w for w in ("q.weight", "k.weight", "v.weight", "o.weight")]
+                order.append(self._ln(stack, i, 0))
+                if i == 0:
+                    order.append(self._sa(stack, i) + "relative_attention_bias.weight")
+        if self.model.proj_v2t is not None:
+            order += ["proj_v2t.weight", "proj_v2t.bias"]
+        order += ["visual_encoder.norm.weight", "visual_encoder.norm.bias"]
+        for i in reversed(range(self.model.vit_depth)):
+            p = f"visual_encoder.blocks.{i}."
+            order += [p + s for s in ("mlp.fc2.weight", "mlp.fc2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "norm2.weight",
+                                      "norm2.bias", "attn.proj.weight", "attn.proj.bias", "attn.qkv.weight", "attn.qkv.bias",
+                                      "norm1.weight", "norm1.bias")]
+        order += ["visual_encoder.pos_embed", "t5_model.shared.weight"]
+        missing = set(named) - set(order)
+        assert not missing, f"parameters without an arena slot: {sorted(missing)[:5]}"
+        return [(n, named[n]) for n in order]
+
+    # ------------------------------------------------------------------------------------------ small helpers
+    def _bf(self, *shape) -> torch.Tensor:
+        return torch.empty(*shape, dtype=torch.bfloat16, device=self.device)
+
+    def _f32(self, *shape) -> torch.Tensor:
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def _partial(self, rows: int, cols: int) -> torch.Tensor:
+        n = L.norm_partial_floats(rows, cols)
+        t = self._ws.get("norm_partial")
+        if t is None or t.numel() < n:
+            t = self._ws["norm_partial"] = self._f32(n)
+        return t
+
+    def _next_seed(self) -> int:
+        self._site += 1
+        return (self._seed * 0x9E3779B1 + self._site * 0x85EBCA6B) & 0xFFFFFFFF
+
+    def _lut(self, nq: int, nk: int, bidirectional: bool) -> torch.Tensor:
+        key = (nq, nk, bidirectional)
+        if key not in self._luts:
+            self._luts[key] = _bucket_lut(nq, nk, bidirectional, self.cfg.buckets, self.cfg.max_distance).to(self.device)
+        return self._luts[key]
+
+    def _drop(self, x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+        if p <= 0.0:
+            return x
+        y = torch.empty_like(x)
+        L.dropout(x, y, x.numel(), p, seed)
+        return y
+
+    # linear helpers ------------------------------------------------------------------------------------------
+    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, wname: str, n_out: int, n_in: int, rows: int, ld_dy=None, ld_x=None,
+               alpha: float = 1.0, shape=None) -> None:
+        """dW[n_out, n_in] += alpha * dy[rows, n_out]^T @ x[rows, n_in]  (fp32 accumulate into the gradient arena)."""
+        L.gemm(dy, x, self.arena.g(wname, shape), n_out, n_in, rows, transA=True, transB=True,
+               lda=ld_dy if ld_dy is not None else n_out, ldb=ld_x if ld_x is not None else n_in, ldc=n_in,
+               accumulate=True, alpha=alpha)
+
+    def _dgrad(self, dy: torch.Tensor, w: torch.Tensor, rows: int, n_in: int, n_out: int, out=None, ld_dy=None, **epi):
+        """dx[rows, n_in] = dy[rows, n_out] @ W[n_out, n_in]."""
+        dx = out if out is not None else self._bf(rows, n_in)
+        L.gemm(dy, w, dx, rows, n_in, n_out, transB=True, lda=ld_dy if ld_dy is not None else n_out, ldb=n_in, **epi)
+        return dx
+
+    # ========================================================================================== T5 sublayers (forward)
+    def _self_attn(self, stack: str, i: int, h, B: int, N: int, bias_diag, key_mask, causal: bool, p: float, tape):
+        a = self.arena
+        M, d, inner = B * N, self.d, self.inner
+        n = self._bf(M, d); rstd = self._f32(M)
+        lnw = a.f(self._ln(stack, i, 0))
+        L.rmsnorm_fwd(h, lnw, n, rstd, M, d, self.cfg.eps)
+        qkv = self._bf(M, 3 * inner)
+        L.gemm(n, a.w(self._sa(stack, i) + "q.weight", (3 * inner, d)), qkv, M, 3 * inner, d)
+        ctx = self._bf(M, inner)
+        ml = self._f32(B, self.H, N, 2) if tape is not None else None
+        seed_a = self._next_seed()
+        st = (N * 3 * inner, 3 * inner)
+        args = L.attn_args(B, self.H, N, N, qkv, qkv[:, inner:], qkv[:, 2 * inner:], ctx, st, st, st, (N * inner, inner),
+                           ml=ml, scale=1.0, bias_diag=bias_diag, key_mask=key_mask, causal=causal, dropout_p=p,
+                           dropout_seed=seed_a)
+        L.attn_fwd(args)
+        out = self._bf(M, d)
+        seed_o = self._next_seed()
+        L.gemm(ctx, a.w(self._sa(stack, i) + "o.weight"), out, M, d, inner, residual=h, dropout_p=p, dropout_seed=seed_o)
+        if tape is not None:
+            tape.append(_Rec(kind="self", stack=stack, i=i, h=h, n=n, rstd=rstd, qkv=qkv, ctx=ctx, ml=ml, args=args,
+                             B=B, N=N, p=p, seed_o=seed_o))
+        return out
+
+    def _cross_attn(self, i: int, h, B: int, Nq: int, mem, S: int, mem_mask, p: float, tape, kv=None):
+        a = self.arena
+        Mq, Mk, d, inner = B * Nq, B * S, self.d, self.inner
+        n = self._bf(Mq, d); rstd = self._f32(Mq)
+        L.rmsnorm_fwd(h, a.f(self._ln("decoder", i, 1)), n, rstd, Mq, d, self.cfg.eps)
+        q = self._bf(Mq, inner)
+        L.gemm(n, a.w(self._ca(i) + "q.weight"), q, Mq, inner, d)
+        if kv is None:
+            kv = self._bf(Mk, 2 * inner)
+            L.gemm(mem, a.w(self._ca(i) + "k.weight", (2 * inner, d)), kv, Mk, 2 * inner, d)
+        ctx = self._bf(Mq, inner)
+        ml = self._f32(B, self.H, Nq, 2) if tape is not None else None
+        seed_a = self._next_seed()
+        kst = (S * 2 * inner, 2 * inner)
+        args = L.attn_args(B, self.H, Nq, S, q, kv, kv[:, inner:], ctx, (Nq * inner, inner), kst, kst, (Nq * inner, inner),
+                           ml=ml, scale=1.0, key_mask=mem_mask, dropout_p=p, dropout_seed=seed_a)
+        L.attn_fwd(args)
+        out = self._bf(Mq, d)
+        seed_o = self._next_seed()
+        L.gemm(ctx, a.w(self._ca(i) + "o.weight"), out, Mq, d, inner, residual=h, dropout_p=p, dropout_seed=seed_o)
+        if tape is not None:
+            tape.append(_Rec(kind="cross", i=i, h=h, n=n, rstd=rstd, q=q, kv=kv, ctx=ctx, ml=ml, args=args, mem=mem,
+                             B=B, Nq=Nq, S=S, p=p, seed_o=seed_o))
+        return out
+
+    def _ffn(self, stack: str, i: int, h, M: int, p: float, tape):
+        a = self.arena
+        d, ff = self.d, self.ff
+        j = 2 if stack == "decoder" else 1
+        n = self._bf(M, d); rstd = self._f32(M)
+        L.rmsnorm_fwd(h, a.f(self._ln(stack, i, j)), n, rstd, M, d, self.cfg.eps)
+        u = self._bf(M, ff)
+        seed_u, seed_o = self._next_seed(), self._next_seed()
+        L.gemm(n, a.w(self._ffp(stack, i) + "wi.weight"), u, M, ff, d, act=L.ACT_RELU, dropout_p=p, dropout_seed=seed_u)
+        out = self._bf(M, d)
+        L.gemm(u, a.w(self._ffp(stack, i) + "wo.weight"), out, M, d, ff, residual=h, dropout_p=p, dropout_seed=seed_o)
+        if tape is not None:
+            tape.append(_Rec(kind="ffn", stack=stack, i=i, h=h, n=n, rstd=rstd, u=u, M=M, p=p, seed_u=seed_u, seed_o=seed_o))
+        return out
+
+    def _final_norm(self, stack: str, h, M: int, p: float, tape):
+        n = self._bf(M, self.d); rstd = self._f32(M)
+        L.rmsnorm_fwd(h, self.arena.f(f"t5_model.{stack}.final_layer_norm.weight"), n, rstd, M, self.d, self.cfg.eps)
+        seed = self._next_seed()
+        out = self._drop(n, p, seed)
+        if tape is not None:
+            tape.append(_Rec(kind="final", stack=stack, h=h, rstd=rstd, M=M, p=p, seed=seed))
+        return out
+
+    def _embed(self, ids: torch.Tensor, p: float, tape):
+        n = ids.numel()
+        out = self._bf(n, self.d)
+        seed = self._next_seed()
+        flat = ids.reshape(-1).contiguous()
+        L.embed_fwd(flat, self.arena.w("t5_model.shared.weight"), out, n, self.d, self.V, p, seed)
+        if tape is not None:
+            tape.append(_Rec(kind="embed", ids=flat, n=n, p=p, seed=seed))
+        return out
+
+    # ========================================================================================== T5 sublayers (backward)
+    def _self_attn_bwd(self, r, dh, dbias_diag):
+        a = self.arena
+        B, N, M, d, inner = r.B, r.N, r.B * r.N, self.d, self.inner
+        sa = self._sa(r.stack, r.i)
+        df = self._drop(dh, r.p, r.seed_o)
+        self._wgrad(df, r.ctx, sa + "o.weight", d, inner, M)
+        dctx = self._dgrad(df, a.w(sa + "o.weight"), M, inner, d)
+        dqkv = self._bf(M, 3 * inner)
+        delta = self._f32(B, self.H, N)
+        st = (N * 3 * inner, 3 * inner)
+        L.attn_bwd(r.args, dctx, (N * inner, inner), delta, dqkv, dqkv[:, inner:], dqkv[:, 2 * inner:], st, st, st,
+                   dbias_diag=dbias_diag)
+        self._wgrad(dqkv, r.n, sa + "q.weight", 3 * inner, d, M, shape=(3 * inner, d))
+        dn = self._dgrad(dqkv, a.w(sa + "q.weight", (3 * inner, d)), M, d, 3 * inner)
+        dx = self._bf(M, d)
+        ln = self._ln(r.stack, r.i, 0)
+        L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), self._partial(M, d), M, d)
+        return dx
+
+    def _cross_attn_bwd(self, r, dh, dmem, first: bool):
+        a = self.arena
+        B, Nq, S, d, inner = r.B, r.Nq, r.S, self.d, self.inner
+        Mq, Mk = B * Nq, B * S
+        ca = self._ca(r.i)
+        df = self._drop(dh, r.p, r.seed_o)
+        self._wgrad(df, r.ctx, ca + "o.weight", d, inner, Mq)
+        dctx = self._dgrad(df, a.w(ca + "o.weight"), Mq, inner, d)
+        dq = self._bf(Mq, inner); dkv = self._bf(Mk, 2 * inner)
+        delta = self._f32(B, self.H, Nq)
+        kst = (S * 2 * inner, 2 * inner)
+        L.attn_bwd(r.args, dctx, (Nq * inner, inner), delta, dq, dkv, dkv[:, inner:], (Nq * inner, inner), kst, kst)
+        self._wgrad(dq, r.n, ca + "q.weight", inner, d, Mq)
+        dn = self._dgrad(dq, a.w(ca + "q.weight"), Mq, d, inner)
+        self._wgrad(dkv, r.mem, ca + "k.weight", 2 * inner, d, Mk, shape=(2 * inner, d))
+        # dmem accumulates over the decoder layers (residual add in the GEMM epilogue, in place)
+        self._dgrad(dkv, a.w(ca + "k.weight", (2 * inner, d)), Mk, d, 2 * inner, out=dmem,
+                    **({} if first else dict(residual=dmem)))
+        dx = self._bf(Mq, d)
+        ln = self._ln("decoder", r.i, 1)
+        L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), self._partial(Mq, d), Mq, d)
+        return dx
+
+    def _ffn_bwd(self, r, dh):
+        a = self.arena
+        M, d, ff = r.M, self.d, self.ff
+        fp = self._ffp(r.stack, r.i)
+        df = self._drop(dh, r.p, r.seed_o)
+        self._wgrad(df, r.u, fp + "wo.weight", d, ff, M)
+        du = self._dgrad(df, a.w(fp + "wo.weight"), M, ff, d, dact=L.ACT_RELU, z=r.u, dropout_p=r.p, dropout_seed=r.seed_u)
+        self._wgrad(du, r.n, fp + "wi.weight", ff, d, M)
+        dn = self._dgrad(du, a.w(fp + "wi.weight"), M, d, ff)
+        dx = self._bf(M, d)
+        ln = self._ln(r.stack, r.i, 2 if r.stack == "decoder" else 1)
+        L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), self._partial(M, d), M, d)
+        return dx
+
+    def _final_norm_bwd(self, r, dout):
+        a = self.arena
+        name = f"t5_model.{r.stack}.final_layer_norm.weight"
+        dn = self._drop(dout, r.p, r.seed)
+        dx = self._bf(r.M, self.d)
+        L.rmsnorm_bwd(r.h, a.f(name), r.rstd, dn, dx, None, a.g(name), self._partial(r.M, self.d), r.M, self.d)
+        return dx
+
+    def _embed_bwd(self, r, dh):
+        L.embed_bwd(r.ids, dh, self.arena.g("t5_model.shared.weight"), r.n, self.d, self.V, r.p, r.seed)
+
+    # ========================================================================================== T5 stacks
+    def _bias_diag(self, stack: str, nq: int, nk: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        lut = self._lut(nq, nk, stack == "encoder")
+        diag = self._f32(self.H, nq + nk - 1)
+        L.bias_diag_fwd(self.arena.f(self._sa(stack, 0) + "relative_attention_bias.weight"), lut, diag, self.H, nq + nk - 1,
+                        self.cfg.buckets)
+        return diag, lut
+
+    def encoder_forward(self, ids: torch.Tensor, mask_u8: torch.Tensor, p: float, tape):
+        B, Lx = ids.shape
+        h = self._embed(ids, p, tape)
+        diag, _ = self._bias_diag("encoder", Lx, Lx)
+        for i in range(self.cfg.n_enc):
+            h = self._self_attn("encoder", i, h, B, Lx, diag, mask_u8, False, p, tape)
+            h = self._ffn("encoder", i, h, B * Lx, p, tape)
+        return self._final_norm("encoder", h, B * Lx, p, tape)
+
+    def decoder_forward(self, dec_ids, dec_mask_u8, mem, S: int, mem_mask_u8, p: float, tape):
+        B, Lo = dec_ids.shape
+        h = self._embed(dec_ids, p, tape)
+        diag, _ = self._bias_diag("decoder", Lo, Lo)
+        for i in range(self.cfg.n_dec):
+            h = self._self_attn("decoder", i, h, B, Lo, diag, dec_mask_u8, True, p, tape)
+            h = self._cross_attn(i, h, B, Lo, mem, S, mem_mask_u8, p, tape)
+            h = self._ffn("decoder", i, h, B * Lo, p, tape)
+        return self._final_norm("decoder", h, B * Lo, p, tape)
+
+    def _stack_backward(self, tape: List[_Rec], dout, stack: str, nq: int, dmem=None):
+        """Replays ``tape`` (records of one stack) in reverse.  Returns nothing: parameter gradients go to the arena,
+        the cross-attention memory gradient to ``dmem``."""
+        a = self.arena
+        lut = self._lut(nq, nq, stack == "encoder")
+        ddiag = torch.zeros(self.H, 2 * nq - 1, dtype=torch.float32, device=self.device)
+        dh = dout
+        first_cross = True
+        for r in reversed(tape):
+            if r.kind == "final":
+                dh = self._final_norm_bwd(r, dh)
+            elif r.kind == "ffn":
+                dh = self._ffn_bwd(r, dh)
+            elif r.kind == "cross":
+                dh = self._cross_attn_bwd(r, dh, dmem, first_cross)
+                first_cross = False
+            elif r.kind == "self":
+                dh = self._self_attn_bwd(r, dh, ddiag)
+            elif r.kind == "embed":
+                self._embed_bwd(r, dh)
+        L.bias_bucket_bwd(ddiag, lut, a.g(self._sa(stack, 0) + "relative_attention_bias.weight"), self.H, 2 * nq - 1,
+                          self.cfg.buckets)
+
+    # ========================================================================================== temporal ViT
+    def vit_forward(self, video: torch.Tensor, tape):
+        """model/vit.py:117-133.  video: [B, T, C] (fp32 or bf16) -> bf16 [B*T, d_model]."""
+        a, m = self.arena, self.model
+        B, T, C = video.shape
+        assert C == self.vd, f"feature dim {C} != embed_dim {self.vd}"
+        M, p = B * T, (m.vis_drop if m.training else 0.0)
+        if video.dtype == torch.float32:
+            xb = self._bf(M, C)
+            L.cast_bf16(video.contiguous().view(-1), xb, M * C)
+        else:
+            xb = video.contiguous().view(M, C)
+        pos = a.w("visual_encoder.pos_embed", (m.num_features, C))
+        idx = None
+        if T != m.num_features:       # nearest-neighbour resize (vit.py:119-123): cold path, plain index ops
+            idx = torch.floor(torch.arange(T, device=self.device, dtype=torch.float32) * (m.num_features / T)).long()
+            idx = idx.clamp_(max=m.num_features - 1)
+            pos = pos.index_select(0, idx).contiguous()
+        x = self._bf(M, C)
+        L.add_bcast(xb, pos, x, M * C, T * C)
+        seed0 = self._next_seed()
+        x = self._drop(x, p, seed0)
+        recs = []
+        Hh, mlp = self.vH, self.vmlp
+        for i in range(m.vit_depth):
+            pre = f"visual_encoder.blocks.{i}."
+            n1 = self._bf(M, C); mean1 = self._f32(M); rstd1 = self._f32(M)
+            L.layernorm_fwd(x, a.f(pre + "norm1.weight"), a.f(pre + "norm1.bias"), n1, mean1, rstd1, M, C, 1e-5)
+            qkv = self._bf(M, 3 * C)
+            L.gemm(n1, a.w(pre + "attn.qkv.weight"), qkv, M, 3 * C, C, bias=a.f(pre + "attn.qkv.bias"))
+            ctx = self._bf(M, C)
+            ml = self._f32(B, Hh, T, 2) if tape is not None else None
+            seed_a, seed_p, seed_u, seed_2 = (self._next_seed() for _ in range(4))
+            st = (T * 3 * C, 3 * C)
+            args = L.attn_args(B, Hh, T, T, qkv, qkv[:, C:], qkv[:, 2 * C:], ctx, st, st, st, (T * C, C), ml=ml,
+                               scale=(C // Hh) ** -0.5, dropout_p=p, dropout_seed=seed_a)
+            L.attn_fwd(args)
+            x1 = self._bf(M, C)
+            L.gemm(ctx, a.w(pre + "attn.proj.weight"), x1, M, C, C, bias=a.f(pre + "attn.proj.bias"), residual=x,
+                   dropout_p=p, dropout_seed=seed_p)
+            n2 = self._bf(M, C); mean2 = self._f32(M); rstd2 = self._f32(M)
+            L.layernorm_fwd(x1, a.f(pre + "norm2.weight"), a.f(pre + "norm2.bias"), n2, mean2, rstd2, M, C, 1e-5)
+            u = self._bf(M, mlp); upre = self._bf(M, mlp) if tape is not None else None
+            L.gemm(n2, a.w(pre + "mlp.fc1.weight"), u, M, mlp, C, bias=a.f(pre + "mlp.fc1.bias"), act=L.ACT_GELU, pre=upre,
+                   dropout_p=p, dropout_seed=seed_u)
+            x2 = self._bf(M, C)
+            L.gemm(u, a.w(pre + "mlp.fc2.weight"), x2, M, C, mlp, bias=a.f(pre + "mlp.fc2.bias"), residual=x1,
+                   dropout_p=p, dropout_seed=seed_2)
+            if tape is not None:
+                recs.append(_Rec(pre=pre, x=x, n1=n1, mean1=mean1, rstd1=rstd1, qkv=qkv, ctx=ctx, args=args, x1=x1, n2=n2,
+                                 mean2=mean2, rstd2=rstd2, u=u, upre=upre, seed_p=seed_p, seed_u=seed_u, seed_2=seed_2))
+            x = x2
+        out = self._bf(M, C); meanf = self._f32(M); rstdf = self._f32(M)
+        L.layernorm_fwd(x, a.f("visual_encoder.norm.weight"), a.f("visual_encoder.norm.bias"), out, meanf, rstdf, M, C, 1e-5)
+        vis = out
+        if m.proj_v2t is not None:
+            vis = self._bf(M, self.d)
+            L.gemm(out, a.w("proj_v2t.weight"), vis, M, self.d, C, bias=a.f("proj_v2t.bias"))
+        if tape is not None:
+            tape.update(B=B, T=T, M=M, p=p, seed0=seed0, idx=idx, recs=recs, xf=x, meanf=meanf, rstdf=rstdf, normed=out)
+        return vis
+
+    def vit_backward(self, tape, dvis: torch.Tensor) -> None:
+        a, m = self.arena, self.model
+        B, T, M, p, C, mlp, Hh = tape["B"], tape["T"], tape["M"], tape["p"], self.vd, self.vmlp, self.vH
+        dvis = dvis.contiguous().view(M, -1)
+        if m.proj_v2t is not None:
+            L.colsum(dvis, M, self.d, a.g("proj_v2t.bias"))
+            self._wgrad(dvis, tape["normed"], "proj_v2t.weight", self.d, C, M)
+            dvis = self._dgrad(dvis, a.w("proj_v2t.weight"), M, C, self.d)
+        dx = self._bf(M, C)
+        L.layernorm_bwd(tape["xf"], a.f("visual_encoder.norm.weight"), tape["meanf"], tape["rstdf"], dvis, dx, None,
+                        a.g("visual_encoder.norm.weight"), a.g("visual_encoder.norm.bias"), self._partial(M, C), M, C)
+        for r in reversed(tape["recs"]):
+            pre = r.pre
+            df2 = self._drop(dx, p, r.seed_2)
+            L.colsum(df2, M, C, a.g(pre + "mlp.fc2.bias"))
+            self._wgrad(df2, r.u, pre + "mlp.fc2.weight", C, mlp, M)
+            du = self._dgrad(df2, a.w(pre + "mlp.fc2.weight"), M, mlp, C, dact=L.ACT_GELU, z=r.upre, dropout_p=p,
+                             dropout_seed=r.seed_u)
+            L.colsum(du, M, mlp, a.g(pre + "mlp.fc1.bias"))
+            self._wgrad(du, r.n2, pre + "mlp.fc1.weight", mlp, C, M)
+            dn2 = self._dgrad(du, a.w(pre + "mlp.fc1.weight"), M, C, mlp)
+            dx1 = self._bf(M, C)
+            L.layernorm_bwd(r.x1, a.f(pre + "norm2.weight"), r.mean2, r.rstd2, dn2, dx1, dx, a.g(pre + "norm2.weight"),
+                            a.g(pre + "norm2.bias"), self._partial(M, C), M, C)
+            df1 = self._drop(dx1, p, r.seed_p)
+            L.colsum(df1, M, C, a.g(pre + "attn.proj.bias"))
+            self._wgrad(df1, r.ctx, pre + "attn.proj.weight", C, C, M)
+            dctx = self._dgrad(df1, a.w(pre + "attn.proj.weight"), M, C, C)
+            dqkv = self._bf(M, 3 * C); delta = self._f32(B, Hh, T)
+            st = (T * 3 * C, 3 * C)
+            L.attn_bwd(r.args, dctx, (T * C, C), delta, dqkv, dqkv[:, C:], dqkv[:, 2 * C:], st, st, st)
+            L.colsum(dqkv, M, 3 * C, a.g(pre + "attn.qkv.bias"))
+            self._wgrad(dqkv, r.n1, pre + "attn.qkv.weight", 3 * C, C, M)
+            dn1 = self._dgrad(dqkv, a.w(pre + "attn.qkv.weight"), M, C, 3 * C)
+            dx0 = self._bf(M, C)
+            L.layernorm_bwd(r.x, a.f(pre + "norm1.weight"), r.mean1, r.rstd1, dn1, dx0, dx1, a.g(pre + "norm1.weight"),
+                            a.g(pre + "norm1.bias"), self._partial(M, C), M, C)
+            dx = dx0
+        dx = self._drop(dx, p, tape["seed0"])
+        gpos = a.g("visual_encoder.pos_embed", (m.num_features, C))
+        if tape["idx"] is None:
+            L.bcast_grad(dx, gpos, M * C, T * C)
+        else:
+            tmp = torch.zeros(T, C, dtype=torch.float32, device=self.device)
+            L.bcast_grad(dx, tmp, M * C, T * C)
+            gpos.index_add_(0, tape["idx"], tmp)
+
+    # ========================================================================================== loss head
+    def t5_loss_forward(self, vis, input_ids, input_mask, output_ids, output_mask, tape):
+        """Encoder on the ASR tokens, [video ; text] memory, decoder on the shifted targets, tied LM head and
+        label-smoothed CE (vid2seq.py:63-98 -> modeling_t5.py:1587-1738).  ``vis``: bf16 [B, T, d] or None."""
+        m, c = self.model, self.cfg
+        train = m.training
+        pe, pd = (m.enc_drop if train else 0.0), (m.dec_drop if train else 0.0)
+        B = output_ids.shape[0]
+        enc_tape, dec_tape = ([], []) if tape is not None else (None, None)
+        parts, masks = [], []
+        T = 0
+        if m.use_video:
+            T = vis.shape[1]
+            parts.append(vis.view(B, T, self.d))
+            masks.append(torch.ones(B, T, dtype=torch.uint8, device=self.device))
+        Lx = 0
+        if m.use_speech:
+            Lx = input_ids.shape[1]
+            in_mask = input_mask.to(torch.uint8).contiguous()
+            enc = self.encoder_forward(input_ids, in_mask, pe, enc_tape)
+            parts.append(enc.view(B, Lx, self.d))
+            masks.append(in_mask)
+        S = T + Lx
+        if len(parts) == 2:                 # torch.cat of vid2seq.py:78-79 (pure data movement)
+            mem = torch.cat(parts, 1).view(B * S, self.d)
+            mem_mask = torch.cat(masks, 1).contiguous()
+        else:
+            mem, mem_mask = parts[0].contiguous().view(B * S, self.d), masks[0]
+        # integer prep (vid2seq.py:86-88, modeling_t5.py:845-868): a few KB of int64
+        targets = output_ids.masked_fill(output_ids == c.pad_id, -100)
+        dec_in = torch.full_like(targets, c.pad_id)
+        dec_in[:, 1:] = targets[:, :-1]
+        dec_in[:, 0] = c.dec_start_id
+        dec_in = dec_in.masked_fill(dec_in == -100, c.pad_id)
+        Lo = dec_in.shape[1]
+        hs = self.decoder_forward(dec_in, output_mask.to(torch.uint8).contiguous(), mem, S, mem_mask, pd, dec_tape)
+        Md = B * Lo
+        logits = self._f32(Md, self.ldv)
+        alpha = self.d ** -0.5                                   # tie_word_embeddings rescale (modeling_t5.py:1709-1712)
+        L.gemm(hs, self.arena.w("t5_model.shared.weight"), logits, Md, self.V, self.d, ldc=self.ldv, alpha=alpha)
+        labels = targets.reshape(-1).contiguous()
+        row = self._f32(Md, 2)
+        acc = torch.zeros(2, dtype=torch.float32, device=self.device)      # (loss_sum, count)
+        L.ce_fwd(logits, self.ldv, labels, Md, self.V, m.label_smoothing, row, acc[0:1], acc[1:2])
+        loss = acc[0] / acc[1]
+        if tape is not None:
+            tape.update(enc=enc_tape, dec=dec_tape, B=B, T=T, Lx=Lx, Lo=Lo, S=S, hs=hs, logits=logits, labels=labels, row=row,
+                        acc=acc, alpha=alpha)
+        return loss
+
+    def t5_loss_backward(self, tape, gloss: torch.Tensor, after_decoder=None, after_encoder=None) -> Optional[torch.Tensor]:
+        """Returns d(loss)/d(vis) (bf16 [B, T, d]) or None.  ``after_decoder`` / ``after_encoder`` are called once the
+        gradients of that stack are complete (data-parallel all-reduce hooks)."""
+        m = self.model
+        B, T, Lx, Lo, S, d = tape["B"], tape["T"], tape["Lx"], tape["Lo"], tape["S"], self.d
+        Md = B * Lo
+        gscale = (gloss.reshape(1).float() / tape["acc"][1:2]).contiguous()
+        dlog = self._bf(Md, self.ldv)
+        L.ce_bwd(tape["logits"], self.ldv, tape["labels"], tape["row"], Md, self.V, m.label_smoothing, gscale, dlog, self.ldv)
+        tape["logits"] = None
+        E = self.arena.w("t5_model.shared.weight")
+        self._wgrad(dlog, tape["hs"], "t5_model.shared.weight", self.V, d, Md, ld_dy=self.ldv, alpha=tape["alpha"])
+        dhs = self._bf(Md, d)
+        L.gemm(dlog, E, dhs, Md, d, self.V, transB=True, lda=self.ldv, ldb=d, alpha=tape["alpha"])
+        del dlog
+        dmem = self._bf(B * S, d)
+        self._stack_backward(tape["dec"], dhs, "decoder", Lo, dmem=dmem)
+        if after_decoder is not None:
+            after_decoder()
+        dmem3 = dmem.view(B, S, d)
+        if m.use_speech:
+            denc = dmem3[:, T:].contiguous().view(B * Lx, d) if T else dmem
+            self._stack_backward(tape["enc"], denc, "encoder", Lx)
+        if after_encoder is not None:
+            after_encoder()
+        if m.use_video:
+            return dmem3[:, :T].contiguous() if Lx else dmem3
+        return None
+
+    # ========================================================================================== public forward
+    def prepare(self) -> None:
+        """Bring the bf16 shadow weights up to date and make sure param.grad views exist."""
+        self.arena.refresh_shadow()
+
+    def forward(self, video, input_tokenized, output_tokenized):
+        m = self.model
+        self.prepare()
+        need_grad = torch.is_grad_enabled()
+        vis = None
+        video_dict = None
+        if m.use_video:
+            if isinstance(video, dict):
+                vis, atts = video["video"], video["atts_vis"]
+            else:
+                vis = _VitFn.apply(self.anchor, self, video, need_grad)
+                atts = torch.ones(vis.shape[:-1], dtype=torch.long, device=self.device)
+            video_dict = {"video": vis, "atts_vis": atts}
+        in_ids = input_tokenized["input_ids"] if m.use_speech else None
+        in_mask = input_tokenized["attention_mask"] if m.use_speech else None
+        loss = _T5LossFn.apply(self.anchor, self, vis, in_ids, in_mask, output_tokenized["input_ids"], output_tokenized["attention_mask"],
+                               need_grad)
+        return {"loss": loss}, video_dict
+
+    def zero_grad(self) -> None:
+        self.arena.grad.zero_()
+        self.arena.attach_grads()
+
+    def _begin_backward(self) -> None:
+        """If the caller dropped the gradients (optimizer.zero_grad(set_to_none=True)) start from a zeroed arena."""
+        if self.arena.attach_grads():
+            self.arena.grad.zero_()
+
+    # ========================================================================================== decoding
+    @torch.no_grad()
+    def encode(self, video, input_tokenized):
+        m = self.model
+        self.prepare()
+        B = video.shape[0] if m.use_video else input_tokenized["input_ids"].shape[0]
+        parts, masks = [], []
+        if m.use_video:
+            T = video.shape[1]
+            parts.append(self.vit_forward(video, None).view(B, T, self.d))
+            masks.append(torch.ones(B, T, dtype=torch.uint8, device=self.device))
+        if m.use_speech:
+            ids = input_tokenized["input_ids"]
+            im = input_tokenized["attention_mask"].to(torch.uint8).contiguous()
+            parts.append(self.encoder_forward(ids, im, 0.0, None).view(B, ids.shape[1], self.d))
+            masks.append(im)
+        mem = torch.cat(parts, 1).contiguous() if len(parts) == 2 else parts[0].contiguous()
+        mask = torch.cat(masks, 1).contiguous() if len(masks) == 2 else masks[0]
+        return mem, mask
+
+    @torch.no_grad()
+    def greedy(self, video, input_tokenized, max_new_tokens: int = 256) -> torch.Tensor:
+        """HF-4.28 greedy_search semantics on a static KV cache: the cross K/V of every layer are
+        projected once; the self K/V grow in place (no torch.cat, no cache reorder)."""
+        a, c = self.arena, self.cfg
+        mem, mem_mask = self.encode(video, input_tokenized)
+        B, S, d = mem.shape
+        inner, H, nl = self.inner, self.H, c.n_dec
+        mem2 = mem.view(B * S, d)
+        cross = []
+        for i in range(nl):
+            kv = self._bf(B * S, 2 * inner)
+            L.gemm(mem2, a.w(self._ca(i) + "k.weight", (2 * inner, d)), kv, B * S, 2 * inner, d)
+            cross.append(kv)
+        maxlen = max_new_tokens
+        cache = [self._bf(B, maxlen, 2 * inner) for _ in range(nl)]
+        diag, _ = self._bias_diag("decoder", maxlen, maxlen)           # [H, 2*maxlen-1]; row t = diag[:, maxlen-1-t + k]
+        seq = torch.full((B, maxlen + 1), c.pad_id, dtype=torch.long, device=self.device)
+        seq[:, 0] = c.dec_start_id
+        unfinished = torch.ones(B, dtype=torch.int32, device=self.device)
+        nxt = torch.empty(B, dtype=torch.long, device=self.device)
+        logits = self._f32(B, self.ldv)
+        E = a.w("t5_model.shared.weight")
+        n = self._bf(B, d); rstd = self._f32(B)
+        qkv = self._bf(B, 3 * inner); q = self._bf(B, inner); ctx = self._bf(B, inner); u = self._bf(B, self.ff)
+        steps = 0
+        for t in range(maxlen):
+            h = self._bf(B, d)
+            L.embed_fwd(seq[:, t].contiguous(), E, h, B, d, self.V)
+            bias_row = diag[:, maxlen - 1 - t:]
+            for i in range(nl):
+                sa, ca, fp = self._sa("decoder", i), self._ca(i), self._ffp("decoder", i)
+                L.rmsnorm_fwd(h, a.f(self._ln("decoder", i, 0)), n, rstd, B, d, c.eps)
+                L.gemm(n, a.w(sa + "q.weight", (3 * inner, d)), qkv, B, 3 * inner, d)
+                L.kv_append(qkv[:, inner:], 3 * inner, cache[i], maxlen * 2 * inner, 2 * inner, B, 2 * inner, t)
+                L.decode_attn(B, H, t + 1, qkv, 3 * inner, cache[i], cache[i][:, :, inner:], maxlen * 2 * inner, 2 * inner,
+                              ctx, inner, bias_row=bias_row, bias_ld=2 * maxlen - 1)
+                h2 = self._bf(B, d)
+                L.gemm(ctx, a.w(sa + "o.weight"), h2, B, d, inner, residual=h)
+                L.rmsnorm_fwd(h2, a.f(self._ln("decoder", i, 1)), n, rstd, B, d, c.eps)
+                L.gemm(n, a.w(ca + "q.weight"), q, B, inner, d)
+                L.decode_attn(B, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
+                              key_mask=mem_mask, mask_ld=S)
+                h3 = self._bf(B, d)
+                L.gemm(ctx, a.w(ca + "o.weight"), h3, B, d, inner, residual=h2)
+                L.rmsnorm_fwd(h3, a.f(self._ln("decoder", i, 2)), n, rstd, B, d, c.eps)
+                L.gemm(n, a.w(fp + "wi.weight"), u, B, self.ff, d, act=L.ACT_RELU)
+                h = self._bf(B, d)
+                L.gemm(u, a.w(fp + "wo.weight"), h, B, d, self.ff, residual=h3)
+            L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, B, d, c.eps)
+            L.gemm(n, E, logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
+            L.argmax_step(logits, self.ldv, B, self.V, nxt, unfinished, c.eos_id, c.pad_id)
+            seq[:, t + 1] = nxt
+            steps = t + 1
+            if int(unfinished.max().item()) == 0:          # same per-step stop test as HF greedy_search
+                break
+        return seq[:, :steps + 1]
+
+    def beam_search(self, video, input_tokenized, num_beams: int, max_new_tokens: int, length_penalty: float):
+        raise NotImplementedError("beam search (num_beams > 1) is not implemented in the HIP decoder yet; "
+                                  "call generate(num_beams=1)")
+
+
+# ==============================================================================================================
+# autograd hooks (coarse: one node for the ViT, one for T5 encoder+decoder+loss)
+# ==============================================================================================================
+class _VitFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, eng: Engine, video: torch.Tensor, need_grad: bool):
+        tape = {} if need_grad else None
+        vis = eng.vit_forward(video, tape)
+        ctx.eng, ctx.tape = eng, tape
+        return vis.view(video.shape[0], video.shape[1], eng.d)
+
+    @staticmethod
+    def backward(ctx, dvis):
+        eng = ctx.eng
+        eng._begin_backward()
+        eng.vit_backward(ctx.tape, dvis.to(torch.bfloat16))
+        ctx.tape = None
+        return None, None, None, None
+
+
+class _T5LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, eng: Engine, vis, in_ids, in_mask, out_ids, out_mask, need_grad: bool):
+        tape = {} if need_grad else None
+        loss = eng.t5_loss_forward(vis, in_ids, in_mask, out_ids, out_mask, tape)
+        ctx.eng, ctx.tape = eng, tape
+        ctx.has_vis = vis is not None
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        eng = ctx.eng
+        eng._begin_backward()
+        dvis = eng.t5_loss_backward(ctx.tape, gloss)
+        ctx.tape = None
+        return None, None, (dvis if ctx.has_vis else None), None, None, None, None, None

@@ -52,7 +52,7 @@ class AdamArgs(C.Structure):
 
 class DecodeAttnArgs(C.Structure):
     _fields_ = [("B", _i32), ("H", _i32), ("Nk", _i32), ("q", _vp), ("q_bs", _i64), ("k", _vp), ("v", _vp),
-                ("kv_bs", _i64), ("kv_rs", _i64), ("o", _vp), ("o_bs", _i64), ("bias_row", _vp),
+                ("kv_bs", _i64), ("kv_rs", _i64), ("o", _vp), ("o_bs", _i64), ("bias_row", _vp), ("bias_ld", _i64),
                 ("key_mask", _vp), ("mask_ld", _i64), ("scale", _f32)]
 
 
@@ -135,6 +135,41 @@ def _need(t: torch.Tensor, dtype, what: str) -> None:
         raise RuntimeError(f"{what}: expected dtype {dtype}, got {t.dtype}")
 
 
+# --------------------------------------------------------------------------------------------- live kernel timing
+class KernelTimer:
+    """HIP-event timing of individual launches on the stream they are issued on (bench.py roofline leg).
+    Usage: ``with KernelTimer() as kt: step()`` then ``kt.summary()`` -> {tag: (launches, total_ms, total_work)}."""
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def end(self, tag: str, work: float, e0) -> None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(torch.cuda.current_stream())
+        self.records.append((tag, work, e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, work, e0, e1 in self.records:
+            n, ms, w = out.get(tag, (0, 0.0, 0.0))
+            out[tag] = (n + 1, ms + e0.elapsed_time(e1), w + work)
+        return out
+
+
 # --------------------------------------------------------------------------------------------- GEMM
 def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, K: int, *, transA=False, transB=False,
          lda=None, ldb=None, ldc=None, accumulate=False, alpha=1.0, bias=None, act=ACT_NONE, pre=None, dact=ACT_NONE,
@@ -162,7 +197,12 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, 
     a.ldr = ldr if ldr is not None else N
     a.dropout_p = dropout_p
     a.dropout_seed = dropout_seed & 0xFFFFFFFF
+    kt = KernelTimer.active
+    if kt is not None:
+        e0 = kt.begin()
     _check(lib().v2s_gemm(C.byref(a), stream_ptr()), "v2s_gemm")
+    if kt is not None:
+        kt.end("gemm_wgrad" if transA else ("gemm_dgrad" if transB else "gemm_nt"), 2.0 * M * N * K, e0)
 
 
 def colsum(X: torch.Tensor, M: int, N: int, out: torch.Tensor, accumulate=True, ldx=None) -> None:
@@ -215,7 +255,12 @@ def attn_args(B, H, Nq, Nk, q, k, v, o, q_st, k_st, v_st, o_st, *, ml=None, scal
 
 
 def attn_fwd(a: AttnArgs) -> None:
+    kt = KernelTimer.active
+    if kt is not None:
+        e0 = kt.begin()
     _check(lib().v2s_attn_fwd(C.byref(a), stream_ptr()), "v2s_attn_fwd")
+    if kt is not None:
+        kt.end("attn_fwd", 4.0 * a.B * a.H * a.Nq * a.Nk * 64, e0)
 
 
 def attn_bwd(a: AttnArgs, d_o, do_st, delta, dq, dk, dv, dq_st, dk_st, dv_st, dbias_diag=None) -> None:
@@ -225,7 +270,12 @@ def attn_bwd(a: AttnArgs, d_o, do_st, delta, dq, dk, dv, dq_st, dk_st, dv_st, db
     a.dq_bs, a.dq_rs = dq_st; a.dk_bs, a.dk_rs = dk_st; a.dv_bs, a.dv_rs = dv_st
     a.dbias_diag = ptr(dbias_diag)
     _check(lib().v2s_attn_delta(C.byref(a), delta.data_ptr(), stream_ptr()), "v2s_attn_delta")
+    kt = KernelTimer.active
+    if kt is not None:
+        e0 = kt.begin()
     _check(lib().v2s_attn_bwd(C.byref(a), stream_ptr()), "v2s_attn_bwd")
+    if kt is not None:
+        kt.end("attn_bwd", 8.0 * a.B * a.H * a.Nq * a.Nk * 64, e0)   # algorithmic: dV, dP, dQ, dK (recompute excluded)
 
 
 def bias_diag_fwd(table, lut, out, H, n, num_buckets):
@@ -300,11 +350,11 @@ def timetoken_renorm(emb, emb_bf16, V, d, num_bins, ws):
            "v2s_timetoken_renorm")
 
 
-def decode_attn(B, H, Nk, q, q_bs, k, v, kv_bs, kv_rs, o, o_bs, bias_row=None, key_mask=None, mask_ld=0, scale=1.0):
+def decode_attn(B, H, Nk, q, q_bs, k, v, kv_bs, kv_rs, o, o_bs, bias_row=None, bias_ld=0, key_mask=None, mask_ld=0, scale=1.0):
     a = DecodeAttnArgs()
     a.B, a.H, a.Nk = B, H, Nk
     a.q, a.q_bs, a.k, a.v, a.kv_bs, a.kv_rs = q.data_ptr(), q_bs, k.data_ptr(), v.data_ptr(), kv_bs, kv_rs
-    a.o, a.o_bs, a.bias_row, a.key_mask, a.mask_ld, a.scale = o.data_ptr(), o_bs, ptr(bias_row), ptr(key_mask), mask_ld, scale
+    a.o, a.o_bs, a.bias_row, a.bias_ld, a.key_mask, a.mask_ld, a.scale = o.data_ptr(), o_bs, ptr(bias_row), bias_ld, ptr(key_mask), mask_ld, scale
     _check(lib().v2s_decode_attn(C.byref(a), stream_ptr()), "v2s_decode_attn")
 
 

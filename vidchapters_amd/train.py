@@ -1,0 +1,180 @@
+"""Training step of the reference's dvc.py loop (dvc.py:71-133), MI355X-native.
+
+``Trainer.step(batch)`` reproduces the recipe exactly -- generative pass, optional denoising pass on the cached
+ViT output, ``loss = generative*l1 + denoising*l2``, clip_grad_norm_, Adam, time-token renorm (twice on the tied
+tensor), LR schedule (util/misc.py:15-42) -- but drives the engine directly (no autograd graph) and runs the
+optimizer as ONE fused kernel over the flat parameter arena.
+
+Data parallelism (new capability: the reference never wraps the model in DDP): one process per
+GPU, every rank holds a replica, the flat fp32 gradient arena is all-reduced (SUM, scaled by 1/world inside the
+Adam kernel) in large contiguous slices on a side stream as soon as the backward pass has finished the
+corresponding parameters (decoder -> encoder+embedding -> ViT), overlapping RCCL over xGMI with the rest of
+backward.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import lib as L
+
+
+def lr_at(step: int, total: int, base_lr: float, schedule: str = "", warmup_frac: float = 0.1) -> float:
+    """util/misc.py:15-42 (adjust_learning_rate)."""
+    warm = round(warmup_frac * total)
+    if schedule == "":
+        return base_lr
+    if step < warm:
+        return base_lr * float(step) / float(max(1, warm))
+    if schedule == "linear_with_warmup":
+        return base_lr * max(0.0, float(total - step) / float(max(1, total - warm)))
+    if schedule == "cosine_with_warmup":
+        return base_lr * (1 + math.cos(math.pi * float(step - warm) / float(max(1, total - warm)))) / 2
+    raise NotImplementedError(schedule)
+
+
+class GradSync:
+    """Slice-wise asynchronous all-reduce of the gradient arena on a dedicated stream."""
+
+    def __init__(self, arena, group=None, chunk_elems: int = 32 * 1024 * 1024):
+        self.arena = arena
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.chunk = chunk_elems            # 128 MiB of fp32 per collective: few, large xGMI transfers
+        self.stream = torch.cuda.Stream() if self.world > 1 else None
+        self.works: List = []
+
+    def range_of(self, first: str, last: str) -> Tuple[int, int]:
+        a = self.arena
+        n = 1
+        for s in a.shapes[last]:
+            n *= s
+        return a.offsets[first], a.offsets[last] + n
+
+    def ready(self, start: int, end: int) -> None:
+        """Gradients in arena[start:end] are final on the current stream: reduce them in the background."""
+        if self.world == 1 or end <= start:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            o = start
+            while o < end:
+                e = min(end, o + self.chunk)
+                self.works.append(dist.all_reduce(self.arena.grad[o:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                o = e
+
+    def finish(self) -> None:
+        if self.world == 1:
+            return
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class Trainer:
+    def __init__(self, model, lr: float = 3e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 clip_max_norm: float = 1.0, generative: float = 1.0, denoising: float = 1.0, schedule: str = "",
+                 fraction_warmup_steps: float = 0.1, num_training_steps: int = 1, group=None):
+        self.model = model
+        self.eng = model.engine()
+        a = self.eng.arena
+        dev = self.eng.device
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.clip, self.gen, self.den = clip_max_norm, generative, denoising
+        self.schedule, self.warm, self.total = schedule, fraction_warmup_steps, num_training_steps
+        self.m = torch.zeros(a.numel, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(a.numel, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        self.sync = GradSync(a, group)
+        self.world = self.sync.world
+        self._sq_ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        self._gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._renorm_ws = torch.empty(self.eng.V + 2, dtype=torch.float32, device=dev)
+        # arena ranges in backward-completion order (engine._arena_order)
+        names = a.names
+        first_enc = next(i for i, n in enumerate(names) if n.startswith("t5_model.encoder."))
+        first_vis = next(i for i, n in enumerate(names) if not n.startswith("t5_model."))
+        self._r_dec = self.sync.range_of(names[0], names[first_enc - 1])
+        self._r_enc = self.sync.range_of(names[first_enc], names[first_vis - 1])
+        self._r_shared = self.sync.range_of("t5_model.shared.weight", "t5_model.shared.weight")
+        self._r_vis = self.sync.range_of(names[first_vis], "visual_encoder.pos_embed")
+
+    # ------------------------------------------------------------------------------------------------
+    def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """One optimizer step on ``batch`` = {video, input_ids, output_ids[, den_input_ids, den_output_ids]}.
+        Returns device scalars (no host sync)."""
+        m, eng = self.model, self.eng
+        assert m.training, "call model.train() first"
+        eng.prepare()
+        eng.arena.grad.zero_()
+        losses: Dict[str, torch.Tensor] = {}
+        vtape: Dict = {}
+        vis = None
+        if m.use_video:
+            vis = eng.vit_forward(batch["video"], vtape).view(batch["video"].shape[0], batch["video"].shape[1], eng.d)
+        tapes = []
+        if self.gen:
+            t1: Dict = {}
+            ids = batch["input_ids"]
+            losses["loss"] = eng.t5_loss_forward(vis, ids, ids != 0, batch["output_ids"], batch["output_ids"] != 0, t1)
+            tapes.append((t1, self.gen))
+        if self.den:
+            t2: Dict = {}
+            ids = batch["den_input_ids"]
+            losses["denoising_loss"] = eng.t5_loss_forward(vis, ids, ids != 0, batch["den_output_ids"],
+                                                           batch["den_output_ids"] != 0, t2)
+            tapes.append((t2, self.den))
+        # backward: later passes first; parameter gradients accumulate in the arena
+        dvis = None
+        for k, (tape, coef) in enumerate(reversed(tapes)):
+            last = (k == len(tapes) - 1)
+            g = torch.full((1,), float(coef), dtype=torch.float32, device=eng.device)
+            dv = self._t5_backward(tape, g, last)
+            if dv is not None:
+                if dvis is None:
+                    dvis = dv
+                else:
+                    L.add(dvis, dv, dvis, dvis.numel())
+        if m.use_video:
+            eng.vit_backward(vtape, dvis)
+            self.sync.ready(*self._r_vis)
+        self.sync.finish()
+        self._optimizer_step()
+        return losses
+
+    def _t5_backward(self, tape, g, last: bool):
+        """eng.t5_loss_backward with the DP hooks placed between the stacks (only on the last pass, when the
+        gradients of a stack are final)."""
+        eng = self.eng
+        if not last or self.world == 1:
+            return eng.t5_loss_backward(tape, g)
+        return eng.t5_loss_backward(tape, g, after_decoder=lambda: self.sync.ready(*self._r_dec),
+                                    after_encoder=lambda: (self.sync.ready(*self._r_enc), self.sync.ready(*self._r_shared)))
+
+    def _optimizer_step(self) -> None:
+        eng, a = self.eng, self.eng.arena
+        self.step_count += 1
+        k = self.step_count - 1
+        # dvc.py:128-133 adjusts the LR *after* optimizer.step(): step 0 runs at args.lr, step k at schedule(k-1)
+        lr = self.lr if k == 0 else lr_at(k - 1, self.total, self.lr, self.schedule, self.warm)
+        self._gnorm_sq.zero_()
+        if self.clip > 0:
+            L.sqnorm(a.grad, a.numel, self._sq_ws, self._gnorm_sq)
+        L.adam_step(a.master, self.m, self.v, a.grad, a.shadow, a.numel, lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                    self.step_count, gnorm_sq=self._gnorm_sq if self.clip > 0 else None, max_norm=self.clip,
+                    grad_scale=1.0 / self.world)
+        if self.model.num_bins:
+            emb = a.f("t5_model.shared.weight")
+            embb = a.w("t5_model.shared.weight")
+            for _ in range(2):      # dvc.py:120-126 renormalises `shared` and then `lm_head` -- the same tied tensor
+                L.timetoken_renorm(emb, embb, eng.V, eng.d, self.model.num_bins, self._renorm_ws)
+
+    def grad_norm(self) -> torch.Tensor:
+        """Global L2 norm of the (world-averaged) gradient of the last step, as a device scalar."""
+        return self._gnorm_sq.sqrt() / self.world
