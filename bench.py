@@ -33,6 +33,15 @@ def flops_per_sample(T=100, L=1000, Lo=256, V=32200, d=768, ff=3072, n_enc=12, n
     return vit + enc + dec + head
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries only the JSON line)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +74,7 @@ def main():
     tok = SyntheticTokenizer(32100, 100)
     model = Vid2Seq(a.model, tokenizer=tok, vis_drop=a.dropout, enc_drop=a.dropout, dec_drop=a.dropout, init_seed=1234,
                     device=dev).train()
+    log(f"model built: {sum(p.numel() for p in model.parameters()) / 1e6:.1f} M parameters")
     trainer = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=a.denoising)
     batch = {k: v.to(dev) for k, v in synth.make_batch(B, T, Lx, Lo, len(tok), 1234 + rank, 768, denoising=a.denoising > 0).items()}
     batch["video"] = batch["video"].to(torch.bfloat16)       # features resident in HBM as bf16 (documented in DESIGN.md)
@@ -74,8 +84,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    log("batch ready; warmup")
+    for i in range(a.warmup):
         losses = trainer.step(batch)
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done, loss {float(losses['loss'].item()):.4f}")
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -87,6 +100,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(losses["loss"].item())
+    log(f"timed region done: {dt / a.steps * 1e3:.1f} ms/step")
     ms_per_step = dt / a.steps * 1e3
     value = world * B * a.steps / dt
 
@@ -113,6 +127,7 @@ def main():
         with L.KernelTimer() as kt:
             trainer.step(batch)
         summ = kt.summary()
+        log("roofline leg done")
         tag = max(summ, key=lambda k: summ[k][1])
         n, ms, work = summ[tag]
         ach = work / (ms / 1e3) / 1e12
@@ -127,7 +142,9 @@ def main():
                                                for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        log("cpu baseline (oracle on host cores) ...")
         out["cpu_baseline"] = cpu_baseline(model, tok, Lx, Lo)
+        log("cpu baseline done")
 
     if rank == 0:
         print(json.dumps(out))

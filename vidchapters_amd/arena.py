@@ -99,9 +99,11 @@ class ParamArena:
 
     def refresh_shadow(self, force: bool = False) -> None:
         """bf16 shadow <- fp32 master when any parameter was modified in place by torch code
-        (external optimizer, load_state_dict, dvc.py's div_): views share the base's version counter."""
+        (external optimizer, load_state_dict, dvc.py's div_)."""
         from . import lib as L
-        v = self.master._version
+        # ``p.data = view`` keeps each Parameter's own version counter, so in-place updates made through the
+        # Parameters (optimizer.step, div_, load_state_dict) show up there, not on the arena tensor
+        v = self.master._version + sum(self.params[n]._version for n in self.names)
         if force or v != self._seen_version:
             L.cast_bf16(self.master, self.shadow, self.numel)
             self._seen_version = v

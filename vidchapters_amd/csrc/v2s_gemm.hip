@@ -289,8 +289,9 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   const long N8 = (a->N + 7) / 8 * 8, K8 = (a->K + 7) / 8 * 8, M8 = (a->M + 7) / 8 * 8;
   V2S_CHECK((a->lda % 8) == 0 && (a->ldb % 8) == 0 && (a->ldc % 8) == 0, V2S_ERR_ALIGN, "v2s_gemm: leading dims must be multiples of 8");
   V2S_CHECK(a->ldc >= N8, V2S_ERR_SHAPE, "v2s_gemm: ldc (%ld) must cover N rounded up to 8 (%ld)", (long)a->ldc, N8);
-  V2S_CHECK((a->K % 8) == 0 || (!a->transA && a->transB && a->lda >= K8), V2S_ERR_SHAPE,
-            "v2s_gemm: ragged K (%d) only for transA=0,transB=1 with lda >= %ld", a->K, K8);
+  // K is walked in 8-element chunks only by NON-transposed operands; transposed ones predicate k exactly
+  V2S_CHECK((a->K % 8) == 0 || (a->transB && (a->transA || a->lda >= K8)), V2S_ERR_SHAPE,
+            "v2s_gemm: ragged K (%d) needs transB=1 and (transA=1 or lda >= %ld with a zero/finite row pad)", a->K, K8);
   V2S_CHECK(!a->transA || a->lda >= M8, V2S_ERR_SHAPE, "v2s_gemm: transA needs lda >= M rounded up to 8");
   V2S_CHECK(!a->transB || a->ldb >= N8, V2S_ERR_SHAPE, "v2s_gemm: transB needs ldb >= N rounded up to 8");
   V2S_CHECK((a->N % 8) == 0 || (!a->bias && !a->residual && !a->z && !a->pre), V2S_ERR_SHAPE,

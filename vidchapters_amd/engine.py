@@ -409,7 +409,7 @@ class Engine:
             L.gemm(u, a.w(pre + "mlp.fc2.weight"), x2, M, C, mlp, bias=a.f(pre + "mlp.fc2.bias"), residual=x1,
                    dropout_p=p, dropout_seed=seed_2)
             if tape is not None:
-                recs.append(_Rec(pre=pre, x=x, n1=n1, mean1=mean1, rstd1=rstd1, qkv=qkv, ctx=ctx, args=args, x1=x1, n2=n2,
+                recs.append(_Rec(pre=pre, x=x, n1=n1, mean1=mean1, rstd1=rstd1, qkv=qkv, ctx=ctx, ml=ml, args=args, x1=x1, n2=n2,
                                  mean2=mean2, rstd2=rstd2, u=u, upre=upre, seed_p=seed_p, seed_u=seed_u, seed_2=seed_2))
             x = x2
         out = self._bf(M, C); meanf = self._f32(M); rstdf = self._f32(M)

@@ -251,6 +251,8 @@ def attn_args(B, H, Nq, Nk, q, k, v, o, q_st, k_st, v_st, o_st, *, ml=None, scal
     a.ml = ptr(ml); a.scale = scale; a.bias_diag = ptr(bias_diag); a.key_mask = ptr(key_mask)
     a.causal, a.causal_off = int(causal), causal_off
     a.dropout_p, a.dropout_seed = dropout_p, dropout_seed & 0xFFFFFFFF
+    # the struct only carries raw pointers: keep every tensor alive for as long as the struct (backward reuses it)
+    a._refs = (q, k, v, o, ml, bias_diag, key_mask)
     return a
 
 
