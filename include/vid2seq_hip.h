@@ -79,6 +79,8 @@ typedef struct v2s_gemm_args {
   int64_t ldr;
   float dropout_p;      /* 0 = off */
   uint32_t dropout_seed;
+  void* workspace;      /* optional fp32 scratch: enables split-K for few-tile/long-K (weight-gradient) shapes */
+  int64_t workspace_bytes;
 } v2s_gemm_args;
 
 int v2s_gemm(const v2s_gemm_args* args, void* stream);
@@ -142,6 +144,11 @@ typedef struct v2s_attn_args {
   void *dq, *dk, *dv;
   int64_t dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
   float* dbias_diag;      /* fp32 [H][Nq+Nk-1], += ; or NULL */
+  /* optional (backward): every relative position d = k-q <= bias_far_lo shares ONE bias bucket, likewise every
+   * d >= bias_far_hi (T5: +-max_distance).  The gradient mass of those regions is then summed without per-diagonal
+   * resolution and deposited on the diagonals bias_far_lo / bias_far_hi themselves, i.e. dbias_diag is exact after
+   * bucket reduction (v2s_bias_bucket_bwd) but not per diagonal.  Disabled when bias_far_lo >= bias_far_hi (0,0). */
+  int32_t bias_far_lo, bias_far_hi;
 } v2s_attn_args;
 
 int v2s_attn_fwd(const v2s_attn_args* a, void* stream);

@@ -92,6 +92,17 @@ def test_gemm_dgrad_wgrad(M, N, K, tr_mode):
     assert e < 2e-5
 
 
+def test_gemm_splitk_workspace():
+    """Weight-gradient shape (few output tiles, long contraction): split-K through a caller workspace."""
+    Mp, Np, Kc = 768, 256, 8000
+    dY, X = rnd(Kc, Mp, seed=5, scale=0.1), rnd(Kc, Np, seed=6, scale=0.1)
+    ws = torch.empty(8 * Mp * Np, dtype=torch.float32, device=DEV)
+    dW = torch.ones(Mp, Np, dtype=torch.float32, device=DEV)
+    L.gemm(dY, X, dW, Mp, Np, Kc, transA=True, transB=True, accumulate=True, alpha=0.5, workspace=ws)
+    ref = 1.0 + 0.5 * (dY.float().T @ X.float())
+    assert relerr(dW, ref) < 2e-5
+
+
 def test_gemm_epilogues():
     M, N, K = 264, 256, 128
     A, B = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.1)

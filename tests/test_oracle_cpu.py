@@ -1,0 +1,175 @@
+"""CPU tests (no GPU): the oracle against the golden vectors captured from the real reference, the host logic
+(parse_chapters, LR schedule, bucket LUT, synthetic generator, arena bookkeeping) and the C-ABI surface."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vid2seq_ref as R
+from vidchapters_amd import synth
+from vidchapters_amd.parse import parse_chapters
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def params(cfg, seed, grad=False):
+    P = synth.init_params(R.param_shapes(cfg), seed, cfg.d_model, cfg.inner, cfg.d_ff)
+    if grad:
+        for v in P.values():
+            v.requires_grad_(True)
+    return P
+
+
+# ------------------------------------------------------------------------------------------ oracle vs reference goldens
+def test_oracle_functions_vs_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "functions.npz"))
+    rel = torch.from_numpy(g["rel"])
+    assert torch.equal(R.relative_position_bucket(rel, True), torch.from_numpy(g["bucket_bi"]))
+    assert torch.equal(R.relative_position_bucket(rel, False), torch.from_numpy(g["bucket_uni"]))
+    cfg = R.RefConfig.small()
+    assert torch.equal(R.shift_right(torch.from_numpy(g["labels"]), cfg), torch.from_numpy(g["shift_right"]))
+    out = R.rms_norm(torch.from_numpy(g["rms_x"]), torch.from_numpy(g["rms_w"]), 1e-6)
+    assert (out - torch.from_numpy(g["rms_out"])).abs().max() < 1e-6
+    ce = R.smoothed_ce(torch.from_numpy(g["ce_logits"]), torch.from_numpy(g["ce_labels"]), 0.1)
+    assert abs(ce.item() - float(g["ce_loss"])) < 1e-6
+    # SURVEY T2 probe values
+    d = torch.arange(-130, 131, 10)
+    assert R.relative_position_bucket(d, True).tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 8, 0, 24, 26, 27, 28, 29, 29, 30, 30, 30, 31, 31, 31, 31]
+    assert R.relative_position_bucket(torch.arange(-130, 11, 10), False).tolist() == [31, 31, 30, 30, 29, 28, 27, 26, 24, 23, 20, 17, 10, 0, 0]
+
+
+@pytest.mark.parametrize("tag,cfg,seed", [
+    ("small", R.RefConfig.small(), 7),
+    ("small_resize_proj", R.RefConfig.small(vit_dim=64, vit_heads=1, num_features=10), 9),
+])
+def test_oracle_forward_backward_vs_reference(golden_dir, tag, cfg, seed):
+    g = np.load(os.path.join(golden_dir, f"{tag}_forward_backward.npz"))
+    P = params(cfg, seed, grad=True)
+    video, ii, oi = (torch.from_numpy(g[k]) for k in ("video", "input_ids", "output_ids"))
+    logits, tgt, _ = R.vid2seq_logits(P, cfg, video, ii, ii != 0, oi, oi != 0)
+    assert (logits - torch.from_numpy(g["logits"])).abs().max() <= 1e-5          # <= 1e-5 abs on logits
+    loss = R.smoothed_ce(logits, tgt, cfg.label_smoothing)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6 * abs(float(g["loss"])) + 1e-7
+    names = list(P)
+    grads = torch.autograd.grad(loss, [P[k] for k in names])
+    for k, gr in zip(names, grads):
+        want = torch.from_numpy(g["grad:" + k])
+        assert (gr - want).abs().max() <= 2e-4 * (want.abs().max() + 1e-12), k
+
+
+def test_oracle_greedy_vs_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "small_greedy.npz"))
+    cfg = R.RefConfig.small()
+    P = params(cfg, 7)
+    ii = torch.from_numpy(g["input_ids"])
+    seq = R.greedy_generate(P, cfg, torch.from_numpy(g["video"]), ii, ii != 0, int(g["max_new"]))
+    assert torch.equal(seq, torch.from_numpy(g["tokens"]))
+
+
+def test_oracle_train_recipe_vs_reference(golden_dir):
+    """Two steps of the reference's own dvc.train_one_epoch (captured) vs oracle.train_step."""
+    g = np.load(os.path.join(golden_dir, "small_train_recipe.npz"))
+    cfg = R.RefConfig.small()
+    P = params(cfg, 5, grad=True)
+    state = {}
+    for i in range(2):
+        batch = {k.split(":", 1)[1]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"b{i}:")}
+        rec = R.train_step(P, state, cfg, batch, lr=3e-4, clip=0.1)
+        if i == 0:
+            assert abs(rec["losses"]["loss"] - float(g["loss0"])) < 1e-5 and abs(rec["grad_norm"] - float(g["gnorm0"])) < 1e-4
+    for k in g.files:
+        if k.startswith("post:"):
+            assert (P[k[5:]].detach() - torch.from_numpy(g[k]).view_as(P[k[5:]])).abs().max() < 5e-6, k
+
+
+def test_incremental_decoding_equals_full_forward():
+    cfg = R.RefConfig.small()
+    P = params(cfg, 3)
+    b = synth.make_batch(2, 10, 20, 9, cfg.vocab, 3, cfg.vit_dim)
+    with torch.no_grad():
+        mem, mm, _ = R.encode(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0)
+        ids = b["output_ids"].clamp(min=0)
+        ones = torch.ones_like(ids)
+        full, _ = R.t5_decoder(P, cfg, ids, ones, mem, mm)
+        past = None
+        for t in range(ids.shape[1]):
+            h, past = R.t5_decoder(P, cfg, ids[:, t:t + 1], ones[:, :t + 1], mem, mm, past=past, use_cache=True)
+            assert (h[:, 0] - full[:, t]).abs().max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ host logic
+def test_parse_chapters_vs_reference(golden_dir):
+    for case in json.load(open(os.path.join(golden_dir, "parse_chapters.json"))):
+        assert parse_chapters(case["text"], case["duration"], case["num_bins"]) == case["expected"]
+        assert R.parse_chapters(case["text"], case["duration"], case["num_bins"]) == case["expected"]
+
+
+def test_lr_schedule_matches_oracle():
+    from vidchapters_amd.train import lr_at
+    for sched in ("", "linear_with_warmup", "cosine_with_warmup"):
+        for step in (0, 1, 9, 10, 11, 57, 99, 100):
+            assert lr_at(step, 100, 3e-4, sched, 0.1) == R.lr_at(step, 100, 3e-4, sched, 0.1)
+
+
+def test_bucket_lut_matches_oracle():
+    from vidchapters_amd.engine import _bucket_lut
+    for nq, nk, bi in ((1000, 1000, True), (256, 256, False), (7, 9, True), (1, 300, False)):
+        lut = _bucket_lut(nq, nk, bi, 32, 128)
+        rel = torch.arange(-(nq - 1), nk)
+        assert torch.equal(lut.long(), R.relative_position_bucket(rel, bi, 32, 128))
+
+
+def test_synth_is_deterministic_and_shaped():
+    a, b = synth.normal((5, 7), 11, 0.5, 1.0), synth.normal((5, 7), 11, 0.5, 1.0)
+    assert torch.equal(a, b) and a.shape == (5, 7) and a.dtype == torch.float32
+    x = synth.normal((200000,), 3)
+    assert abs(x.mean().item()) < 0.01 and abs(x.std().item() - 1.0) < 0.01
+    ids = synth.token_batch(6, 50, 612, 2)
+    for row in ids:
+        n = int((row != 0).sum())
+        assert 35 <= n <= 50 and row[n - 1] == 1 and (row[n:] == 0).all() and (row[:n - 1] >= 2).all()
+
+
+def test_module_surface_and_state_dict_keys():
+    """State-dict keys/shapes equal the reference's -- they are exactly the oracle's parameter inventory plus
+    the three tied aliases -- and the GPU-only product path fails loudly on CPU instead of falling back."""
+    from vidchapters_amd import SyntheticTokenizer, Vid2Seq
+    cfg = R.RefConfig.small()
+    m = Vid2Seq(dict(d_model=cfg.d_model, d_kv=cfg.d_kv, heads=cfg.heads, d_ff=cfg.d_ff, n_enc=cfg.n_enc, n_dec=cfg.n_dec),
+                num_features=cfg.num_features, embed_dim=cfg.vit_dim, depth=cfg.vit_depth, heads=cfg.vit_heads, mlp_dim=cfg.vit_mlp,
+                tokenizer=SyntheticTokenizer(512, 100), init_seed=7)
+    sd = m.state_dict()
+    want = dict(R.param_shapes(cfg))
+    for a in R.TIED_ALIASES:
+        want[a] = want["t5_model.shared.weight"]
+    assert set(sd) == set(want)
+    for k, shp in want.items():
+        assert tuple(sd[k].shape) == tuple(shp), k
+    assert sd["t5_model.lm_head.weight"].data_ptr() == sd["t5_model.shared.weight"].data_ptr()
+    P = params(cfg, 7)
+    for k, v in P.items():
+        assert torch.equal(sd[k], v), k                       # same deterministic init as the oracle's parameters
+    ids = torch.ones(1, 4, dtype=torch.long)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(1, 10, cfg.vit_dim), {"input_ids": ids, "attention_mask": ids != 0}, {"input_ids": ids, "attention_mask": ids != 0})
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from vidchapters_amd import lib as L
+    header = open(os.path.join(ROOT, "include", "vid2seq_hip.h")).read()
+    declared = set(re.findall(r"\b(v2s_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    so = ctypes.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(so, name), f"{name} declared in include/vid2seq_hip.h but not exported"
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    l = L.lib()
+    assert l.v2s_version() == 1
+    assert l.v2s_set_option(b"no_such_option", 1) != 0 and b"unknown option" in l.v2s_last_error()
+    # argument validation happens on the host before any launch: exercisable without a GPU
+    a = L.GemmArgs()
+    assert l.v2s_gemm(ctypes.byref(a), None) != 0 and b"v2s_gemm" in l.v2s_last_error()

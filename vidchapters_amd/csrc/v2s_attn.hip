@@ -11,13 +11,24 @@
 // other operand reproduces with two ds_read_b64_tr_b16 transpose reads from a row-major LDS tile.
 // One LDS image (32-byte column chunks XOR-swizzled by (row>>1)&3) serves both the ds_read_b128 row
 // fragments and the transpose reads without bank conflicts.
+//
+// head_dim 64 makes these kernels VALU-bound (few MFMA flops per score element), so the per-element work is
+// specialised at compile time (bias / causal / dropout) and per tile at run time:
+//   * "clean" tiles (no masked or out-of-range key, no causal edge) take a branch-free path;
+//   * tiles whose keys are all masked (padding tail) or all in the causal future are skipped outright once
+//     every row of the wave has seen a real key -- their probabilities are exactly 0 then, so the result is
+//     bit-identical to processing them (rows that have seen no real key keep the reference's uniform
+//     distribution semantics and are never skipped);
+//   * the relative-position bias window is staged in LDS in four 1-float-shifted copies so that each lane
+//     fetches its 4 consecutive diagonals with one aligned ds_read_b128.
 #include <math.h>
 #include "v2s_common.h"
 
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr float MASKED2 = -3.0e38f;  // finite stand-in for finfo(float32).min in the log2 domain
+constexpr float MASKED2 = -3.0e38f;     // finite stand-in for finfo(float32).min in the log2 domain
+constexpr float REAL_MIN = -1.0e37f;    // running max above this <=> the row has seen an unmasked key
 constexpr int HD = 64;
 
 struct AttnP {
@@ -36,6 +47,7 @@ struct AttnP {
   bf16_t *dq, *dk, *dv;
   long dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
   float* dbias_diag;
+  int far_lo, far_hi;   // all relative positions <= far_lo (>= far_hi) share one bias bucket
 };
 
 // byte offset of element (row, d) inside a [rows][64] bf16 LDS tile
@@ -97,12 +109,44 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
   return f;
 }
 
-constexpr int KV_TILE = 8192;                   // one [64][64] bf16 tile
-constexpr int STAGE = 2 * KV_TILE + 192 * 4 + 64 + 64 * 16;  // K,V (or Q,dO) + bias window + flags + (m,l,delta,pad)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; x <= ~0 here
+
+// ---- LDS stage layout ---------------------------------------------------------------------------------
+constexpr int KV_TILE = 8192;                 // one [64][64] bf16 tile
+constexpr int OFF_BIAS = 2 * KV_TILE;         // 4 x 192 floats: copy s holds w[i+s] at index i
+constexpr int BIAS_COPY = 192;                // floats per copy
+constexpr int OFF_FLAG = OFF_BIAS + 4 * BIAS_COPY * 4;   // 64 key flags (0 keep, 1 masked, 2 out of range)
+constexpr int OFF_STATE = OFF_FLAG + 64;      // int[2]: OR of flags, AND of (flag != 0)
+constexpr int OFF_MS = OFF_STATE + 16;        // dkv kernel: m[64], 1/l[64], delta[64]
+constexpr int STAGE = OFF_MS + 3 * 64 * 4;    // 20304 -> keep 16-byte multiple
+static_assert(STAGE % 16 == 0 && OFF_MS % 16 == 0 && OFF_BIAS % 16 == 0, "LDS carve alignment");
+
+// bias window write: thread i (< 192) holds w[i]; copy s stores it at index i - s
+__device__ __forceinline__ void bias_store(char* stage, int tid, float w) {
+  float* b = reinterpret_cast<float*>(stage + OFF_BIAS);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (tid - s >= 0) b[s * BIAS_COPY + tid - s] = w;
+}
+// aligned read of w[i0 .. i0+3] for any i0 >= 0
+__device__ __forceinline__ float4 bias_read4(const char* stage, int i0) {
+  const int s = i0 & 3;
+  return *reinterpret_cast<const float4*>(stage + OFF_BIAS + (s * BIAS_COPY + (i0 - s)) * 4);
+}
+
+// flags of one tile -> (any, all) in LDS state words; executed by the first wave (tid < 64)
+__device__ __forceinline__ void state_store(char* stage, int tid, uint32_t flag) {
+  const unsigned long long any = __ballot(flag != 0);
+  if (tid == 0) {
+    int* st = reinterpret_cast<int*>(stage + OFF_STATE);
+    st[0] = any != 0ull;
+    st[1] = any == ~0ull;
+  }
+}
 
 // ====================================================================================== forward
 // block = 4 waves x 32 query rows; loop over 64-key tiles.
-template <bool TR>
+template <bool TR, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
@@ -135,29 +179,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
 
   const int ntiles = (p.Nk + 63) >> 6;
   const float sc2 = p.scale * LOG2E;
+  const int qmin = Q0 + wq0, qmax = qmin + 31;
   uint4 rk[2], rv[2];
   float rbias = 0.f;
-  uint8_t rflag = 0;
+  uint32_t rflag = 0;
 
   auto prefetch = [&](int t) {
     const int k0 = t * 64;
     tile_load(kp, p.k_rs, k0, p.Nk, tid, rk);
     tile_load(vp, p.v_rs, k0, p.Nk, tid, rv);
-    if (p.bias_diag && tid < 192) {
+    if (BIAS && tid < 192) {
       const int idx = k0 - Q0 - 127 + tid + p.Nq - 1;
       rbias = (idx >= 0 && idx < p.Nq + p.Nk - 1) ? p.bias_diag[(long)h * (p.Nq + p.Nk - 1) + idx] * LOG2E : 0.f;
     }
     if (tid < 64) {
       const int k = k0 + tid;
-      rflag = (k >= p.Nk) ? 2 : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1 : 0);
+      rflag = (k >= p.Nk) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
     }
   };
   auto commit = [&](int s) {
     char* st = smem + s * STAGE;
     tile_store(st, tid, rk);
     tile_store(st + KV_TILE, tid, rv);
-    if (tid < 192) reinterpret_cast<float*>(st + 2 * KV_TILE)[tid] = rbias;
-    if (tid < 64) reinterpret_cast<uint8_t*>(st + 2 * KV_TILE + 768)[tid] = rflag;
+    if (BIAS && tid < 192) bias_store(st, tid, rbias);
+    if (tid < 64) {
+      reinterpret_cast<uint8_t*>(st + OFF_FLAG)[tid] = (uint8_t)rflag;
+      state_store(st, tid, rflag);
+    }
   };
 
   prefetch(0);
@@ -167,77 +215,101 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
   for (int t = 0; t < ntiles; ++t) {
     const char* sK = smem + (t & 1) * STAGE;
     const char* sV = sK + KV_TILE;
-    const float* bw = reinterpret_cast<const float*>(sK + 2 * KV_TILE);
-    const uint8_t* fl = reinterpret_cast<const uint8_t*>(sK + 2 * KV_TILE + 768);
     const int k0 = t * 64;
     if (t + 1 < ntiles) prefetch(t + 1);
 
-    f32x4 st[2][4];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) st[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const bf16x8 kf = row_frag(sK, kb * 16, ks, lane);
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], st[qb][kb], 0, 0, 0);
-      }
+    const int* tstate = reinterpret_cast<const int*>(sK + OFF_STATE);
+    const bool any_flag = tstate[0] != 0, all_flag = tstate[1] != 0;
+    const bool future = CAUSAL && (k0 > qmax + p.causal_off);            // every element causally masked
+    const bool edge = CAUSAL && (k0 + 63 > qmin + p.causal_off);         // some element causally masked
+    const bool seen = __all((m[0] > REAL_MIN) && (m[1] > REAL_MIN));     // every row already saw a real key
+    const bool skip = (all_flag || future) && seen;
 
-    bf16x8 pf[2][2];
+    if (!skip) {
+      f32x4 st[2][4];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const int qq = wq0 + qb * 16 + li, q = Q0 + qq;
-      float mx = -INFINITY;
+      for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const uint32_t f4 = *reinterpret_cast<const uint32_t*>(fl + kb * 16 + 4 * g);
+        for (int kb = 0; kb < 4; ++kb) st[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kk = kb * 16 + 4 * g + r;
-          float s = st[qb][kb][r] * sc2;
-          if (p.bias_diag) s += bw[kk + 127 - qq];
-          uint32_t f = (f4 >> (8 * r)) & 0xffu;
-          if (p.causal && (k0 + kk) > q + p.causal_off) f |= 1u;
-          s = (f & 2u) ? -INFINITY : ((f & 1u) ? MASKED2 : s);
-          st[qb][kb][r] = s;
-          mx = fmaxf(mx, s);
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const bf16x8 kf = row_frag(sK, kb * 16, ks, lane);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], st[qb][kb], 0, 0, 0);
         }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m[qb], mx);
-      const float alpha = exp2f(m[qb] - mn);
-      m[qb] = mn;
-      float rs = 0.f;
+
+      bf16x8 pf[2][2];
+      const bool clean = !any_flag && !edge;
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+      for (int qb = 0; qb < 2; ++qb) {
+        const int qq = wq0 + qb * 16 + li, q = Q0 + qq;
+        float mx = -INFINITY;
+        if (clean) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pv = exp2f(st[qb][kb][r] - mn);
-          rs += pv;
-          if (p.p16) {
-            const unsigned long long e = (((unsigned long long)(b * p.H + h) * p.Nq + q) * p.Nk) + (k0 + kb * 16 + 4 * g + r);
-            pv = v2s_keep(e, p.seed, p.p16) ? pv * p.inv_keep : 0.f;
+          for (int kb = 0; kb < 4; ++kb) {
+            float4 bw = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BIAS) bw = bias_read4(sK, kb * 16 + 4 * g + 127 - qq);
+            st[qb][kb][0] = fmaf(st[qb][kb][0], sc2, bw.x);
+            st[qb][kb][1] = fmaf(st[qb][kb][1], sc2, bw.y);
+            st[qb][kb][2] = fmaf(st[qb][kb][2], sc2, bw.z);
+            st[qb][kb][3] = fmaf(st[qb][kb][3], sc2, bw.w);
+            mx = fmaxf(fmaxf(mx, fmaxf(st[qb][kb][0], st[qb][kb][1])), fmaxf(st[qb][kb][2], st[qb][kb][3]));
           }
-          st[qb][kb][r] = pv;
+        } else {
+          const uint8_t* fl = reinterpret_cast<const uint8_t*>(sK + OFF_FLAG);
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
+            const uint32_t f4 = *reinterpret_cast<const uint32_t*>(fl + kb * 16 + 4 * g);
+            float4 bw = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BIAS) bw = bias_read4(sK, kb * 16 + 4 * g + 127 - qq);
+            const float bwv[4] = {bw.x, bw.y, bw.z, bw.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int kk = kb * 16 + 4 * g + r;
+              float s = fmaf(st[qb][kb][r], sc2, bwv[r]);
+              uint32_t f = (f4 >> (8 * r)) & 0xffu;
+              if (CAUSAL && (k0 + kk) > q + p.causal_off) f |= 1u;
+              s = (f & 2u) ? -INFINITY : ((f & 1u) ? MASKED2 : s);
+              st[qb][kb][r] = s;
+              mx = fmaxf(mx, s);
+            }
+          }
         }
-      lsum[qb] = lsum[qb] * alpha + rs;
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m[qb], mx);
+        const float alpha = fast_exp2(m[qb] - mn);
+        m[qb] = mn;
+        float rs = 0.f;
 #pragma unroll
-      for (int db = 0; db < 4; ++db) ot[qb][db] *= alpha;
-      pf[qb][0] = pack_frag(st[qb][0], st[qb][1]);
-      pf[qb][1] = pack_frag(st[qb][2], st[qb][3]);
-    }
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
+          for (int r = 0; r < 4; ++r) {
+            float pv = fast_exp2(st[qb][kb][r] - mn);
+            rs += pv;
+            if (DROP) {
+              const unsigned long long e = (((unsigned long long)(b * p.H + h) * p.Nq + q) * p.Nk) + (k0 + kb * 16 + 4 * g + r);
+              pv = v2s_keep(e, p.seed, p.p16) ? pv * p.inv_keep : 0.f;
+            }
+            st[qb][kb][r] = pv;
+          }
+        lsum[qb] = lsum[qb] * alpha + rs;
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const bf16x8 vf = col_frag<TR>(sV, kh * 32, db * 16, lane);
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) ot[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][kh], ot[qb][db], 0, 0, 0);
+        for (int db = 0; db < 4; ++db) ot[qb][db] *= alpha;
+        pf[qb][0] = pack_frag(st[qb][0], st[qb][1]);
+        pf[qb][1] = pack_frag(st[qb][2], st[qb][3]);
       }
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const bf16x8 vf = col_frag<TR>(sV, kh * 32, db * 16, lane);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) ot[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][kh], ot[qb][db], 0, 0, 0);
+        }
+    }
     if (t + 1 < ntiles) commit((t + 1) & 1);
     __syncthreads();
   }
@@ -290,7 +362,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p, float* _
 
 // ====================================================================================== backward: dQ (+ dbias)
 // same decomposition as the forward: wave = 32 query rows, loop over key tiles.
-template <bool TR>
+// Tiles that are fully masked / fully in the causal future contribute exactly zero to dQ and dbias whenever
+// the row statistics come from a real key (m > REAL_MIN), and are skipped under that condition.
+template <bool TR, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2*STAGE + (Nk+128)*4 (dbias window) bytes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
@@ -298,11 +372,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int qblk = id % nqb, bh = id / nqb, h = bh % p.H, b = bh / p.H;
   const int Q0 = qblk * 128, wq0 = wave * 32;
+  const bool want_dbias = BIAS && p.dbias_diag != nullptr;
   float* dbw = reinterpret_cast<float*>(smem + 2 * STAGE);   // index: (k - q) + (Q0 + 127)  in [0, Nk+127)
   const int ndb = p.Nk + 127;
-  if (p.dbias_diag) {
+  if (want_dbias) {
     for (int i = tid; i < ndb; i += 256) dbw[i] = 0.f;
   }
+  float acc_lo = 0.f, acc_hi = 0.f;    // bias-gradient mass of the two "far" buckets (no per-diagonal resolution needed)
 
   const bf16_t* qp = p.q + (long)b * p.q_bs + h * HD;
   const bf16_t* dop = p.d_o + (long)b * p.do_bs + h * HD;
@@ -324,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
       qf[qb][ks] = __builtin_bit_cast(bf16x8, v);
       dof[qb][ks] = __builtin_bit_cast(bf16x8, w);
     }
-    m2[qb] = 0.f; linv[qb] = 1.f; dl[qb] = 0.f;
+    m2[qb] = 0.f; linv[qb] = 0.f; dl[qb] = 0.f;     // rows >= Nq: linv = 0 => P = 0 => dS = 0
     if (q < p.Nq) {
       const long r = ((long)(b * p.H + h)) * p.Nq + q;
       m2[qb] = p.ml[r * 2];
@@ -332,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
       dl[qb] = p.delta[r];
     }
   }
+  const bool seen = __all((m2[0] > REAL_MIN) && (m2[1] > REAL_MIN));
   f32x4 dqt[2][4];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
@@ -340,28 +417,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 
   const int ntiles = (p.Nk + 63) >> 6;
   const float sc2 = p.scale * LOG2E;
+  const int qmin = Q0 + wq0, qmax = qmin + 31;
   uint4 rk[2], rv[2];
   float rbias = 0.f;
-  uint8_t rflag = 0;
+  uint32_t rflag = 0;
   auto prefetch = [&](int t) {
     const int k0 = t * 64;
     tile_load(kp, p.k_rs, k0, p.Nk, tid, rk);
     tile_load(vp, p.v_rs, k0, p.Nk, tid, rv);
-    if (p.bias_diag && tid < 192) {
+    if (BIAS && tid < 192) {
       const int idx = k0 - Q0 - 127 + tid + p.Nq - 1;
       rbias = (idx >= 0 && idx < p.Nq + p.Nk - 1) ? p.bias_diag[(long)h * (p.Nq + p.Nk - 1) + idx] * LOG2E : 0.f;
     }
     if (tid < 64) {
       const int k = k0 + tid;
-      rflag = (k >= p.Nk) ? 2 : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1 : 0);
+      rflag = (k >= p.Nk) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
     }
   };
   auto commit = [&](int s) {
     char* st = smem + s * STAGE;
     tile_store(st, tid, rk);
     tile_store(st + KV_TILE, tid, rv);
-    if (tid < 192) reinterpret_cast<float*>(st + 2 * KV_TILE)[tid] = rbias;
-    if (tid < 64) reinterpret_cast<uint8_t*>(st + 2 * KV_TILE + 768)[tid] = rflag;
+    if (BIAS && tid < 192) bias_store(st, tid, rbias);
+    if (tid < 64) {
+      reinterpret_cast<uint8_t*>(st + OFF_FLAG)[tid] = (uint8_t)rflag;
+      state_store(st, tid, rflag);
+    }
   };
   prefetch(0);
   commit(0);
@@ -370,65 +451,95 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   for (int t = 0; t < ntiles; ++t) {
     const char* sK = smem + (t & 1) * STAGE;
     const char* sV = sK + KV_TILE;
-    const float* bw = reinterpret_cast<const float*>(sK + 2 * KV_TILE);
-    const uint8_t* fl = reinterpret_cast<const uint8_t*>(sK + 2 * KV_TILE + 768);
     const int k0 = t * 64;
     if (t + 1 < ntiles) prefetch(t + 1);
 
-    f32x4 st[2][4], dp[2][4];
+    const int* tstate = reinterpret_cast<const int*>(sK + OFF_STATE);
+    const bool any_flag = tstate[0] != 0, all_flag = tstate[1] != 0;
+    const bool future = CAUSAL && (k0 > qmax + p.causal_off);
+    const bool edge = CAUSAL && (k0 + 63 > qmin + p.causal_off);
+    const bool skip = (all_flag || future) && seen;
+
+    if (!skip) {
+      f32x4 st[2][4], dp[2][4];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+      for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) { st[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int kb = 0; kb < 4; ++kb) { st[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const bf16x8 kf = row_frag(sK, kb * 16, ks, lane);
-        const bf16x8 vf = row_frag(sV, kb * 16, ks, lane);
+        for (int kb = 0; kb < 4; ++kb) {
+          const bf16x8 kf = row_frag(sK, kb * 16, ks, lane);
+          const bf16x8 vf = row_frag(sV, kb * 16, ks, lane);
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], st[qb][kb], 0, 0, 0);
-          dp[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qb][ks], dp[qb][kb], 0, 0, 0);
-        }
-      }
-    bf16x8 dsf[2][2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const int qq = wq0 + qb * 16 + li, q = Q0 + qq;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const uint32_t f4 = *reinterpret_cast<const uint32_t*>(fl + kb * 16 + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kk = kb * 16 + 4 * g + r;
-          float s = st[qb][kb][r] * sc2;
-          if (p.bias_diag) s += bw[kk + 127 - qq];
-          uint32_t f = (f4 >> (8 * r)) & 0xffu;
-          if (p.causal && (k0 + kk) > q + p.causal_off) f |= 1u;
-          s = (f & 2u) ? -INFINITY : ((f & 1u) ? MASKED2 : s);
-          const float pr = exp2f(s - m2[qb]) * linv[qb];
-          float dpv = dp[qb][kb][r];
-          if (p.p16) {
-            const unsigned long long e = (((unsigned long long)(b * p.H + h) * p.Nq + q) * p.Nk) + (k0 + kk);
-            dpv = v2s_keep(e, p.seed, p.p16) ? dpv * p.inv_keep : 0.f;
+          for (int qb = 0; qb < 2; ++qb) {
+            st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], st[qb][kb], 0, 0, 0);
+            dp[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qb][ks], dp[qb][kb], 0, 0, 0);
           }
-          const float ds = (q < p.Nq) ? pr * (dpv - dl[qb]) : 0.f;
-          st[qb][kb][r] = ds;
-          if (p.dbias_diag && ds != 0.f) atomicAdd(&dbw[(k0 + kk) + 127 - qq], ds);
         }
+      const bool clean = !any_flag && !edge;
+      // bias-gradient routing for this (wave, tile): relative positions d = k - q span [dmin, dmax]
+      const int dmin = k0 - qmax, dmax = k0 + 63 - qmin;
+      const int route = !want_dbias ? 0 : (dmax <= p.far_lo ? 1 : (dmin >= p.far_hi ? 2 : 3));   // 1: far-low, 2: far-high, 3: per diagonal
+      bf16x8 dsf[2][2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int qq = wq0 + qb * 16 + li, q = Q0 + qq;
+        const uint8_t* fl = reinterpret_cast<const uint8_t*>(sK + OFF_FLAG);
+        float lsum_ds = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          float4 bw = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (BIAS) bw = bias_read4(sK, kb * 16 + 4 * g + 127 - qq);
+          const float bwv[4] = {bw.x, bw.y, bw.z, bw.w};
+          uint32_t f4 = 0;
+          if (!clean) f4 = *reinterpret_cast<const uint32_t*>(fl + kb * 16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kk = kb * 16 + 4 * g + r;
+            float s = fmaf(st[qb][kb][r], sc2, bwv[r]);
+            if (!clean) {
+              uint32_t f = (f4 >> (8 * r)) & 0xffu;
+              if (CAUSAL && (k0 + kk) > q + p.causal_off) f |= 1u;
+              s = (f & 2u) ? -INFINITY : ((f & 1u) ? MASKED2 : s);
+            }
+            const float pr = fast_exp2(s - m2[qb]) * linv[qb];
+            float dpv = dp[qb][kb][r];
+            if (DROP) {
+              const unsigned long long e = (((unsigned long long)(b * p.H + h) * p.Nq + q) * p.Nk) + (k0 + kk);
+              dpv = v2s_keep(e, p.seed, p.p16) ? dpv * p.inv_keep : 0.f;
+            }
+            const float ds = pr * (dpv - dl[qb]);
+            st[qb][kb][r] = ds;
+            if (BIAS) {
+              if (route == 3) {
+                const int d = (k0 + kk) - q;
+                if (d <= p.far_lo) acc_lo += ds;
+                else if (d >= p.far_hi) acc_hi += ds;
+                else if (ds != 0.f) atomicAdd(&dbw[(k0 + kk) + 127 - qq], ds);
+              } else {
+                lsum_ds += ds;
+              }
+            }
+          }
+        }
+        if (BIAS) {
+          if (route == 1) acc_lo += lsum_ds;
+          else if (route == 2) acc_hi += lsum_ds;
+        }
+        dsf[qb][0] = pack_frag(st[qb][0], st[qb][1]);
+        dsf[qb][1] = pack_frag(st[qb][2], st[qb][3]);
       }
-      dsf[qb][0] = pack_frag(st[qb][0], st[qb][1]);
-      dsf[qb][1] = pack_frag(st[qb][2], st[qb][3]);
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const bf16x8 ktf = col_frag<TR>(sK, kh * 32, db * 16, lane);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) dqt[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qb][kh], dqt[qb][db], 0, 0, 0);
+        }
     }
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const bf16x8 ktf = col_frag<TR>(sK, kh * 32, db * 16, lane);
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) dqt[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qb][kh], dqt[qb][db], 0, 0, 0);
-      }
     if (t + 1 < ntiles) commit((t + 1) & 1);
     __syncthreads();
   }
@@ -447,9 +558,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
       }
     }
   }
-  if (p.dbias_diag) {
-    // dbw index i <-> (k - q) = i - (Q0 + 127);  global index = (k - q) + Nq - 1
+  if (want_dbias) {
+    // dbw index i <-> (k - q) = i - (Q0 + 127);  global index = (k - q) + Nq - 1.  The far-bucket masses go to the
+    // diagonals far_lo / far_hi themselves (same bucket): dbias_diag is meaningful after bucket reduction.
     float* dst = p.dbias_diag + (long)h * (p.Nq + p.Nk - 1);
+    acc_lo = wave_sum(acc_lo);
+    acc_hi = wave_sum(acc_hi);
+    if (lane == 0) {
+      const int glo = p.far_lo + p.Nq - 1, ghi = p.far_hi + p.Nq - 1;
+      if (acc_lo != 0.f && glo >= 0 && glo < p.Nq + p.Nk - 1) atomicAdd(dst + glo, acc_lo);
+      if (acc_hi != 0.f && ghi >= 0 && ghi < p.Nq + p.Nk - 1) atomicAdd(dst + ghi, acc_hi);
+    }
     for (int i = tid; i < ndb; i += 256) {
       const int gi = i - (Q0 + 127) + p.Nq - 1;
       const float v = dbw[i];
@@ -460,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 
 // ====================================================================================== backward: dK, dV
 // wave = 32 keys (2 key blocks), block = 128 keys, loop over 64-query tiles (Q and dO tiles in LDS).
-template <bool TR>
+template <bool TR, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
@@ -491,6 +610,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     }
     kflag[kb] = (k >= p.Nk) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
   }
+  const bool keys_clean = __all(kflag[0] == 0u && kflag[1] == 0u);
+  const int kmin = K0 + wk0, kmax = kmin + 31;
   f32x4 dkt[2][4], dvt[2][4];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
@@ -501,19 +622,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   const float sc2 = p.scale * LOG2E;
   uint4 rq[2], rdo[2];
   float rbias = 0.f;
-  float rm = 0.f, rl = 1.f, rd = 0.f;
+  float rm = 0.f, rl = 0.f, rd = 0.f;
   // bias window for this (128-key block, 64-query tile): index (k - q) - dmin, dmin = K0 - (q0 + 63); 191 entries
   auto prefetch = [&](int t) {
     const int q0 = t * 64;
     tile_load(qp, p.q_rs, q0, p.Nq, tid, rq);
     tile_load(dop, p.do_rs, q0, p.Nq, tid, rdo);
-    if (p.bias_diag && tid < 192) {
+    if (BIAS && tid < 192) {
       const int idx = K0 - q0 - 63 + tid + p.Nq - 1;
       rbias = (idx >= 0 && idx < p.Nq + p.Nk - 1) ? p.bias_diag[(long)h * (p.Nq + p.Nk - 1) + idx] * LOG2E : 0.f;
     }
     if (tid < 64) {
       const int q = q0 + tid;
-      rm = 0.f; rl = 1.f; rd = 0.f;
+      rm = 0.f; rl = 0.f; rd = 0.f;                 // rows >= Nq: 1/l = 0 => P = 0
       if (q < p.Nq) {
         const long r = ((long)(b * p.H + h)) * p.Nq + q;
         rm = p.ml[r * 2]; rl = 1.0f / p.ml[r * 2 + 1]; rd = p.delta[r];
@@ -524,93 +645,111 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     char* st = smem + s * STAGE;
     tile_store(st, tid, rq);
     tile_store(st + KV_TILE, tid, rdo);
-    if (tid < 192) reinterpret_cast<float*>(st + 2 * KV_TILE)[tid] = rbias;
+    if (BIAS && tid < 192) bias_store(st, tid, rbias);
     if (tid < 64) {
-      float* ms = reinterpret_cast<float*>(st + 2 * KV_TILE + 768 + 64);
+      float* ms = reinterpret_cast<float*>(st + OFF_MS);
       ms[tid] = rm; ms[64 + tid] = rl; ms[128 + tid] = rd;
+      // "every query row of this tile has real statistics": lets all-masked / all-future key blocks skip the tile
+      const unsigned long long real = __ballot(rm > REAL_MIN || rl == 0.f);
+      if (tid == 0) reinterpret_cast<int*>(st + OFF_STATE)[0] = (real == ~0ull);
     }
   };
   prefetch(0);
   commit(0);
   __syncthreads();
 
+  const bool keys_all_masked = __all(kflag[0] != 0u && kflag[1] != 0u);
   for (int t = 0; t < ntiles; ++t) {
     const char* sQ = smem + (t & 1) * STAGE;
     const char* sDO = sQ + KV_TILE;
-    const float* bw = reinterpret_cast<const float*>(sQ + 2 * KV_TILE);
-    const float* ms = reinterpret_cast<const float*>(sQ + 2 * KV_TILE + 768 + 64);
+    const float* ms = reinterpret_cast<const float*>(sQ + OFF_MS);
     const int q0 = t * 64;
     if (t + 1 < ntiles) prefetch(t + 1);
 
-    // two halves of 32 query rows each (keeps the live score registers at 2x2 fragments)
+    const bool rows_real = reinterpret_cast<const int*>(sQ + OFF_STATE)[0] != 0;
+    const bool future = CAUSAL && (kmin > q0 + 63 + p.causal_off);     // every (q, k) pair of this tile is causally masked
+    const bool edge = CAUSAL && (kmax > q0 + p.causal_off);
+    const bool skip = (keys_all_masked || future) && rows_real;
+
+    if (!skip) {
+      const bool clean = keys_clean && !edge && (q0 + 63 < p.Nq);
+      // two halves of 32 query rows each (keeps the live score registers at 2x2 fragments)
 #pragma unroll
-    for (int qh = 0; qh < 2; ++qh) {
-      // S[q][key] and dP[q][key]:  D[row = q = qb*16 + 4g + r][col = key = kb*16 + li]
-      f32x4 st[2][2], dp[2][2];
+      for (int qh = 0; qh < 2; ++qh) {
+        // S[q][key] and dP[q][key]:  D[row = q = qb*16 + 4g + r][col = key = kb*16 + li]
+        f32x4 st[2][2], dp[2][2];
 #pragma unroll
-      for (int qi = 0; qi < 2; ++qi)
+        for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) { st[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          for (int kb = 0; kb < 2; ++kb) { st[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int qi = 0; qi < 2; ++qi) {
+            const bf16x8 qfr = row_frag(sQ, (2 * qh + qi) * 16, ks, lane);
+            const bf16x8 dfr = row_frag(sDO, (2 * qh + qi) * 16, ks, lane);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+              st[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kb][ks], st[qi][kb], 0, 0, 0);
+              dp[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[kb][ks], dp[qi][kb], 0, 0, 0);
+            }
+          }
+        // P (dropped) -> dp registers become Pd ; st registers become dS
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
-          const bf16x8 qfr = row_frag(sQ, (2 * qh + qi) * 16, ks, lane);
-          const bf16x8 dfr = row_frag(sDO, (2 * qh + qi) * 16, ks, lane);
+          const int qb = 2 * qh + qi;
+          const float4 mv = *reinterpret_cast<const float4*>(ms + qb * 16 + 4 * g);
+          const float4 lv = *reinterpret_cast<const float4*>(ms + 64 + qb * 16 + 4 * g);
+          const float4 dv4 = *reinterpret_cast<const float4*>(ms + 128 + qb * 16 + 4 * g);
+          const float mr[4] = {mv.x, mv.y, mv.z, mv.w}, lr[4] = {lv.x, lv.y, lv.z, lv.w}, dr[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb) {
-            st[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kb][ks], st[qi][kb], 0, 0, 0);
-            dp[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[kb][ks], dp[qi][kb], 0, 0, 0);
-          }
-        }
-      // P (dropped) -> dp registers become Pd ; st registers become dS
-#pragma unroll
-      for (int qi = 0; qi < 2; ++qi) {
-        const int qb = 2 * qh + qi;
-        const float4 mv = *reinterpret_cast<const float4*>(ms + qb * 16 + 4 * g);
-        const float4 lv = *reinterpret_cast<const float4*>(ms + 64 + qb * 16 + 4 * g);
-        const float4 dv4 = *reinterpret_cast<const float4*>(ms + 128 + qb * 16 + 4 * g);
-        const float mr[4] = {mv.x, mv.y, mv.z, mv.w}, lr[4] = {lv.x, lv.y, lv.z, lv.w}, dr[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const int kk = wk0 + kb * 16 + li, k = K0 + kk;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int qq = qb * 16 + 4 * g + r, q = q0 + qq;
-            float s = st[qi][kb][r] * sc2;
-            if (p.bias_diag) s += bw[kk + 63 - qq];
-            uint32_t f = kflag[kb];
-            if (p.causal && k > q + p.causal_off) f |= 1u;
-            s = (f & 2u) ? -INFINITY : ((f & 1u) ? MASKED2 : s);
-            const float pr = (q < p.Nq) ? exp2f(s - mr[r]) * lr[r] : 0.f;
-            float dpv = dp[qi][kb][r];
-            float pd = pr;
-            if (p.p16) {
-              const unsigned long long e = (((unsigned long long)(b * p.H + h) * p.Nq + q) * p.Nk) + k;
-              const bool keep = v2s_keep(e, p.seed, p.p16);
-              dpv = keep ? dpv * p.inv_keep : 0.f;
-              pd = keep ? pr * p.inv_keep : 0.f;
+            const int kk = wk0 + kb * 16 + li, k = K0 + kk;
+            // window entries for r = 0..3 sit at decreasing indices i0 - r with i0 = kk + 63 - (qb*16 + 4g)
+            float bwv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (BIAS) {
+              const float4 bw = bias_read4(sQ, kk + 63 - (qb * 16 + 4 * g) - 3);
+              bwv[0] = bw.w; bwv[1] = bw.z; bwv[2] = bw.y; bwv[3] = bw.x;
             }
-            st[qi][kb][r] = pr * (dpv - dr[r]);
-            dp[qi][kb][r] = pd;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int qq = qb * 16 + 4 * g + r, q = q0 + qq;
+              float s = fmaf(st[qi][kb][r], sc2, bwv[r]);
+              if (!clean) {
+                uint32_t f = kflag[kb];
+                if (CAUSAL && k > q + p.causal_off) f |= 1u;
+                s = (f & 2u) ? -INFINITY : ((f & 1u) ? MASKED2 : s);
+              }
+              const float pr = fast_exp2(s - mr[r]) * lr[r];
+              float dpv = dp[qi][kb][r];
+              float pd = pr;
+              if (DROP) {
+                const unsigned long long e = (((unsigned long long)(b * p.H + h) * p.Nq + q) * p.Nk) + k;
+                const bool keep = v2s_keep(e, p.seed, p.p16);
+                dpv = keep ? dpv * p.inv_keep : 0.f;
+                pd = keep ? pr * p.inv_keep : 0.f;
+              }
+              st[qi][kb][r] = pr * (dpv - dr[r]);
+              dp[qi][kb][r] = pd;
+            }
           }
         }
-      }
-      // dV^T[d][key] += dO^T[d][q] * Pd[q][key] ; dK^T[d][key] += Q^T[d][q] * dS[q][key]
-      bf16x8 pdf[2], dsf[2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        pdf[kb] = pack_frag(dp[0][kb], dp[1][kb]);
-        dsf[kb] = pack_frag(st[0][kb], st[1][kb]);
-      }
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const bf16x8 dot = col_frag<TR>(sDO, qh * 32, db * 16, lane);
-        const bf16x8 qt = col_frag<TR>(sQ, qh * 32, db * 16, lane);
+        // dV^T[d][key] += dO^T[d][q] * Pd[q][key] ; dK^T[d][key] += Q^T[d][q] * dS[q][key]
+        bf16x8 pdf[2], dsf[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-          dvt[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pdf[kb], dvt[kb][db], 0, 0, 0);
-          dkt[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb], dkt[kb][db], 0, 0, 0);
+          pdf[kb] = pack_frag(dp[0][kb], dp[1][kb]);
+          dsf[kb] = pack_frag(st[0][kb], st[1][kb]);
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const bf16x8 dot = col_frag<TR>(sDO, qh * 32, db * 16, lane);
+          const bf16x8 qt = col_frag<TR>(sQ, qh * 32, db * 16, lane);
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            dvt[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pdf[kb], dvt[kb][db], 0, 0, 0);
+            dkt[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb], dkt[kb][db], 0, 0, 0);
+          }
         }
       }
     }
@@ -683,6 +822,9 @@ int fill(AttnP& p, const v2s_attn_args* a, const char* who, bool bwd) {
   p.dq = (bf16_t*)a->dq; p.dk = (bf16_t*)a->dk; p.dv = (bf16_t*)a->dv;
   p.dq_bs = a->dq_bs; p.dq_rs = a->dq_rs; p.dk_bs = a->dk_bs; p.dk_rs = a->dk_rs; p.dv_bs = a->dv_bs; p.dv_rs = a->dv_rs;
   p.dbias_diag = a->dbias_diag;
+  // far buckets: disabled (every diagonal resolved) unless the caller states lo < hi
+  if (a->bias_far_lo < a->bias_far_hi) { p.far_lo = a->bias_far_lo; p.far_hi = a->bias_far_hi; }
+  else { p.far_lo = -(1 << 30); p.far_hi = (1 << 30); }
   if (bwd) {
     V2S_CHECK(a->d_o && a->ml && a->dq && a->dk && a->dv, V2S_ERR_ARG, "%s: backward needs d_o, ml, dq, dk, dv", who);
     V2S_CHECK(((a->do_rs | a->do_bs | a->dq_rs | a->dk_rs | a->dv_rs | a->dq_bs | a->dk_bs | a->dv_bs) % 8) == 0, V2S_ERR_ALIGN, "%s: grad strides must be multiples of 8", who);
@@ -690,14 +832,38 @@ int fill(AttnP& p, const v2s_attn_args* a, const char* who, bool bwd) {
   return V2S_OK;
 }
 
+// compile-time specialisation dispatch: (tr_read, bias, causal, dropout)
+#define V2S_DISPATCH4(KERNEL, tr, bias, causal, drop, ...)                                                    \
+  do {                                                                                                        \
+    const int key__ = ((tr) ? 8 : 0) | ((bias) ? 4 : 0) | ((causal) ? 2 : 0) | ((drop) ? 1 : 0);              \
+    switch (key__) {                                                                                          \
+      case 0: hipLaunchKernelGGL((KERNEL<false, false, false, false>), __VA_ARGS__); break;                   \
+      case 1: hipLaunchKernelGGL((KERNEL<false, false, false, true>), __VA_ARGS__); break;                    \
+      case 2: hipLaunchKernelGGL((KERNEL<false, false, true, false>), __VA_ARGS__); break;                    \
+      case 3: hipLaunchKernelGGL((KERNEL<false, false, true, true>), __VA_ARGS__); break;                     \
+      case 4: hipLaunchKernelGGL((KERNEL<false, true, false, false>), __VA_ARGS__); break;                    \
+      case 5: hipLaunchKernelGGL((KERNEL<false, true, false, true>), __VA_ARGS__); break;                     \
+      case 6: hipLaunchKernelGGL((KERNEL<false, true, true, false>), __VA_ARGS__); break;                     \
+      case 7: hipLaunchKernelGGL((KERNEL<false, true, true, true>), __VA_ARGS__); break;                      \
+      case 8: hipLaunchKernelGGL((KERNEL<true, false, false, false>), __VA_ARGS__); break;                    \
+      case 9: hipLaunchKernelGGL((KERNEL<true, false, false, true>), __VA_ARGS__); break;                     \
+      case 10: hipLaunchKernelGGL((KERNEL<true, false, true, false>), __VA_ARGS__); break;                    \
+      case 11: hipLaunchKernelGGL((KERNEL<true, false, true, true>), __VA_ARGS__); break;                     \
+      case 12: hipLaunchKernelGGL((KERNEL<true, true, false, false>), __VA_ARGS__); break;                    \
+      case 13: hipLaunchKernelGGL((KERNEL<true, true, false, true>), __VA_ARGS__); break;                     \
+      case 14: hipLaunchKernelGGL((KERNEL<true, true, true, false>), __VA_ARGS__); break;                     \
+      default: hipLaunchKernelGGL((KERNEL<true, true, true, true>), __VA_ARGS__); break;                      \
+    }                                                                                                         \
+  } while (0)
+
 }  // namespace
 
 extern "C" int v2s_attn_fwd(const v2s_attn_args* a, void* stream) {
   AttnP p;
   if (int e = fill(p, a, "v2s_attn_fwd", false)) return e;
   const int grid = ((p.Nq + 127) / 128) * p.H * p.B;
-  if (v2s_opt_tr_read()) hipLaunchKernelGGL((attn_fwd_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  V2S_DISPATCH4(attn_fwd_kernel, v2s_opt_tr_read() != 0, p.bias_diag != nullptr, p.causal != 0, p.p16 != 0, dim3(grid), dim3(256), 0,
+                (hipStream_t)stream, p);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
@@ -717,22 +883,14 @@ extern "C" int v2s_attn_bwd(const v2s_attn_args* a, void* stream) {
   if (int e = fill(p, a, "v2s_attn_bwd", true)) return e;
   V2S_CHECK(a->delta != nullptr, V2S_ERR_ARG, "v2s_attn_bwd: delta missing (call v2s_attn_delta first)");
   hipStream_t s = (hipStream_t)stream;
-  const bool tr = v2s_opt_tr_read() != 0;
+  const bool tr = v2s_opt_tr_read() != 0, bias = p.bias_diag != nullptr, causal = p.causal != 0, drop = p.p16 != 0;
   const int gq = ((p.Nq + 127) / 128) * p.H * p.B;
   const size_t dyn = 2 * (size_t)STAGE + (size_t)(p.Nk + 128) * 4;
-  V2S_CHECK(dyn <= 160 * 1024, V2S_ERR_SHAPE, "v2s_attn_bwd: Nk=%d too large for the LDS dbias window", p.Nk);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  if (tr) hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), dim3(gq), dim3(256), dyn, s, p);
-  else hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), dim3(gq), dim3(256), dyn, s, p);
+  V2S_CHECK(dyn <= 64 * 1024, V2S_ERR_SHAPE, "v2s_attn_bwd: Nk=%d too large for the LDS dbias window", p.Nk);
+  V2S_DISPATCH4(attn_bwd_dq_kernel, tr, bias, causal, drop, dim3(gq), dim3(256), dyn, s, p);
   V2S_LAUNCH_CHECK();
   const int gk = ((p.Nk + 127) / 128) * p.H * p.B;
-  if (tr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), dim3(gk), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), dim3(gk), dim3(256), 0, s, p);
+  V2S_DISPATCH4(attn_bwd_dkv_kernel, tr, bias, causal, drop, dim3(gk), dim3(256), 0, s, p);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

@@ -34,6 +34,8 @@ struct GemmP {
   const bf16_t* residual; long ldr;
   uint32_t p16; float inv_keep; uint32_t seed;
   int tilesM, tilesN;
+  int splitk, kper;      // split-K (wgrad): slice z covers K range [z*kper, min(K,(z+1)*kper)) and writes ws[z][M][N]
+  float* ws;
 };
 
 // swizzle of the [k][row] (transposed-operand) LDS image: XOR the 32-byte column chunk with bits of k
@@ -125,10 +127,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int nwg = p.tilesM * p.tilesN;
-  const int id = xcd_remap(blockIdx.x, nwg);
+  const int nwg = p.tilesM * p.tilesN * p.splitk;
+  const int id0 = xcd_remap(blockIdx.x, nwg);
+  const int slice = id0 % p.splitk, id = id0 / p.splitk;   // slices of one tile are neighbours (same XCD)
   const int tm = id / p.tilesN, tn = id - tm * p.tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = slice * p.kper, kend = min(p.K, kbeg + p.kper);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -137,9 +141,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmP p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   uint4 ra[4], rb[4];
-  const int nk = (p.K + BK - 1) / BK;
-  load_tile<TA>(p.A, p.lda, m0, p.M, 0, p.K, tid, ra);
-  load_tile<TB>(p.B, p.ldb, n0, p.N, 0, p.K, tid, rb);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  load_tile<TA>(p.A, p.lda, m0, p.M, kbeg, kend, tid, ra);
+  load_tile<TB>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
   store_tile<TA>(smem, tid, ra);
   store_tile<TB>(smem + A_BYTES, tid, rb);
   __syncthreads();
@@ -149,8 +153,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmP p) {
     const char* sb = sa + A_BYTES;
     const bool more = (t + 1 < nk);
     if (more) {
-      load_tile<TA>(p.A, p.lda, m0, p.M, (t + 1) * BK, p.K, tid, ra);
-      load_tile<TB>(p.B, p.ldb, n0, p.N, (t + 1) * BK, p.K, tid, rb);
+      load_tile<TA>(p.A, p.lda, m0, p.M, kbeg + (t + 1) * BK, kend, tid, ra);
+      load_tile<TB>(p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BK, kend, tid, rb);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -233,6 +237,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmP p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += rf[j];
     }
+    if (p.splitk > 1) {     // raw partial sums of this K slice; splitk_reduce_kernel applies alpha and accumulates into C
+      float* wp = p.ws + ((long)slice * p.M + gm) * p.N + gn;
+      *reinterpret_cast<float4*>(wp) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(wp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      continue;
+    }
     if (p.c_f32) {
       float* cp = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
       float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
@@ -246,6 +256,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmP p) {
     } else {
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
     }
+  }
+}
+
+// C[m][n] (+)= alpha * sum_z ws[z][m][n]   (deterministic: fixed slice order)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc, int M,
+                                                            int N, int S, float alpha, int accumulate) {
+  const int n4 = N >> 2;
+  const long total = (long)M * n4;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int m = (int)(t / n4), c = (int)(t - (long)m * n4) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < S; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + ((long)z * M + m) * N + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* cp = C + (long)m * ldc + c;
+    float4 o = make_float4(s.x * alpha, s.y * alpha, s.z * alpha, s.w * alpha);
+    if (accumulate) {
+      const float4 c0 = *reinterpret_cast<const float4*>(cp);
+      o.x += c0.x; o.y += c0.y; o.z += c0.z; o.w += c0.w;
+    }
+    *reinterpret_cast<float4*>(cp) = o;
   }
 }
 
@@ -313,7 +345,25 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   p.inv_keep = p.p16 ? 1.0f / (1.0f - (float)p.p16 / 65536.0f) : 1.0f;
   p.seed = a->dropout_seed;
   p.tilesM = (a->M + BM - 1) / BM; p.tilesN = (a->N + BN - 1) / BN;
-  const dim3 grid(p.tilesM * p.tilesN), block(NTHREADS);
+  // split-K: weight-gradient GEMMs have few output tiles (768x768 -> 36) but a huge contraction (all tokens);
+  // slice K so that ~3 workgroups per CU are in flight.  Only for "C += " into fp32 with a plain epilogue.
+  p.splitk = 1; p.kper = a->K; p.ws = (float*)a->workspace;
+  const int tiles = p.tilesM * p.tilesN;
+  if (a->workspace && a->c_dtype == V2S_F32 && !a->bias && !a->act && !a->dact && !a->residual && !a->pre &&
+      a->dropout_p == 0.f && tiles < 512 && a->K >= 1024 && (a->N % 8) == 0) {
+    int s = (768 + tiles - 1) / tiles;
+    const int maxs = a->K / 512;
+    if (s > maxs) s = maxs;
+    const long per_slice = (long)a->M * a->N * 4;
+    if ((long)s * per_slice > a->workspace_bytes) s = (int)(a->workspace_bytes / per_slice);
+    if (s > 1) {
+      int kper = ((a->K + s - 1) / s + BK - 1) / BK * BK;
+      p.kper = kper;
+      p.splitk = (a->K + kper - 1) / kper;
+      p.alpha = 1.0f;           // alpha and the accumulate are applied by the reduction
+    }
+  }
+  const dim3 grid(p.tilesM * p.tilesN * p.splitk), block(NTHREADS);
   hipStream_t s = (hipStream_t)stream;
   const bool tr = v2s_opt_tr_read() != 0;
   if (!a->transA && !a->transB) {
@@ -326,6 +376,13 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
     else hipLaunchKernelGGL((gemm_kernel<true, true, false>), grid, block, 0, s, p);
   }
   V2S_LAUNCH_CHECK();
+  if (p.splitk > 1) {
+    long blocks = ((long)a->M * (a->N / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.ws, (float*)a->C, (long)a->ldc, a->M, a->N,
+                       p.splitk, a->alpha, a->accumulate);
+    V2S_LAUNCH_CHECK();
+  }
   return V2S_OK;
 }
 

@@ -9,7 +9,7 @@
 namespace {
 
 constexpr int MAXC = 4;  // chunks of 8 columns per lane -> cols <= 2048
-constexpr int BWD_BLOCKS = 512;
+constexpr int BWD_BLOCKS = 256;
 
 template <bool LN>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
@@ -155,14 +155,17 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
   }
 }
 
-// out[c] += sum_b partial[b][c]
+// out[c] += sum_b partial[b][c]: block = 64 columns x 4 row groups, coalesced 256-byte row reads
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                              int nblocks, int cols) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * cols + c];
-  out[c] += s;
+  if (c < cols)
+    for (int b = rg; b < nblocks; b += 4) s += partial[(long)b * cols + c];
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < cols) out[c] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 int bwd_blocks(int rows) { return (rows + 3) / 4 < BWD_BLOCKS ? (rows + 3) / 4 : BWD_BLOCKS; }
@@ -205,7 +208,7 @@ extern "C" int v2s_rmsnorm_bwd(const void* x, const float* w, const float* rstd,
   hipLaunchKernelGGL((norm_bwd_kernel<false>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, (const float*)nullptr, rstd,
                      (const bf16_t*)dy, (bf16_t*)dx, (const bf16_t*)dx_add, partial, rows, cols);
   V2S_LAUNCH_CHECK();
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial, dw, nb, cols);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, dw, nb, cols);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
@@ -219,9 +222,9 @@ extern "C" int v2s_layernorm_bwd(const void* x, const float* w, const float* mea
   hipLaunchKernelGGL((norm_bwd_kernel<true>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy,
                      (bf16_t*)dx, (const bf16_t*)dx_add, partial, rows, cols);
   V2S_LAUNCH_CHECK();
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial, dw, nb, cols);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, dw, nb, cols);
   V2S_LAUNCH_CHECK();
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial + (long)nb * cols, db, nb, cols);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial + (long)nb * cols, db, nb, cols);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

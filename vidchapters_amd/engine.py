@@ -58,6 +58,7 @@ class Engine:
         self.arena = ParamArena(self._arena_order(), device)
         assert self.arena.adjacent(*[self._sa("encoder", 0) + w for w in ("q.weight", "k.weight", "v.weight")])
         self._luts: Dict[Tuple[int, int, bool], torch.Tensor] = {}
+        self._far: Dict[Tuple[int, int, bool], Tuple[int, int]] = {}
         self._seed = 0x1234
         self._site = 0
         self._ws: Dict[str, torch.Tensor] = {}
@@ -127,6 +128,12 @@ class Engine:
             t = self._ws["norm_partial"] = self._f32(n)
         return t
 
+    def _splitk_ws(self) -> torch.Tensor:
+        t = self._ws.get("splitk")
+        if t is None:     # 8 slices of the largest few-tile weight gradient (d_ff x d_model)
+            t = self._ws["splitk"] = self._f32(8 * max(self.ff * self.d, 3 * self.inner * self.d, self.vmlp * self.vd))
+        return t
+
     def _next_seed(self) -> int:
         self._site += 1
         return (self._seed * 0x9E3779B1 + self._site * 0x85EBCA6B) & 0xFFFFFFFF
@@ -134,7 +141,17 @@ class Engine:
     def _lut(self, nq: int, nk: int, bidirectional: bool) -> torch.Tensor:
         key = (nq, nk, bidirectional)
         if key not in self._luts:
-            self._luts[key] = _bucket_lut(nq, nk, bidirectional, self.cfg.buckets, self.cfg.max_distance).to(self.device)
+            lut = _bucket_lut(nq, nk, bidirectional, self.cfg.buckets, self.cfg.max_distance)
+            # far regions: largest d <= 0 such that every d' <= d shares lut[d]'s bucket, smallest d >= 1 likewise
+            v = lut.tolist()
+            lo_i = 0
+            while lo_i + 1 < len(v) and v[lo_i + 1] == v[0] and (lo_i + 1) - (nq - 1) <= 0:
+                lo_i += 1
+            hi_i = len(v) - 1
+            while hi_i - 1 >= 0 and v[hi_i - 1] == v[-1] and (hi_i - 1) - (nq - 1) >= 1:
+                hi_i -= 1
+            self._far[key] = (lo_i - (nq - 1), hi_i - (nq - 1))
+            self._luts[key] = lut.to(self.device)
         return self._luts[key]
 
     def _drop(self, x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
@@ -150,7 +167,7 @@ class Engine:
         """dW[n_out, n_in] += alpha * dy[rows, n_out]^T @ x[rows, n_in]  (fp32 accumulate into the gradient arena)."""
         L.gemm(dy, x, self.arena.g(wname, shape), n_out, n_in, rows, transA=True, transB=True,
                lda=ld_dy if ld_dy is not None else n_out, ldb=ld_x if ld_x is not None else n_in, ldc=n_in,
-               accumulate=True, alpha=alpha)
+               accumulate=True, alpha=alpha, workspace=self._splitk_ws())
 
     def _dgrad(self, dy: torch.Tensor, w: torch.Tensor, rows: int, n_in: int, n_out: int, out=None, ld_dy=None, **epi):
         """dx[rows, n_in] = dy[rows, n_out] @ W[n_out, n_in]."""
@@ -253,8 +270,9 @@ class Engine:
         dqkv = self._bf(M, 3 * inner)
         delta = self._f32(B, self.H, N)
         st = (N * 3 * inner, 3 * inner)
+        self._lut(N, N, r.stack == "encoder")
         L.attn_bwd(r.args, dctx, (N * inner, inner), delta, dqkv, dqkv[:, inner:], dqkv[:, 2 * inner:], st, st, st,
-                   dbias_diag=dbias_diag)
+                   dbias_diag=dbias_diag, far=self._far[(N, N, r.stack == "encoder")])
         self._wgrad(dqkv, r.n, sa + "q.weight", 3 * inner, d, M, shape=(3 * inner, d))
         dn = self._dgrad(dqkv, a.w(sa + "q.weight", (3 * inner, d)), M, d, 3 * inner)
         dx = self._bf(M, d)

@@ -28,7 +28,7 @@ class GemmArgs(C.Structure):
                 ("A", _vp), ("B", _vp), ("lda", _i64), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
                 ("c_dtype", _i32), ("accumulate", _i32), ("alpha", _f32), ("bias", _vp), ("act", _i32),
                 ("pre", _vp), ("dact", _i32), ("z", _vp), ("ldz", _i64), ("residual", _vp), ("ldr", _i64),
-                ("dropout_p", _f32), ("dropout_seed", _u32)]
+                ("dropout_p", _f32), ("dropout_seed", _u32), ("workspace", _vp), ("workspace_bytes", _i64)]
 
 
 class AttnArgs(C.Structure):
@@ -41,7 +41,7 @@ class AttnArgs(C.Structure):
                 ("d_o", _vp), ("do_bs", _i64), ("do_rs", _i64), ("delta", _vp),
                 ("dq", _vp), ("dk", _vp), ("dv", _vp),
                 ("dq_bs", _i64), ("dq_rs", _i64), ("dk_bs", _i64), ("dk_rs", _i64), ("dv_bs", _i64), ("dv_rs", _i64),
-                ("dbias_diag", _vp)]
+                ("dbias_diag", _vp), ("bias_far_lo", _i32), ("bias_far_hi", _i32)]
 
 
 class AdamArgs(C.Structure):
@@ -173,7 +173,7 @@ class KernelTimer:
 # --------------------------------------------------------------------------------------------- GEMM
 def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, K: int, *, transA=False, transB=False,
          lda=None, ldb=None, ldc=None, accumulate=False, alpha=1.0, bias=None, act=ACT_NONE, pre=None, dact=ACT_NONE,
-         z=None, ldz=None, residual=None, ldr=None, dropout_p=0.0, dropout_seed=0) -> None:
+         z=None, ldz=None, residual=None, ldr=None, dropout_p=0.0, dropout_seed=0, workspace=None) -> None:
     """C[M,N] (+)= epilogue(alpha * A(m,k) B(n,k)); see include/vid2seq_hip.h for layouts."""
     _need(A, torch.bfloat16, "gemm A"); _need(B, torch.bfloat16, "gemm B")
     a = GemmArgs()
@@ -197,6 +197,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, 
     a.ldr = ldr if ldr is not None else N
     a.dropout_p = dropout_p
     a.dropout_seed = dropout_seed & 0xFFFFFFFF
+    if workspace is not None:
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     kt = KernelTimer.active
     if kt is not None:
         e0 = kt.begin()
@@ -265,12 +267,13 @@ def attn_fwd(a: AttnArgs) -> None:
         kt.end("attn_fwd", 4.0 * a.B * a.H * a.Nq * a.Nk * 64, e0)
 
 
-def attn_bwd(a: AttnArgs, d_o, do_st, delta, dq, dk, dv, dq_st, dk_st, dv_st, dbias_diag=None) -> None:
+def attn_bwd(a: AttnArgs, d_o, do_st, delta, dq, dk, dv, dq_st, dk_st, dv_st, dbias_diag=None, far=(0, 0)) -> None:
     a.d_o = d_o.data_ptr(); a.do_bs, a.do_rs = do_st
     a.delta = delta.data_ptr()
     a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     a.dq_bs, a.dq_rs = dq_st; a.dk_bs, a.dk_rs = dk_st; a.dv_bs, a.dv_rs = dv_st
     a.dbias_diag = ptr(dbias_diag)
+    a.bias_far_lo, a.bias_far_hi = far
     _check(lib().v2s_attn_delta(C.byref(a), delta.data_ptr(), stream_ptr()), "v2s_attn_delta")
     kt = KernelTimer.active
     if kt is not None:
