@@ -36,7 +36,8 @@ extern "C" {
 
 int v2s_version(void);
 const char* v2s_last_error(void);
-/* runtime switches: "tr_read" (1: ds_read_b64_tr_b16 operand transposes, 0: scalar LDS gathers) */
+/* runtime switches: "tr_read" (1: ds_read_b64_tr_b16 operand transposes, 0: scalar LDS gathers);
+ * "gemm_dma" (1: LDS-DMA GEMM main loop where K % 64 == 0, 0: register-staged loop everywhere) */
 int v2s_set_option(const char* name, int value);
 int v2s_get_option(const char* name);
 
@@ -94,20 +95,17 @@ int v2s_colsum(const void* X, int64_t ldx, int32_t M, int32_t N, float* out, int
  *   rmsnorm: modeling_t5.py:263-277 (T5LayerNorm): y = w * x * rsqrt(mean(x^2)+eps)
  *   layernorm: torch nn.LayerNorm used at vit.py:64,69,99 (eps 1e-5, affine)
  *   x,y bf16 [rows][cols]; w,b fp32 [cols]; rstd/mean fp32 [rows] (saved for backward)
- *   backward: dx bf16; dw/db fp32 [cols], accumulated (+=) into the caller's gradient buffers;
- *   `partial` = fp32 workspace of v2s_norm_partial_floats(rows, cols) elements.
+ *   backward: dx bf16; dw/db fp32 [cols], accumulated (+=, hardware float atomics) into the caller's gradient buffers.
  *   `dx_add` (bf16, may be NULL) is added to dx: the residual-stream gradient that bypasses the norm.
  * ---------------------------------------------------------------------------------------------- */
-int64_t v2s_norm_partial_floats(int32_t rows, int32_t cols);
 int v2s_rmsnorm_fwd(const void* x, const float* w, void* y, float* rstd, int32_t rows, int32_t cols,
                     float eps, void* stream);
 int v2s_rmsnorm_bwd(const void* x, const float* w, const float* rstd, const void* dy, void* dx,
-                    const void* dx_add, float* dw, float* partial, int32_t rows, int32_t cols, void* stream);
+                    const void* dx_add, float* dw, int32_t rows, int32_t cols, void* stream);
 int v2s_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
                       int32_t rows, int32_t cols, float eps, void* stream);
 int v2s_layernorm_bwd(const void* x, const float* w, const float* mean, const float* rstd, const void* dy,
-                      void* dx, const void* dx_add, float* dw, float* db, float* partial, int32_t rows,
-                      int32_t cols, void* stream);
+                      void* dx, const void* dx_add, float* dw, float* db, int32_t rows, int32_t cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention (flash-style, scores never materialised)

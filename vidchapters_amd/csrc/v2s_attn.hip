@@ -109,6 +109,19 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
   return f;
 }
 
+// attention-probability dropout: keep(b,h,q,k) from a per-row seed and a light 32-bit mix of (row seed + k/2); the two
+// 16-bit halves decide keys 2j and 2j+1.  Same definition in all three kernels (forward mask == backward mask).
+__device__ __forceinline__ uint32_t drop_rowseed(uint32_t seed, uint32_t rowid) { return v2s_hash32(seed ^ (rowid * 0x9E3779B1u)); }
+__device__ __forceinline__ uint32_t drop_mix(uint32_t rowseed, uint32_t kpair) {
+  uint32_t x = (rowseed + kpair) * 0x9E3779B1u;
+  x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+  return x;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t rowseed, uint32_t k, uint32_t p16) {
+  const uint32_t h = drop_mix(rowseed, k >> 1);
+  return ((k & 1u) ? (h >> 16) : (h & 0xffffu)) >= p16;
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; x <= ~0 here
 
 // ---- LDS stage layout ---------------------------------------------------------------------------------
@@ -117,8 +130,8 @@ constexpr int OFF_BIAS = 2 * KV_TILE;         // 4 x 192 floats: copy s holds w[
 constexpr int BIAS_COPY = 192;                // floats per copy
 constexpr int OFF_FLAG = OFF_BIAS + 4 * BIAS_COPY * 4;   // 64 key flags (0 keep, 1 masked, 2 out of range)
 constexpr int OFF_STATE = OFF_FLAG + 64;      // int[2]: OR of flags, AND of (flag != 0)
-constexpr int OFF_MS = OFF_STATE + 16;        // dkv kernel: m[64], 1/l[64], delta[64]
-constexpr int STAGE = OFF_MS + 3 * 64 * 4;    // 20304 -> keep 16-byte multiple
+constexpr int OFF_MS = OFF_STATE + 16;        // dkv kernel: m[64], 1/l[64], delta[64], dropout row seed[64]
+constexpr int STAGE = OFF_MS + 4 * 64 * 4;    // + 64 dropout row seeds (dkv kernel)
 static_assert(STAGE % 16 == 0 && OFF_MS % 16 == 0 && OFF_BIAS % 16 == 0, "LDS carve alignment");
 
 // bias window write: thread i (< 192) holds w[i]; copy s stores it at index i - s
@@ -283,18 +296,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
         const float alpha = fast_exp2(m[qb] - mn);
         m[qb] = mn;
         float rs = 0.f;
+        const uint32_t rseed = DROP ? drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q)) : 0u;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < 4; ++kb) {
+          uint32_t h01 = 0, h23 = 0;
+          if (DROP) {   // keys k0+kb*16+4g .. +3 : two 32-bit mixes give four 16-bit draws
+            const uint32_t kp = (uint32_t)(k0 + kb * 16 + 4 * g) >> 1;
+            h01 = drop_mix(rseed, kp); h23 = drop_mix(rseed, kp + 1);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float pv = fast_exp2(st[qb][kb][r] - mn);
             rs += pv;
             if (DROP) {
-              const unsigned long long e = (((unsigned long long)(b * p.H + h) * p.Nq + q) * p.Nk) + (k0 + kb * 16 + 4 * g + r);
-              pv = v2s_keep(e, p.seed, p.p16) ? pv * p.inv_keep : 0.f;
+              const uint32_t hh = (r < 2) ? h01 : h23;
+              const uint32_t r16 = (r & 1) ? (hh >> 16) : (hh & 0xffffu);
+              pv = (r16 >= p.p16) ? pv * p.inv_keep : 0.f;
             }
             st[qb][kb][r] = pv;
           }
+        }
         lsum[qb] = lsum[qb] * alpha + rs;
 #pragma unroll
         for (int db = 0; db < 4; ++db) ot[qb][db] *= alpha;
@@ -488,8 +509,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
         const int qq = wq0 + qb * 16 + li, q = Q0 + qq;
         const uint8_t* fl = reinterpret_cast<const uint8_t*>(sK + OFF_FLAG);
         float lsum_ds = 0.f;
+        const uint32_t rseed = DROP ? drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q)) : 0u;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
+          uint32_t h01 = 0, h23 = 0;
+          if (DROP) {
+            const uint32_t kp = (uint32_t)(k0 + kb * 16 + 4 * g) >> 1;
+            h01 = drop_mix(rseed, kp); h23 = drop_mix(rseed, kp + 1);
+          }
           float4 bw = make_float4(0.f, 0.f, 0.f, 0.f);
           if (BIAS) bw = bias_read4(sK, kb * 16 + 4 * g + 127 - qq);
           const float bwv[4] = {bw.x, bw.y, bw.z, bw.w};
@@ -507,8 +534,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
             const float pr = fast_exp2(s - m2[qb]) * linv[qb];
             float dpv = dp[qb][kb][r];
             if (DROP) {
-              const unsigned long long e = (((unsigned long long)(b * p.H + h) * p.Nq + q) * p.Nk) + (k0 + kk);
-              dpv = v2s_keep(e, p.seed, p.p16) ? dpv * p.inv_keep : 0.f;
+              const uint32_t hh = (r < 2) ? h01 : h23;
+              const uint32_t r16 = (r & 1) ? (hh >> 16) : (hh & 0xffffu);
+              dpv = (r16 >= p.p16) ? dpv * p.inv_keep : 0.f;
             }
             const float ds = pr * (dpv - dl[qb]);
             st[qb][kb][r] = ds;
@@ -623,6 +651,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   uint4 rq[2], rdo[2];
   float rbias = 0.f;
   float rm = 0.f, rl = 0.f, rd = 0.f;
+  uint32_t rseed = 0;
   // bias window for this (128-key block, 64-query tile): index (k - q) - dmin, dmin = K0 - (q0 + 63); 191 entries
   auto prefetch = [&](int t) {
     const int q0 = t * 64;
@@ -634,6 +663,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     }
     if (tid < 64) {
       const int q = q0 + tid;
+      if (DROP) rseed = drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q));
       rm = 0.f; rl = 0.f; rd = 0.f;                 // rows >= Nq: 1/l = 0 => P = 0
       if (q < p.Nq) {
         const long r = ((long)(b * p.H + h)) * p.Nq + q;
@@ -649,6 +679,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     if (tid < 64) {
       float* ms = reinterpret_cast<float*>(st + OFF_MS);
       ms[tid] = rm; ms[64 + tid] = rl; ms[128 + tid] = rd;
+      if (DROP) reinterpret_cast<uint32_t*>(ms)[192 + tid] = rseed;
       // "every query row of this tile has real statistics": lets all-masked / all-future key blocks skip the tile
       const unsigned long long real = __ballot(rm > REAL_MIN || rl == 0.f);
       if (tid == 0) reinterpret_cast<int*>(st + OFF_STATE)[0] = (real == ~0ull);
@@ -702,6 +733,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
           const float4 lv = *reinterpret_cast<const float4*>(ms + 64 + qb * 16 + 4 * g);
           const float4 dv4 = *reinterpret_cast<const float4*>(ms + 128 + qb * 16 + 4 * g);
           const float mr[4] = {mv.x, mv.y, mv.z, mv.w}, lr[4] = {lv.x, lv.y, lv.z, lv.w}, dr[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+          uint4 sd4 = make_uint4(0, 0, 0, 0);
+          if (DROP) sd4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(ms) + 192 + qb * 16 + 4 * g);
+          const uint32_t sdr[4] = {sd4.x, sd4.y, sd4.z, sd4.w};
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb) {
             const int kk = wk0 + kb * 16 + li, k = K0 + kk;
@@ -724,8 +758,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
               float dpv = dp[qi][kb][r];
               float pd = pr;
               if (DROP) {
-                const unsigned long long e = (((unsigned long long)(b * p.H + h) * p.Nq + q) * p.Nk) + k;
-                const bool keep = v2s_keep(e, p.seed, p.p16);
+                const bool keep = drop_keep(sdr[r], (uint32_t)k, p.p16);
                 dpv = keep ? dpv * p.inv_keep : 0.f;
                 pd = keep ? pr * p.inv_keep : 0.f;
               }

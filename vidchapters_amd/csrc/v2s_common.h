@@ -33,7 +33,8 @@ void v2s_set_error(const char* fmt, ...);
     }                                                                         \
   } while (0)
 
-int v2s_opt_tr_read();  // 1 = use ds_read_b64_tr_b16 for transposed operand fragments
+int v2s_opt_tr_read();   // 1 = use ds_read_b64_tr_b16 for transposed operand fragments
+int v2s_opt_gemm_dma();  // 1 = LDS-DMA (global_load_lds) GEMM main loop where K % 64 == 0
 
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

@@ -2,14 +2,14 @@
 // fp32 statistics.  HBM-bound (reads x once, writes y once).
 //   RMSNorm  : model/modeling_t5.py:263-277 (T5LayerNorm.forward)
 //   LayerNorm: torch nn.LayerNorm as used at model/vit.py:64,69,99 (eps 1e-5, affine)
-// Backward produces dx (+ fused residual-gradient add) and per-block partial dw/db that a second
-// kernel reduces deterministically into the caller's fp32 gradient (+=).
+// Backward produces dx (+ fused residual-gradient add); dw/db are reduced per wave in registers, per block in LDS and
+// added to the caller's fp32 gradient with one hardware float atomic per column per block.
 #include "v2s_common.h"
 
 namespace {
 
 constexpr int MAXC = 4;  // chunks of 8 columns per lane -> cols <= 2048
-constexpr int BWD_BLOCKS = 256;
+constexpr int BWD_BLOCKS = 1024;
 
 template <bool LN>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
@@ -74,19 +74,19 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const bf16_t* __restrict_
   }
 }
 
-template <bool LN>
+template <bool LN, int NCH>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                        const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
-                                                       const bf16_t* __restrict__ dx_add, float* __restrict__ partial,
-                                                       int rows, int cols) {
-  __shared__ float red[4][2048];
+                                                       const bf16_t* __restrict__ dx_add, float* __restrict__ dw_out,
+                                                       float* __restrict__ db_out, int rows, int cols) {
+  __shared__ float red[4][NCH * 512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = cols >> 3;
-  float dwacc[MAXC][8], dbacc[MAXC][8];
-  float wv[MAXC][8];
+  float dwacc[NCH][8], dbacc[NCH][8];
+  float wv[NCH][8];
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = lane + i * 64;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dwacc[i][j] = 0.f; dbacc[i][j] = 0.f; wv[i][j] = 0.f; }
@@ -99,10 +99,10 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const float rstd = rstd_in[row];
     const float mean = LN ? mean_in[row] : 0.f;
-    float xh[MAXC][8], g[MAXC][8];
+    float xh[NCH][8], g[NCH][8];
     float sg = 0.f, sgx = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = lane + i * 64;
       if (c < nch) {
         float xv[8], dv[8];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
     sgx = wave_sum(sgx) / cols;
     sg = LN ? wave_sum(sg) / cols : 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = lane + i * 64;
       if (c < nch) {
         float o[8];
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
   for (int pass = 0; pass < (LN ? 2 : 1); ++pass) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = lane + i * 64;
       if (c < nch) {
 #pragma unroll
@@ -150,22 +150,9 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
       }
     }
     __syncthreads();
-    float* dst = partial + ((long)pass * gridDim.x + blockIdx.x) * cols;
-    for (int c = threadIdx.x; c < cols; c += 256) dst[c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    float* dst = pass ? db_out : dw_out;
+    for (int c = threadIdx.x; c < cols; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
   }
-}
-
-// out[c] += sum_b partial[b][c]: block = 64 columns x 4 row groups, coalesced 256-byte row reads
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                             int nblocks, int cols) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < cols)
-    for (int b = rg; b < nblocks; b += 4) s += partial[(long)b * cols + c];
-  red[rg][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (rg == 0 && c < cols) out[c] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 int bwd_blocks(int rows) { return (rows + 3) / 4 < BWD_BLOCKS ? (rows + 3) / 4 : BWD_BLOCKS; }
@@ -179,8 +166,6 @@ int check_shape(const char* who, int rows, int cols) {
 }
 
 }  // namespace
-
-extern "C" int64_t v2s_norm_partial_floats(int32_t rows, int32_t cols) { return 2LL * bwd_blocks(rows) * cols; }
 
 extern "C" int v2s_rmsnorm_fwd(const void* x, const float* w, void* y, float* rstd, int32_t rows, int32_t cols,
                                float eps, void* stream) {
@@ -201,30 +186,31 @@ extern "C" int v2s_layernorm_fwd(const void* x, const float* w, const float* b, 
 }
 
 extern "C" int v2s_rmsnorm_bwd(const void* x, const float* w, const float* rstd, const void* dy, void* dx,
-                               const void* dx_add, float* dw, float* partial, int32_t rows, int32_t cols, void* stream) {
+                               const void* dx_add, float* dw, int32_t rows, int32_t cols, void* stream) {
   if (int e = check_shape("v2s_rmsnorm_bwd", rows, cols)) return e;
   const int nb = bwd_blocks(rows);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL((norm_bwd_kernel<false>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, (const float*)nullptr, rstd,
-                     (const bf16_t*)dy, (bf16_t*)dx, (const bf16_t*)dx_add, partial, rows, cols);
-  V2S_LAUNCH_CHECK();
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, dw, nb, cols);
+  if (cols <= 1024)
+    hipLaunchKernelGGL((norm_bwd_kernel<false, 2>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, (const float*)nullptr, rstd,
+                       (const bf16_t*)dy, (bf16_t*)dx, (const bf16_t*)dx_add, dw, (float*)nullptr, rows, cols);
+  else
+    hipLaunchKernelGGL((norm_bwd_kernel<false, 4>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, (const float*)nullptr, rstd,
+                       (const bf16_t*)dy, (bf16_t*)dx, (const bf16_t*)dx_add, dw, (float*)nullptr, rows, cols);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
 
 extern "C" int v2s_layernorm_bwd(const void* x, const float* w, const float* mean, const float* rstd, const void* dy,
-                                 void* dx, const void* dx_add, float* dw, float* db, float* partial, int32_t rows,
-                                 int32_t cols, void* stream) {
+                                 void* dx, const void* dx_add, float* dw, float* db, int32_t rows, int32_t cols, void* stream) {
   if (int e = check_shape("v2s_layernorm_bwd", rows, cols)) return e;
   const int nb = bwd_blocks(rows);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL((norm_bwd_kernel<true>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy,
-                     (bf16_t*)dx, (const bf16_t*)dx_add, partial, rows, cols);
-  V2S_LAUNCH_CHECK();
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, dw, nb, cols);
-  V2S_LAUNCH_CHECK();
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial + (long)nb * cols, db, nb, cols);
+  if (cols <= 1024)
+    hipLaunchKernelGGL((norm_bwd_kernel<true, 2>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy,
+                       (bf16_t*)dx, (const bf16_t*)dx_add, dw, db, rows, cols);
+  else
+    hipLaunchKernelGGL((norm_bwd_kernel<true, 4>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy,
+                       (bf16_t*)dx, (const bf16_t*)dx_add, dw, db, rows, cols);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

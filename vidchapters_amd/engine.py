@@ -121,13 +121,6 @@ class Engine:
     def _f32(self, *shape) -> torch.Tensor:
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 
-    def _partial(self, rows: int, cols: int) -> torch.Tensor:
-        n = L.norm_partial_floats(rows, cols)
-        t = self._ws.get("norm_partial")
-        if t is None or t.numel() < n:
-            t = self._ws["norm_partial"] = self._f32(n)
-        return t
-
     def _splitk_ws(self) -> torch.Tensor:
         t = self._ws.get("splitk")
         if t is None:     # 8 slices of the largest few-tile weight gradient (d_ff x d_model)
@@ -277,7 +270,7 @@ class Engine:
         dn = self._dgrad(dqkv, a.w(sa + "q.weight", (3 * inner, d)), M, d, 3 * inner)
         dx = self._bf(M, d)
         ln = self._ln(r.stack, r.i, 0)
-        L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), self._partial(M, d), M, d)
+        L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), M, d)
         return dx
 
     def _cross_attn_bwd(self, r, dh, dmem, first: bool):
@@ -300,7 +293,7 @@ class Engine:
                     **({} if first else dict(residual=dmem)))
         dx = self._bf(Mq, d)
         ln = self._ln("decoder", r.i, 1)
-        L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), self._partial(Mq, d), Mq, d)
+        L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), Mq, d)
         return dx
 
     def _ffn_bwd(self, r, dh):
@@ -314,7 +307,7 @@ class Engine:
         dn = self._dgrad(du, a.w(fp + "wi.weight"), M, d, ff)
         dx = self._bf(M, d)
         ln = self._ln(r.stack, r.i, 2 if r.stack == "decoder" else 1)
-        L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), self._partial(M, d), M, d)
+        L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), M, d)
         return dx
 
     def _final_norm_bwd(self, r, dout):
@@ -322,7 +315,7 @@ class Engine:
         name = f"t5_model.{r.stack}.final_layer_norm.weight"
         dn = self._drop(dout, r.p, r.seed)
         dx = self._bf(r.M, self.d)
-        L.rmsnorm_bwd(r.h, a.f(name), r.rstd, dn, dx, None, a.g(name), self._partial(r.M, self.d), r.M, self.d)
+        L.rmsnorm_bwd(r.h, a.f(name), r.rstd, dn, dx, None, a.g(name), r.M, self.d)
         return dx
 
     def _embed_bwd(self, r, dh):
@@ -450,7 +443,7 @@ class Engine:
             dvis = self._dgrad(dvis, a.w("proj_v2t.weight"), M, C, self.d)
         dx = self._bf(M, C)
         L.layernorm_bwd(tape["xf"], a.f("visual_encoder.norm.weight"), tape["meanf"], tape["rstdf"], dvis, dx, None,
-                        a.g("visual_encoder.norm.weight"), a.g("visual_encoder.norm.bias"), self._partial(M, C), M, C)
+                        a.g("visual_encoder.norm.weight"), a.g("visual_encoder.norm.bias"), M, C)
         for r in reversed(tape["recs"]):
             pre = r.pre
             df2 = self._drop(dx, p, r.seed_2)
@@ -463,7 +456,7 @@ class Engine:
             dn2 = self._dgrad(du, a.w(pre + "mlp.fc1.weight"), M, C, mlp)
             dx1 = self._bf(M, C)
             L.layernorm_bwd(r.x1, a.f(pre + "norm2.weight"), r.mean2, r.rstd2, dn2, dx1, dx, a.g(pre + "norm2.weight"),
-                            a.g(pre + "norm2.bias"), self._partial(M, C), M, C)
+                            a.g(pre + "norm2.bias"), M, C)
             df1 = self._drop(dx1, p, r.seed_p)
             L.colsum(df1, M, C, a.g(pre + "attn.proj.bias"))
             self._wgrad(df1, r.ctx, pre + "attn.proj.weight", C, C, M)
@@ -476,7 +469,7 @@ class Engine:
             dn1 = self._dgrad(dqkv, a.w(pre + "attn.qkv.weight"), M, C, 3 * C)
             dx0 = self._bf(M, C)
             L.layernorm_bwd(r.x, a.f(pre + "norm1.weight"), r.mean1, r.rstd1, dn1, dx0, dx1, a.g(pre + "norm1.weight"),
-                            a.g(pre + "norm1.bias"), self._partial(M, C), M, C)
+                            a.g(pre + "norm1.bias"), M, C)
             dx = dx0
         dx = self._drop(dx, p, tape["seed0"])
         gpos = a.g("visual_encoder.pos_embed", (m.num_features, C))

@@ -64,11 +64,10 @@ SYMBOLS = {
     "v2s_get_option": (C.c_int, [C.c_char_p]),
     "v2s_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "v2s_colsum": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
-    "v2s_norm_partial_floats": (_i64, [_i32, _i32]),
     "v2s_rmsnorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
-    "v2s_rmsnorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "v2s_rmsnorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "v2s_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
-    "v2s_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "v2s_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "v2s_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "v2s_attn_delta": (C.c_int, [C.POINTER(AttnArgs), _vp, _vp]),
     "v2s_attn_bwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
@@ -214,19 +213,15 @@ def colsum(X: torch.Tensor, M: int, N: int, out: torch.Tensor, accumulate=True, 
 
 
 # --------------------------------------------------------------------------------------------- norms
-def norm_partial_floats(rows: int, cols: int) -> int:
-    return int(lib().v2s_norm_partial_floats(rows, cols))
-
-
 def rmsnorm_fwd(x, w, y, rstd, rows, cols, eps):
     _need(x, torch.bfloat16, "rmsnorm x"); _need(w, torch.float32, "rmsnorm w")
     _check(lib().v2s_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows, cols, eps, stream_ptr()),
            "v2s_rmsnorm_fwd")
 
 
-def rmsnorm_bwd(x, w, rstd, dy, dx, dx_add, dw, partial, rows, cols):
+def rmsnorm_bwd(x, w, rstd, dy, dx, dx_add, dw, rows, cols):
     _check(lib().v2s_rmsnorm_bwd(x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(), ptr(dx_add),
-                                 dw.data_ptr(), partial.data_ptr(), rows, cols, stream_ptr()), "v2s_rmsnorm_bwd")
+                                 dw.data_ptr(), rows, cols, stream_ptr()), "v2s_rmsnorm_bwd")
 
 
 def layernorm_fwd(x, w, b, y, mean, rstd, rows, cols, eps):
@@ -235,9 +230,9 @@ def layernorm_fwd(x, w, b, y, mean, rstd, rows, cols, eps):
                                    rows, cols, eps, stream_ptr()), "v2s_layernorm_fwd")
 
 
-def layernorm_bwd(x, w, mean, rstd, dy, dx, dx_add, dw, db, partial, rows, cols):
+def layernorm_bwd(x, w, mean, rstd, dy, dx, dx_add, dw, db, rows, cols):
     _check(lib().v2s_layernorm_bwd(x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(),
-                                   ptr(dx_add), dw.data_ptr(), db.data_ptr(), partial.data_ptr(), rows, cols, stream_ptr()),
+                                   ptr(dx_add), dw.data_ptr(), db.data_ptr(), rows, cols, stream_ptr()),
            "v2s_layernorm_bwd")
 
 
