@@ -92,6 +92,33 @@ def test_gemm_dgrad_wgrad(M, N, K, tr_mode):
     assert e < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 256), (8200, 2056, 320), (16384, 512, 128), (16400, 520, 192)])
+def test_gemm_big_tiles(M, N, K):
+    """Shapes that dispatch to the 256x256 / 256x128 LDS-DMA kernel (K % 64 == 0, >= 240 tiles), incl. ragged edges."""
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    bias = rnd(N, seed=9, dtype=torch.float32)
+    C = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    L.gemm(A, B, C, M, N, K, bias=bias)
+    assert relerr(C, A.float() @ B.float().T + bias) < 2e-5
+    W = rnd(K, N, seed=4)                                        # dgrad: dy[M,K] @ W[K,N]
+    L.gemm(A, W, C, M, N, K, transB=True)
+    assert relerr(C, A.float() @ W.float()) < 2e-5
+    L.set_option("gemm_big", 0)
+    C0 = torch.empty_like(C)
+    L.gemm(A, W, C0, M, N, K, transB=True)
+    L.set_option("gemm_big", 1)
+    assert relerr(C, C0) < 2e-6                                  # same products, different tile shape / summation grouping
+
+
+def test_gemm_big_wgrad_splitk():
+    Mp, Np, Kc = 1024, 512, 4096
+    dY, X = rnd(Kc, Mp, seed=5, scale=0.1), rnd(Kc, Np, seed=6, scale=0.1)
+    ws = torch.empty(32 * Mp * Np, dtype=torch.float32, device=DEV)
+    dW = torch.ones(Mp, Np, dtype=torch.float32, device=DEV)
+    L.gemm(dY, X, dW, Mp, Np, Kc, transA=True, transB=True, accumulate=True, alpha=0.5, workspace=ws)
+    assert relerr(dW, 1.0 + 0.5 * (dY.float().T @ X.float())) < 2e-5
+
+
 def test_gemm_splitk_workspace():
     """Weight-gradient shape (few output tiles, long contraction): split-K through a caller workspace."""
     Mp, Np, Kc = 768, 256, 8000

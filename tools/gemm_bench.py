@@ -23,9 +23,9 @@ shapes = [("enc qkv fwd", 32000, 2304, 768, 0, 0), ("enc o fwd", 32000, 768, 768
           ("enc qkv dgrad", 32000, 768, 2304, 0, 1), ("enc wi dgrad", 32000, 768, 3072, 0, 1), ("enc wo dgrad", 32000, 3072, 768, 0, 1),
           ("lm head fwd", 8192, 32200, 768, 0, 0)]
 ws = torch.empty(64 * 1024 * 1024 // 4, device=dev)
-for dma in (1, 0):
-    L.set_option("gemm_dma", dma)
-    print(f"--- gemm_dma={dma}")
+for big in (1, 2, 0):
+    L.set_option("gemm_big", big)
+    print(f"--- gemm_big={big}")
     for name, M, N, K, ta, tb in shapes:
         tf, us = bench(M, N, K, bool(ta), bool(tb), f32=(name == "lm head fwd"))
         print(f"{name:16s} M={M:6d} N={N:6d} K={K:6d}: {tf:7.1f} TF/s  {us:8.1f} us")

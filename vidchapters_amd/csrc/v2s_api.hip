@@ -8,6 +8,7 @@
 static thread_local char g_err[512] = "";
 static std::atomic<int> g_tr_read{1};
 static std::atomic<int> g_gemm_dma{1};
+static std::atomic<int> g_gemm_big{1};
 
 void v2s_set_error(const char* fmt, ...) {
   va_list ap;
@@ -18,19 +19,22 @@ void v2s_set_error(const char* fmt, ...) {
 
 int v2s_opt_tr_read() { return g_tr_read.load(std::memory_order_relaxed); }
 int v2s_opt_gemm_dma() { return g_gemm_dma.load(std::memory_order_relaxed); }
+int v2s_opt_gemm_big() { return g_gemm_big.load(std::memory_order_relaxed); }
 
 extern "C" int v2s_version(void) { return V2S_ABI_VERSION; }
 extern "C" const char* v2s_last_error(void) { return g_err; }
 
 extern "C" int v2s_set_option(const char* name, int value) {
   if (name && strcmp(name, "tr_read") == 0) { g_tr_read.store(value ? 1 : 0); return V2S_OK; }
-  if (name && strcmp(name, "gemm_dma") == 0) { g_gemm_dma.store(value ? 1 : 0); return V2S_OK; }
+  if (name && strcmp(name, "gemm_dma") == 0) { g_gemm_dma.store(value); return V2S_OK; }
+  if (name && strcmp(name, "gemm_big") == 0) { g_gemm_big.store(value); return V2S_OK; }
   v2s_set_error("v2s_set_option: unknown option '%s'", name ? name : "(null)");
   return V2S_ERR_ARG;
 }
 extern "C" int v2s_get_option(const char* name) {
   if (name && strcmp(name, "tr_read") == 0) return g_tr_read.load();
   if (name && strcmp(name, "gemm_dma") == 0) return g_gemm_dma.load();
+  if (name && strcmp(name, "gemm_big") == 0) return g_gemm_big.load();
   v2s_set_error("v2s_get_option: unknown option '%s'", name ? name : "(null)");
   return V2S_ERR_ARG;
 }

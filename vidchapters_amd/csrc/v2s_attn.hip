@@ -109,17 +109,13 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
   return f;
 }
 
-// attention-probability dropout: keep(b,h,q,k) from a per-row seed and a light 32-bit mix of (row seed + k/2); the two
-// 16-bit halves decide keys 2j and 2j+1.  Same definition in all three kernels (forward mask == backward mask).
+// attention-probability dropout: keep(b,h,q,k) <=> ((rowseed(b,h,q) ^ (k * C1)) * C2) >= (p16 << 16): a per-row seed (one
+// full hash per row) and one xor-multiply per element, decided on the top 16 bits of the product.  Same definition in
+// all three kernels (forward mask == backward mask).
+constexpr uint32_t DROP_C1 = 0x9E3779B1u, DROP_C2 = 0x85EBCA77u;
 __device__ __forceinline__ uint32_t drop_rowseed(uint32_t seed, uint32_t rowid) { return v2s_hash32(seed ^ (rowid * 0x9E3779B1u)); }
-__device__ __forceinline__ uint32_t drop_mix(uint32_t rowseed, uint32_t kpair) {
-  uint32_t x = (rowseed + kpair) * 0x9E3779B1u;
-  x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
-  return x;
-}
-__device__ __forceinline__ bool drop_keep(uint32_t rowseed, uint32_t k, uint32_t p16) {
-  const uint32_t h = drop_mix(rowseed, k >> 1);
-  return ((k & 1u) ? (h >> 16) : (h & 0xffffu)) >= p16;
+__device__ __forceinline__ bool drop_keep(uint32_t rowseed, uint32_t kc1, uint32_t thr) {   // kc1 = k * DROP_C1, thr = p16 << 16
+  return ((rowseed ^ kc1) * DROP_C2) >= thr;
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; x <= ~0 here
@@ -297,22 +293,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
         m[qb] = mn;
         float rs = 0.f;
         const uint32_t rseed = DROP ? drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q)) : 0u;
+        const uint32_t thr = p.p16 << 16;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-          uint32_t h01 = 0, h23 = 0;
-          if (DROP) {   // keys k0+kb*16+4g .. +3 : two 32-bit mixes give four 16-bit draws
-            const uint32_t kp = (uint32_t)(k0 + kb * 16 + 4 * g) >> 1;
-            h01 = drop_mix(rseed, kp); h23 = drop_mix(rseed, kp + 1);
-          }
+          const uint32_t kc = (uint32_t)(k0 + kb * 16 + 4 * g) * DROP_C1;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float pv = fast_exp2(st[qb][kb][r] - mn);
             rs += pv;
-            if (DROP) {
-              const uint32_t hh = (r < 2) ? h01 : h23;
-              const uint32_t r16 = (r & 1) ? (hh >> 16) : (hh & 0xffffu);
-              pv = (r16 >= p.p16) ? pv * p.inv_keep : 0.f;
-            }
+            if (DROP) pv = drop_keep(rseed, kc + (uint32_t)r * DROP_C1, thr) ? pv * p.inv_keep : 0.f;
             st[qb][kb][r] = pv;
           }
         }
@@ -430,6 +419,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
     }
   }
   const bool seen = __all((m2[0] > REAL_MIN) && (m2[1] > REAL_MIN));
+  const float isc2 = 1.0f / (p.scale * LOG2E);
+  const float ninit[2] = {-m2[0] * isc2, -m2[1] * isc2};
   f32x4 dqt[2][4];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
@@ -482,11 +473,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
     const bool skip = (all_flag || future) && seen;
 
     if (!skip) {
+      // the score accumulators start at -m/sc2 so that fma(acc, sc2, bias) is already (s - m) in the log2 domain
       f32x4 st[2][4], dp[2][4];
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) { st[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int kb = 0; kb < 4; ++kb) { st[qb][kb] = f32x4{ninit[qb], ninit[qb], ninit[qb], ninit[qb]}; dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -510,38 +502,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
         const uint8_t* fl = reinterpret_cast<const uint8_t*>(sK + OFF_FLAG);
         float lsum_ds = 0.f;
         const uint32_t rseed = DROP ? drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q)) : 0u;
+        const uint32_t thr = p.p16 << 16;
+        const float li_q = linv[qb], dl_q = dl[qb];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-          uint32_t h01 = 0, h23 = 0;
-          if (DROP) {
-            const uint32_t kp = (uint32_t)(k0 + kb * 16 + 4 * g) >> 1;
-            h01 = drop_mix(rseed, kp); h23 = drop_mix(rseed, kp + 1);
-          }
           float4 bw = make_float4(0.f, 0.f, 0.f, 0.f);
           if (BIAS) bw = bias_read4(sK, kb * 16 + 4 * g + 127 - qq);
           const float bwv[4] = {bw.x, bw.y, bw.z, bw.w};
-          uint32_t f4 = 0;
-          if (!clean) f4 = *reinterpret_cast<const uint32_t*>(fl + kb * 16 + 4 * g);
+          const uint32_t kc = (uint32_t)(k0 + kb * 16 + 4 * g) * DROP_C1;
+          float x[4];
+          if (clean) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = fmaf(st[qb][kb][r], sc2, bwv[r]);
+          } else {
+            const uint32_t f4 = *reinterpret_cast<const uint32_t*>(fl + kb * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              uint32_t f = (f4 >> (8 * r)) & 0xffu;
+              if (CAUSAL && (k0 + kb * 16 + 4 * g + r) > q + p.causal_off) f |= 1u;
+              x[r] = (f & 2u) ? -INFINITY : ((f & 1u) ? (MASKED2 - m2[qb]) : fmaf(st[qb][kb][r], sc2, bwv[r]));
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int kk = kb * 16 + 4 * g + r;
-            float s = fmaf(st[qb][kb][r], sc2, bwv[r]);
-            if (!clean) {
-              uint32_t f = (f4 >> (8 * r)) & 0xffu;
-              if (CAUSAL && (k0 + kk) > q + p.causal_off) f |= 1u;
-              s = (f & 2u) ? -INFINITY : ((f & 1u) ? MASKED2 : s);
-            }
-            const float pr = fast_exp2(s - m2[qb]) * linv[qb];
+            const float pr = fast_exp2(x[r]) * li_q;
             float dpv = dp[qb][kb][r];
-            if (DROP) {
-              const uint32_t hh = (r < 2) ? h01 : h23;
-              const uint32_t r16 = (r & 1) ? (hh >> 16) : (hh & 0xffffu);
-              dpv = (r16 >= p.p16) ? dpv * p.inv_keep : 0.f;
-            }
-            const float ds = pr * (dpv - dl[qb]);
+            if (DROP) dpv = drop_keep(rseed, kc + (uint32_t)r * DROP_C1, thr) ? dpv * p.inv_keep : 0.f;
+            const float ds = pr * (dpv - dl_q);
             st[qb][kb][r] = ds;
             if (BIAS) {
               if (route == 3) {
+                const int kk = kb * 16 + 4 * g + r;
                 const int d = (k0 + kk) - q;
                 if (d <= p.far_lo) acc_lo += ds;
                 else if (d >= p.far_hi) acc_hi += ds;
@@ -647,7 +638,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     for (int db = 0; db < 4; ++db) { dkt[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int ntiles = (p.Nq + 63) >> 6;
-  const float sc2 = p.scale * LOG2E;
+  const float sc2 = p.scale * LOG2E, isc2 = 1.0f / sc2;
+  const uint32_t thr = p.p16 << 16;
   uint4 rq[2], rdo[2];
   float rbias = 0.f;
   float rm = 0.f, rl = 0.f, rd = 0.f;
@@ -708,11 +700,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh) {
         // S[q][key] and dP[q][key]:  D[row = q = qb*16 + 4g + r][col = key = kb*16 + li]
+        // score accumulators start at -m[q]/sc2 (row q = 4g + r), see the dQ kernel
         f32x4 st[2][2], dp[2][2];
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
+        for (int qi = 0; qi < 2; ++qi) {
+          const float4 mi4 = *reinterpret_cast<const float4*>(ms + (2 * qh + qi) * 16 + 4 * g);
+          const f32x4 init = f32x4{-mi4.x * isc2, -mi4.y * isc2, -mi4.z * isc2, -mi4.w * isc2};
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb) { st[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          for (int kb = 0; kb < 2; ++kb) { st[qi][kb] = init; dp[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -739,26 +735,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb) {
             const int kk = wk0 + kb * 16 + li, k = K0 + kk;
+            const uint32_t kc = (uint32_t)k * DROP_C1;
             // window entries for r = 0..3 sit at decreasing indices i0 - r with i0 = kk + 63 - (qb*16 + 4g)
             float bwv[4] = {0.f, 0.f, 0.f, 0.f};
             if (BIAS) {
               const float4 bw = bias_read4(sQ, kk + 63 - (qb * 16 + 4 * g) - 3);
               bwv[0] = bw.w; bwv[1] = bw.z; bwv[2] = bw.y; bwv[3] = bw.x;
             }
+            float x[4];
+            if (clean) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int qq = qb * 16 + 4 * g + r, q = q0 + qq;
-              float s = fmaf(st[qi][kb][r], sc2, bwv[r]);
-              if (!clean) {
+              for (int r = 0; r < 4; ++r) x[r] = fmaf(st[qi][kb][r], sc2, bwv[r]);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int q = q0 + qb * 16 + 4 * g + r;
                 uint32_t f = kflag[kb];
                 if (CAUSAL && k > q + p.causal_off) f |= 1u;
-                s = (f & 2u) ? -INFINITY : ((f & 1u) ? MASKED2 : s);
+                x[r] = (f & 2u) ? -INFINITY : ((f & 1u) ? (MASKED2 - mr[r]) : fmaf(st[qi][kb][r], sc2, bwv[r]));
               }
-              const float pr = fast_exp2(s - mr[r]) * lr[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pr = fast_exp2(x[r]) * lr[r];
               float dpv = dp[qi][kb][r];
               float pd = pr;
               if (DROP) {
-                const bool keep = drop_keep(sdr[r], (uint32_t)k, p.p16);
+                const bool keep = drop_keep(sdr[r], kc, thr);
                 dpv = keep ? dpv * p.inv_keep : 0.f;
                 pd = keep ? pr * p.inv_keep : 0.f;
               }

@@ -35,6 +35,7 @@ void v2s_set_error(const char* fmt, ...);
 
 int v2s_opt_tr_read();   // 1 = use ds_read_b64_tr_b16 for transposed operand fragments
 int v2s_opt_gemm_dma();  // 1 = LDS-DMA (global_load_lds) GEMM main loop where K % 64 == 0
+int v2s_opt_gemm_big();  // 0 = never, 1 = 256x256/256x128 tiles where they fill the chip, 2 = 256x128 only
 
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -69,17 +70,34 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// counter-based dropout RNG: one 32-bit hash per PAIR of elements, 16 bits each.
+// counter-based dropout RNG.  Activations are always processed in aligned chunks of 8 consecutive elements (linear index
+// e0 = multiple of 8): four light 32-bit mixes of (seed + pair index) give eight 16-bit draws; element e0+j is kept iff
+// its draw >= p16.  Every kernel that applies or re-applies a mask (GEMM epilogue, elementwise dropout, embedding)
+// calls this one function with the same linear index, so forward and backward masks agree by construction.
 __device__ __forceinline__ uint32_t v2s_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-// keep-decision for element index e (64-bit) under (seed, p16): drop iff r16 < p16
-__device__ __forceinline__ bool v2s_keep(unsigned long long e, uint32_t seed, uint32_t p16) {
-  unsigned long long pair = e >> 1;
-  uint32_t h = v2s_hash32((uint32_t)pair ^ seed) ^ v2s_hash32((uint32_t)(pair >> 32) + 0x9e3779b9u * (seed | 1u));
-  uint32_t r16 = (e & 1) ? (h >> 16) : (h & 0xffffu);
-  return r16 >= p16;
+__device__ __forceinline__ uint32_t v2s_mix32(uint32_t x) {
+  x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+  return x;
+}
+// bit j of the result = keep element e0 + j
+__device__ __forceinline__ uint32_t v2s_keep8(unsigned long long e0, uint32_t seed, uint32_t p16) {
+  const uint32_t base = seed * 0x9E3779B1u + (uint32_t)(e0 >> 1) + (uint32_t)(e0 >> 33) * 0x85EBCA6Bu;
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t h = v2s_mix32(base + i);
+    m |= ((h & 0xffffu) >= p16 ? 1u : 0u) << (2 * i);
+    m |= ((h >> 16) >= p16 ? 1u : 0u) << (2 * i + 1);
+  }
+  return m;
+}
+__device__ __forceinline__ void v2s_drop8(float (&v)[8], unsigned long long e0, uint32_t seed, uint32_t p16, float inv_keep) {
+  const uint32_t m = v2s_keep8(e0, seed, p16);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = ((m >> j) & 1u) ? v[j] * inv_keep : 0.f;
 }
 
 // exact-erf GELU and its derivative (torch nn.GELU default, vit.py:9)

@@ -122,6 +122,65 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowbase, int ks
 }
 
 // ---- epilogue shared by both main loops: accumulators -> LDS (fp32 [128][128]) -> vector post-ops -> global
+// post-ops + store of ONE 8-wide row chunk (gm, gn..gn+7) whose raw accumulators are in v[]
+__device__ __forceinline__ void epilogue_chunk(const GemmP& p, float (&v)[8], int gm, int gn, int slice) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+  if (p.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gn);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + gn + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+  }
+  if (p.pre) *reinterpret_cast<uint4*>(p.pre + (long)gm * p.ldc + gn) = pack8(v);
+  if (p.act == V2S_ACT_RELU) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+  } else if (p.act == V2S_ACT_GELU) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+  }
+  if (p.dact != V2S_ACT_NONE) {
+    float zf[8];
+    unpack8(*reinterpret_cast<const uint4*>(p.z + (long)gm * p.ldz + gn), zf);
+    if (p.dact == V2S_ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = zf[j] > 0.f ? v[j] : 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= dgelu_f(zf[j]);
+    }
+  }
+  if (p.p16) {
+    v2s_drop8(v, (unsigned long long)gm * (unsigned long long)p.N + gn, p.seed, p.p16, p.inv_keep);
+  }
+  if (p.residual) {
+    float rf[8];
+    unpack8(*reinterpret_cast<const uint4*>(p.residual + (long)gm * p.ldr + gn), rf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += rf[j];
+  }
+  if (p.splitk > 1) {     // raw partial sums of this K slice; splitk_reduce_kernel applies alpha and accumulates into C
+    float* wp = p.ws + ((long)slice * p.M + gm) * p.N + gn;
+    *reinterpret_cast<float4*>(wp) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(wp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    return;
+  }
+  if (p.c_f32) {
+    float* cp = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
+    float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+    if (p.accumulate) {
+      const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+      o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w;
+      o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
+    }
+    *reinterpret_cast<float4*>(cp) = o0;
+    *reinterpret_cast<float4*>(cp + 4) = o1;
+  } else {
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
+  }
+}
+
+// epilogue of the 128x128 kernels: accumulators -> LDS (fp32 [128][128]) -> 8-wide row chunks
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, const f32x4 (&acc)[4][4], int m0, int n0, int slice,
                                               int tid, int lane, int wm, int wn) {
   float* cs = reinterpret_cast<float*>(smem);
@@ -133,7 +192,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, const 
       for (int r = 0; r < 4; ++r)
         cs[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * BN + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
   __syncthreads();
-
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
     const int c = tid + it * NTHREADS;
@@ -141,67 +199,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, const 
     const int gm = m0 + row, gn = n0 + cc;
     if (gm >= p.M || gn >= p.N) continue;
     float v[8];
-    {
-      const float4 x0 = *reinterpret_cast<const float4*>(cs + row * BN + cc);
-      const float4 x1 = *reinterpret_cast<const float4*>(cs + row * BN + cc + 4);
-      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
-    if (p.bias) {
-      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gn);
-      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + gn + 4);
-      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-    }
-    if (p.pre) *reinterpret_cast<uint4*>(p.pre + (long)gm * p.ldc + gn) = pack8(v);
-    if (p.act == V2S_ACT_RELU) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-    } else if (p.act == V2S_ACT_GELU) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
-    }
-    if (p.dact != V2S_ACT_NONE) {
-      float zf[8];
-      unpack8(*reinterpret_cast<const uint4*>(p.z + (long)gm * p.ldz + gn), zf);
-      if (p.dact == V2S_ACT_RELU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = zf[j] > 0.f ? v[j] : 0.f;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= dgelu_f(zf[j]);
-      }
-    }
-    if (p.p16) {
-      const unsigned long long e0 = (unsigned long long)gm * (unsigned long long)p.N + gn;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = v2s_keep(e0 + j, p.seed, p.p16) ? v[j] * p.inv_keep : 0.f;
-    }
-    if (p.residual) {
-      float rf[8];
-      unpack8(*reinterpret_cast<const uint4*>(p.residual + (long)gm * p.ldr + gn), rf);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += rf[j];
-    }
-    if (p.splitk > 1) {     // raw partial sums of this K slice; splitk_reduce_kernel applies alpha and accumulates into C
-      float* wp = p.ws + ((long)slice * p.M + gm) * p.N + gn;
-      *reinterpret_cast<float4*>(wp) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(wp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      continue;
-    }
-    if (p.c_f32) {
-      float* cp = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
-      float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
-      if (p.accumulate) {
-        const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
-        o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w;
-        o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
-      }
-      *reinterpret_cast<float4*>(cp) = o0;
-      *reinterpret_cast<float4*>(cp + 4) = o1;
-    } else {
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)gm * p.ldc + gn) = pack8(v);
-    }
+    const float4 x0 = *reinterpret_cast<const float4*>(cs + row * BN + cc);
+    const float4 x1 = *reinterpret_cast<const float4*>(cs + row * BN + cc + 4);
+    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+    epilogue_chunk(p, v, gm, gn, slice);
   }
 }
 
@@ -269,12 +270,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmP p) {
 // 1 KiB per wave-instruction at (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
 // address; reads use the same involution (read_frag).  Rows beyond the matrix edge are clamped to the last valid row /
 // chunk: they only feed output rows/columns that are never stored.
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void gbl_void_t;
+// The DMA is issued from inline asm on purpose: for the builtin, hipcc cannot prove that the LDS stage being written and
+// the stage being read are disjoint and puts s_waitcnt vmcnt(0) in front of the first ds_read of every K-step, which
+// serialises load and compute.  From asm the DMA is invisible to the compiler's counters; we wait ourselves
+// (dma_wait) right before the barrier that publishes the stage.  M0 carries the wave-uniform LDS byte address.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
+}
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst_uniform) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <bool T>
-__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long ld, int row0, int R, int R8, int k0, char* tile,
-                                         int wave, int lane) {
+__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long ld, int row0, int R, int R8, int k0,
+                                         uint32_t tile_addr, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = wave * 4 + i;           // 1 KiB chunk of the 16 KiB tile
@@ -292,7 +304,7 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long l
       grow = grow <= R8 - 8 ? grow : R8 - 8;
       src = base + (long)(k0 + k) * ld + grow;
     }
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(tile + c * 1024), 16, 0, 0);
+    glds16(src, __builtin_amdgcn_readfirstlane(tile_addr + c * 1024));
   }
 }
 
@@ -317,15 +329,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const GemmP p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (kend - kbeg) / BK;
-  dma_tile<TA>(p.A, p.lda, m0, p.M, M8, kbeg, smem, wave, lane);
-  dma_tile<TB>(p.B, p.ldb, n0, p.N, N8, kbeg, smem + A_BYTES, wave, lane);
-  __syncthreads();          // hipcc drains the DMA (vmcnt(0)) before the barrier
+  const uint32_t sbase = lds_addr(smem);
+  dma_tile<TA>(p.A, p.lda, m0, p.M, M8, kbeg, sbase, wave, lane);
+  dma_tile<TB>(p.B, p.ldb, n0, p.N, N8, kbeg, sbase + A_BYTES, wave, lane);
+  dma_wait();
+  __syncthreads();
 
   for (int t = 0; t < nk; ++t) {
     const char* sa = smem + (t & 1) * STAGE_BYTES;
     const char* sb = sa + A_BYTES;
     if (t + 1 < nk) {
-      char* da = smem + ((t + 1) & 1) * STAGE_BYTES;
+      const uint32_t da = sbase + ((t + 1) & 1) * STAGE_BYTES;
       dma_tile<TA>(p.A, p.lda, m0, p.M, M8, kbeg + (t + 1) * BK, da, wave, lane);
       dma_tile<TB>(p.B, p.ldb, n0, p.N, N8, kbeg + (t + 1) * BK, da + A_BYTES, wave, lane);
     }
@@ -342,9 +356,148 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const GemmP p) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
+    dma_wait();
     __syncthreads();
   }
   gemm_epilogue(p, smem, acc, m0, n0, slice, tid, lane, wm, wn);
+}
+
+// =====================================================================================================================
+// 256 x BN2 x 64 tile kernel (BN2 = 256 or 128), 8 waves, LDS-DMA double buffer (2 x 64 / 2 x 48 KiB), one block per CU.
+// Twice (1.33x) the flops per staged byte of the 128x128 kernels: those are limited by bytes-in-flight x latency, not by
+// the matrix pipe.  Wave grid 2(M) x 4(N) with 128x64 per wave (BN2=256) or 4 x 2 with 64x64 (BN2=128).
+// Transposed operands use the same [k][row] LDS image as the small kernel with a row pitch of ROWS*2 bytes.
+template <int ROWS, bool T>
+__device__ __forceinline__ void dma_tile_big(const bf16_t* __restrict__ base, long ld, int row0, int R, int R8, int k0,
+                                             uint32_t tile_addr, int wave, int lane) {
+  constexpr int NCHUNK = ROWS * 64 * 2 / 1024;     // 1 KiB chunks in the tile (32 or 16)
+  constexpr int PER_WAVE = NCHUNK / 8;
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int c = wave * PER_WAVE + i;
+    const bf16_t* src;
+    if (!T) {                             // [ROWS][64 k]: chunk = 8 rows x 128 B
+      const int row = c * 8 + (lane >> 3), pos = lane & 7;
+      const int chunk = pos ^ ((row >> 1) & 7);
+      int grow = row0 + row;
+      grow = grow < R ? grow : R - 1;
+      src = base + (long)grow * ld + k0 + chunk * 8;
+    } else {                              // [64 k][ROWS]: k-row pitch ROWS*2 bytes
+      constexpr int SLOTS = ROWS / 8;     // 16-byte slots per k-row (32 or 16)
+      constexpr int KPC = 64 / SLOTS;     // k-rows per 1 KiB chunk (2 or 4)
+      const int k = c * KPC + lane / SLOTS, pos16 = lane % SLOTS;
+      const int c16 = ((((pos16 >> 1) ^ tr_g(k)) << 1) | (pos16 & 1));
+      int grow = row0 + c16 * 8;
+      grow = grow <= R8 - 8 ? grow : R8 - 8;
+      src = base + (long)(k0 + k) * ld + grow;
+    }
+    glds16(src, __builtin_amdgcn_readfirstlane(tile_addr + c * 1024));
+  }
+}
+
+template <int ROWS, bool T>
+__device__ __forceinline__ bf16x8 read_frag_big(const char* lds, int rowbase, int ks, int lane) {
+  if (!T) {
+    const int row = rowbase + (lane & 15);
+    const int chunk = ks * 4 + (lane >> 4);
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)));
+  } else {
+    constexpr int PITCH = ROWS * 2;
+    const int i = lane & 15;
+    const int k = ks * 32 + (lane >> 4) * 8 + (i >> 2);
+    const int m = rowbase + (i & 3) * 4;
+    const int k1 = k + 4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((V2S_LDS s16x4*)(lds + k * PITCH + (((m >> 4) ^ tr_g(k)) << 5) + ((m & 15) << 1)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((V2S_LDS s16x4*)(lds + k1 * PITCH + (((m >> 4) ^ tr_g(k1)) << 5) + ((m & 15) << 1)));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <bool TA, bool TB, int BN2>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmP p) {
+  constexpr int BM2 = 256;
+  constexpr int A_B = BM2 * 64 * 2, B_B = BN2 * 64 * 2, STG = A_B + B_B;
+  constexpr int WN = BN2 / 64, WM = 8 / WN;          // 4x2 or 2x4 ... (WM x WN) waves
+  constexpr int MI = BM2 / WM / 16;                  // 16-row fragments per wave: 8 (BN2=256) or 4 (BN2=128)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * STG bytes
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nwg = p.tilesM * p.tilesN * p.splitk;
+  const int id0 = xcd_remap(blockIdx.x, nwg);
+  const int slice = id0 % p.splitk, id = id0 / p.splitk;
+  const int tm = id / p.tilesN, tn = id - tm * p.tilesN;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+  const int kbeg = slice * p.kper, kend = min(p.K, kbeg + p.kper);
+  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
+
+  f32x4 acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (kend - kbeg) / BK;
+  const uint32_t sbase = lds_addr(smem);
+  dma_tile_big<BM2, TA>(p.A, p.lda, m0, p.M, M8, kbeg, sbase, wave, lane);
+  dma_tile_big<BN2, TB>(p.B, p.ldb, n0, p.N, N8, kbeg, sbase + A_B, wave, lane);
+  dma_wait();
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const char* sa = smem + (t & 1) * STG;
+    const char* sb = sa + A_B;
+    if (t + 1 < nk) {
+      const uint32_t da = sbase + ((t + 1) & 1) * STG;
+      dma_tile_big<BM2, TA>(p.A, p.lda, m0, p.M, M8, kbeg + (t + 1) * BK, da, wave, lane);
+      dma_tile_big<BN2, TB>(p.B, p.ldb, n0, p.N, N8, kbeg + (t + 1) * BK, da + A_B, wave, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = read_frag_big<BN2, TB>(sb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const bf16x8 af = read_frag_big<BM2, TA>(sa, wm * (MI * 16) + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    dma_wait();
+    __syncthreads();
+  }
+
+  // epilogue in passes of 64 tile rows (fp32 staging 64 x BN2 <= 64 KiB): pass ps takes fragments i in [ps*IPP, (ps+1)*IPP)
+  float* cs = reinterpret_cast<float*>(smem);
+  constexpr int IPP = 64 / WM / 16;                 // fragments per wave per pass: 2 (WM=2) or 1 (WM=4)
+  constexpr int NPASS = MI / IPP;                   // 4
+  constexpr int CPR = BN2 / 8;                      // 8-wide chunks per row
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+    for (int ii = 0; ii < IPP; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cs[(wm * (IPP * 16) + ii * 16 + (lane >> 4) * 4 + r) * BN2 + wn * 64 + j * 16 + (lane & 15)] = acc[ps * IPP + ii][j][r];
+    __syncthreads();
+#pragma unroll 1
+    for (int c = tid; c < 64 * CPR; c += 512) {
+      const int lr = c / CPR, cc = (c % CPR) * 8;                 // local row in the 64-row staging block
+      const int w = lr / (IPP * 16), rr = lr % (IPP * 16);        // owning wave row, row inside its IPP*16 rows
+      const int gm = m0 + w * (MI * 16) + ps * (IPP * 16) + rr, gn = n0 + cc;
+      if (gm >= p.M || gn >= p.N) continue;
+      float v[8];
+      const float4 x0 = *reinterpret_cast<const float4*>(cs + lr * BN2 + cc);
+      const float4 x1 = *reinterpret_cast<const float4*>(cs + lr * BN2 + cc + 4);
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+      epilogue_chunk(p, v, gm, gn, slice);
+    }
+    __syncthreads();
+  }
 }
 
 // C[m][n] (+)= alpha * sum_z ws[z][m][n]   (deterministic: fixed slice order)
@@ -432,31 +585,70 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   p.p16 = (uint32_t)(a->dropout_p * 65536.0f + 0.5f);
   p.inv_keep = p.p16 ? 1.0f / (1.0f - (float)p.p16 / 65536.0f) : 1.0f;
   p.seed = a->dropout_seed;
-  p.tilesM = (a->M + BM - 1) / BM; p.tilesN = (a->N + BN - 1) / BN;
+  hipStream_t s = (hipStream_t)stream;
+  const bool tr = v2s_opt_tr_read() != 0;
+  const bool plain_split = a->workspace && a->c_dtype == V2S_F32 && !a->bias && !a->act && !a->dact && !a->residual && !a->pre &&
+                           a->dropout_p == 0.f && a->K >= 1024 && (a->N % 8) == 0;
+  // tile choice: the 256-row kernel (one 8-wave block per CU) when K % 64 == 0 and it yields enough tiles, else 128x128
+  int bm = BM, bn = BN;
+  const int big_mode = v2s_opt_gemm_big();
+  // measured on the step's shapes (tools/gemm_bench.py, TF/s): N >= 1024 -> 256x256 for every variant (wi fwd 801 vs 711,
+  // wo dgrad 856 vs 753, wo wgrad 922 vs 684, LM head 754 vs 571); N < 1024 -> 256x128 for plain NT (o fwd 727 vs 667,
+  // wo fwd 1032 vs 885) but the 128x128 DMA kernel for the transposed variants (dgrad 1000-1040 vs 931-953)
+  if (big_mode && tr && (a->K % BK) == 0 && a->M >= 256 && a->N >= 128) {
+    const bool wide = a->N >= 1024 && big_mode != 2;
+    const int bn2 = wide ? 256 : 128;
+    const long t2 = (long)((a->M + 255) / 256) * ((a->N + bn2 - 1) / bn2);
+    const bool transposed = a->transA || a->transB;
+    if ((wide || !transposed || big_mode == 2) && (t2 >= 240 || (plain_split && t2 >= 8))) { bm = 256; bn = bn2; }
+  }
+  p.tilesM = (a->M + bm - 1) / bm; p.tilesN = (a->N + bn - 1) / bn;
   // split-K: weight-gradient GEMMs have few output tiles (768x768 -> 36) but a huge contraction (all tokens);
-  // slice K so that ~3 workgroups per CU are in flight.  Only for "C += " into fp32 with a plain epilogue.
+  // slice K so that the chip is filled.  Only for fp32 outputs with a plain epilogue; partials go to the workspace.
   p.splitk = 1; p.kper = a->K; p.ws = (float*)a->workspace;
   const int tiles = p.tilesM * p.tilesN;
-  if (a->workspace && a->c_dtype == V2S_F32 && !a->bias && !a->act && !a->dact && !a->residual && !a->pre &&
-      a->dropout_p == 0.f && tiles < 512 && a->K >= 1024 && (a->N % 8) == 0) {
-    int s = (768 + tiles - 1) / tiles;
+  const int want = (bm == 256) ? 512 : 768;
+  if (plain_split && tiles < want) {
+    int sp = (want + tiles - 1) / tiles;
     const int maxs = a->K / 512;
-    if (s > maxs) s = maxs;
+    if (sp > maxs) sp = maxs;
     const long per_slice = (long)a->M * a->N * 4;
-    if ((long)s * per_slice > a->workspace_bytes) s = (int)(a->workspace_bytes / per_slice);
-    if (s > 1) {
-      int kper = ((a->K + s - 1) / s + BK - 1) / BK * BK;
+    if ((long)sp * per_slice > a->workspace_bytes) sp = (int)(a->workspace_bytes / per_slice);
+    if (sp > 1) {
+      int kper = ((a->K + sp - 1) / sp + BK - 1) / BK * BK;
       p.kper = kper;
       p.splitk = (a->K + kper - 1) / kper;
       p.alpha = 1.0f;           // alpha and the accumulate are applied by the reduction
     }
   }
-  const dim3 grid(p.tilesM * p.tilesN * p.splitk), block(NTHREADS);
-  hipStream_t s = (hipStream_t)stream;
-  const bool tr = v2s_opt_tr_read() != 0;
+  const unsigned nblocks = (unsigned)(p.tilesM * p.tilesN * p.splitk);
+  if (bm == 256) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)gemm_big_kernel<true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+      (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+      (void)hipFuncSetAttribute((const void*)gemm_big_kernel<true, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+      attr_done = true;
+    }
+    const size_t dyn = 2 * (size_t)(256 * 64 * 2 + bn * 64 * 2);
+    const dim3 grid(nblocks), block(512);
+#define V2S_BIG(TA_, TB_)                                                                              \
+    do {                                                                                               \
+      if (bn == 256) hipLaunchKernelGGL((gemm_big_kernel<TA_, TB_, 256>), grid, block, dyn, s, p);     \
+      else hipLaunchKernelGGL((gemm_big_kernel<TA_, TB_, 128>), grid, block, dyn, s, p);               \
+    } while (0)
+    if (!a->transA && !a->transB) V2S_BIG(false, false);
+    else if (!a->transA && a->transB) V2S_BIG(false, true);
+    else V2S_BIG(true, true);
+#undef V2S_BIG
+  } else {
+  const dim3 grid(nblocks), block(NTHREADS);
   // measured (tools/gemm_bench.py): the DMA loop wins for the transposed-operand variants (dgrad +5..18 %, wgrad +2..9 %),
   // the register-staged loop for plain NT (forward) shapes
-  const bool dma = v2s_opt_gemm_dma() != 0 && tr && (a->transA || a->transB) && (a->K % BK) == 0 && (p.kper % BK) == 0 &&
+  const bool dma = v2s_opt_gemm_dma() != 0 && tr && (a->transA || a->transB || v2s_opt_gemm_dma() == 2) && (a->K % BK) == 0 && (p.kper % BK) == 0 &&
                    a->M >= 8 && a->N >= 8;
   if (dma) {
     if (!a->transA && !a->transB) hipLaunchKernelGGL((gemm_dma_kernel<false, false>), grid, block, 0, s, p);
@@ -470,6 +662,7 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   } else {
     if (tr) hipLaunchKernelGGL((gemm_kernel<true, true, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<true, true, false>), grid, block, 0, s, p);
+  }
   }
   V2S_LAUNCH_CHECK();
   if (p.splitk > 1) {

@@ -28,8 +28,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__
     if (p16) {
       float f[8];
       unpack8(v, f);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = v2s_keep((unsigned long long)row * d + c * 8 + j, seed, p16) ? f[j] * inv_keep : 0.f;
+      v2s_drop8(f, (unsigned long long)row * d + c * 8, seed, p16, inv_keep);
       v = pack8(f);
     }
     *reinterpret_cast<uint4*>(out + row * d + c * 8) = v;
@@ -49,12 +48,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long* __restrict__
     float f[8];
     unpack8(*reinterpret_cast<const uint4*>(dy + row * d + c * 8), f);
     float* dst = dtable + id * d + c * 8;
+    if (p16) v2s_drop8(f, (unsigned long long)row * d + c * 8, seed, p16, inv_keep);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float g = f[j];
-      if (p16) g = v2s_keep((unsigned long long)row * d + c * 8 + j, seed, p16) ? g * inv_keep : 0.f;
-      if (g != 0.f) atomicAdd(dst + j, g);
-    }
+    for (int j = 0; j < 8; ++j)
+      if (f[j] != 0.f) atomicAdd(dst + j, f[j]);
   }
 }
 
@@ -72,8 +69,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const bf16_t* __restrict__ x, c
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] += a[j];
     } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = v2s_keep((unsigned long long)t * 8 + j, seed, p16) ? f[j] * inv_keep : 0.f;
+      v2s_drop8(f, (unsigned long long)t * 8, seed, p16, inv_keep);
     }
     *reinterpret_cast<uint4*>(y + t * 8) = pack8(f);
   }

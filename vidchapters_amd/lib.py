@@ -140,8 +140,9 @@ class KernelTimer:
     Usage: ``with KernelTimer() as kt: step()`` then ``kt.summary()`` -> {tag: (launches, total_ms, total_work)}."""
     active = None
 
-    def __init__(self):
+    def __init__(self, detail: bool = False):
         self.records = []
+        self.detail = detail
 
     def __enter__(self):
         KernelTimer.active = self
@@ -203,7 +204,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, 
         e0 = kt.begin()
     _check(lib().v2s_gemm(C.byref(a), stream_ptr()), "v2s_gemm")
     if kt is not None:
-        kt.end("gemm_wgrad" if transA else ("gemm_dgrad" if transB else "gemm_nt"), 2.0 * M * N * K, e0)
+        kind = "gemm_wgrad" if transA else ("gemm_dgrad" if transB else "gemm_nt")
+        if kt.detail:
+            kind += f":{M}x{N}x{K}" + (":drop" if dropout_p > 0 else "") + (":res" if residual is not None else "") + \
+                    (":act" if act or dact else "") + (":bias" if bias is not None else "") + (":f32" if a.c_dtype == V2S_F32 else "")
+        kt.end(kind, 2.0 * M * N * K, e0)
 
 
 def colsum(X: torch.Tensor, M: int, N: int, out: torch.Tensor, accumulate=True, ldx=None) -> None:
