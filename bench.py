@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--model", default="t5-base")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="single-stream execution (A/B for the stream overlap)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -75,6 +76,7 @@ def main():
     model = Vid2Seq(a.model, tokenizer=tok, vis_drop=a.dropout, enc_drop=a.dropout, dec_drop=a.dropout, init_seed=1234,
                     device=dev).train()
     log(f"model built: {sum(p.numel() for p in model.parameters()) / 1e6:.1f} M parameters")
+    model.engine().overlap = not a.no_overlap
     trainer = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=a.denoising)
     batch = {k: v.to(dev) for k, v in synth.make_batch(B, T, Lx, Lo, len(tok), 1234 + rank, 768, denoising=a.denoising > 0).items()}
     batch["video"] = batch["video"].to(torch.bfloat16)       # features resident in HBM as bf16 (documented in DESIGN.md)
@@ -124,8 +126,12 @@ def main():
     }
 
     if rank == 0 and not a.no_roofline:
+        eng = model.engine()
+        was = eng.overlap
+        eng.overlap = False                 # per-launch durations are only meaningful without concurrent kernels
         with L.KernelTimer() as kt:
             trainer.step(batch)
+        eng.overlap = was
         summ = kt.summary()
         log("roofline leg done")
         tag = max(summ, key=lambda k: summ[k][1])
@@ -152,20 +158,23 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(model, tok, Lx, Lo):
+def cpu_baseline(model, tok, Lx, Lo, threads=32, batch=4):
     """The CPU oracle (fp32 torch port of the reference path, pinned against the reference in the build container)
-    timed on this box's host cores on a bounded sample: ONE optimizer step at B=1 of the same workload."""
+    timed on this box's host cores on a bounded sample: ONE optimizer step at B=4 of the same workload.
+    32 threads: on the 2 x 64-core GPU host more threads are slower for these matrix sizes (measured: B=1 step
+    3.4 s at 32 threads, 13.7 s at 128)."""
     from oracle import vid2seq_ref as R
     from vidchapters_amd import synth
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = min(threads, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     cfg = R.RefConfig(vocab=len(tok))
     P = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
-    b = synth.make_batch(1, 100, Lx, Lo, len(tok), 99, 768)
+    b = synth.make_batch(batch, 100, Lx, Lo, len(tok), 99, 768)
     t0 = time.perf_counter()
     rec = R.train_step(P, {}, cfg, b, lr=3e-4, clip=1.0, generative=1.0, denoising=0.0)
     dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 optimizer step (fwd+bwd+clip+Adam+renorm) at B=1, 100 frames, {Lx} ASR tokens, {Lo} target tokens, "
+    return {"value": round(batch / dt, 4), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"1 optimizer step (fwd+bwd+clip+Adam+renorm) at B={batch}, 100 frames, {Lx} ASR tokens, {Lo} target tokens, "
                       f"fp32 torch CPU oracle, dropout 0; {dt:.1f} s", "loss": round(rec["losses"]["loss"], 5)}
 
 

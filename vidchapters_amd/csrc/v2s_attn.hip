@@ -492,20 +492,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
           }
         }
       const bool clean = !any_flag && !edge;
-      // bias-gradient routing for this (wave, tile): relative positions d = k - q span [dmin, dmax]
-      const int dmin = k0 - qmax, dmax = k0 + 63 - qmin;
-      const int route = !want_dbias ? 0 : (dmax <= p.far_lo ? 1 : (dmin >= p.far_hi ? 2 : 3));   // 1: far-low, 2: far-high, 3: per diagonal
+      // bias-gradient routing per 16x16 block (qb, kb): relative positions d = k - q span a 31-wide range; blocks entirely in
+      // a far bucket just sum their dS (1: far-low, 2: far-high), only the near-diagonal blocks (3) resolve diagonals
       bf16x8 dsf[2][2];
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const int qq = wq0 + qb * 16 + li, q = Q0 + qq;
         const uint8_t* fl = reinterpret_cast<const uint8_t*>(sK + OFF_FLAG);
-        float lsum_ds = 0.f;
         const uint32_t rseed = DROP ? drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q)) : 0u;
         const uint32_t thr = p.p16 << 16;
         const float li_q = linv[qb], dl_q = dl[qb];
+        const int qlo = Q0 + wq0 + qb * 16;            // rows of this block: qlo .. qlo+15
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
+          float lsum_ds = 0.f;
+          const int klo = k0 + kb * 16;
+          const int route = !want_dbias ? 0 : ((klo + 15 - qlo) <= p.far_lo ? 1 : ((klo - (qlo + 15)) >= p.far_hi ? 2 : 3));
           float4 bw = make_float4(0.f, 0.f, 0.f, 0.f);
           if (BIAS) bw = bias_read4(sK, kb * 16 + 4 * g + 127 - qq);
           const float bwv[4] = {bw.x, bw.y, bw.z, bw.w};
@@ -542,10 +544,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
               }
             }
           }
-        }
-        if (BIAS) {
-          if (route == 1) acc_lo += lsum_ds;
-          else if (route == 2) acc_hi += lsum_ds;
+          if (BIAS) {
+            if (route == 1) acc_lo += lsum_ds;
+            else if (route == 2) acc_hi += lsum_ds;
+          }
         }
         dsf[qb][0] = pack_frag(st[qb][0], st[qb][1]);
         dsf[qb][1] = pack_frag(st[qb][2], st[qb][3]);

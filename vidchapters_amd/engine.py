@@ -65,6 +65,13 @@ class Engine:
         # autograd anchor: the coarse Functions take it as an input so that their outputs get a grad_fn even though
         # parameter gradients are written straight into the arena (backward returns None for it)
         self.anchor = torch.zeros(1, device=device, requires_grad=True)
+        # HIP streams: weight-gradient GEMMs are off the critical path of backward (nothing downstream reads them before
+        # the optimizer), so they run on `wstream` next to the dgrad / attention kernels of the main stream and fill the
+        # CUs those leave idle (tails, epilogues, small decoder/ViT launches).  `vstream` lets the temporal ViT (small
+        # launches, independent of the T5 encoder) run beside the encoder in both directions (train.Trainer).
+        self.overlap = True
+        self.wstream = torch.cuda.Stream(device=device)
+        self.vstream = torch.cuda.Stream(device=device)
         self.arena.refresh_shadow(force=True)
 
     # ------------------------------------------------------------------------------------------ names / arena order
@@ -157,10 +164,30 @@ class Engine:
     # linear helpers ------------------------------------------------------------------------------------------
     def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, wname: str, n_out: int, n_in: int, rows: int, ld_dy=None, ld_x=None,
                alpha: float = 1.0, shape=None) -> None:
-        """dW[n_out, n_in] += alpha * dy[rows, n_out]^T @ x[rows, n_in]  (fp32 accumulate into the gradient arena)."""
-        L.gemm(dy, x, self.arena.g(wname, shape), n_out, n_in, rows, transA=True, transB=True,
-               lda=ld_dy if ld_dy is not None else n_out, ldb=ld_x if ld_x is not None else n_in, ldc=n_in,
-               accumulate=True, alpha=alpha, workspace=self._splitk_ws())
+        """dW[n_out, n_in] += alpha * dy[rows, n_out]^T @ x[rows, n_in]  (fp32 accumulate into the gradient arena).
+        Runs on the weight-gradient stream unless the target is the tied embedding (whose gradient is also written by
+        the embedding scatter-add on the main stream)."""
+        def launch():
+            L.gemm(dy, x, self.arena.g(wname, shape), n_out, n_in, rows, transA=True, transB=True,
+                   lda=ld_dy if ld_dy is not None else n_out, ldb=ld_x if ld_x is not None else n_in, ldc=n_in,
+                   accumulate=True, alpha=alpha, workspace=self._splitk_ws())
+        if not self.overlap or wname == "t5_model.shared.weight":
+            if self.overlap:      # the shared split-K workspace is owned by wstream: wait for its users first
+                torch.cuda.current_stream().wait_stream(self.wstream)
+            launch()
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.wstream.wait_event(ev)
+        with torch.cuda.stream(self.wstream):
+            launch()
+        dy.record_stream(self.wstream)
+        x.record_stream(self.wstream)
+
+    def join_wgrads(self) -> None:
+        """Make the current stream wait for every weight-gradient GEMM issued so far."""
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.wstream)
 
     def _dgrad(self, dy: torch.Tensor, w: torch.Tensor, rows: int, n_in: int, n_out: int, out=None, ld_dy=None, **epi):
         """dx[rows, n_in] = dy[rows, n_out] @ W[n_out, n_in]."""
@@ -481,7 +508,7 @@ class Engine:
             gpos.index_add_(0, tape["idx"], tmp)
 
     # ========================================================================================== loss head
-    def t5_loss_forward(self, vis, input_ids, input_mask, output_ids, output_mask, tape):
+    def t5_loss_forward(self, vis, input_ids, input_mask, output_ids, output_mask, tape, vis_ready=None):
         """Encoder on the ASR tokens, [video ; text] memory, decoder on the shifted targets, tied LM head and
         label-smoothed CE (vid2seq.py:63-98 -> modeling_t5.py:1587-1738).  ``vis``: bf16 [B, T, d] or None."""
         m, c = self.model, self.cfg
@@ -503,6 +530,9 @@ class Engine:
             parts.append(enc.view(B, Lx, self.d))
             masks.append(in_mask)
         S = T + Lx
+        if vis_ready is not None:           # the ViT ran on its own stream beside the encoder
+            torch.cuda.current_stream().wait_event(vis_ready)
+            vis.record_stream(torch.cuda.current_stream())
         if len(parts) == 2:                 # torch.cat of vid2seq.py:78-79 (pure data movement)
             mem = torch.cat(parts, 1).view(B * S, self.d)
             mem_mask = torch.cat(masks, 1).contiguous()
@@ -547,17 +577,18 @@ class Engine:
         del dlog
         dmem = self._bf(B * S, d)
         self._stack_backward(tape["dec"], dhs, "decoder", Lo, dmem=dmem)
-        if after_decoder is not None:
-            after_decoder()
         dmem3 = dmem.view(B, S, d)
+        dvis = None
+        if m.use_video:
+            dvis = dmem3[:, :T].contiguous() if Lx else dmem3
+        if after_decoder is not None:
+            after_decoder(dvis)               # DP hook / ViT backward may start now, beside the encoder backward
         if m.use_speech:
             denc = dmem3[:, T:].contiguous().view(B * Lx, d) if T else dmem
             self._stack_backward(tape["enc"], denc, "encoder", Lx)
         if after_encoder is not None:
             after_encoder()
-        if m.use_video:
-            return dmem3[:, :T].contiguous() if Lx else dmem3
-        return None
+        return dvis
 
     # ========================================================================================== public forward
     def prepare(self) -> None:
@@ -691,6 +722,7 @@ class _VitFn(torch.autograd.Function):
         eng = ctx.eng
         eng._begin_backward()
         eng.vit_backward(ctx.tape, dvis.to(torch.bfloat16))
+        eng.join_wgrads()
         ctx.tape = None
         return None, None, None, None
 
@@ -709,5 +741,6 @@ class _T5LossFn(torch.autograd.Function):
         eng = ctx.eng
         eng._begin_backward()
         dvis = eng.t5_loss_backward(ctx.tape, gloss)
+        eng.join_wgrads()
         ctx.tape = None
         return None, None, (dvis if ctx.has_vis else None), None, None, None, None, None

@@ -111,51 +111,92 @@ class Trainer:
         Returns device scalars (no host sync)."""
         m, eng = self.model, self.eng
         assert m.training, "call model.train() first"
+        main = torch.cuda.current_stream()
+        overlap = eng.overlap
         eng.prepare()
         eng.arena.grad.zero_()
         losses: Dict[str, torch.Tensor] = {}
         vtape: Dict = {}
-        vis = None
+        vis, vis_ready = None, None
         if m.use_video:
-            vis = eng.vit_forward(batch["video"], vtape).view(batch["video"].shape[0], batch["video"].shape[1], eng.d)
+            video = batch["video"]
+            if overlap:          # temporal ViT on its own stream, beside the T5 encoder of the first pass
+                eng.vstream.wait_stream(main)
+                with torch.cuda.stream(eng.vstream):
+                    vis = eng.vit_forward(video, vtape).view(video.shape[0], video.shape[1], eng.d)
+                    vis_ready = torch.cuda.Event()
+                    vis_ready.record(eng.vstream)
+                video.record_stream(eng.vstream)
+            else:
+                vis = eng.vit_forward(video, vtape).view(video.shape[0], video.shape[1], eng.d)
         tapes = []
         if self.gen:
             t1: Dict = {}
             ids = batch["input_ids"]
-            losses["loss"] = eng.t5_loss_forward(vis, ids, ids != 0, batch["output_ids"], batch["output_ids"] != 0, t1)
+            losses["loss"] = eng.t5_loss_forward(vis, ids, ids != 0, batch["output_ids"], batch["output_ids"] != 0, t1,
+                                                 vis_ready=vis_ready)
             tapes.append((t1, self.gen))
         if self.den:
             t2: Dict = {}
             ids = batch["den_input_ids"]
             losses["denoising_loss"] = eng.t5_loss_forward(vis, ids, ids != 0, batch["den_output_ids"],
-                                                           batch["den_output_ids"] != 0, t2)
+                                                           batch["den_output_ids"] != 0, t2, vis_ready=vis_ready)
             tapes.append((t2, self.den))
-        # backward: later passes first; parameter gradients accumulate in the arena
-        dvis = None
+
+        # backward: later passes first; parameter gradients accumulate in the arena.  The ViT backward starts as soon as
+        # the decoder stack of the LAST pass has produced d(loss)/d(vis) and runs beside that pass's encoder backward.
+        state = {"dvis": None}
+
+        def add_dvis(dv):
+            if dv is None:
+                return
+            if state["dvis"] is None:
+                state["dvis"] = dv
+            else:
+                L.add(state["dvis"], dv, state["dvis"], dv.numel())
+
+        def launch_vit_backward():
+            if not m.use_video:
+                return
+            dvis = state["dvis"]
+            if overlap:
+                eng.vstream.wait_stream(main)
+                with torch.cuda.stream(eng.vstream):
+                    eng.vit_backward(vtape, dvis)
+                dvis.record_stream(eng.vstream)
+            else:
+                eng.vit_backward(vtape, dvis)
+
+        n = len(tapes)
         for k, (tape, coef) in enumerate(reversed(tapes)):
-            last = (k == len(tapes) - 1)
+            last = (k == n - 1)
             g = torch.full((1,), float(coef), dtype=torch.float32, device=eng.device)
-            dv = self._t5_backward(tape, g, last)
-            if dv is not None:
-                if dvis is None:
-                    dvis = dv
-                else:
-                    L.add(dvis, dv, dvis, dvis.numel())
+
+            def after_decoder(dv, last=last):
+                add_dvis(dv)
+                if last:
+                    if self.world > 1:
+                        eng.join_wgrads()
+                        self.sync.ready(*self._r_dec)
+                    launch_vit_backward()
+
+            def after_encoder(last=last):
+                if last and self.world > 1:
+                    eng.join_wgrads()
+                    self.sync.ready(*self._r_enc)
+                    self.sync.ready(*self._r_shared)
+
+            eng.t5_loss_backward(tape, g, after_decoder=after_decoder, after_encoder=after_encoder)
+        if n == 0:
+            launch_vit_backward()
+        if m.use_video and overlap:
+            main.wait_stream(eng.vstream)
+        eng.join_wgrads()
         if m.use_video:
-            eng.vit_backward(vtape, dvis)
             self.sync.ready(*self._r_vis)
         self.sync.finish()
         self._optimizer_step()
         return losses
-
-    def _t5_backward(self, tape, g, last: bool):
-        """eng.t5_loss_backward with the DP hooks placed between the stacks (only on the last pass, when the
-        gradients of a stack are final)."""
-        eng = self.eng
-        if not last or self.world == 1:
-            return eng.t5_loss_backward(tape, g)
-        return eng.t5_loss_backward(tape, g, after_decoder=lambda: self.sync.ready(*self._r_dec),
-                                    after_encoder=lambda: (self.sync.ready(*self._r_enc), self.sync.ready(*self._r_shared)))
 
     def _optimizer_step(self) -> None:
         eng, a = self.eng, self.eng.arena
