@@ -376,17 +376,20 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p, float* _
 // the row statistics come from a real key (m > REAL_MIN), and are skipped under that condition.
 template <bool TR, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2*STAGE + (Nk+128)*4 (dbias window) bytes
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2*STAGE + (Nk+128)*8 (dbias window) bytes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int nqb = (p.Nq + 127) >> 7;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int qblk = id % nqb, bh = id / nqb, h = bh % p.H, b = bh / p.H;
   const int Q0 = qblk * 128, wq0 = wave * 32;
   const bool want_dbias = BIAS && p.dbias_diag != nullptr;
-  float* dbw = reinterpret_cast<float*>(smem + 2 * STAGE);   // index: (k - q) + (Q0 + 127)  in [0, Nk+127)
+  // per-diagonal bias-gradient window of this block, index (k - q) + (Q0 + 127) in [0, Nk+127), accumulated in 64-bit
+  // fixed point (2^-40 units): LDS float atomics run at ~0.33 lane-ops/clk/CU on gfx950, 64-bit integer ones at ~8
+  // (tools/ubench/lds_atomic.hip) -- and the integer sum is exact and order-independent.
+  unsigned long long* dbw = reinterpret_cast<unsigned long long*>(smem + 2 * STAGE);
   const int ndb = p.Nk + 127;
   if (want_dbias) {
-    for (int i = tid; i < ndb; i += 256) dbw[i] = 0.f;
+    for (int i = tid; i < ndb; i += 256) dbw[i] = 0ull;
   }
   float acc_lo = 0.f, acc_hi = 0.f;    // bias-gradient mass of the two "far" buckets (no per-diagonal resolution needed)
 
@@ -533,12 +536,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
             const float ds = pr * (dpv - dl_q);
             st[qb][kb][r] = ds;
             if (BIAS) {
-              if (route == 3) {
+              if (route == 3) {     // near-diagonal block: branch-free per element (no exec-mask juggling in the hot loop)
                 const int kk = kb * 16 + 4 * g + r;
                 const int d = (k0 + kk) - q;
-                if (d <= p.far_lo) acc_lo += ds;
-                else if (d >= p.far_hi) acc_hi += ds;
-                else if (ds != 0.f) atomicAdd(&dbw[(k0 + kk) + 127 - qq], ds);
+                const bool lo = d <= p.far_lo, hi = d >= p.far_hi;
+                acc_lo += lo ? ds : 0.f;
+                acc_hi += hi ? ds : 0.f;
+                atomicAdd(&dbw[(k0 + kk) + 127 - qq], (unsigned long long)(long long)(((lo || hi) ? 0.f : ds) * 1099511627776.0f));
               } else {
                 lsum_ds += ds;
               }
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
     }
     for (int i = tid; i < ndb; i += 256) {
       const int gi = i - (Q0 + 127) + p.Nq - 1;
-      const float v = dbw[i];
+      const float v = (float)((double)(long long)dbw[i] * (1.0 / 1099511627776.0));
       if (gi >= 0 && gi < p.Nq + p.Nk - 1 && v != 0.f) atomicAdd(dst + gi, v);
     }
   }
@@ -923,7 +927,7 @@ extern "C" int v2s_attn_bwd(const v2s_attn_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool tr = v2s_opt_tr_read() != 0, bias = p.bias_diag != nullptr, causal = p.causal != 0, drop = p.p16 != 0;
   const int gq = ((p.Nq + 127) / 128) * p.H * p.B;
-  const size_t dyn = 2 * (size_t)STAGE + (size_t)(p.Nk + 128) * 4;
+  const size_t dyn = 2 * (size_t)STAGE + (size_t)(p.Nk + 128) * 8;
   V2S_CHECK(dyn <= 64 * 1024, V2S_ERR_SHAPE, "v2s_attn_bwd: Nk=%d too large for the LDS dbias window", p.Nk);
   V2S_DISPATCH4(attn_bwd_dq_kernel, tr, bias, causal, drop, dim3(gq), dim3(256), dyn, s, p);
   V2S_LAUNCH_CHECK();
