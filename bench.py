@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream execution (A/B for the stream overlap)")
+    ap.add_argument("--no-generate", action="store_true", help="skip the greedy generate() leg (cfg-4, reported as an extra field)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,6 +148,9 @@ def main():
         out["kernel_breakdown_ms_per_step"] = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] / 1e3) / 1e12, 1)}
                                                for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}
 
+    if rank == 0 and world == 1 and not a.no_generate:
+        out["generate_greedy"] = generate_leg(model, tok, dev, Lx)
+
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline (oracle on host cores) ...")
         out["cpu_baseline"] = cpu_baseline(model, tok, Lx, Lo)
@@ -156,6 +160,27 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def generate_leg(model, tok, dev, Lx, B=64, new_tokens=256):
+    """cfg-4: greedy generate() at B=64, 100 frames + Lx ASR tokens, up to 256 new tokens (extra field, not `value`)."""
+    from vidchapters_amd import synth
+    model.eval()
+    b = synth.make_batch(B, 100, Lx, 8, len(tok), 4321, 768)
+    video = b["video"].to(dev).to(torch.bfloat16)
+    ids = b["input_ids"].to(dev)
+    inp = {"input_ids": ids, "attention_mask": ids != 0}
+    eng = model.engine()
+    eng.greedy(video, inp, max_new_tokens=8)            # warm-up (allocations, LUTs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    toks = eng.greedy(video, inp, max_new_tokens=new_tokens, stop_at_eos=False)      # fixed 256 decode steps
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = toks.shape[1] - 1
+    model.train()
+    return {"batch": B, "decode_steps": int(steps), "seconds": round(dt, 4), "sequences_per_s": round(B / dt, 2),
+            "ms_per_decode_step": round(dt / max(steps, 1) * 1e3, 3), "note": "encode + 256 greedy decode steps (EOS stop disabled so that every run decodes the full length), static KV cache"}
 
 
 def cpu_baseline(model, tok, Lx, Lo, threads=32, batch=4):

@@ -230,13 +230,25 @@ typedef struct v2s_decode_attn_args {
   const uint8_t* key_mask;                /* [B][mask_ld] or NULL */
   int64_t mask_ld;
   float scale;
+  /* optional device-resident step counter (hipGraph-replayable decode loops): when pos_dev != NULL the number of keys is
+   * *pos_dev + 1 (Nk is only an upper bound) and bias_row is advanced by (bias_maxlen - 1 - *pos_dev) elements, i.e. the
+   * row of a [H][2*bias_maxlen-1] relative-position diagonal table that belongs to query position *pos_dev */
+  const int32_t* pos_dev;
+  int32_t bias_maxlen;
+  int32_t kv_group;                        /* >1: KV batch index = b / kv_group (beams sharing the cross K/V); 0/1 = b */
 } v2s_decode_attn_args;
 int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream);
 int v2s_argmax_step(const float* logits, int64_t ld, int32_t rows, int32_t V, int64_t* next_tok,
                     int32_t* unfinished, int32_t eos_id, int32_t pad_id, void* stream);
-/* append new K/V rows ([B][H*64], strided) into the cache at position pos */
+/* same, and additionally stores the token at seq_out[row*seq_ld + *pos_dev + 1] (device-resident step counter) */
+int v2s_argmax_step_seq(const float* logits, int64_t ld, int32_t rows, int32_t V, int64_t* next_tok,
+                        int32_t* unfinished, int32_t eos_id, int32_t pad_id, int64_t* seq_out, int64_t seq_ld,
+                        const int32_t* pos_dev, void* stream);
+/* append new K/V rows ([B][H*64], strided) into the cache at position pos (or *pos_dev when pos_dev != NULL) */
 int v2s_kv_append(const void* src, int64_t src_bs, void* cache, int64_t cache_bs, int64_t cache_rs,
-                  int32_t B, int32_t width, int32_t pos, void* stream);
+                  int32_t B, int32_t width, int32_t pos, const int32_t* pos_dev, void* stream);
+/* *ctr += delta (one thread; closes a captured decode step) */
+int v2s_counter_add(int32_t* ctr, int32_t delta, void* stream);
 
 #ifdef __cplusplus
 }

@@ -644,9 +644,13 @@ class Engine:
         return mem, mask
 
     @torch.no_grad()
-    def greedy(self, video, input_tokenized, max_new_tokens: int = 256) -> torch.Tensor:
+    def greedy(self, video, input_tokenized, max_new_tokens: int = 256, stop_at_eos: bool = True, use_graph: bool = True) -> torch.Tensor:
         """HF-4.28 greedy_search semantics on a static KV cache: the cross K/V of every layer are
-        projected once; the self K/V grow in place (no torch.cat, no cache reorder)."""
+        projected once; the self K/V grow in place (no torch.cat, no cache reorder).  One decode step is ~150 small
+        launches, so it is captured ONCE into a hipGraph (through torch.cuda.CUDAGraph) and replayed: every
+        step-dependent quantity (cache position, number of keys, bias row, output column) is read by the kernels from a
+        device-resident step counter, so the same graph serves all steps.  The all-rows-finished test of HF is evaluated
+        every 8 replays; the returned tensor is trimmed to exactly the length HF would have produced."""
         a, c = self.arena, self.cfg
         mem, mem_mask = self.encode(video, input_tokenized)
         B, S, d = mem.shape
@@ -659,47 +663,67 @@ class Engine:
             cross.append(kv)
         maxlen = max_new_tokens
         cache = [self._bf(B, maxlen, 2 * inner) for _ in range(nl)]
-        diag, _ = self._bias_diag("decoder", maxlen, maxlen)           # [H, 2*maxlen-1]; row t = diag[:, maxlen-1-t + k]
+        diag, _ = self._bias_diag("decoder", maxlen, maxlen)           # [H, 2*maxlen-1]; row t starts at column maxlen-1-t
         seq = torch.full((B, maxlen + 1), c.pad_id, dtype=torch.long, device=self.device)
         seq[:, 0] = c.dec_start_id
         unfinished = torch.ones(B, dtype=torch.int32, device=self.device)
-        nxt = torch.empty(B, dtype=torch.long, device=self.device)
+        nxt = torch.full((B,), c.dec_start_id, dtype=torch.long, device=self.device)   # token fed to the next step
+        pos = torch.zeros(1, dtype=torch.int32, device=self.device)                   # device-resident step counter
         logits = self._f32(B, self.ldv)
         E = a.w("t5_model.shared.weight")
         n = self._bf(B, d); rstd = self._f32(B)
         qkv = self._bf(B, 3 * inner); q = self._bf(B, inner); ctx = self._bf(B, inner); u = self._bf(B, self.ff)
-        steps = 0
-        for t in range(maxlen):
-            h = self._bf(B, d)
-            L.embed_fwd(seq[:, t].contiguous(), E, h, B, d, self.V)
-            bias_row = diag[:, maxlen - 1 - t:]
+        ha, hb = self._bf(B, d), self._bf(B, d)
+        eos = c.eos_id if stop_at_eos else -1
+
+        def step():
+            h, h2 = ha, hb
+            L.embed_fwd(nxt, E, h, B, d, self.V)
             for i in range(nl):
                 sa, ca, fp = self._sa("decoder", i), self._ca(i), self._ffp("decoder", i)
                 L.rmsnorm_fwd(h, a.f(self._ln("decoder", i, 0)), n, rstd, B, d, c.eps)
                 L.gemm(n, a.w(sa + "q.weight", (3 * inner, d)), qkv, B, 3 * inner, d)
-                L.kv_append(qkv[:, inner:], 3 * inner, cache[i], maxlen * 2 * inner, 2 * inner, B, 2 * inner, t)
-                L.decode_attn(B, H, t + 1, qkv, 3 * inner, cache[i], cache[i][:, :, inner:], maxlen * 2 * inner, 2 * inner,
-                              ctx, inner, bias_row=bias_row, bias_ld=2 * maxlen - 1)
-                h2 = self._bf(B, d)
+                L.kv_append(qkv[:, inner:], 3 * inner, cache[i], maxlen * 2 * inner, 2 * inner, B, 2 * inner, 0, pos_dev=pos)
+                L.decode_attn(B, H, maxlen, qkv, 3 * inner, cache[i], cache[i][:, :, inner:], maxlen * 2 * inner, 2 * inner,
+                              ctx, inner, bias_row=diag, bias_ld=2 * maxlen - 1, pos_dev=pos, bias_maxlen=maxlen)
                 L.gemm(ctx, a.w(sa + "o.weight"), h2, B, d, inner, residual=h)
                 L.rmsnorm_fwd(h2, a.f(self._ln("decoder", i, 1)), n, rstd, B, d, c.eps)
                 L.gemm(n, a.w(ca + "q.weight"), q, B, inner, d)
                 L.decode_attn(B, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
                               key_mask=mem_mask, mask_ld=S)
-                h3 = self._bf(B, d)
-                L.gemm(ctx, a.w(ca + "o.weight"), h3, B, d, inner, residual=h2)
-                L.rmsnorm_fwd(h3, a.f(self._ln("decoder", i, 2)), n, rstd, B, d, c.eps)
+                L.gemm(ctx, a.w(ca + "o.weight"), h, B, d, inner, residual=h2)
+                L.rmsnorm_fwd(h, a.f(self._ln("decoder", i, 2)), n, rstd, B, d, c.eps)
                 L.gemm(n, a.w(fp + "wi.weight"), u, B, self.ff, d, act=L.ACT_RELU)
-                h = self._bf(B, d)
-                L.gemm(u, a.w(fp + "wo.weight"), h, B, d, self.ff, residual=h3)
+                L.gemm(u, a.w(fp + "wo.weight"), h2, B, d, self.ff, residual=h)
+                h, h2 = h2, h
             L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, B, d, c.eps)
             L.gemm(n, E, logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
-            L.argmax_step(logits, self.ldv, B, self.V, nxt, unfinished, c.eos_id, c.pad_id)
-            seq[:, t + 1] = nxt
-            steps = t + 1
-            if int(unfinished.max().item()) == 0:          # same per-step stop test as HF greedy_search
+            L.argmax_step_seq(logits, self.ldv, B, self.V, nxt, unfinished, eos, c.pad_id, seq, maxlen + 1, pos)
+            L.counter_add(pos, 1)
+
+        step()                                   # step 0 eagerly (also warms every code path before capture)
+        done_steps = 1
+        graph = None
+        if use_graph and maxlen > 1:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+        while done_steps < maxlen:
+            if stop_at_eos and (done_steps % 8 == 1) and int(unfinished.max().item()) == 0:
                 break
-        return seq[:, :steps + 1]
+            if graph is not None:
+                graph.replay()
+            else:
+                step()
+            done_steps += 1
+        out = seq[:, :done_steps + 1]
+        if stop_at_eos:
+            # HF stops right after the step in which the last unfinished row emitted EOS: trim the pads decoded after that
+            is_eos = out[:, 1:] == c.eos_id
+            first = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((B,), done_steps, device=self.device))
+            out = out[:, :int(first.max().item()) + 1]
+        return out
 
     def beam_search(self, video, input_tokenized, num_beams: int, max_new_tokens: int, length_penalty: float):
         raise NotImplementedError("beam search (num_beams > 1) is not implemented in the HIP decoder yet; "

@@ -53,7 +53,8 @@ class AdamArgs(C.Structure):
 class DecodeAttnArgs(C.Structure):
     _fields_ = [("B", _i32), ("H", _i32), ("Nk", _i32), ("q", _vp), ("q_bs", _i64), ("k", _vp), ("v", _vp),
                 ("kv_bs", _i64), ("kv_rs", _i64), ("o", _vp), ("o_bs", _i64), ("bias_row", _vp), ("bias_ld", _i64),
-                ("key_mask", _vp), ("mask_ld", _i64), ("scale", _f32)]
+                ("key_mask", _vp), ("mask_ld", _i64), ("scale", _f32), ("pos_dev", _vp), ("bias_maxlen", _i32),
+                ("kv_group", _i32)]
 
 
 #: every symbol include/vid2seq_hip.h declares (checked by tests/test_abi.py)
@@ -87,7 +88,9 @@ SYMBOLS = {
     "v2s_timetoken_renorm": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "v2s_decode_attn": (C.c_int, [C.POINTER(DecodeAttnArgs), _vp]),
     "v2s_argmax_step": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
-    "v2s_kv_append": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "v2s_argmax_step_seq": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "v2s_kv_append": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "v2s_counter_add": (C.c_int, [_vp, _i32, _vp]),
 }
 
 _LIB = None
@@ -355,11 +358,13 @@ def timetoken_renorm(emb, emb_bf16, V, d, num_bins, ws):
            "v2s_timetoken_renorm")
 
 
-def decode_attn(B, H, Nk, q, q_bs, k, v, kv_bs, kv_rs, o, o_bs, bias_row=None, bias_ld=0, key_mask=None, mask_ld=0, scale=1.0):
+def decode_attn(B, H, Nk, q, q_bs, k, v, kv_bs, kv_rs, o, o_bs, bias_row=None, bias_ld=0, key_mask=None, mask_ld=0, scale=1.0,
+                pos_dev=None, bias_maxlen=0, kv_group=0):
     a = DecodeAttnArgs()
     a.B, a.H, a.Nk = B, H, Nk
     a.q, a.q_bs, a.k, a.v, a.kv_bs, a.kv_rs = q.data_ptr(), q_bs, k.data_ptr(), v.data_ptr(), kv_bs, kv_rs
     a.o, a.o_bs, a.bias_row, a.bias_ld, a.key_mask, a.mask_ld, a.scale = o.data_ptr(), o_bs, ptr(bias_row), bias_ld, ptr(key_mask), mask_ld, scale
+    a.pos_dev, a.bias_maxlen, a.kv_group = ptr(pos_dev), bias_maxlen, kv_group
     _check(lib().v2s_decode_attn(C.byref(a), stream_ptr()), "v2s_decode_attn")
 
 
@@ -368,6 +373,15 @@ def argmax_step(logits, ld, rows, V, next_tok, unfinished, eos_id, pad_id):
                                  stream_ptr()), "v2s_argmax_step")
 
 
-def kv_append(src, src_bs, cache, cache_bs, cache_rs, B, width, pos):
-    _check(lib().v2s_kv_append(src.data_ptr(), src_bs, cache.data_ptr(), cache_bs, cache_rs, B, width, pos, stream_ptr()),
+def kv_append(src, src_bs, cache, cache_bs, cache_rs, B, width, pos, pos_dev=None):
+    _check(lib().v2s_kv_append(src.data_ptr(), src_bs, cache.data_ptr(), cache_bs, cache_rs, B, width, pos, ptr(pos_dev), stream_ptr()),
            "v2s_kv_append")
+
+
+def argmax_step_seq(logits, ld, rows, V, next_tok, unfinished, eos_id, pad_id, seq_out, seq_ld, pos_dev):
+    _check(lib().v2s_argmax_step_seq(logits.data_ptr(), ld, rows, V, next_tok.data_ptr(), unfinished.data_ptr(), eos_id, pad_id,
+                                     seq_out.data_ptr(), seq_ld, pos_dev.data_ptr(), stream_ptr()), "v2s_argmax_step_seq")
+
+
+def counter_add(ctr, delta):
+    _check(lib().v2s_counter_add(ctr.data_ptr(), delta, stream_ptr()), "v2s_counter_add")
