@@ -247,6 +247,13 @@ int v2s_argmax_step_seq(const float* logits, int64_t ld, int32_t rows, int32_t V
 /* append new K/V rows ([B][H*64], strided) into the cache at position pos (or *pos_dev when pos_dev != NULL) */
 int v2s_kv_append(const void* src, int64_t src_bs, void* cache, int64_t cache_bs, int64_t cache_rs,
                   int32_t B, int32_t width, int32_t pos, const int32_t* pos_dev, void* stream);
+/* beam search (HF 4.28 beam_search, call site vid2seq.py:150-162): per row the K best of log_softmax(logits) + beam_scores[row],
+ * sorted descending (K in {2,4,8,16}); and the beam reorder of the self-attention cache (modeling_t5.py:1771-1793):
+ * dst[b, 0:len, :] = src[idx[b], 0:len, :] for [B][*][width] bf16 caches with batch stride bs and row stride rs */
+int v2s_topk_logprob(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const float* beam_scores,
+                     float* out_val, int32_t* out_idx, void* stream);
+int v2s_kv_gather(const void* src, void* dst, const int32_t* idx, int64_t bs, int64_t rs, int32_t B, int32_t len,
+                  int32_t width, void* stream);
 /* *ctr += delta (one thread; closes a captured decode step) */
 int v2s_counter_add(int32_t* ctr, int32_t delta, void* stream);
 

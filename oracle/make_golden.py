@@ -298,6 +298,63 @@ def case_decode(m, P, cfg, batch, tag, max_new=24):
     npz(f"{tag}_greedy.npz", video=batch["video"], input_ids=batch["input_ids"], tokens=seq_ref, max_new=max_new)
 
 
+
+def beam_case_params(cfg, seed, fac, fav=None):
+    """Weights for the beam-search cases: synthetic init with a sharper embedding (x6) and the EOS row set to ``fac`` x the
+    greedy favourite token's row, so that EOS competes and finished hypotheses appear."""
+    P = synth.init_params(R.param_shapes(cfg), seed, cfg.d_model, cfg.inner, cfg.d_ff)
+    E = P["t5_model.shared.weight"] * 6.0
+    P["t5_model.shared.weight"] = E
+    b = synth.make_batch(4, cfg.num_features, 24, 12, cfg.vocab, seed, cfg.vit_dim)
+    if fav is None:
+        g = R.greedy_generate(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, 6)
+        fav = int(torch.mode(g[:, 1:].flatten()).values)
+    E[1] = E[fav] * fac
+    return P, b, fav
+
+
+def case_beam(cfg, num_beams=4, max_new=16):
+    """Beam search lives in the un-vendored transformers==4.28.0 dependency: the oracle restates BeamSearchScorer and is
+    cross-checked here against the INSTALLED transformers' generate (not 4.28 -> 'parity unpinned' for the scorer)."""
+    import transformers
+    from transformers.modeling_outputs import BaseModelOutput
+    print(f"[small beam search] num_beams={num_beams} max_new={max_new}; installed transformers {transformers.__version__}")
+    seeds, facs, favs, vids, ids, toks = [], [], [], [], [], []
+    n_eos = 0
+    for seed in (40, 43, 47):
+        for fac in (0.9, 1.05):
+            P, b, fav = beam_case_params(cfg, seed, fac)
+            out = R.beam_generate(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, num_beams, max_new, 1.0)
+            hf = transformers.T5ForConditionalGeneration(transformers.T5Config(
+                vocab_size=cfg.vocab, d_model=cfg.d_model, d_kv=cfg.d_kv, d_ff=cfg.d_ff, num_layers=cfg.n_enc,
+                num_decoder_layers=cfg.n_dec, num_heads=cfg.heads, feed_forward_proj="relu", dropout_rate=0.0,
+                tie_word_embeddings=True, pad_token_id=0, eos_token_id=1, decoder_start_token_id=0))
+            sd = {k[len("t5_model."):]: v for k, v in P.items() if k.startswith("t5_model.")}
+            for a in ("encoder.embed_tokens.weight", "decoder.embed_tokens.weight", "lm_head.weight"):
+                sd[a] = sd["shared.weight"]
+            hf.load_state_dict(sd, strict=False); hf.eval()
+            mem, mm, _ = R.encode(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0)
+            with torch.no_grad():
+                ref = hf.generate(encoder_outputs=BaseModelOutput(last_hidden_state=mem), attention_mask=mm, num_beams=num_beams,
+                                  do_sample=False, max_new_tokens=max_new, min_length=1, length_penalty=1.0, early_stopping=False)
+
+            def norm(x):
+                x = x.tolist()
+                x = x[:x.index(1) + 1] if 1 in x else x
+                while x and x[-1] == 0:
+                    x.pop()
+                return x
+            for i in range(out.shape[0]):
+                assert norm(out[i]) == norm(ref[i]), (seed, fac, i, norm(out[i]), norm(ref[i]))
+                n_eos += 1 in norm(out[i])
+            pad = torch.zeros(out.shape[0], max_new + 1, dtype=torch.long)
+            pad[:, :out.shape[1]] = out
+            seeds.append(seed); facs.append(fac); favs.append(fav); vids.append(b["video"]); ids.append(b["input_ids"]); toks.append(pad)
+    print(f"  OK  oracle == installed-HF generate(num_beams={num_beams}) on {len(seeds)} cases x 4 rows ({n_eos} rows end in EOS)")
+    npz("small_beam.npz", seed=np.array(seeds), fac=np.array(facs, dtype=np.float32), fav=np.array(favs),
+        video=torch.stack(vids), input_ids=torch.stack(ids), tokens=torch.stack(toks), num_beams=num_beams, max_new=max_new)
+
+
 def case_train_recipe(v2s, cfg, seed=5):
     """dvc.py:train_one_epoch (the real one) for 2 steps on a fake loader vs oracle train_step."""
     print("[train recipe: reference dvc.train_one_epoch x2 steps]")
@@ -427,6 +484,7 @@ def main():
     cfg2 = R.RefConfig.small(vit_dim=64, vit_heads=1, num_features=10)
     case_tiny(v2s, "small_resize_proj", cfg2, B=2, T=7, L=16, Lo=9, seed=9)
     case_train_recipe(v2s, cfg)
+    case_beam(cfg)
     if not a.skip_full:
         case_full(v2s)
     print("ALL GOLDEN CASES OK")

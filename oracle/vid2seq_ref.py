@@ -368,6 +368,97 @@ def greedy_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, max
     return seq
 
 
+class _BeamHyps:
+    """transformers==4.28.0 generation/beam_search.py:BeamHypotheses (early_stopping=False heuristic)."""
+
+    def __init__(self, num_beams: int, length_penalty: float):
+        self.num_beams, self.length_penalty = num_beams, length_penalty
+        self.beams: List[Tuple[float, torch.Tensor]] = []
+        self.worst_score = 1e9
+
+    def add(self, hyp: torch.Tensor, sum_logprobs: float) -> None:
+        score = sum_logprobs / (hyp.shape[-1] ** self.length_penalty)
+        if len(self.beams) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, hyp))
+            if len(self.beams) > self.num_beams:
+                sorted_next = sorted([(s, i) for i, (s, _) in enumerate(self.beams)])
+                del self.beams[sorted_next[0][1]]
+                self.worst_score = sorted_next[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs: float, cur_len: int) -> bool:
+        if len(self.beams) < self.num_beams:
+            return False
+        return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
+
+
+@torch.no_grad()
+def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_beams: int = 4, max_new_tokens: int = 256,
+                  length_penalty: float = 1.0):
+    """vid2seq.py:150-162 with num_beams>1, do_sample=False, early_stopping=False, num_return_sequences=1:
+    transformers==4.28.0 GenerationMixin.beam_search + BeamSearchScorer (un-vendored dependency -> restated from the
+    published algorithm; *parity unpinned by reference tests*, cross-checked against the installed transformers'
+    generate in oracle/make_golden.py).  Returns int64 [B, <= 1+max_new_tokens] (start token first, pad after EOS)."""
+    memory, mem_mask, _ = encode(P, cfg, video, input_ids, input_mask)
+    B, nb = memory.shape[0], num_beams
+    V = P["t5_model.shared.weight"].shape[0]
+    max_length = max_new_tokens + 1
+    mem = memory.repeat_interleave(nb, 0)
+    mmask = mem_mask.repeat_interleave(nb, 0)
+    seq = torch.full((B * nb, 1), cfg.dec_start_id, dtype=torch.long)
+    beam_scores = torch.zeros(B, nb)
+    beam_scores[:, 1:] = -1e9
+    beam_scores = beam_scores.view(-1)
+    hyps = [_BeamHyps(nb, length_penalty) for _ in range(B)]
+    done = [False] * B
+    past = None
+    while True:
+        step_in = seq if past is None else seq[:, -1:]
+        h, past = t5_decoder(P, cfg, step_in, torch.ones(B * nb, seq.shape[1], dtype=torch.long), mem, mmask, past=past, use_cache=True)
+        logp = torch.log_softmax(lm_logits(P, cfg, h[:, -1:]).squeeze(1).float(), dim=-1) + beam_scores[:, None]
+        top_s, top_i = torch.topk(logp.view(B, nb * V), 2 * nb, dim=1, largest=True, sorted=True)
+        nidx, ntok = top_i // V, top_i % V
+        cur_len = seq.shape[-1]
+        new_scores = torch.zeros(B, nb); new_tok = torch.zeros(B, nb, dtype=torch.long); new_idx = torch.zeros(B, nb, dtype=torch.long)
+        for b in range(B):
+            if done[b]:
+                new_tok[b] = cfg.pad_id
+                continue
+            k = 0
+            for rank in range(2 * nb):
+                t, sc, bi = int(ntok[b, rank]), float(top_s[b, rank]), b * nb + int(nidx[b, rank])
+                if t == cfg.eos_id:
+                    if rank >= nb:
+                        continue
+                    hyps[b].add(seq[bi].clone(), sc)
+                else:
+                    new_scores[b, k], new_tok[b, k], new_idx[b, k] = sc, t, bi
+                    k += 1
+                if k == nb:
+                    break
+            done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len)
+        beam_scores, bt, bidx = new_scores.view(-1), new_tok.view(-1), new_idx.view(-1)
+        seq = torch.cat([seq[bidx], bt[:, None]], -1)
+        past = [tuple(x.index_select(0, bidx) for x in layer) for layer in past]      # modeling_t5.py:1771-1793
+        if all(done) or seq.shape[-1] >= max_length:
+            break
+    for b in range(B):                                                              # BeamSearchScorer.finalize
+        if done[b]:
+            continue
+        for j in range(nb):
+            hyps[b].add(seq[b * nb + j], float(beam_scores[b * nb + j]))
+    best = [sorted(hb.beams, key=lambda x: x[0])[-1][1] for hb in hyps]
+    lens = [len(x) for x in best]
+    out_len = min(max(lens) + 1, max_length)
+    out = torch.full((B, out_len), cfg.pad_id, dtype=torch.long)
+    for b, hyp in enumerate(best):
+        out[b, :lens[b]] = hyp
+        if lens[b] < out_len:
+            out[b, lens[b]] = cfg.eos_id
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # caller-side recipe (dvc.py) restated
 # ----------------------------------------------------------------------------------------------

@@ -408,6 +408,29 @@ def test_optimizer_kernels():
     assert relerr(emb, ref) < 1e-6 and torch.equal(embb, emb.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("K", [2, 8, 16])
+def test_topk_logprob_and_kv_gather(K):
+    rows, V, ld = 12, 3211, 3216
+    g = torch.Generator().manual_seed(K)
+    logits = torch.zeros(rows, ld)
+    logits[:, :V] = torch.randn(rows, V, generator=g) * 3
+    logits[:, V:] = 1e9                                            # pad columns must never be read
+    bs = torch.randn(rows, generator=g)
+    val = torch.zeros(rows, K, device=DEV); idx = torch.zeros(rows, K, dtype=torch.int32, device=DEV)
+    L.topk_logprob(logits.to(DEV), ld, rows, V, K, bs.to(DEV), val, idx)
+    ref = torch.log_softmax(logits[:, :V].double(), -1) + bs[:, None].double()
+    rv, ri = torch.topk(ref, K, dim=1)
+    assert torch.equal(idx.cpu().long(), ri)
+    assert (val.cpu().double() - rv).abs().max() < 1e-5
+    # gather
+    B, maxlen, W, n = 6, 20, 256, 13
+    src = rnd(B, maxlen, W, seed=5); dst = torch.zeros_like(src)
+    sel = torch.tensor([3, 3, 0, 5, 1, 1], dtype=torch.int32, device=DEV)
+    L.kv_gather(src, dst, sel, maxlen * W, W, B, n, W)
+    assert torch.equal(dst[:, :n], src[sel.long(), :n]) and dst[:, n:].abs().sum().item() == 0
+
+
+
 def test_decode_kernels():
     B, H, Nk = 3, 4, 333
     W = H * 64

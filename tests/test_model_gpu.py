@@ -204,6 +204,45 @@ def test_greedy_vs_reference_golden(golden_dir):
     assert isinstance(text, list) and len(text) == want.shape[0] and all(isinstance(t, str) for t in text)
 
 
+def test_beam_search_vs_golden(golden_dir):
+    """num_beams=4 (vid2seq.py:150-162 default).  Fixture = oracle outputs that agree with the installed transformers'
+    generate (the 4.28 scorer itself is un-vendored: parity unpinned).  bf16 logits can flip a near-tie between two beams, so the
+    bar is: every returned row is a valid hypothesis (start token, pad after EOS), and at least 3/4 of all rows are identical to
+    the fp32 fixture token for token."""
+    g = np.load(os.path.join(golden_dir, "small_beam.npz"))
+    cfg = R.RefConfig.small()
+    nb, max_new = int(g["num_beams"]), int(g["max_new"])
+    rows = same = 0
+    for i in range(len(g["seed"])):
+        model = build(cfg, int(g["seed"][i])).eval()
+        with torch.no_grad():
+            E = model.t5_model.shared.weight
+            E.mul_(6.0)
+            E[1] = E[int(g["fav"][i])] * float(g["fac"][i])
+        video, ids = torch.from_numpy(g["video"][i]).to(DEV), torch.from_numpy(g["input_ids"][i])
+        want = torch.from_numpy(g["tokens"][i])
+        for use_graph in (True, False):
+            out = model.engine().beam_search(video, tok(ids), num_beams=nb, max_new_tokens=max_new, length_penalty=1.0,
+                                             use_graph=use_graph).cpu()
+            assert out[:, 0].eq(0).all() and out.shape[1] <= max_new + 1
+            if use_graph:
+                first = out
+            else:
+                assert torch.equal(out, first)                     # graph replay == eager launches
+        for r in range(out.shape[0]):
+            o = out[r].tolist()
+            if 1 in o:
+                assert all(t == 0 for t in o[o.index(1) + 1:])
+            w = want[r, :out.shape[1]].tolist()
+            rows += 1
+            same += (o == w and int(want[r, out.shape[1]:].abs().sum()) == 0)
+    print(f"beam search rows identical to the fp32 fixture: {same}/{rows}")
+    assert same * 4 >= rows * 3
+    text = model.generate(video, tok(ids), num_beams=nb, max_length=max_new)
+    assert isinstance(text, list) and len(text) == out.shape[0]
+
+
+
 def test_dropout_training_mode_runs_and_differs():
     cfg = R.RefConfig.small()
     model = build(cfg, 8, vis_drop=0.1, enc_drop=0.1, dec_drop=0.1)

@@ -70,6 +70,54 @@ def test_oracle_greedy_vs_reference(golden_dir):
     assert torch.equal(seq, torch.from_numpy(g["tokens"]))
 
 
+def beam_case(g, i, cfg):
+    """Rebuild case i of tests/golden/small_beam.npz (weights are synthetic + the EOS-row edit oracle/make_golden.py describes)."""
+    P = synth.init_params(R.param_shapes(cfg), int(g["seed"][i]), cfg.d_model, cfg.inner, cfg.d_ff)
+    E = P["t5_model.shared.weight"] * 6.0
+    E[1] = E[int(g["fav"][i])] * float(g["fac"][i])
+    P["t5_model.shared.weight"] = E
+    return P, torch.from_numpy(g["video"][i]), torch.from_numpy(g["input_ids"][i]), torch.from_numpy(g["tokens"][i])
+
+
+def test_oracle_beam_search_vs_golden(golden_dir):
+    """Beam search = un-vendored transformers 4.28 BeamSearchScorer: the fixture holds oracle outputs that agreed with the
+    installed transformers' generate when it was written (parity unpinned w.r.t. 4.28 itself)."""
+    g = np.load(os.path.join(golden_dir, "small_beam.npz"))
+    cfg = R.RefConfig.small()
+    for i in range(len(g["seed"])):
+        P, video, ids, want = beam_case(g, i, cfg)
+        out = R.beam_generate(P, cfg, video, ids, ids != 0, int(g["num_beams"]), int(g["max_new"]), 1.0)
+        assert torch.equal(out, want[:, :out.shape[1]]) and int(want[:, out.shape[1]:].abs().sum()) == 0
+
+
+def test_host_beam_scorer_matches_oracle(golden_dir):
+    """vidchapters_amd.beam.BeamScorer (the product's host bookkeeping) driven by the oracle's decoder through the same
+    per-beam top-2nb interface the device kernel provides."""
+    from vidchapters_amd.beam import BeamScorer
+    g = np.load(os.path.join(golden_dir, "small_beam.npz"))
+    cfg = R.RefConfig.small()
+    nb, max_new = int(g["num_beams"]), int(g["max_new"])
+    for i in (0, 1, 3):
+        P, video, ids, want = beam_case(g, i, cfg)
+        with torch.no_grad():
+            mem, mmask, _ = R.encode(P, cfg, video, ids, ids != 0)
+            B = mem.shape[0]
+            mem, mmask = mem.repeat_interleave(nb, 0), mmask.repeat_interleave(nb, 0)
+            sc = BeamScorer(B, nb, 1.0, cfg.eos_id, cfg.pad_id, cfg.dec_start_id, max_new + 1)
+            past, finished = None, False
+            while not finished:
+                seq = torch.from_numpy(sc.seqs[:, :sc.cur_len])
+                step_in = seq if past is None else seq[:, -1:]
+                h, past = R.t5_decoder(P, cfg, step_in, torch.ones(B * nb, sc.cur_len, dtype=torch.long), mem, mmask, past=past, use_cache=True)
+                logp = torch.log_softmax(R.lm_logits(P, cfg, h[:, -1:]).squeeze(1).float(), -1) + torch.from_numpy(sc.scores.reshape(-1))[:, None]
+                v, t = torch.topk(logp, 2 * nb, dim=1)
+                _, src, finished = sc.advance(v.numpy(), t.numpy().astype(np.int32))
+                past = [tuple(x.index_select(0, torch.from_numpy(src).long()) for x in layer) for layer in past]
+            out = torch.from_numpy(sc.finalize())
+        assert torch.equal(out, want[:, :out.shape[1]]) and int(want[:, out.shape[1]:].abs().sum()) == 0
+
+
+
 def test_oracle_train_recipe_vs_reference(golden_dir):
     """Two steps of the reference's own dvc.train_one_epoch (captured) vs oracle.train_step."""
     g = np.load(os.path.join(golden_dir, "small_train_recipe.npz"))

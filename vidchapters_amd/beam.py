@@ -1,0 +1,102 @@
+"""Host side of beam search: hypothesis bookkeeping between two device steps.
+
+Mirrors what the reference gets from ``transformers==4.28.0`` ``BeamSearchScorer``/``BeamHypotheses`` when
+``Vid2Seq.generate`` (model/vid2seq.py:150-162) runs with ``num_beams>1, do_sample=False, early_stopping=False,
+num_return_sequences=1``.  The device produces, for every live beam, its 2*num_beams best continuations
+(``v2s_topk_logprob``); everything here is small integer/float bookkeeping on numpy arrays.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class _Heap:
+    """Keeps the num_beams best finished hypotheses of one batch entry, scored by sum_logprobs / len**length_penalty."""
+    __slots__ = ("cap", "lp", "items", "worst")
+
+    def __init__(self, cap: int, lp: float):
+        self.cap, self.lp, self.items, self.worst = cap, lp, [], 1e9
+
+    def push(self, tokens: np.ndarray, sum_logprobs: float) -> None:
+        score = sum_logprobs / (len(tokens) ** self.lp)
+        if len(self.items) < self.cap or score > self.worst:
+            self.items.append((score, tokens))
+            if len(self.items) > self.cap:
+                order = sorted(range(len(self.items)), key=lambda i: (self.items[i][0], i))
+                del self.items[order[0]]
+                self.worst = min(s for s, _ in self.items)
+            else:
+                self.worst = min(score, self.worst)
+
+    def full_and_unbeatable(self, best_sum_logprobs: float, cur_len: int) -> bool:
+        return len(self.items) >= self.cap and self.worst >= best_sum_logprobs / cur_len ** self.lp
+
+    def best(self) -> np.ndarray:
+        top = 0
+        for i in range(1, len(self.items)):
+            if self.items[i][0] >= self.items[top][0]:
+                top = i
+        return self.items[top][1]
+
+
+class BeamScorer:
+    def __init__(self, batch: int, num_beams: int, length_penalty: float, eos_id: int, pad_id: int, start_id: int, max_length: int):
+        self.B, self.nb, self.eos, self.pad, self.max_length = batch, num_beams, eos_id, pad_id, max_length
+        self.heaps = [_Heap(num_beams, length_penalty) for _ in range(batch)]
+        self.done = np.zeros(batch, dtype=bool)
+        self.seqs = np.full((batch * num_beams, max_length), pad_id, dtype=np.int64)
+        self.seqs[:, 0] = start_id
+        self.cur_len = 1
+        self.scores = np.zeros((batch, num_beams), dtype=np.float32)
+        self.scores[:, 1:] = -1e9
+
+    def advance(self, cand_val: np.ndarray, cand_tok: np.ndarray):
+        """cand_val/cand_tok: [B*nb, K] per-beam sorted candidates.  Returns (tokens [B*nb] int64, source rows [B*nb] int32,
+        finished) and updates ``self.scores`` / ``self.seqs``."""
+        B, nb = self.B, self.nb
+        K = cand_val.shape[1]
+        val = cand_val.reshape(B, nb * K)
+        tok = cand_tok.reshape(B, nb * K)
+        order = np.argsort(-val, axis=1, kind="stable")[:, :2 * nb]
+        new_tok = np.full((B, nb), self.pad, dtype=np.int64)
+        new_src = np.zeros((B, nb), dtype=np.int32)
+        new_sc = np.zeros((B, nb), dtype=np.float32)
+        for b in range(B):
+            if self.done[b]:
+                continue
+            k = 0
+            for rank in range(2 * nb):
+                j = int(order[b, rank])
+                t, sc, src = int(tok[b, j]), float(val[b, j]), b * nb + j // K
+                if t == self.eos:
+                    if rank < nb:
+                        self.heaps[b].push(self.seqs[src, :self.cur_len].copy(), sc)
+                    continue
+                new_tok[b, k], new_src[b, k], new_sc[b, k] = t, src, sc
+                k += 1
+                if k == nb:
+                    break
+            if self.heaps[b].full_and_unbeatable(float(val[b, order[b, 0]]), self.cur_len):
+                self.done[b] = True
+        self.scores = new_sc
+        src = new_src.reshape(-1)
+        self.seqs = self.seqs[src]
+        if self.cur_len < self.max_length:
+            self.seqs[:, self.cur_len] = new_tok.reshape(-1)
+        self.cur_len += 1
+        return new_tok.reshape(-1), src, bool(self.done.all()) or self.cur_len >= self.max_length
+
+    def finalize(self) -> np.ndarray:
+        for b in range(self.B):
+            if self.done[b]:
+                continue
+            for j in range(self.nb):
+                self.heaps[b].push(self.seqs[b * self.nb + j, :self.cur_len].copy(), float(self.scores[b, j]))
+        best = [h.best() for h in self.heaps]
+        out_len = min(max(len(x) for x in best) + 1, self.max_length)
+        out = np.full((self.B, out_len), self.pad, dtype=np.int64)
+        for b, hyp in enumerate(best):
+            out[b, :len(hyp)] = hyp
+            if len(hyp) < out_len:
+                out[b, len(hyp)] = self.eos
+        return out

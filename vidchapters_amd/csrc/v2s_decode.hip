@@ -163,6 +163,89 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict
       *reinterpret_cast<const uint4*>(src + (long)b * src_bs + c * 8);
 }
 
+
+// ---- beam search helpers ----------------------------------------------------------------------------------------
+// per row: log-softmax over V fp32 logits, add the row's running beam score, keep the K best (value, token) pairs, sorted
+// descending (HF 4.28 beam_search: log_softmax + beam_scores[:, None] then topk over the beams of a batch entry; the top-2*nb
+// of a batch entry are always among the per-beam top-2*nb, which the host merges).
+template <int K>
+__global__ __launch_bounds__(256) void topk_logprob_kernel(const float* __restrict__ logits, long ld, int V,
+                                                           const float* __restrict__ beam_scores, float* __restrict__ out_val,
+                                                           int* __restrict__ out_idx) {
+  __shared__ float sv[256 * K];
+  __shared__ int si[256 * K];
+  __shared__ float red_m[4], red_s[4], best_v[4];
+  __shared__ int best_t[4], best_o[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* z = logits + (long)row * ld;
+  float tv[K]; int ti[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+  float m = -INFINITY, ssum = 0.f;
+  for (int i = tid; i < V; i += 256) {
+    const float v = z[i];
+    const float mn = fmaxf(m, v);
+    ssum = ssum * __expf(m - mn) + __expf(v - mn);
+    m = mn;
+    if (v > tv[K - 1]) {                       // insert into the sorted (descending) list; equal values keep the lower index first
+      tv[K - 1] = v; ti[K - 1] = i;
+#pragma unroll
+      for (int j = K - 1; j > 0; --j) {
+        if (tv[j] > tv[j - 1]) { const float a = tv[j]; tv[j] = tv[j - 1]; tv[j - 1] = a; const int b = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = b; }
+      }
+    }
+  }
+  // block log-sum-exp
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(ssum, o, 64);
+    const float mn = fmaxf(m, m2);
+    ssum = (m == -INFINITY ? 0.f : ssum * __expf(m - mn)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mn));
+    m = mn;
+  }
+  if (lane == 0) { red_m[wave] = m; red_s[wave] = ssum; }
+#pragma unroll
+  for (int j = 0; j < K; ++j) { sv[tid * K + j] = tv[j]; si[tid * K + j] = ti[j]; }
+  __syncthreads();
+  float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+  float S = 0.f;
+  for (int w = 0; w < 4; ++w) S += red_s[w] * __expf(red_m[w] - M);
+  const float lse = M + logf(S);
+  const float base = beam_scores ? beam_scores[row] : 0.f;
+  // K rounds of block-wide argmax over the heads of the 256 sorted lists
+  int head = 0;
+  for (int r = 0; r < K; ++r) {
+    float v = head < K ? sv[tid * K + head] : -INFINITY;
+    int t = head < K ? si[tid * K + head] : 0x7fffffff;
+    int owner = tid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(v, o, 64); const int t2 = __shfl_xor(t, o, 64); const int o2 = __shfl_xor(owner, o, 64);
+      if (v2 > v || (v2 == v && t2 < t)) { v = v2; t = t2; owner = o2; }
+    }
+    __syncthreads();
+    if (lane == 0) { best_v[wave] = v; best_t[wave] = t; best_o[wave] = owner; }
+    __syncthreads();
+    float bv = best_v[0]; int bt = best_t[0], bo = best_o[0];
+    for (int w = 1; w < 4; ++w)
+      if (best_v[w] > bv || (best_v[w] == bv && best_t[w] < bt)) { bv = best_v[w]; bt = best_t[w]; bo = best_o[w]; }
+    if (tid == bo) ++head;
+    if (tid == 0) { out_val[(long)row * K + r] = bv - lse + base; out_idx[(long)row * K + r] = bt; }
+  }
+}
+
+// dst[b, 0:len, :] = src[idx[b], 0:len, :]   (beam reorder of the growing self-attention cache, modeling_t5.py:1771-1793)
+__global__ __launch_bounds__(256) void kv_gather_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                        const int* __restrict__ idx, long bs, long rs, int len, int width8) {
+  const int b = blockIdx.y;
+  const long sb = idx[b];
+  const long total = (long)len * width8;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const long r = t / width8; const int c = (int)(t - r * width8);
+    *reinterpret_cast<uint4*>(dst + (long)b * bs + r * rs + c * 8) = *reinterpret_cast<const uint4*>(src + sb * bs + r * rs + c * 8);
+  }
+}
+
 }  // namespace
 
 extern "C" int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream) {
@@ -211,6 +294,31 @@ extern "C" int v2s_kv_append(const void* src, int64_t src_bs, void* cache, int64
   const int total = B * (width / 8);
   hipLaunchKernelGGL(kv_append_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (long)src_bs,
                      (bf16_t*)cache, (long)cache_bs, (long)cache_rs, B, width / 8, pos, pos_dev);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_topk_logprob(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const float* beam_scores,
+                                float* out_val, int32_t* out_idx, void* stream) {
+  V2S_CHECK(logits && out_val && out_idx && rows > 0 && V > 0, V2S_ERR_ARG, "v2s_topk_logprob: bad args");
+  V2S_CHECK(K == 2 || K == 4 || K == 8 || K == 16, V2S_ERR_ARG, "v2s_topk_logprob: K must be 2, 4, 8 or 16 (got %d)", K);
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 2) hipLaunchKernelGGL((topk_logprob_kernel<2>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx);
+  else if (K == 4) hipLaunchKernelGGL((topk_logprob_kernel<4>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx);
+  else if (K == 8) hipLaunchKernelGGL((topk_logprob_kernel<8>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx);
+  else hipLaunchKernelGGL((topk_logprob_kernel<16>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_kv_gather(const void* src, void* dst, const int32_t* idx, int64_t bs, int64_t rs, int32_t B, int32_t len,
+                             int32_t width, void* stream) {
+  V2S_CHECK(src && dst && idx && B > 0 && len > 0 && width > 0 && (width % 8) == 0 && ((bs | rs) % 8) == 0 && src != dst, V2S_ERR_ARG,
+            "v2s_kv_gather: bad args");
+  long blocks = ((long)len * (width / 8) + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(kv_gather_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, idx,
+                     (long)bs, (long)rs, len, width / 8);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

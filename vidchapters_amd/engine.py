@@ -16,6 +16,7 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import lib as L
@@ -725,9 +726,100 @@ class Engine:
             out = out[:, :int(first.max().item()) + 1]
         return out
 
-    def beam_search(self, video, input_tokenized, num_beams: int, max_new_tokens: int, length_penalty: float):
-        raise NotImplementedError("beam search (num_beams > 1) is not implemented in the HIP decoder yet; "
-                                  "call generate(num_beams=1)")
+    @torch.no_grad()
+    def beam_search(self, video, input_tokenized, num_beams: int, max_new_tokens: int, length_penalty: float = 1.0,
+                    use_graph: bool = True) -> torch.Tensor:
+        """HF-4.28 beam_search + BeamSearchScorer semantics (call site vid2seq.py:150-162) on static caches.
+        The encoder memory is NOT replicated per beam: cross K/V are projected once per batch entry and the nb beams of an
+        entry read the same rows (``kv_group``).  A step = decoder forward for B*nb rows -> ``v2s_topk_logprob`` (log-softmax +
+        running beam score + per-beam top 2*nb), captured as a hipGraph; the host merges the candidates (beam.BeamScorer) and
+        sends back next tokens, scores and source rows; the self-attention cache is reordered by ``v2s_kv_gather`` into the
+        other half of a ping-pong pair only when the source rows are not the identity (one graph per half)."""
+        from .beam import BeamScorer
+        a, c = self.arena, self.cfg
+        mem, mem_mask = self.encode(video, input_tokenized)
+        B, S, d = mem.shape
+        nb = num_beams
+        R = B * nb
+        K = 2 * nb
+        if K not in (2, 4, 8, 16):
+            raise ValueError(f"num_beams must be 1, 2, 4 or 8 (got {nb})")
+        inner, H, nl = self.inner, self.H, c.n_dec
+        mem2 = mem.view(B * S, d)
+        cross = []
+        for i in range(nl):
+            kv = self._bf(B * S, 2 * inner)
+            L.gemm(mem2, a.w(self._ca(i) + "k.weight", (2 * inner, d)), kv, B * S, 2 * inner, d)
+            cross.append(kv)
+        maxlen = max_new_tokens
+        caches = [[self._bf(R, maxlen, 2 * inner) for _ in range(nl)] for _ in range(2)]
+        diag, _ = self._bias_diag("decoder", maxlen, maxlen)
+        nxt = torch.full((R,), c.dec_start_id, dtype=torch.long, device=self.device)
+        pos = torch.zeros(1, dtype=torch.int32, device=self.device)
+        bscore = torch.zeros(R, dtype=torch.float32, device=self.device)
+        src_dev = torch.zeros(R, dtype=torch.int32, device=self.device)
+        cand_val = self._f32(R, K); cand_tok = torch.zeros(R, K, dtype=torch.int32, device=self.device)
+        logits = self._f32(R, self.ldv)
+        E = a.w("t5_model.shared.weight")
+        n = self._bf(R, d); rstd = self._f32(R)
+        qkv = self._bf(R, 3 * inner); q = self._bf(R, inner); ctx = self._bf(R, inner); u = self._bf(R, self.ff)
+        ha, hb = self._bf(R, d), self._bf(R, d)
+        cbs = maxlen * 2 * inner
+
+        def step(cache):
+            h, h2 = ha, hb
+            L.embed_fwd(nxt, E, h, R, d, self.V)
+            for i in range(nl):
+                sa, ca, fp = self._sa("decoder", i), self._ca(i), self._ffp("decoder", i)
+                L.rmsnorm_fwd(h, a.f(self._ln("decoder", i, 0)), n, rstd, R, d, c.eps)
+                L.gemm(n, a.w(sa + "q.weight", (3 * inner, d)), qkv, R, 3 * inner, d)
+                L.kv_append(qkv[:, inner:], 3 * inner, cache[i], cbs, 2 * inner, R, 2 * inner, 0, pos_dev=pos)
+                L.decode_attn(R, H, maxlen, qkv, 3 * inner, cache[i], cache[i][:, :, inner:], cbs, 2 * inner,
+                              ctx, inner, bias_row=diag, bias_ld=2 * maxlen - 1, pos_dev=pos, bias_maxlen=maxlen)
+                L.gemm(ctx, a.w(sa + "o.weight"), h2, R, d, inner, residual=h)
+                L.rmsnorm_fwd(h2, a.f(self._ln("decoder", i, 1)), n, rstd, R, d, c.eps)
+                L.gemm(n, a.w(ca + "q.weight"), q, R, inner, d)
+                L.decode_attn(R, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
+                              key_mask=mem_mask, mask_ld=S, kv_group=nb)
+                L.gemm(ctx, a.w(ca + "o.weight"), h, R, d, inner, residual=h2)
+                L.rmsnorm_fwd(h, a.f(self._ln("decoder", i, 2)), n, rstd, R, d, c.eps)
+                L.gemm(n, a.w(fp + "wi.weight"), u, R, self.ff, d, act=L.ACT_RELU)
+                L.gemm(u, a.w(fp + "wo.weight"), h2, R, d, self.ff, residual=h)
+                h, h2 = h2, h
+            L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, R, d, c.eps)
+            L.gemm(n, E, logits, R, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
+            L.topk_logprob(logits, self.ldv, R, self.V, K, bscore, cand_val, cand_tok)
+            L.counter_add(pos, 1)
+
+        scorer = BeamScorer(B, nb, length_penalty, c.eos_id, c.pad_id, c.dec_start_id, max_new_tokens + 1)
+        bscore.copy_(torch.from_numpy(scorer.scores.reshape(-1)))
+        identity = np.arange(R, dtype=np.int32)
+        graphs = [None, None]
+        cur = 0
+        for t in range(maxlen):
+            if t == 0 or not use_graph:
+                step(caches[cur])
+            else:
+                if graphs[cur] is None:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    pos_keep = pos.clone()
+                    with torch.cuda.graph(g):
+                        step(caches[cur])
+                    pos.copy_(pos_keep)            # capture does not execute, but keep the counter explicit
+                    graphs[cur] = g
+                graphs[cur].replay()
+            tok, src, finished = scorer.advance(cand_val.cpu().numpy(), cand_tok.cpu().numpy())
+            if finished:
+                break
+            nxt.copy_(torch.from_numpy(tok))
+            bscore.copy_(torch.from_numpy(scorer.scores.reshape(-1)))
+            if not np.array_equal(src, identity):
+                src_dev.copy_(torch.from_numpy(src))
+                for i in range(nl):
+                    L.kv_gather(caches[cur][i], caches[cur ^ 1][i], src_dev, cbs, 2 * inner, R, t + 1, 2 * inner)
+                cur ^= 1
+        return torch.from_numpy(scorer.finalize()).to(self.device)
 
 
 # ==============================================================================================================

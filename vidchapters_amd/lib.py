@@ -91,6 +91,8 @@ SYMBOLS = {
     "v2s_argmax_step_seq": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "v2s_kv_append": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "v2s_counter_add": (C.c_int, [_vp, _i32, _vp]),
+    "v2s_topk_logprob": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "v2s_kv_gather": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
 }
 
 _LIB = None
@@ -385,3 +387,13 @@ def argmax_step_seq(logits, ld, rows, V, next_tok, unfinished, eos_id, pad_id, s
 
 def counter_add(ctr, delta):
     _check(lib().v2s_counter_add(ctr.data_ptr(), delta, stream_ptr()), "v2s_counter_add")
+
+
+def topk_logprob(logits, ld, rows, V, K, beam_scores, out_val, out_idx):
+    _check(lib().v2s_topk_logprob(logits.data_ptr(), ld, rows, V, K, ptr(beam_scores), out_val.data_ptr(), out_idx.data_ptr(),
+                                  stream_ptr()), "v2s_topk_logprob")
+
+
+def kv_gather(src, dst, idx, bs, rs, B, length, width):
+    _need(idx, torch.int32, "kv_gather idx")
+    _check(lib().v2s_kv_gather(src.data_ptr(), dst.data_ptr(), idx.data_ptr(), bs, rs, B, length, width, stream_ptr()), "v2s_kv_gather")
