@@ -85,6 +85,8 @@ typedef struct v2s_gemm_args {
 } v2s_gemm_args;
 
 int v2s_gemm(const v2s_gemm_args* args, void* stream);
+/* symbol of the kernel variant the calling thread's last v2s_gemm dispatched (for profiling: matches rocprofv3 kernel names) */
+const char* v2s_last_gemm_kernel(void);
 
 /* column sums of a bf16 matrix (bias gradients of the ViT linears: autograd of vit.py:41,53,17,20)
  * out[n] (+)= sum_m X[m][n];  out fp32 */

@@ -929,11 +929,16 @@ extern "C" int v2s_attn_bwd(const v2s_attn_args* a, void* stream) {
   const int gq = ((p.Nq + 127) / 128) * p.H * p.B;
   const size_t dyn = 2 * (size_t)STAGE + (size_t)(p.Nk + 128) * 8;
   V2S_CHECK(dyn <= 64 * 1024, V2S_ERR_SHAPE, "v2s_attn_bwd: Nk=%d too large for the LDS dbias window", p.Nk);
-  V2S_DISPATCH4(attn_bwd_dq_kernel, tr, bias, causal, drop, dim3(gq), dim3(256), dyn, s, p);
-  V2S_LAUNCH_CHECK();
-  const int gk = ((p.Nk + 127) / 128) * p.H * p.B;
-  V2S_DISPATCH4(attn_bwd_dkv_kernel, tr, bias, causal, drop, dim3(gk), dim3(256), 0, s, p);
-  V2S_LAUNCH_CHECK();
+  const int part = v2s_opt_attn_bwd_part();      // profiling aid: 1 = dQ kernel only, 2 = dK/dV kernel only (0 = both)
+  if (part != 2) {
+    V2S_DISPATCH4(attn_bwd_dq_kernel, tr, bias, causal, drop, dim3(gq), dim3(256), dyn, s, p);
+    V2S_LAUNCH_CHECK();
+  }
+  if (part != 1) {
+    const int gk = ((p.Nk + 127) / 128) * p.H * p.B;
+    V2S_DISPATCH4(attn_bwd_dkv_kernel, tr, bias, causal, drop, dim3(gk), dim3(256), 0, s, p);
+    V2S_LAUNCH_CHECK();
+  }
   return V2S_OK;
 }
 

@@ -500,6 +500,259 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmP p) {
   }
 }
 
+
+// =====================================================================================================================
+// Persistent 256 x BN2 x 64 kernel: one 8-wave block per CU walks its share of the (tile, K-slice) work items.
+//  * the accumulators are produced TRANSPOSED (mfma(b_frag, a_frag): lane = row m, 4 consecutive columns n), and one
+//    v_permlane16_swap per register pair turns two neighbouring 16x16 fragments into 8 consecutive columns per lane, so the
+//    epilogue runs straight from registers on 16-byte row chunks: no LDS staging, no barriers;
+//  * because the epilogue needs no LDS, the first K-stage of the NEXT work item is already in flight (LDS-DMA) while the
+//    current one is post-processed and stored, which hides the prologue latency that a K=768 GEMM cannot amortise.
+template <bool TA, bool TB, int BN2>
+__global__ __launch_bounds__(512, 1) void gemm_pers_kernel(const GemmP p) {
+  constexpr int BM2 = 256;
+  constexpr int A_B = BM2 * 64 * 2, B_B = BN2 * 64 * 2, STG = A_B + B_B;
+  constexpr int WN = BN2 / 64, WM = 8 / WN;
+  constexpr int MI = BM2 / WM / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nitems = p.tilesM * p.tilesN * p.splitk;
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
+  const uint32_t sbase = lds_addr(smem);
+
+  f32x4 acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int m0, n0, slice, kbeg, nk;
+  auto item = [&](int round, int& om0, int& on0, int& oslice, int& okbeg, int& onk) -> bool {
+    const int base = round * G;
+    const int cnt = min(G, nitems - base);
+    if (bid >= cnt) return false;
+    const int id0 = base + xcd_remap(bid, cnt);
+    oslice = id0 % p.splitk;
+    const int id = id0 / p.splitk;
+    const int tm = id / p.tilesN, tn = id - tm * p.tilesN;
+    om0 = tm * BM2; on0 = tn * BN2;
+    okbeg = oslice * p.kper;
+    onk = (min(p.K, okbeg + p.kper) - okbeg) / BK;
+    return true;
+  };
+  if (!item(0, m0, n0, slice, kbeg, nk)) return;
+  dma_tile_big<BM2, TA>(p.A, p.lda, m0, p.M, M8, kbeg, sbase, wave, lane);
+  dma_tile_big<BN2, TB>(p.B, p.ldb, n0, p.N, N8, kbeg, sbase + A_B, wave, lane);
+  dma_wait();
+  __syncthreads();
+
+  auto compute = [&](const char* sa, const char* sb) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = read_frag_big<BN2, TB>(sb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const bf16x8 af = read_frag_big<BM2, TA>(sa, wm * (MI * 16) + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  int st = 0;
+  for (int round = 0;; ++round) {
+    int m1 = 0, n1 = 0, slice1 = 0, kbeg1 = 0, nk1 = 0;
+    const bool has_next = item(round + 1, m1, n1, slice1, kbeg1, nk1);
+    for (int t = 0; t + 1 < nk; ++t) {
+      const char* sa = smem + st * STG;
+      const uint32_t da = sbase + (st ^ 1) * STG;
+      dma_tile_big<BM2, TA>(p.A, p.lda, m0, p.M, M8, kbeg + (t + 1) * BK, da, wave, lane);
+      dma_tile_big<BN2, TB>(p.B, p.ldb, n0, p.N, N8, kbeg + (t + 1) * BK, da + A_B, wave, lane);
+      compute(sa, sa + A_B);
+      dma_wait();
+      __syncthreads();
+      st ^= 1;
+    }
+    {   // last K-step of this item: the next item's first stage is fetched underneath the epilogue
+      const char* sa = smem + st * STG;
+      const uint32_t da = sbase + (st ^ 1) * STG;
+      if (has_next) {
+        dma_tile_big<BM2, TA>(p.A, p.lda, m1, p.M, M8, kbeg1, da, wave, lane);
+        dma_tile_big<BN2, TB>(p.B, p.ldb, n1, p.N, N8, kbeg1, da + A_B, wave, lane);
+      }
+      compute(sa, sa + A_B);
+      const int g = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int gm = m0 + wm * (MI * 16) + i * 16 + (lane & 15);
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * jp][r]), __float_as_uint(acc[i][2 * jp + 1][r]), false, false);
+            v[r] = __uint_as_float(sw[0]);
+            v[4 + r] = __uint_as_float(sw[1]);
+          }
+          const int gn = n0 + wn * 64 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
+          if (gm < p.M && gn < p.N) epilogue_chunk(p, v, gm, gn, slice);
+          __builtin_amdgcn_sched_barrier(0);      // keep the chunk epilogues sequential: interleaving them spills
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dma_wait();
+      __syncthreads();
+      st ^= 1;
+    }
+    if (!has_next) break;
+    m0 = m1; n0 = n1; slice = slice1; kbeg = kbeg1; nk = nk1;
+  }
+}
+
+
+// =====================================================================================================================
+// 256 x 128 x 32 tile kernel, 4 waves (2 x 2, 128 x 64 per wave), 3-stage LDS-DMA ring (3 x 24 KiB), TWO blocks per CU.
+// The K=768 GEMMs of the step spend as long in prologue + epilogue as in the main loop; with one block per CU nothing runs on
+// the matrix pipe meanwhile.  Two co-resident blocks overlap one block's epilogue / first loads with the other's MFMAs while
+// keeping the 128x64 per-wave register tile (12 fragment reads per 32 MFMAs) of the 8-wave kernel.  Prefetch distance is two
+// K-steps: the wait before the barrier leaves the newest stage in flight (s_waitcnt vmcnt(PER)).
+// LDS image of a K-contiguous operand: [row][32 k] = 64 B rows, 16-byte slot g of row r stored at slot g ^ 2*((r>>2)&1): with
+// ds_read_b128's lane groups ({0-3,12-15,20-27}, ...) every group then covers all 64 banks exactly once.
+template <int N>
+__device__ __forceinline__ void dma_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int ROWS, bool T>
+__device__ __forceinline__ void dma_tile_w4(const bf16_t* __restrict__ base, long ld, int row0, int R, int R8, int k0,
+                                            uint32_t tile_addr, int wave, int lane) {
+  constexpr int NCHUNK = ROWS * 32 * 2 / 1024;     // 1 KiB chunks in the tile (16 or 8)
+  constexpr int PER_WAVE = NCHUNK / 4;
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int c = wave * PER_WAVE + i;
+    const bf16_t* src;
+    if (!T) {                             // chunk = 16 rows x 64 B
+      const int row = c * 16 + (lane >> 2), pos = lane & 3;
+      const int g = pos ^ (((row >> 2) & 1) << 1);
+      int grow = row0 + row;
+      grow = grow < R ? grow : R - 1;
+      src = base + (long)grow * ld + k0 + g * 8;
+    } else {                              // [32 k][ROWS]: k-row pitch ROWS*2 bytes
+      constexpr int SLOTS = ROWS / 8;
+      constexpr int KPC = 64 / SLOTS;
+      const int k = c * KPC + lane / SLOTS, pos16 = lane % SLOTS;
+      const int c16 = ((((pos16 >> 1) ^ tr_g(k)) << 1) | (pos16 & 1));
+      int grow = row0 + c16 * 8;
+      grow = grow <= R8 - 8 ? grow : R8 - 8;
+      src = base + (long)(k0 + k) * ld + grow;
+    }
+    glds16(src, __builtin_amdgcn_readfirstlane(tile_addr + c * 1024));
+  }
+}
+
+template <int ROWS, bool T>
+__device__ __forceinline__ bf16x8 read_frag_w4(const char* lds, int rowbase, int lane) {
+  if (!T) {
+    const int r = lane & 15, g = lane >> 4;
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (rowbase + r) * 64 + ((g ^ (((r >> 2) & 1) << 1)) << 4)));
+  } else {
+    return read_frag_big<ROWS, true>(lds, rowbase, 0, lane);
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_w4_kernel(const GemmP p) {
+  constexpr int BM2 = 256, BN2 = 128, KT = 32, NST = 3;
+  constexpr int A_B = BM2 * KT * 2, B_B = BN2 * KT * 2, STG = A_B + B_B;      // 16 + 8 KiB
+  constexpr int PER = (BM2 + BN2) * KT * 2 / 1024 / 4;                          // DMA instructions per wave per stage (6)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // NST * STG = 72 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = p.tilesM * p.tilesN * p.splitk;
+  const int id0 = xcd_remap(blockIdx.x, nwg);
+  const int slice = id0 % p.splitk, id = id0 / p.splitk;
+  const int tm = id / p.tilesN, tn = id - tm * p.tilesN;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+  const int kbeg = slice * p.kper, kend = min(p.K, kbeg + p.kper);
+  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (kend - kbeg) / KT;
+  const uint32_t sbase = lds_addr(smem);
+  dma_tile_w4<BM2, TA>(p.A, p.lda, m0, p.M, M8, kbeg, sbase, wave, lane);
+  dma_tile_w4<BN2, TB>(p.B, p.ldb, n0, p.N, N8, kbeg, sbase + A_B, wave, lane);
+  if (nk > 1) {
+    dma_tile_w4<BM2, TA>(p.A, p.lda, m0, p.M, M8, kbeg + KT, sbase + STG, wave, lane);
+    dma_tile_w4<BN2, TB>(p.B, p.ldb, n0, p.N, N8, kbeg + KT, sbase + STG + A_B, wave, lane);
+  }
+  int st = 0, st2 = 2;                   // stage being computed, stage being filled (t + 2)
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) dma_wait_n<PER>(); else dma_wait_n<0>();
+    __syncthreads();
+    if (t + 2 < nk) {
+      const uint32_t da = sbase + st2 * STG;
+      dma_tile_w4<BM2, TA>(p.A, p.lda, m0, p.M, M8, kbeg + (t + 2) * KT, da, wave, lane);
+      dma_tile_w4<BN2, TB>(p.B, p.ldb, n0, p.N, N8, kbeg + (t + 2) * KT, da + A_B, wave, lane);
+    }
+    const char* sa = smem + st * STG;
+    const char* sb = sa + A_B;
+    bf16x8 bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = read_frag_w4<BN2, TB>(sb, wn * 64 + j * 16, lane);
+    bf16x8 af = read_frag_w4<BM2, TA>(sa, wm * 128, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      bf16x8 afn = af;
+      if (i + 1 < 8) afn = read_frag_w4<BM2, TA>(sa, wm * 128 + (i + 1) * 16, lane);     // one fragment ahead of the MFMAs
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
+      af = afn;
+    }
+    st = st == NST - 1 ? 0 : st + 1;
+    st2 = st2 == NST - 1 ? 0 : st2 + 1;
+  }
+  __syncthreads();
+
+  // epilogue: two passes of 128 tile rows through a 64 KiB fp32 staging block (pass ps takes fragments i in [4 ps, 4 ps + 4))
+  float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cs[(wm * 64 + ii * 16 + (lane >> 4) * 4 + r) * BN2 + wn * 64 + j * 16 + (lane & 15)] = acc[ps * 4 + ii][j][r];
+    __syncthreads();
+#pragma unroll 1
+    for (int c = tid; c < 128 * 16; c += 256) {
+      const int lr = c >> 4, cc = (c & 15) * 8;
+      const int gm = m0 + (lr >> 6) * 128 + ps * 64 + (lr & 63), gn = n0 + cc;
+      if (gm >= p.M || gn >= p.N) continue;
+      float v[8];
+      const float4 x0 = *reinterpret_cast<const float4*>(cs + lr * BN2 + cc);
+      const float4 x1 = *reinterpret_cast<const float4*>(cs + lr * BN2 + cc + 4);
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+      epilogue_chunk(p, v, gm, gn, slice);
+    }
+    if (ps == 0) __syncthreads();
+  }
+}
+
 // C[m][n] (+)= alpha * sum_z ws[z][m][n]   (deterministic: fixed slice order)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc, int M,
                                                             int N, int S, float alpha, int accumulate) {
@@ -553,6 +806,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 
 }  // namespace
 
+static thread_local const char* g_last_gemm = "";
+extern "C" const char* v2s_last_gemm_kernel(void) { return g_last_gemm; }
+
 extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   V2S_CHECK(a != nullptr, V2S_ERR_ARG, "v2s_gemm: null args");
   V2S_CHECK(a->M > 0 && a->N > 0 && a->K > 0, V2S_ERR_SHAPE, "v2s_gemm: non-positive shape %d %d %d", a->M, a->N, a->K);
@@ -602,6 +858,14 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
     const bool transposed = a->transA || a->transB;
     if ((wide || !transposed || big_mode == 2) && (t2 >= 240 || (plain_split && t2 >= 8))) { bm = 256; bn = bn2; }
   }
+  // 4-wave 256x128x32 kernel, two blocks per CU.  With the split-K cost model below, measured (tools/gemm_bench.py wgrad, TF/s,
+  // w4 / 128x128 DMA / 8-wave 256-row): qkv 2304x768x32000 756/678/-, wi 3072x768x32000 798/761/-, o 768x768x32000 476/545/-,
+  // wo 768x3072x32000 865/693/871, ViT K=3200 shapes 290/389/-, decoder K=8192 shapes 553-625/656-723/-, cross-kv 680/837/-:
+  // w4 only for the big-output long-contraction weight gradients, never for NT/dgrad shapes (see the NT table above)
+  bool w4 = false;
+  const bool w4_ok = tr && (a->K % 32) == 0 && a->M >= 128 && a->N >= 64;
+  if (w4_ok && (big_mode >= 3 || (big_mode == 1 && a->transA && a->transB && a->N < 1024 &&
+                                  (long)a->M * a->N >= 2304L * 768L && a->K >= 16384))) { w4 = true; bm = 256; bn = 128; }
   p.tilesM = (a->M + bm - 1) / bm; p.tilesN = (a->N + bn - 1) / bn;
   // split-K: weight-gradient GEMMs have few output tiles (768x768 -> 36) but a huge contraction (all tokens);
   // slice K so that the chip is filled.  Only for fp32 outputs with a plain epilogue; partials go to the workspace.
@@ -611,6 +875,18 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   if (plain_split && tiles < want) {
     int sp = (want + tiles - 1) / tiles;
     const int maxs = a->K / 512;
+    if (v2s_opt_gemm_split() != 0) {
+      // all blocks of a split GEMM are equally long, so time ~ rounds x (K/sp + per-block overhead) + reduction(sp): pick the
+      // slice count that minimises it (block slots: 256 for the one-block-per-CU kernels, 512 for the two-per-CU ones)
+      const int slots = (bm == 256 && !w4) ? 256 : 512;
+      long best = -1;
+      for (int c = 1; c <= maxs; ++c) {
+        const long rounds = ((long)tiles * c + slots - 1) / slots;
+        const long kp = ((a->K + c - 1) / c + BK - 1) / BK * BK;
+        const long cost = rounds * (kp + 384) + 16L * c;
+        if (best < 0 || cost < best) { best = cost; sp = c; }
+      }
+    }
     if (sp > maxs) sp = maxs;
     const long per_slice = (long)a->M * a->N * 4;
     if ((long)sp * per_slice > a->workspace_bytes) sp = (int)(a->workspace_bytes / per_slice);
@@ -622,7 +898,20 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
     }
   }
   const unsigned nblocks = (unsigned)(p.tilesM * p.tilesN * p.splitk);
-  if (bm == 256) {
+  if (w4) {
+    static bool attr4 = false;
+    if (!attr4) {
+      (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+      (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+      (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+      attr4 = true;
+    }
+    const dim3 grid(nblocks), block(256);
+    g_last_gemm = !a->transB ? "gemm_w4_kernel<false, false>" : (!a->transA ? "gemm_w4_kernel<false, true>" : "gemm_w4_kernel<true, true>");
+    if (!a->transA && !a->transB) hipLaunchKernelGGL((gemm_w4_kernel<false, false>), grid, block, 73728, s, p);
+    else if (!a->transA && a->transB) hipLaunchKernelGGL((gemm_w4_kernel<false, true>), grid, block, 73728, s, p);
+    else hipLaunchKernelGGL((gemm_w4_kernel<true, true>), grid, block, 73728, s, p);
+  } else if (bm == 256) {
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -631,15 +920,39 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
       (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
       (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
       (void)hipFuncSetAttribute((const void*)gemm_big_kernel<true, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+      (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+      (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<false, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+      (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<true, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
       attr_done = true;
     }
     const size_t dyn = 2 * (size_t)(256 * 64 * 2 + bn * 64 * 2);
-    const dim3 grid(nblocks), block(512);
+    const bool pers = v2s_opt_gemm_pers() != 0;
+    static int n_cu = 0;
+    if (pers && n_cu == 0) {
+      int dev = 0; hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+      if (n_cu <= 0) n_cu = 256;
+    }
+    const dim3 grid(pers ? (nblocks < (unsigned)n_cu ? nblocks : (unsigned)n_cu) : nblocks), block(512);
 #define V2S_BIG(TA_, TB_)                                                                              \
     do {                                                                                               \
-      if (bn == 256) hipLaunchKernelGGL((gemm_big_kernel<TA_, TB_, 256>), grid, block, dyn, s, p);     \
+      if (pers) {                                                                                      \
+        if (bn == 256) hipLaunchKernelGGL((gemm_pers_kernel<TA_, TB_, 256>), grid, block, dyn, s, p);  \
+        else hipLaunchKernelGGL((gemm_pers_kernel<TA_, TB_, 128>), grid, block, dyn, s, p);            \
+      } else if (bn == 256) hipLaunchKernelGGL((gemm_big_kernel<TA_, TB_, 256>), grid, block, dyn, s, p);     \
       else hipLaunchKernelGGL((gemm_big_kernel<TA_, TB_, 128>), grid, block, dyn, s, p);               \
     } while (0)
+    {
+      static const char* names[2][2][3] = {
+          {{"gemm_big_kernel<false, false, 256>", "gemm_big_kernel<false, true, 256>", "gemm_big_kernel<true, true, 256>"},
+           {"gemm_big_kernel<false, false, 128>", "gemm_big_kernel<false, true, 128>", "gemm_big_kernel<true, true, 128>"}},
+          {{"gemm_pers_kernel<false, false, 256>", "gemm_pers_kernel<false, true, 256>", "gemm_pers_kernel<true, true, 256>"},
+           {"gemm_pers_kernel<false, false, 128>", "gemm_pers_kernel<false, true, 128>", "gemm_pers_kernel<true, true, 128>"}}};
+      g_last_gemm = names[pers ? 1 : 0][bn == 256 ? 0 : 1][!a->transB ? 0 : (!a->transA ? 1 : 2)];
+    }
     if (!a->transA && !a->transB) V2S_BIG(false, false);
     else if (!a->transA && a->transB) V2S_BIG(false, true);
     else V2S_BIG(true, true);
@@ -650,6 +963,9 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   // the register-staged loop for plain NT (forward) shapes
   const bool dma = v2s_opt_gemm_dma() != 0 && tr && (a->transA || a->transB || v2s_opt_gemm_dma() == 2) && (a->K % BK) == 0 && (p.kper % BK) == 0 &&
                    a->M >= 8 && a->N >= 8;
+  if (dma) g_last_gemm = !a->transB ? "gemm_dma_kernel<false, false>" : (!a->transA ? "gemm_dma_kernel<false, true>" : "gemm_dma_kernel<true, true>");
+  else g_last_gemm = !a->transB ? "gemm_kernel<false, false, true>" : (!a->transA ? (tr ? "gemm_kernel<false, true, true>" : "gemm_kernel<false, true, false>")
+                                                                                    : (tr ? "gemm_kernel<true, true, true>" : "gemm_kernel<true, true, false>"));
   if (dma) {
     if (!a->transA && !a->transB) hipLaunchKernelGGL((gemm_dma_kernel<false, false>), grid, block, 0, s, p);
     else if (!a->transA && a->transB) hipLaunchKernelGGL((gemm_dma_kernel<false, true>), grid, block, 0, s, p);

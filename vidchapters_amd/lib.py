@@ -91,6 +91,7 @@ SYMBOLS = {
     "v2s_argmax_step_seq": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "v2s_kv_append": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "v2s_counter_add": (C.c_int, [_vp, _i32, _vp]),
+    "v2s_last_gemm_kernel": (C.c_char_p, []),
     "v2s_topk_logprob": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "v2s_kv_gather": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
 }
@@ -132,6 +133,10 @@ def set_option(name: str, value: int) -> None:
     _check(lib().v2s_set_option(name.encode(), int(value)), "v2s_set_option")
 
 
+def get_option(name: str) -> int:
+    return int(lib().v2s_get_option(name.encode()))
+
+
 def _need(t: torch.Tensor, dtype, what: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"{what}: tensor must live on the GPU (HIP path has no CPU fallback)")
@@ -145,9 +150,10 @@ class KernelTimer:
     Usage: ``with KernelTimer() as kt: step()`` then ``kt.summary()`` -> {tag: (launches, total_ms, total_work)}."""
     active = None
 
-    def __init__(self, detail: bool = False):
+    def __init__(self, detail: bool = False, by_symbol: bool = False):
         self.records = []
         self.detail = detail
+        self.by_symbol = by_symbol        # tag GEMMs with the dispatched kernel symbol instead of the role
 
     def __enter__(self):
         KernelTimer.active = self
@@ -210,6 +216,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, 
     _check(lib().v2s_gemm(C.byref(a), stream_ptr()), "v2s_gemm")
     if kt is not None:
         kind = "gemm_wgrad" if transA else ("gemm_dgrad" if transB else "gemm_nt")
+        if kt.by_symbol:
+            kind = lib().v2s_last_gemm_kernel().decode() + (" + splitk_reduce_kernel" if workspace is not None else "")
         if kt.detail:
             kind += f":{M}x{N}x{K}" + (":drop" if dropout_p > 0 else "") + (":res" if residual is not None else "") + \
                     (":act" if act or dact else "") + (":bias" if bias is not None else "") + (":f32" if a.c_dtype == V2S_F32 else "")
@@ -269,7 +277,10 @@ def attn_fwd(a: AttnArgs) -> None:
         e0 = kt.begin()
     _check(lib().v2s_attn_fwd(C.byref(a), stream_ptr()), "v2s_attn_fwd")
     if kt is not None:
-        kt.end("attn_fwd", 4.0 * a.B * a.H * a.Nq * a.Nk * 64, e0)
+        tag = "attn_fwd"
+        if kt.by_symbol:
+            tag = "attn_fwd_kernel<" + ", ".join("true" if f else "false" for f in (get_option("tr_read") != 0, bool(a.bias_diag), bool(a.causal), a.dropout_p > 0)) + ">"
+        kt.end(tag, 4.0 * a.B * a.H * a.Nq * a.Nk * 64, e0)
 
 
 def attn_bwd(a: AttnArgs, d_o, do_st, delta, dq, dk, dv, dq_st, dk_st, dv_st, dbias_diag=None, far=(0, 0)) -> None:
@@ -281,6 +292,16 @@ def attn_bwd(a: AttnArgs, d_o, do_st, delta, dq, dk, dv, dq_st, dk_st, dv_st, db
     a.bias_far_lo, a.bias_far_hi = far
     _check(lib().v2s_attn_delta(C.byref(a), delta.data_ptr(), stream_ptr()), "v2s_attn_delta")
     kt = KernelTimer.active
+    if kt is not None and kt.by_symbol:          # time the two kernels of the call separately, tagged with their symbols
+        flags = ", ".join("true" if f else "false" for f in (get_option("tr_read") != 0, bool(a.bias_diag), bool(a.causal), a.dropout_p > 0))
+        work = 8.0 * a.B * a.H * a.Nq * a.Nk * 64
+        for part, name, share in ((1, "attn_bwd_dq_kernel", 0.5), (2, "attn_bwd_dkv_kernel", 0.5)):
+            set_option("attn_bwd_part", part)
+            e0 = kt.begin()
+            _check(lib().v2s_attn_bwd(C.byref(a), stream_ptr()), "v2s_attn_bwd")
+            kt.end(f"{name}<{flags}>", work * share, e0)     # algorithmic: dP+dQ (dq kernel), dV+dK (dkv kernel); recompute excluded
+        set_option("attn_bwd_part", 0)
+        return
     if kt is not None:
         e0 = kt.begin()
     _check(lib().v2s_attn_bwd(C.byref(a), stream_ptr()), "v2s_attn_bwd")
