@@ -36,8 +36,12 @@ extern "C" {
 
 int v2s_version(void);
 const char* v2s_last_error(void);
-/* runtime switches: "tr_read" (1: ds_read_b64_tr_b16 operand transposes, 0: scalar LDS gathers);
- * "gemm_dma" (1: LDS-DMA GEMM main loop where K % 64 == 0, 0: register-staged loop everywhere) */
+/* runtime switches (tuning / profiling aids; defaults are what the product path uses):
+ *   "tr_read"       1: ds_read_b64_tr_b16 operand transposes (default), 0: scalar LDS gathers
+ *   "gemm_dma"      1: LDS-DMA 128x128 main loop for transposed-operand GEMMs (default), 2: for every variant, 0: register-staged
+ *   "gemm_big"      1: tile-size heuristics (default), 0: 128x128 only, 2: 256x128 8-wave only, 3: force the 4-wave 256x128x32 kernel
+ *   "gemm_split"    1: split-K slice count from the rounds x length cost model (default), 0: fixed block-count target
+ *   "attn_bwd_part" 0: v2s_attn_bwd launches dQ and dK/dV kernels (default), 1: dQ only, 2: dK/dV only (per-kernel timing) */
 int v2s_set_option(const char* name, int value);
 int v2s_get_option(const char* name);
 

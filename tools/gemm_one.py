@@ -7,7 +7,6 @@ M, N, K, ta, tb, big = (int(x) for x in sys.argv[1:7])
 f32 = len(sys.argv) > 7
 dev = "cuda"
 L.set_option("gemm_big", big)
-L.set_option("gemm_pers", 0)
 A = torch.randn((K, M) if ta else (M, K), device=dev).to(torch.bfloat16)
 B = torch.randn((K, N) if tb else (N, K), device=dev).to(torch.bfloat16)
 C = torch.zeros(M, N, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)

@@ -502,123 +502,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmP p) {
 
 
 // =====================================================================================================================
-// Persistent 256 x BN2 x 64 kernel: one 8-wave block per CU walks its share of the (tile, K-slice) work items.
-//  * the accumulators are produced TRANSPOSED (mfma(b_frag, a_frag): lane = row m, 4 consecutive columns n), and one
-//    v_permlane16_swap per register pair turns two neighbouring 16x16 fragments into 8 consecutive columns per lane, so the
-//    epilogue runs straight from registers on 16-byte row chunks: no LDS staging, no barriers;
-//  * because the epilogue needs no LDS, the first K-stage of the NEXT work item is already in flight (LDS-DMA) while the
-//    current one is post-processed and stored, which hides the prologue latency that a K=768 GEMM cannot amortise.
-template <bool TA, bool TB, int BN2>
-__global__ __launch_bounds__(512, 1) void gemm_pers_kernel(const GemmP p) {
-  constexpr int BM2 = 256;
-  constexpr int A_B = BM2 * 64 * 2, B_B = BN2 * 64 * 2, STG = A_B + B_B;
-  constexpr int WN = BN2 / 64, WM = 8 / WN;
-  constexpr int MI = BM2 / WM / 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int nitems = p.tilesM * p.tilesN * p.splitk;
-  const int G = gridDim.x, bid = blockIdx.x;
-  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
-  const uint32_t sbase = lds_addr(smem);
-
-  f32x4 acc[MI][4];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  int m0, n0, slice, kbeg, nk;
-  auto item = [&](int round, int& om0, int& on0, int& oslice, int& okbeg, int& onk) -> bool {
-    const int base = round * G;
-    const int cnt = min(G, nitems - base);
-    if (bid >= cnt) return false;
-    const int id0 = base + xcd_remap(bid, cnt);
-    oslice = id0 % p.splitk;
-    const int id = id0 / p.splitk;
-    const int tm = id / p.tilesN, tn = id - tm * p.tilesN;
-    om0 = tm * BM2; on0 = tn * BN2;
-    okbeg = oslice * p.kper;
-    onk = (min(p.K, okbeg + p.kper) - okbeg) / BK;
-    return true;
-  };
-  if (!item(0, m0, n0, slice, kbeg, nk)) return;
-  dma_tile_big<BM2, TA>(p.A, p.lda, m0, p.M, M8, kbeg, sbase, wave, lane);
-  dma_tile_big<BN2, TB>(p.B, p.ldb, n0, p.N, N8, kbeg, sbase + A_B, wave, lane);
-  dma_wait();
-  __syncthreads();
-
-  auto compute = [&](const char* sa, const char* sb) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 bfr[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = read_frag_big<BN2, TB>(sb, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const bf16x8 af = read_frag_big<BM2, TA>(sa, wm * (MI * 16) + i * 16, ks, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
-      }
-    }
-  };
-
-  int st = 0;
-  for (int round = 0;; ++round) {
-    int m1 = 0, n1 = 0, slice1 = 0, kbeg1 = 0, nk1 = 0;
-    const bool has_next = item(round + 1, m1, n1, slice1, kbeg1, nk1);
-    for (int t = 0; t + 1 < nk; ++t) {
-      const char* sa = smem + st * STG;
-      const uint32_t da = sbase + (st ^ 1) * STG;
-      dma_tile_big<BM2, TA>(p.A, p.lda, m0, p.M, M8, kbeg + (t + 1) * BK, da, wave, lane);
-      dma_tile_big<BN2, TB>(p.B, p.ldb, n0, p.N, N8, kbeg + (t + 1) * BK, da + A_B, wave, lane);
-      compute(sa, sa + A_B);
-      dma_wait();
-      __syncthreads();
-      st ^= 1;
-    }
-    {   // last K-step of this item: the next item's first stage is fetched underneath the epilogue
-      const char* sa = smem + st * STG;
-      const uint32_t da = sbase + (st ^ 1) * STG;
-      if (has_next) {
-        dma_tile_big<BM2, TA>(p.A, p.lda, m1, p.M, M8, kbeg1, da, wave, lane);
-        dma_tile_big<BN2, TB>(p.B, p.ldb, n1, p.N, N8, kbeg1, da + A_B, wave, lane);
-      }
-      compute(sa, sa + A_B);
-      const int g = lane >> 4;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int gm = m0 + wm * (MI * 16) + i * 16 + (lane & 15);
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          float v[8];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * jp][r]), __float_as_uint(acc[i][2 * jp + 1][r]), false, false);
-            v[r] = __uint_as_float(sw[0]);
-            v[4 + r] = __uint_as_float(sw[1]);
-          }
-          const int gn = n0 + wn * 64 + (2 * jp + (g & 1)) * 16 + (g >> 1) * 8;
-          if (gm < p.M && gn < p.N) epilogue_chunk(p, v, gm, gn, slice);
-          __builtin_amdgcn_sched_barrier(0);      // keep the chunk epilogues sequential: interleaving them spills
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dma_wait();
-      __syncthreads();
-      st ^= 1;
-    }
-    if (!has_next) break;
-    m0 = m1; n0 = n1; slice = slice1; kbeg = kbeg1; nk = nk1;
-  }
-}
-
-
-// =====================================================================================================================
 // 256 x 128 x 32 tile kernel, 4 waves (2 x 2, 128 x 64 per wave), 3-stage LDS-DMA ring (3 x 24 KiB), TWO blocks per CU.
 // The K=768 GEMMs of the step spend as long in prologue + epilogue as in the main loop; with one block per CU nothing runs on
 // the matrix pipe meanwhile.  Two co-resident blocks overlap one block's epilogue / first loads with the other's MFMAs while
@@ -752,6 +635,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(const GemmP p) {
     if (ps == 0) __syncthreads();
   }
 }
+
 
 // C[m][n] (+)= alpha * sum_z ws[z][m][n]   (deterministic: fixed slice order)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc, int M,
@@ -920,39 +804,20 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
       (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
       (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
       (void)hipFuncSetAttribute((const void*)gemm_big_kernel<true, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-      (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-      (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<false, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-      (void)hipFuncSetAttribute((const void*)gemm_pers_kernel<true, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
       attr_done = true;
     }
     const size_t dyn = 2 * (size_t)(256 * 64 * 2 + bn * 64 * 2);
-    const bool pers = v2s_opt_gemm_pers() != 0;
-    static int n_cu = 0;
-    if (pers && n_cu == 0) {
-      int dev = 0; hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-      if (n_cu <= 0) n_cu = 256;
+    const dim3 grid(nblocks), block(512);
+    {
+      static const char* names[2][3] = {{"gemm_big_kernel<false, false, 256>", "gemm_big_kernel<false, true, 256>", "gemm_big_kernel<true, true, 256>"},
+                                        {"gemm_big_kernel<false, false, 128>", "gemm_big_kernel<false, true, 128>", "gemm_big_kernel<true, true, 128>"}};
+      g_last_gemm = names[bn == 256 ? 0 : 1][!a->transB ? 0 : (!a->transA ? 1 : 2)];
     }
-    const dim3 grid(pers ? (nblocks < (unsigned)n_cu ? nblocks : (unsigned)n_cu) : nblocks), block(512);
 #define V2S_BIG(TA_, TB_)                                                                              \
     do {                                                                                               \
-      if (pers) {                                                                                      \
-        if (bn == 256) hipLaunchKernelGGL((gemm_pers_kernel<TA_, TB_, 256>), grid, block, dyn, s, p);  \
-        else hipLaunchKernelGGL((gemm_pers_kernel<TA_, TB_, 128>), grid, block, dyn, s, p);            \
-      } else if (bn == 256) hipLaunchKernelGGL((gemm_big_kernel<TA_, TB_, 256>), grid, block, dyn, s, p);     \
+      if (bn == 256) hipLaunchKernelGGL((gemm_big_kernel<TA_, TB_, 256>), grid, block, dyn, s, p);     \
       else hipLaunchKernelGGL((gemm_big_kernel<TA_, TB_, 128>), grid, block, dyn, s, p);               \
     } while (0)
-    {
-      static const char* names[2][2][3] = {
-          {{"gemm_big_kernel<false, false, 256>", "gemm_big_kernel<false, true, 256>", "gemm_big_kernel<true, true, 256>"},
-           {"gemm_big_kernel<false, false, 128>", "gemm_big_kernel<false, true, 128>", "gemm_big_kernel<true, true, 128>"}},
-          {{"gemm_pers_kernel<false, false, 256>", "gemm_pers_kernel<false, true, 256>", "gemm_pers_kernel<true, true, 256>"},
-           {"gemm_pers_kernel<false, false, 128>", "gemm_pers_kernel<false, true, 128>", "gemm_pers_kernel<true, true, 128>"}}};
-      g_last_gemm = names[pers ? 1 : 0][bn == 256 ? 0 : 1][!a->transB ? 0 : (!a->transA ? 1 : 2)];
-    }
     if (!a->transA && !a->transB) V2S_BIG(false, false);
     else if (!a->transA && a->transB) V2S_BIG(false, true);
     else V2S_BIG(true, true);
