@@ -116,7 +116,7 @@ def main():
         "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"cfg-2: Vid2Seq {a.model} train step (generative pass"
+        "config": {"workload": f"{'cfg-2' if a.model == 't5-base' else 'cfg-5'}: Vid2Seq {a.model} train step (generative pass"
                                f"{' + denoising pass' if a.denoising > 0 else ''}), per-GPU batch {B}, 100 frames x 768, "
                                f"{Lx} ASR tokens, {Lo} target tokens, dropout {a.dropout}, fp32 master weights + fused clip/Adam/renorm",
                    "global_batch": world * B, "parallelism": f"dp{world}", "weights": "deterministic synthetic init (no checkpoints offline)"},
@@ -146,6 +146,18 @@ def main():
                            "algorithmic_gflop_per_launch": round(work / n / 1e9, 2),
                            "note": "achieved = sum over the step's launches of this kernel of 2*M*N*K (attention: 4*B*H*Nq*Nk*64 fwd, "
                                    "8*... bwd) / their summed HIP-event durations, measured with stream overlap disabled"}
+        # HBM traffic of that kernel: from the committed PMC passes (tools/pmc_traffic.sh -> profiles/*.json; rocprofv3 --pmc cannot
+        # wrap this whole script on this stack -- it crashes in torch's integer kernels), launch-weighted over the step's shapes
+        try:
+            for fn in sorted(os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles"))):
+                if fn.endswith(".json") and "pmc_traffic" in fn:
+                    pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", fn)))
+                    if pj.get("kernel") == tag:
+                        out["roofline"]["traffic"] = round(pj["traffic"])
+                        out["roofline"]["traffic_unit"] = "bytes per launch (PMC, offline: profiles/" + fn + ")"
+                        out["roofline"]["algorithmic_bytes_per_launch"] = round(pj["algorithmic"])
+        except OSError:
+            pass
         out["kernel_breakdown_ms_per_step"] = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] / 1e3) / 1e12, 1)}
                                                for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}
 

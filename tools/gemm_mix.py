@@ -1,0 +1,24 @@
+"""Launch the step's GEMM shapes of ONE kernel variant in a fixed order (3 launches each) so that a rocprofv3 --pmc pass can
+attribute HBM traffic per shape by dispatch order.  usage: gemm_mix.py  (shape list below = the dgrad/NT shapes that dispatch to
+gemm_dma_kernel<false, true> in the cfg-2 step, with their per-step launch counts)"""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vidchapters_amd import lib as L
+
+# (M, N, K, launches per step)  -- dx = dy @ W  (transB)
+SHAPES = [(32000, 768, 3072, 12), (32000, 768, 2304, 12), (35200, 768, 1536, 12), (32000, 768, 768, 12), (8192, 768, 768, 36),
+          (8192, 768, 3072, 12), (8192, 768, 2304, 12), (3200, 768, 2304, 12), (3200, 768, 2048, 12), (3200, 2048, 768, 12),
+          (3200, 768, 768, 12)]
+if __name__ == "__main__":
+    dev = "cuda"
+    names = []
+    for M, N, K, _ in SHAPES:
+        A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        B = torch.randn(K, N, device=dev).to(torch.bfloat16)
+        C = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        for _ in range(3):
+            L.gemm(A, B, C, M, N, K, transB=True)
+        names.append(L.lib().v2s_last_gemm_kernel().decode())
+    torch.cuda.synchronize()
+    print(json.dumps(names))

@@ -1,0 +1,29 @@
+"""Turn the two PMC passes of tools/pmc_traffic.sh into profiles/<name>.json: per-shape and launch-weighted HBM traffic of the
+dominant GEMM kernel.  Corrections as MI355X_MICROARCH.md (HBM section) prescribes for gfx950: FETCH_SIZE counts wide coalesced
+16-B/lane reads at half their bytes -> doubled; WRITE_SIZE is taken as is (it reproduces the C matrix size exactly here)."""
+import csv, json, sys, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gemm_mix import SHAPES
+src, out = sys.argv[1], sys.argv[2]
+def per_dispatch(counter):
+    rows = list(csv.DictReader(open(f"{src}/{counter}/p_counter_collection.csv")))
+    rows = [r for r in rows if "gemm" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return [(r["Kernel_Name"], float(r["Counter_Value"])) for r in rows]
+f, w = per_dispatch("FETCH_SIZE"), per_dispatch("WRITE_SIZE")
+assert len(f) == len(w) == 3 * len(SHAPES), (len(f), len(w))
+shapes, tot_t, tot_a, tot_n = [], 0.0, 0.0, 0
+for i, (M, N, K, cnt) in enumerate(SHAPES):
+    name = f[3 * i + 2][0]
+    fetch_kb = f[3 * i + 2][1]; write_kb = w[3 * i + 2][1]          # third (warm) launch of the shape
+    traffic = (2.0 * fetch_kb + write_kb) * 1024
+    alg = 2.0 * (M * K + K * N + M * N)
+    shapes.append({"M": M, "N": N, "K": K, "launches_per_step": cnt, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+                   "traffic_bytes": traffic, "algorithmic_bytes": alg, "ratio": round(traffic / alg, 3)})
+    tot_t += traffic * cnt; tot_a += alg * cnt; tot_n += cnt
+kern = name.replace("void (anonymous namespace)::", "").split("((anonymous")[0]
+res = {"kernel": kern, "unit": "bytes per launch", "traffic": tot_t / tot_n, "algorithmic": tot_a / tot_n, "launches_per_step": tot_n,
+       "correction": "traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE halves wide coalesced reads)", "shapes": shapes}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "shapes"}, indent=1))
+for s in shapes: print(s)
