@@ -161,8 +161,25 @@ def main():
         out["kernel_breakdown_ms_per_step"] = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] / 1e3) / 1e12, 1)}
                                                for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}
 
-    if rank == 0 and world == 1 and not a.no_generate:
+    if rank == 0 and world == 1 and not a.no_generate and a.denoising == 0:
+        # S2 of SURVEY.md 8d, reported alongside: the dvc.py default two-pass step (generative + denoising pass on the cached
+        # video_dict, L~800 / Lo~301 span-corruption shapes from synth.make_batch), same optimizer recipe
+        tr2 = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=1.0)
+        b2 = {k: v.to(dev) for k, v in synth.make_batch(B, T, Lx, Lo, len(tok), 1234, 768, denoising=True).items()}
+        b2["video"] = b2["video"].to(torch.bfloat16)
+        tr2.step(b2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            l2 = tr2.step(b2)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / 3
+        out["two_pass_step"] = {"ms_per_step": round(dt2 * 1e3, 3), "samples_per_s": round(B / dt2, 2),
+                                "den_input_tokens": int(b2["den_input_ids"].shape[1]), "den_target_tokens": int(b2["den_output_ids"].shape[1]),
+                                "loss": round(float(l2["loss"].item()), 5)}
+        del tr2, b2
         out["generate_greedy"] = generate_leg(model, tok, dev, Lx)
+        out["generate_beam4"] = beam_leg(model, tok, dev, Lx)
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline (oracle on host cores) ...")
@@ -194,6 +211,26 @@ def generate_leg(model, tok, dev, Lx, B=64, new_tokens=256):
     model.train()
     return {"batch": B, "decode_steps": int(steps), "seconds": round(dt, 4), "sequences_per_s": round(B / dt, 2),
             "ms_per_decode_step": round(dt / max(steps, 1) * 1e3, 3), "note": "encode + 256 greedy decode steps (EOS stop disabled so that every run decodes the full length), static KV cache"}
+
+
+def beam_leg(model, tok, dev, Lx, B=16, new_tokens=64, num_beams=4):
+    """The reference's default decoding (num_beams=4, vid2seq.py:100-111) at B=16 (64 live beams), 64 new tokens."""
+    from vidchapters_amd import synth
+    model.eval()
+    b = synth.make_batch(B, 100, Lx, 8, len(tok), 4321, 768)
+    video = b["video"].to(dev).to(torch.bfloat16)
+    ids = b["input_ids"].to(dev)
+    inp = {"input_ids": ids, "attention_mask": ids != 0}
+    eng = model.engine()
+    eng.beam_search(video, inp, num_beams=num_beams, max_new_tokens=4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    toks = eng.beam_search(video, inp, num_beams=num_beams, max_new_tokens=new_tokens)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    model.train()
+    return {"batch": B, "num_beams": num_beams, "max_new_tokens": new_tokens, "returned_length": int(toks.shape[1]), "seconds": round(dt, 4),
+            "sequences_per_s": round(B / dt, 2), "note": "encode + beam search with the HF-4.28 stopping rule (synthetic weights: length varies)"}
 
 
 def cpu_baseline(model, tok, Lx, Lo, threads=32, batch=4):

@@ -119,6 +119,47 @@ def test_gemm_big_wgrad_splitk():
     assert relerr(dW, 1.0 + 0.5 * (dY.float().T @ X.float())) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [(512, 256, 96, False, False), (300, 200, 64, False, False), (256, 128, 32, False, False),
+                                          (512, 384, 160, False, True), (1000, 520, 224, True, True), (2304, 768, 2048, True, True)])
+def test_gemm_w4_kernel(M, N, K, ta, tb):
+    """The 4-wave 256x128x32 three-stage kernel (dispatched by default only for the large weight gradients) forced on every
+    variant, incl. ragged edges, a one-stage contraction, and an epilogue chain."""
+    A = rnd(*((K, M) if ta else (M, K)), seed=31, scale=0.25)
+    B = rnd(*((K, N) if tb else (N, K)), seed=32, scale=0.25)
+    ref = (A.float().T if ta else A.float()) @ (B.float() if tb else B.float().T)
+    L.set_option("gemm_big", 3)
+    try:
+        C = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+        L.gemm(A, B, C, M, N, K, transA=ta, transB=tb)
+        assert relerr(C, ref) < 2e-5
+        if not ta:
+            bias = rnd(N, seed=33, dtype=torch.float32); res = rnd(M, N, seed=34)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            L.gemm(A, B, out, M, N, K, transB=tb, bias=bias, act=L.ACT_RELU, residual=res)
+            assert relerr(out, torch.relu(ref + bias) + res.float()) < 1e-2
+        else:
+            ws = torch.empty(16 * M * N, dtype=torch.float32, device=DEV)
+            dW = torch.ones(M, N, dtype=torch.float32, device=DEV)
+            L.gemm(A, B, dW, M, N, K, transA=True, transB=True, accumulate=True, alpha=0.5, workspace=ws)
+            assert relerr(dW, 1.0 + 0.5 * ref) < 2e-5
+    finally:
+        L.set_option("gemm_big", 1)
+
+
+@pytest.mark.parametrize("split", [0, 1])
+def test_gemm_splitk_policies_agree(split):
+    Mp, Np, Kc = 768, 768, 8192
+    dY, X = rnd(Kc, Mp, seed=5, scale=0.1), rnd(Kc, Np, seed=6, scale=0.1)
+    ws = torch.empty(32 * Mp * Np, dtype=torch.float32, device=DEV)
+    dW = torch.zeros(Mp, Np, dtype=torch.float32, device=DEV)
+    L.set_option("gemm_split", split)
+    try:
+        L.gemm(dY, X, dW, Mp, Np, Kc, transA=True, transB=True, accumulate=True, workspace=ws)
+    finally:
+        L.set_option("gemm_split", 1)
+    assert relerr(dW, dY.float().T @ X.float()) < 2e-5
+
+
 def test_gemm_splitk_workspace():
     """Weight-gradient shape (few output tiles, long contraction): split-K through a caller workspace."""
     Mp, Np, Kc = 768, 256, 8000

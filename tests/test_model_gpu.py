@@ -98,6 +98,25 @@ def test_ablation_flags_vs_oracle(use_video, use_speech):
     assert abs(got["loss"].item() - want["loss"].item()) <= 2e-2 * abs(want["loss"].item())
 
 
+def test_vc_variant_num_bins_zero_vs_oracle():
+    """vc.py's use of the same module: no time tokens (num_bins=0, vocab = text tokens only), single pass, and an evaluation
+    batch made of the chapters of ONE video (vc.py:140-154: video[0] -> [n_chap, T, 768])."""
+    cfg = R.RefConfig.small(vocab=512, num_bins=0)
+    model = build(cfg, 23, tokenizer=SyntheticTokenizer(512, 0)).eval()
+    P = synth.init_params(R.param_shapes(cfg), 23, cfg.d_model, cfg.inner, cfg.d_ff)
+    b = synth.make_batch(3, 10, 30, 12, cfg.vocab, 35, cfg.vit_dim)
+    video = b["video"][:1].expand(3, -1, -1).contiguous()          # chapters of one video share its features
+    with torch.no_grad():
+        want, _ = R.vid2seq_forward(P, cfg, video, b["input_ids"], b["input_ids"] != 0, b["output_ids"], b["output_ids"] != 0)
+        got, _ = model(video.to(DEV), tok(b["input_ids"]), tok(b["output_ids"]))
+    assert abs(got["loss"].item() - want["loss"].item()) <= 2e-2 * abs(want["loss"].item())
+    toks = model.engine().greedy(video.to(DEV), tok(b["input_ids"]), max_new_tokens=6).cpu()
+    ref = R.greedy_generate(P, cfg, video, b["input_ids"], b["input_ids"] != 0, 6)
+    n = min(toks.shape[1], ref.shape[1])
+    assert (toks[:, :n] == ref[:, :n]).float().mean() > 0.8
+
+
+
 def test_ragged_batch_and_two_pass_vs_oracle():
     """Ragged lengths (a 1-token row, a full row, >64 and >128 keys so several attention tiles are partly masked) and
     the cached video_dict path of dvc.py:78-92."""
