@@ -180,6 +180,7 @@ def main():
         del tr2, b2
         out["generate_greedy"] = generate_leg(model, tok, dev, Lx)
         out["generate_beam4"] = beam_leg(model, tok, dev, Lx)
+        out["input_pipeline"] = input_leg(dev, B, Lx, Lo)
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline (oracle on host cores) ...")
@@ -231,6 +232,28 @@ def beam_leg(model, tok, dev, Lx, B=16, new_tokens=64, num_beams=4):
     model.train()
     return {"batch": B, "num_beams": num_beams, "max_new_tokens": new_tokens, "returned_length": int(toks.shape[1]), "seconds": round(dt, 4),
             "sequences_per_s": round(B / dt, 2), "note": "encode + beam search with the HF-4.28 stopping rule (synthetic weights: length varies)"}
+
+
+def input_leg(dev, B, Lx, Lo, frames=300):
+    """Host -> device batch preparation (vidchapters_amd.data.DeviceBatcher: frame subsampling, padding, pinned H2D, bf16 cast and
+    span corruption on the GPU) for one cfg-2 batch from host-resident fp32 features; runs on a side stream in training, so the
+    PCIe-inclusive step rate is min(step rate, this rate).  Extra field, never `value`."""
+    import numpy as np
+    from vidchapters_amd.data import DeviceBatcher
+    rng = np.random.RandomState(0)
+    samples = []
+    for _ in range(B):
+        ins = rng.randint(2, 32100, size=Lx).astype(np.int64); ins[-1] = 1
+        outs = rng.randint(2, 32200, size=Lo).astype(np.int64); outs[-1] = 1
+        samples.append({"video": rng.randn(frames, 768).astype(np.float32), "input_tokens": ins, "output_tokens": outs})
+    batcher = DeviceBatcher(dev, max_feats=100, num_text_tokens=32100)
+    batcher(samples); batcher.ready.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        batcher(samples); batcher.ready.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    return {"ms_per_batch": round(dt * 1e3, 3), "samples_per_s": round(B / dt, 1), "h2d_bytes_per_batch": B * (100 * 768 * 4 + (Lx + Lo) * 8 + Lx + 4),
+            "note": f"{frames} source frames/sample -> 100, single host thread incl. numpy span-mask RNG"}
 
 
 def cpu_baseline(model, tok, Lx, Lo, threads=32, batch=4):

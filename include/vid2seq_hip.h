@@ -260,6 +260,14 @@ int v2s_topk_logprob(const float* logits, int64_t ld, int32_t rows, int32_t V, i
                      float* out_val, int32_t* out_idx, void* stream);
 int v2s_kv_gather(const void* src, void* dst, const int32_t* idx, int64_t bs, int64_t rs, int32_t B, int32_t len,
                   int32_t width, void* stream);
+/* T5 span corruption of a 0-padded id batch on the device (util/t5.py:3-32 as used by dataset/dvc_dataset.py:127-145).
+ * ids [B][ld_ids] int64, lens [B] valid lengths (<= max_len), noise [B][ld_noise] uint8 (1 = noise token; the reference draws it
+ * with numpy's RNG on the host).  den_in / den_out rows receive the corrupted input / target sequence incl. the trailing EOS and
+ * are 0-filled up to ld_in / ld_out -- the caller sizes them from the mask (row length = kept + spans + 1); out_lens [B][2] gets
+ * the two lengths.  Sentinel k of a row = num_text_tokens - k.  Rows with lens <= 1 give [0] / [eos]. */
+int v2s_span_corrupt(const int64_t* ids, int64_t ld_ids, const int32_t* lens, const uint8_t* noise, int64_t ld_noise, int32_t B,
+                     int32_t max_len, int64_t num_text_tokens, int64_t eos, int64_t* den_in, int64_t ld_in, int64_t* den_out,
+                     int64_t ld_out, int32_t* out_lens, void* stream);
 /* *ctr += delta (one thread; closes a captured decode step) */
 int v2s_counter_add(int32_t* ctr, int32_t delta, void* stream);
 

@@ -355,6 +355,70 @@ def case_beam(cfg, num_beams=4, max_new=16):
         video=torch.stack(vids), input_ids=torch.stack(ids), tokens=torch.stack(toks), num_beams=num_beams, max_new=max_new)
 
 
+
+def case_data():
+    """Input-side data formats: run the reference's own dataset/dvc_dataset.py + util/t5.py functions on seeded
+    inputs, check oracle/data_ref.py against them bit for bit, and store inputs + expected outputs."""
+    print("[data pipeline: dataset/dvc_dataset.py + util/t5.py]")
+    from oracle import data_ref as D
+    sys.path.insert(0, REF)
+    ut5 = importlib.import_module("util.t5")
+    if "dataset" not in sys.modules:          # skip dataset/__init__.py (imports vc_dataset -> ffmpeg, absent here)
+        pkg = types.ModuleType("dataset"); pkg.__path__ = [os.path.join(REF, "dataset")]
+        sys.modules["dataset"] = pkg
+    dd = importlib.import_module("dataset.dvc_dataset")
+
+    class Tok:                      # duck type used by util/t5.py and the dataset (len, eos_token_id)
+        eos_token_id = 1
+        def __len__(self): return 32200
+    tok, num_bins = Tok(), 100
+    ntext = len(tok) - num_bins
+    ds = dd.DenseVideoCaptioning_Dataset.__new__(dd.DenseVideoCaptioning_Dataset)
+    ds.features, ds.max_feats, ds.features_dim, ds.num_bins, ds.num_text_tokens = {}, 100, 16, num_bins, ntext
+    arrs = {}
+    rng = np.random.RandomState(0)
+    for n in (37, 100, 251, 1000):
+        f = rng.randn(n, 16).astype(np.float32)
+        ds.features = {"v": torch.from_numpy(f)}
+        want = ds._get_video("v").numpy()
+        assert np.array_equal(D.get_video(f, 100), want)
+        arrs[f"frames_{n}"] = f; arrs[f"video_{n}"] = want
+    tt_in = np.array([[0.0, 10.0], [9.99, 10.0], [10.0, 10.0], [33.3, 120.5], [119.9, 120.5], [5.0, 7.0]])
+    tt = np.array([ds.time_tokenize(x, d, num_bins) for x, d in tt_in])
+    assert np.array_equal(tt, np.array([D.time_tokenize(x, d, num_bins, ntext) for x, d in tt_in]))
+    arrs["time_in"], arrs["time_tok"] = tt_in, tt
+    lens = [2, 3, 5, 37, 200, 999, 1000]
+    for L_ in lens:
+        ids = rng.randint(2, ntext, size=L_).astype(np.int64)
+        ids[-1] = 1
+        np.random.seed(100 + L_)
+        mask = ut5.random_spans_noise_mask(L_, 0.25, 5)
+        np.random.seed(100 + L_)
+        mask_o = D.random_spans_noise_mask(L_, 0.25, 5)
+        assert np.array_equal(mask, mask_o), L_
+        m = np.asarray([mask])
+        in_s = ut5.create_sentinel_ids(m.astype(np.int8), tok, num_bins)
+        lab_s = ut5.create_sentinel_ids((~m).astype(np.int8), tok, num_bins)
+        den_out = ut5.filter_input_ids(ids[None], lab_s, tok)[0]
+        den_in = ut5.filter_input_ids(ids[None], in_s, tok)[0]
+        oi, oo = D.span_corrupt(ids, mask, ntext, 1)
+        assert np.array_equal(oi, den_in) and np.array_equal(oo, den_out), L_
+        arrs[f"sc_ids_{L_}"], arrs[f"sc_mask_{L_}"], arrs[f"sc_in_{L_}"], arrs[f"sc_out_{L_}"] = ids, mask, den_in.astype(np.int64), den_out.astype(np.int64)
+    arrs["sc_lens"] = np.array(lens)
+    # collate
+    batch = [{"video_id": str(i), "duration": 1.0, "video": torch.zeros(100, 16),
+              "input_tokens": torch.from_numpy(arrs[f"sc_ids_{L_}"]), "output_tokens": torch.from_numpy(arrs[f"sc_in_{L_}"]),
+              "denoising_input_tokens": torch.from_numpy(arrs[f"sc_in_{L_}"]), "denoising_output_tokens": torch.from_numpy(arrs[f"sc_out_{L_}"])}
+             for i, L_ in enumerate([5, 37, 200])]
+    col = dd.densevideocaptioning_collate_fn(batch)
+    for k_ref, k_mine, src in (("input_tokens", "col_in", "sc_ids"), ("denoising_output_tokens", "col_dout", "sc_out")):
+        mine = D.collate([arrs[f"{src}_{L_}"] for L_ in (5, 37, 200)])
+        assert np.array_equal(col[k_ref].numpy(), mine)
+        arrs[k_mine] = mine
+    print(f"  OK  frame sampling x4, time tokens x{len(tt)}, span corruption x{len(lens)} (masks from the seeded global numpy RNG), collate")
+    npz("data_pipeline.npz", **arrs)
+
+
 def case_train_recipe(v2s, cfg, seed=5):
     """dvc.py:train_one_epoch (the real one) for 2 steps on a fake loader vs oracle train_step."""
     print("[train recipe: reference dvc.train_one_epoch x2 steps]")
@@ -485,6 +549,7 @@ def main():
     case_tiny(v2s, "small_resize_proj", cfg2, B=2, T=7, L=16, Lo=9, seed=9)
     case_train_recipe(v2s, cfg)
     case_beam(cfg)
+    case_data()
     if not a.skip_full:
         case_full(v2s)
     print("ALL GOLDEN CASES OK")

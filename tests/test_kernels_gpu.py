@@ -6,6 +6,7 @@ goldens is in test_model_gpu.py.)
 """
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -470,6 +471,54 @@ def test_topk_logprob_and_kv_gather(K):
     L.kv_gather(src, dst, sel, maxlen * W, W, B, n, W)
     assert torch.equal(dst[:, :n], src[sel.long(), :n]) and dst[:, n:].abs().sum().item() == 0
 
+
+
+def test_span_corrupt_vs_reference_golden(golden_dir):
+    """v2s_span_corrupt against the outputs of the reference's util/t5.py (bit-exact), as ONE ragged batch incl. the
+    lens <= 1 rule of dataset/dvc_dataset.py:141-144."""
+    import os
+    g = np.load(os.path.join(golden_dir, "data_pipeline.npz"))
+    lens = [int(x) for x in g["sc_lens"]] + [1]
+    Lm = max(lens); B = len(lens)
+    ids = torch.zeros(B, Lm, dtype=torch.int64); noise = torch.zeros(B, Lm, dtype=torch.uint8)
+    for i, n in enumerate(lens[:-1]):
+        ids[i, :n] = torch.from_numpy(g[f"sc_ids_{n}"]); noise[i, :n] = torch.from_numpy(g[f"sc_mask_{n}"].astype(np.uint8))
+    ids[-1, 0] = 1
+    want_in = [g[f"sc_in_{n}"] for n in lens[:-1]] + [np.array([0])]
+    want_out = [g[f"sc_out_{n}"] for n in lens[:-1]] + [np.array([1])]
+    li, lo = max(len(x) for x in want_in), max(len(x) for x in want_out)
+    den_in = torch.full((B, li), -7, dtype=torch.int64, device=DEV); den_out = torch.full((B, lo), -7, dtype=torch.int64, device=DEV)
+    out_lens = torch.zeros(B, 2, dtype=torch.int32, device=DEV)
+    L.span_corrupt(ids.to(DEV), torch.tensor(lens, dtype=torch.int32, device=DEV), noise.to(DEV), Lm, 32100, 1, den_in, den_out, out_lens)
+    den_in, den_out, out_lens = den_in.cpu().numpy(), den_out.cpu().numpy(), out_lens.cpu().numpy()
+    for i in range(B):
+        assert out_lens[i].tolist() == [len(want_in[i]), len(want_out[i])]
+        assert np.array_equal(den_in[i, :len(want_in[i])], want_in[i]) and not den_in[i, len(want_in[i]):].any()
+        assert np.array_equal(den_out[i, :len(want_out[i])], want_out[i]) and not den_out[i, len(want_out[i]):].any()
+
+
+def test_device_batcher_vs_oracle():
+    from oracle import data_ref as D
+    from vidchapters_amd.data import DeviceBatcher
+    rng = np.random.RandomState(3)
+    samples = []
+    for n_frames, n_in, n_out in ((40, 60, 9), (100, 1, 5), (333, 250, 31), (1200, 17, 2)):
+        ins = rng.randint(2, 32100, size=n_in).astype(np.int64); ins[-1] = 1
+        outs = rng.randint(2, 32200, size=n_out).astype(np.int64); outs[-1] = 1
+        samples.append({"video": rng.randn(n_frames, 64).astype(np.float32), "input_tokens": ins, "output_tokens": outs})
+    np.random.seed(11)
+    masks = [D.random_spans_noise_mask(len(s["input_tokens"]), 0.25, 5) if len(s["input_tokens"]) > 1 else np.zeros(1, bool) for s in samples]
+    np.random.seed(11)
+    batcher = DeviceBatcher(DEV, max_feats=100, num_text_tokens=32100)
+    b = batcher(samples)                                        # draws the same masks from the seeded global numpy RNG
+    batcher.ready.synchronize()
+    want_video = np.stack([D.get_video(s["video"], 100) for s in samples])
+    assert torch.equal(b["video"].cpu(), torch.from_numpy(want_video).to(torch.bfloat16))
+    assert np.array_equal(b["input_ids"].cpu().numpy(), D.collate([s["input_tokens"] for s in samples]))
+    assert np.array_equal(b["output_ids"].cpu().numpy(), D.collate([s["output_tokens"] for s in samples]))
+    pairs = [D.span_corrupt(s["input_tokens"], m, 32100, 1) for s, m in zip(samples, masks)]
+    assert np.array_equal(b["den_input_ids"].cpu().numpy(), D.collate([p[0] for p in pairs]))
+    assert np.array_equal(b["den_output_ids"].cpu().numpy(), D.collate([p[1] for p in pairs]))
 
 
 def test_decode_kernels():

@@ -150,6 +150,34 @@ def test_incremental_decoding_equals_full_forward():
 
 
 # ------------------------------------------------------------------------------------------ host logic
+# ------------------------------------------------------------------------------------------ data formats
+def test_data_oracle_and_host_pipeline_vs_reference_golden(golden_dir):
+    """oracle/data_ref.py (checker) and vidchapters_amd/data.py (product host code) against outputs of the reference's own
+    dataset/dvc_dataset.py + util/t5.py functions: bit-exact."""
+    from oracle import data_ref as D
+    from vidchapters_amd import data as P
+    g = np.load(os.path.join(golden_dir, "data_pipeline.npz"))
+    for n in (37, 100, 251, 1000):
+        assert np.array_equal(D.get_video(g[f"frames_{n}"], 100), g[f"video_{n}"])
+        assert np.array_equal(P.subsample_or_pad(g[f"frames_{n}"], 100), g[f"video_{n}"])
+    ntext = 32100
+    for (x, dur), want in zip(g["time_in"], g["time_tok"]):
+        assert D.time_tokenize(x, dur, 100, ntext) == want == P.time_tokenize(x, dur, 100, ntext)
+    for L_ in g["sc_lens"]:
+        ids, mask = g[f"sc_ids_{L_}"], g[f"sc_mask_{L_}"]
+        for mod in (D, P):
+            np.random.seed(100 + int(L_))
+            assert np.array_equal(mod.random_spans_noise_mask(int(L_), 0.25, 5), mask)
+        di, do = D.span_corrupt(ids, mask, ntext, 1)
+        assert np.array_equal(di, g[f"sc_in_{L_}"]) and np.array_equal(do, g[f"sc_out_{L_}"])
+        assert P.corrupted_lengths(mask) == (len(di), len(do))
+    assert np.array_equal(D.collate([g[f"sc_ids_{L_}"] for L_ in (5, 37, 200)]), g["col_in"])
+    assert np.array_equal(P.pad_ids([g[f"sc_ids_{L_}"] for L_ in (5, 37, 200)]).numpy(), g["col_in"])
+    seq = P.assemble_sequence([(0.0, 2.5), (2.5, 9.0)], [[11, 12, 13], [14]], 10.0, 100, ntext, 8)
+    assert np.array_equal(seq, D.assemble([(0.0, 2.5), (2.5, 9.0)], [[11, 12, 13], [14]], 10.0, 100, ntext, 8, 1))
+    assert seq.tolist() == [32100, 32124, 11, 12, 13, 32124, 32189, 1]
+
+
 def test_parse_chapters_vs_reference(golden_dir):
     for case in json.load(open(os.path.join(golden_dir, "parse_chapters.json"))):
         assert parse_chapters(case["text"], case["duration"], case["num_bins"]) == case["expected"]

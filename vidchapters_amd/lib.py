@@ -92,6 +92,7 @@ SYMBOLS = {
     "v2s_kv_append": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "v2s_counter_add": (C.c_int, [_vp, _i32, _vp]),
     "v2s_last_gemm_kernel": (C.c_char_p, []),
+    "v2s_span_corrupt": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "v2s_topk_logprob": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "v2s_kv_gather": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
 }
@@ -418,3 +419,11 @@ def topk_logprob(logits, ld, rows, V, K, beam_scores, out_val, out_idx):
 def kv_gather(src, dst, idx, bs, rs, B, length, width):
     _need(idx, torch.int32, "kv_gather idx")
     _check(lib().v2s_kv_gather(src.data_ptr(), dst.data_ptr(), idx.data_ptr(), bs, rs, B, length, width, stream_ptr()), "v2s_kv_gather")
+
+
+def span_corrupt(ids, lens, noise, max_len, num_text_tokens, eos, den_in, den_out, out_lens):
+    _need(ids, torch.int64, "span_corrupt ids"); _need(lens, torch.int32, "span_corrupt lens"); _need(noise, torch.uint8, "span_corrupt noise")
+    _need(den_in, torch.int64, "span_corrupt den_in"); _need(den_out, torch.int64, "span_corrupt den_out")
+    _check(lib().v2s_span_corrupt(ids.data_ptr(), ids.stride(0), lens.data_ptr(), noise.data_ptr(), noise.stride(0), ids.shape[0], max_len,
+                                  num_text_tokens, eos, den_in.data_ptr(), den_in.stride(0), den_out.data_ptr(), den_out.stride(0),
+                                  out_lens.data_ptr(), stream_ptr()), "v2s_span_corrupt")
