@@ -40,6 +40,7 @@ const char* v2s_last_error(void);
  *   "tr_read"       1: ds_read_b64_tr_b16 operand transposes (default), 0: scalar LDS gathers
  *   "gemm_dma"      1: LDS-DMA 128x128 main loop for transposed-operand GEMMs (default), 2: for every variant, 0: register-staged
  *   "gemm_big"      1: tile-size heuristics (default), 0: 128x128 only, 2: 256x128 8-wave only, 3: force the 4-wave 256x128x32 kernel
+ *   "gemm_skinny"   1: dedicated weight-streaming kernel for M <= 64 (cached decoding; default), 0: general tiles
  *   "gemm_split"    1: split-K slice count from the rounds x length cost model (default), 0: fixed block-count target
  *   "attn_bwd_part" 0: v2s_attn_bwd launches dQ and dK/dV kernels (default), 1: dQ only, 2: dK/dV only (per-kernel timing) */
 int v2s_set_option(const char* name, int value);
@@ -254,10 +255,11 @@ int v2s_argmax_step_seq(const float* logits, int64_t ld, int32_t rows, int32_t V
 int v2s_kv_append(const void* src, int64_t src_bs, void* cache, int64_t cache_bs, int64_t cache_rs,
                   int32_t B, int32_t width, int32_t pos, const int32_t* pos_dev, void* stream);
 /* beam search (HF 4.28 beam_search, call site vid2seq.py:150-162): per row the K best of log_softmax(logits) + beam_scores[row],
- * sorted descending (K in {2,4,8,16}); and the beam reorder of the self-attention cache (modeling_t5.py:1771-1793):
+ * sorted descending (K in {2,4,8,16}); ban_token >= 0 is excluded from the candidates (not from the softmax) while
+ * *pos_dev + 1 < min_length (HF's MinLengthLogitsProcessor on EOS, applied to log-probs; pos_dev = device step counter); and the beam reorder of the self-attention cache (modeling_t5.py:1771-1793):
  * dst[b, 0:len, :] = src[idx[b], 0:len, :] for [B][*][width] bf16 caches with batch stride bs and row stride rs */
 int v2s_topk_logprob(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const float* beam_scores,
-                     float* out_val, int32_t* out_idx, void* stream);
+                     float* out_val, int32_t* out_idx, int32_t ban_token, const int32_t* pos_dev, int32_t min_length, void* stream);
 int v2s_kv_gather(const void* src, void* dst, const int32_t* idx, int64_t bs, int64_t rs, int32_t B, int32_t len,
                   int32_t width, void* stream);
 /* T5 span corruption of a 0-padded id batch on the device (util/t5.py:3-32 as used by dataset/dvc_dataset.py:127-145).

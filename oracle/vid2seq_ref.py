@@ -395,7 +395,7 @@ class _BeamHyps:
 
 @torch.no_grad()
 def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_beams: int = 4, max_new_tokens: int = 256,
-                  length_penalty: float = 1.0):
+                  length_penalty: float = 1.0, min_length: int = 1):
     """vid2seq.py:150-162 with num_beams>1, do_sample=False, early_stopping=False, num_return_sequences=1:
     transformers==4.28.0 GenerationMixin.beam_search + BeamSearchScorer (un-vendored dependency -> restated from the
     published algorithm; *parity unpinned by reference tests*, cross-checked against the installed transformers'
@@ -416,7 +416,10 @@ def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_b
     while True:
         step_in = seq if past is None else seq[:, -1:]
         h, past = t5_decoder(P, cfg, step_in, torch.ones(B * nb, seq.shape[1], dtype=torch.long), mem, mmask, past=past, use_cache=True)
-        logp = torch.log_softmax(lm_logits(P, cfg, h[:, -1:]).squeeze(1).float(), dim=-1) + beam_scores[:, None]
+        logp = torch.log_softmax(lm_logits(P, cfg, h[:, -1:]).squeeze(1).float(), dim=-1)
+        if seq.shape[-1] < min_length:                         # MinLengthLogitsProcessor (applied to the log-probs in 4.28 beam_search)
+            logp[:, cfg.eos_id] = -float("inf")
+        logp = logp + beam_scores[:, None]
         top_s, top_i = torch.topk(logp.view(B, nb * V), 2 * nb, dim=1, largest=True, sorted=True)
         nidx, ntok = top_i // V, top_i % V
         cur_len = seq.shape[-1]

@@ -161,6 +161,30 @@ def test_gemm_splitk_policies_agree(split):
     assert relerr(dW, dY.float().T @ X.float()) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 768, 768), (64, 2304, 768), (37, 768, 3072), (1, 32200, 768), (64, 616, 128)])
+def test_gemm_skinny_decode_kernel(M, N, K):
+    """M <= 64 weight-streaming kernel used by the cached decoder (incl. a ragged N and the epilogues the decode step uses)."""
+    A, B = rnd(M, K, seed=41, scale=0.5), rnd(N, K, seed=42, scale=0.1)
+    ref = A.float() @ B.float().T
+    ld = (N + 7) // 8 * 8
+    C = torch.zeros(M, ld, dtype=torch.float32, device=DEV)
+    L.gemm(A, B, C, M, N, K, ldc=ld, alpha=0.25)
+    assert L.lib().v2s_last_gemm_kernel() == b"gemm_skinny_kernel"
+    assert relerr(C[:, :N], 0.25 * ref) < 2e-5
+    if N % 8 == 0:
+        res = rnd(M, N, seed=43)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        L.gemm(A, B, out, M, N, K, act=L.ACT_RELU, residual=res)
+        assert relerr(out, torch.relu(ref) + res.float()) < 1e-2
+        L.set_option("gemm_skinny", 0)
+        try:
+            out2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            L.gemm(A, B, out2, M, N, K, act=L.ACT_RELU, residual=res)
+        finally:
+            L.set_option("gemm_skinny", 1)
+        assert relerr(out, out2) < 1e-2
+
+
 def test_gemm_splitk_workspace():
     """Weight-gradient shape (few output tiles, long contraction): split-K through a caller workspace."""
     Mp, Np, Kc = 768, 256, 8000
@@ -464,6 +488,14 @@ def test_topk_logprob_and_kv_gather(K):
     rv, ri = torch.topk(ref, K, dim=1)
     assert torch.equal(idx.cpu().long(), ri)
     assert (val.cpu().double() - rv).abs().max() < 1e-5
+    # min_length: the banned token stays in the softmax but is no candidate while pos + 1 < min_length
+    ban = int(ri[0, 0]); pos = torch.tensor([2], dtype=torch.int32, device=DEV)
+    ref2 = ref.clone(); ref2[:, ban] = -float("inf")
+    rv2, ri2 = torch.topk(ref2, K, dim=1)
+    L.topk_logprob(logits.to(DEV), ld, rows, V, K, bs.to(DEV), val, idx, ban_token=ban, pos_dev=pos, min_length=4)
+    assert torch.equal(idx.cpu().long(), ri2) and (val.cpu().double() - rv2).abs().max() < 1e-5
+    L.topk_logprob(logits.to(DEV), ld, rows, V, K, bs.to(DEV), val, idx, ban_token=ban, pos_dev=pos, min_length=3)
+    assert torch.equal(idx.cpu().long(), ri)
     # gather
     B, maxlen, W, n = 6, 20, 256, 13
     src = rnd(B, maxlen, W, seed=5); dst = torch.zeros_like(src)

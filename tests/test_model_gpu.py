@@ -255,10 +255,39 @@ def test_beam_search_vs_golden(golden_dir):
             w = want[r, :out.shape[1]].tolist()
             rows += 1
             same += (o == w and int(want[r, out.shape[1]:].abs().sum()) == 0)
+    # min_length (MinLengthLogitsProcessor): EOS banned until the decoder sequence has min_length tokens
+    P = synth.init_params(R.param_shapes(cfg), int(g["seed"][i]), cfg.d_model, cfg.inner, cfg.d_ff)
+    Ew = P["t5_model.shared.weight"] * 6.0
+    Ew[1] = Ew[int(g["fav"][i])] * float(g["fac"][i])
+    P["t5_model.shared.weight"] = Ew
+    want_ml = R.beam_generate(P, cfg, video.cpu(), ids, ids != 0, nb, max_new, 1.0, min_length=7)
+    got_ml = model.engine().beam_search(video, tok(ids), num_beams=nb, max_new_tokens=max_new, min_length=7).cpu()
+    assert all(1 not in row[:6] for row in got_ml.tolist())
+    print("min_length=7:", "identical" if torch.equal(got_ml, want_ml) else (got_ml.tolist(), want_ml.tolist()))
+    assert got_ml.shape == want_ml.shape and (got_ml == want_ml).float().mean() > 0.9
     print(f"beam search rows identical to the fp32 fixture: {same}/{rows}")
     assert same * 4 >= rows * 3
     text = model.generate(video, tok(ids), num_beams=nb, max_length=max_new)
     assert isinstance(text, list) and len(text) == out.shape[0]
+
+
+
+def test_checkpoint_load_after_engine_build_takes_effect():
+    """load_state_dict (dvc.py:354-361) into a model whose arena / bf16 shadow already exist: the next forward must see the
+    loaded weights (the shadow refresh is keyed on the parameters' version counters)."""
+    cfg = R.RefConfig.small()
+    b = synth.make_batch(2, 10, 40, 17, cfg.vocab, 9, cfg.vit_dim)
+    args = (b["video"].to(DEV), tok(b["input_ids"]), tok(b["output_ids"]))
+    a = build(cfg, 41).eval()
+    ref = build(cfg, 42).eval()
+    with torch.no_grad():
+        la = a(*args)[0]["loss"].item()
+        want = ref(*args)[0]["loss"].item()
+        ck = {k: v.detach().cpu().clone() for k, v in ref.state_dict().items()}
+        res = a.load_state_dict(ck, strict=False)
+        assert not res.missing_keys and not res.unexpected_keys
+        got = a(*args)[0]["loss"].item()
+    assert la != want and got == want
 
 
 

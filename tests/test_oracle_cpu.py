@@ -234,6 +234,41 @@ def test_module_surface_and_state_dict_keys():
         m(torch.zeros(1, 10, cfg.vit_dim), {"input_ids": ids, "attention_mask": ids != 0}, {"input_ids": ids, "attention_mask": ids != 0})
 
 
+def _small_model(seed, num_bins=100, base=512):
+    from vidchapters_amd import SyntheticTokenizer, Vid2Seq
+    cfg = R.RefConfig.small(vocab=base + num_bins, num_bins=num_bins)
+    m = Vid2Seq(dict(d_model=cfg.d_model, d_kv=cfg.d_kv, heads=cfg.heads, d_ff=cfg.d_ff, n_enc=cfg.n_enc, n_dec=cfg.n_dec),
+                num_features=cfg.num_features, embed_dim=cfg.vit_dim, depth=cfg.vit_depth, heads=cfg.vit_heads, mlp_dim=cfg.vit_mlp,
+                tokenizer=SyntheticTokenizer(base, num_bins), num_bins=num_bins, init_seed=seed)
+    return m, cfg
+
+
+def test_reference_format_checkpoint_loads(tmp_path):
+    """a checkpoint in the reference's format ({"model": state_dict} with the four embedding keys stored as separate,
+    equal tensors) loads through the caller's own lines -- dvc.py:354-361 as is, vc.py:300-308 after its 4-key row slicing --
+    and leaves the embedding tied."""
+    src, cfg = _small_model(3)
+    ck = {k: v.clone() for k, v in src.state_dict().items()}                 # clones: the aliases become independent tensors
+    torch.save({"model": ck, "epoch": 0}, tmp_path / "ck.pth")
+    checkpoint = torch.load(tmp_path / "ck.pth", map_location="cpu")
+    dst, _ = _small_model(4)
+    res = dst.load_state_dict(checkpoint["model"], strict=False)              # dvc.py:358
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    t5 = dst.t5_model
+    assert t5.lm_head.weight.data_ptr() == t5.shared.weight.data_ptr() == t5.encoder.embed_tokens.weight.data_ptr()
+    # vc.py:300-308: drop the time-token rows of the 4 embedding keys, load into a model built with num_bins=0
+    n_text = cfg.vocab - cfg.num_bins
+    for k in ("t5_model.shared.weight", "t5_model.encoder.embed_tokens.weight", "t5_model.decoder.embed_tokens.weight", "t5_model.lm_head.weight"):
+        checkpoint["model"][k] = checkpoint["model"][k][:n_text]
+    vc, _ = _small_model(5, num_bins=0)
+    res = vc.load_state_dict(checkpoint["model"], strict=False)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(vc.t5_model.shared.weight, src.t5_model.shared.weight[:n_text])
+    assert torch.equal(vc.visual_encoder.pos_embed, src.visual_encoder.pos_embed)
+
+
 def test_c_abi_exports_every_declared_symbol():
     from vidchapters_amd import lib as L
     header = open(os.path.join(ROOT, "include", "vid2seq_hip.h")).read()

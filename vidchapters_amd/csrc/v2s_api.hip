@@ -10,6 +10,7 @@ static std::atomic<int> g_tr_read{1};
 static std::atomic<int> g_gemm_dma{1};
 static std::atomic<int> g_gemm_big{1};
 static std::atomic<int> g_gemm_split{1};
+static std::atomic<int> g_gemm_skinny{1};
 static std::atomic<int> g_attn_bwd_part{0};
 
 void v2s_set_error(const char* fmt, ...) {
@@ -23,6 +24,7 @@ int v2s_opt_tr_read() { return g_tr_read.load(std::memory_order_relaxed); }
 int v2s_opt_gemm_dma() { return g_gemm_dma.load(std::memory_order_relaxed); }
 int v2s_opt_gemm_big() { return g_gemm_big.load(std::memory_order_relaxed); }
 int v2s_opt_gemm_split() { return g_gemm_split.load(std::memory_order_relaxed); }
+int v2s_opt_gemm_skinny() { return g_gemm_skinny.load(std::memory_order_relaxed); }
 int v2s_opt_attn_bwd_part() { return g_attn_bwd_part.load(std::memory_order_relaxed); }
 
 extern "C" int v2s_version(void) { return V2S_ABI_VERSION; }
@@ -33,6 +35,7 @@ extern "C" int v2s_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_dma") == 0) { g_gemm_dma.store(value); return V2S_OK; }
   if (name && strcmp(name, "gemm_big") == 0) { g_gemm_big.store(value); return V2S_OK; }
   if (name && strcmp(name, "gemm_split") == 0) { g_gemm_split.store(value); return V2S_OK; }
+  if (name && strcmp(name, "gemm_skinny") == 0) { g_gemm_skinny.store(value); return V2S_OK; }
   if (name && strcmp(name, "attn_bwd_part") == 0) { g_attn_bwd_part.store(value); return V2S_OK; }
   v2s_set_error("v2s_set_option: unknown option '%s'", name ? name : "(null)");
   return V2S_ERR_ARG;
@@ -42,6 +45,7 @@ extern "C" int v2s_get_option(const char* name) {
   if (name && strcmp(name, "gemm_dma") == 0) return g_gemm_dma.load();
   if (name && strcmp(name, "gemm_big") == 0) return g_gemm_big.load();
   if (name && strcmp(name, "gemm_split") == 0) return g_gemm_split.load();
+  if (name && strcmp(name, "gemm_skinny") == 0) return g_gemm_skinny.load();
   if (name && strcmp(name, "attn_bwd_part") == 0) return g_attn_bwd_part.load();
   v2s_set_error("v2s_get_option: unknown option '%s'", name ? name : "(null)");
   return V2S_ERR_ARG;

@@ -171,13 +171,15 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict
 template <int K>
 __global__ __launch_bounds__(256) void topk_logprob_kernel(const float* __restrict__ logits, long ld, int V,
                                                            const float* __restrict__ beam_scores, float* __restrict__ out_val,
-                                                           int* __restrict__ out_idx) {
+                                                           int* __restrict__ out_idx, int ban_tok, const int* __restrict__ pos_dev, int min_length) {
   __shared__ float sv[256 * K];
   __shared__ int si[256 * K];
   __shared__ float red_m[4], red_s[4], best_v[4];
   __shared__ int best_t[4], best_o[4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* z = logits + (long)row * ld;
+  // HF MinLengthLogitsProcessor: EOS is not a candidate while the decoder sequence (start token + decoded) is shorter than min_length
+  const int ban = (ban_tok >= 0 && (pos_dev ? *pos_dev + 1 : 0) < min_length) ? ban_tok : -1;
   float tv[K]; int ti[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void topk_logprob_kernel(const float* __restri
     const float mn = fmaxf(m, v);
     ssum = ssum * __expf(m - mn) + __expf(v - mn);
     m = mn;
-    if (v > tv[K - 1]) {                       // insert into the sorted (descending) list; equal values keep the lower index first
+    if (v > tv[K - 1] && i != ban) {           // insert (a banned token -- EOS below min_length -- counts in the softmax only) into the sorted (descending) list; equal values keep the lower index first
       tv[K - 1] = v; ti[K - 1] = i;
 #pragma unroll
       for (int j = K - 1; j > 0; --j) {
@@ -299,14 +301,14 @@ extern "C" int v2s_kv_append(const void* src, int64_t src_bs, void* cache, int64
 }
 
 extern "C" int v2s_topk_logprob(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const float* beam_scores,
-                                float* out_val, int32_t* out_idx, void* stream) {
+                                float* out_val, int32_t* out_idx, int32_t ban_token, const int32_t* pos_dev, int32_t min_length, void* stream) {
   V2S_CHECK(logits && out_val && out_idx && rows > 0 && V > 0, V2S_ERR_ARG, "v2s_topk_logprob: bad args");
   V2S_CHECK(K == 2 || K == 4 || K == 8 || K == 16, V2S_ERR_ARG, "v2s_topk_logprob: K must be 2, 4, 8 or 16 (got %d)", K);
   hipStream_t s = (hipStream_t)stream;
-  if (K == 2) hipLaunchKernelGGL((topk_logprob_kernel<2>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx);
-  else if (K == 4) hipLaunchKernelGGL((topk_logprob_kernel<4>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx);
-  else if (K == 8) hipLaunchKernelGGL((topk_logprob_kernel<8>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx);
-  else hipLaunchKernelGGL((topk_logprob_kernel<16>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx);
+  if (K == 2) hipLaunchKernelGGL((topk_logprob_kernel<2>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length);
+  else if (K == 4) hipLaunchKernelGGL((topk_logprob_kernel<4>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length);
+  else if (K == 8) hipLaunchKernelGGL((topk_logprob_kernel<8>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length);
+  else hipLaunchKernelGGL((topk_logprob_kernel<16>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

@@ -637,6 +637,65 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(const GemmP p) {
 }
 
 
+
+// =====================================================================================================================
+// Skinny GEMM for cached decoding (M <= 64 rows: one token per live sequence / beam): C[M][N] = A[M][K] . B[N][K]^T.
+// The weight matrix B is the only real traffic (read once); the 128-wide tiles above would occupy 6..24 CUs for it.  Here a block
+// owns 16 output columns: its 4 waves split K four ways, each streaming its [16][K/4] weight slab straight from HBM into MFMA
+// B-fragments (16 B per lane, no LDS) against the L2-resident activations, then the four partial 64x16 tiles are summed through
+// LDS and the usual epilogue runs on 8-wide chunks.  Grid = N/16 blocks (48..200 for the decoder projections, 2013 for the LM head).
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
+  __shared__ float part[4][64][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16;
+  const int kq = p.K >> 2;                       // K % 128 == 0
+  const int kbeg = wave * kq;
+  const int r = lane & 15, kc = (lane >> 4) * 8;
+  int brow = n0 + r; brow = brow < p.N ? brow : p.N - 1;
+  const bf16_t* bp = p.B + (long)brow * p.ldb + kbeg + kc;
+  const bf16_t* ap[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = i * 16 + r; m = m < p.M ? m : p.M - 1;
+    ap[i] = p.A + (long)m * p.lda + kbeg + kc;
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // one K-step (32) of fragments is always in flight underneath the MFMAs of the previous one
+  uint4 bq = *reinterpret_cast<const uint4*>(bp);
+  uint4 aq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aq[i] = *reinterpret_cast<const uint4*>(ap[i]);
+  for (int k = 0; k < kq; k += 32) {
+    const bf16x8 bfr = __builtin_bit_cast(bf16x8, bq);
+    bf16x8 af[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8, aq[i]);
+    const int kn = (k + 32 < kq) ? k + 32 : k;
+    bq = *reinterpret_cast<const uint4*>(bp + kn);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aq[i] = *reinterpret_cast<const uint4*>(ap[i] + kn);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part[wave][i * 16 + (lane >> 4) * 4 + q][lane & 15] = acc[i][q];
+  __syncthreads();
+  if (tid < 128) {
+    const int m = tid >> 1, c = (tid & 1) * 8;
+    const int gn = n0 + c;
+    if (m < p.M && gn < p.N) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = part[0][m][c + j] + part[1][m][c + j] + part[2][m][c + j] + part[3][m][c + j];
+      epilogue_chunk(p, v, m, gn, 0);
+    }
+  }
+}
+
 // C[m][n] (+)= alpha * sum_z ws[z][m][n]   (deterministic: fixed slice order)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc, int M,
                                                             int N, int S, float alpha, int accumulate) {
@@ -729,6 +788,13 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   const bool tr = v2s_opt_tr_read() != 0;
   const bool plain_split = a->workspace && a->c_dtype == V2S_F32 && !a->bias && !a->act && !a->dact && !a->residual && !a->pre &&
                            a->dropout_p == 0.f && a->K >= 1024 && (a->N % 8) == 0;
+  if (a->M <= 64 && !a->transA && !a->transB && (a->K % 128) == 0 && v2s_opt_gemm_skinny() != 0) {
+    p.tilesM = 1; p.tilesN = (a->N + 15) / 16; p.splitk = 1; p.kper = a->K; p.ws = nullptr;
+    g_last_gemm = "gemm_skinny_kernel";
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)p.tilesN), dim3(256), 0, s, p);
+    V2S_LAUNCH_CHECK();
+    return V2S_OK;
+  }
   // tile choice: the 256-row kernel (one 8-wave block per CU) when K % 64 == 0 and it yields enough tiles, else 128x128
   int bm = BM, bn = BN;
   const int big_mode = v2s_opt_gemm_big();

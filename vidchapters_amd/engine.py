@@ -728,7 +728,7 @@ class Engine:
 
     @torch.no_grad()
     def beam_search(self, video, input_tokenized, num_beams: int, max_new_tokens: int, length_penalty: float = 1.0,
-                    use_graph: bool = True) -> torch.Tensor:
+                    use_graph: bool = True, min_length: int = 1) -> torch.Tensor:
         """HF-4.28 beam_search + BeamSearchScorer semantics (call site vid2seq.py:150-162) on static caches.
         The encoder memory is NOT replicated per beam: cross K/V are projected once per batch entry and the nb beams of an
         entry read the same rows (``kv_group``).  A step = decoder forward for B*nb rows -> ``v2s_topk_logprob`` (log-softmax +
@@ -788,7 +788,8 @@ class Engine:
                 h, h2 = h2, h
             L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, R, d, c.eps)
             L.gemm(n, E, logits, R, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
-            L.topk_logprob(logits, self.ldv, R, self.V, K, bscore, cand_val, cand_tok)
+            L.topk_logprob(logits, self.ldv, R, self.V, K, bscore, cand_val, cand_tok, ban_token=c.eos_id, pos_dev=pos,
+                           min_length=min_length)
             L.counter_add(pos, 1)
 
         scorer = BeamScorer(B, nb, length_penalty, c.eos_id, c.pad_id, c.dec_start_id, max_new_tokens + 1)

@@ -262,7 +262,7 @@ class Vid2Seq(nn.Module):
             raise NotImplementedError("repetition_penalty != 1 / num_captions != 1 are not implemented")
         if num_beams > 1:
             toks = eng.beam_search(video, input_tokenized, num_beams=num_beams, max_new_tokens=max_length,
-                                   length_penalty=length_penalty)
+                                   length_penalty=length_penalty, min_length=min_length)
         else:
             toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length)
         return self.t5_tokenizer.batch_decode(toks, skip_special_tokens=True)
