@@ -1,0 +1,13 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/${1:-prof_decode}; mkdir -p $OUT
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python $R/tools/decode_prof.py > $OUT/trace.log 2>&1
+rm -f $OUT/trace/t_kernel_trace.csv
+python - <<PY
+import csv, glob
+rows = list(csv.DictReader(open(glob.glob("$OUT/trace/*_kernel_stats.csv")[0])))
+for r in rows[:22]:
+    n = r["Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:80]
+    print(f"{n:82s} {int(r['Calls']):6d} {int(r['TotalDurationNs'])/1e6:9.3f} ms {float(r['AverageNs'])/1e3:8.1f} us {float(r['Percentage']):6.2f}%")
+PY

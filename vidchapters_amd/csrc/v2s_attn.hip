@@ -109,13 +109,14 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
   return f;
 }
 
-// attention-probability dropout: keep(b,h,q,k) <=> ((rowseed(b,h,q) ^ (k * C1)) * C2) >= (p16 << 16): a per-row seed (one
-// full hash per row) and one xor-multiply per element, decided on the top 16 bits of the product.  Same definition in
-// all three kernels (forward mask == backward mask).
-constexpr uint32_t DROP_C1 = 0x9E3779B1u, DROP_C2 = 0x85EBCA77u;
+// attention-probability dropout: keep(b,h,q,k) <=> mul24(rowseed(b,h,q) ^ (k * C1), C2) >= (p16 << 16): a per-row seed (one
+// full hash per row) and one xor-multiply per element, decided on the top 16 bits of the low product word.  The multiply is the
+// 24-bit one (v_mul_u32_u24, full rate; v_mul_lo_u32 is quarter rate and was ~1/6 of the VALU time of a tile).  Same definition
+// in all three kernels (forward mask == backward mask).
+constexpr uint32_t DROP_C1 = 0x9E3779B1u, DROP_C2 = 0x00EBCA77u;
 __device__ __forceinline__ uint32_t drop_rowseed(uint32_t seed, uint32_t rowid) { return v2s_hash32(seed ^ (rowid * 0x9E3779B1u)); }
 __device__ __forceinline__ bool drop_keep(uint32_t rowseed, uint32_t kc1, uint32_t thr) {   // kc1 = k * DROP_C1, thr = p16 << 16
-  return ((rowseed ^ kc1) * DROP_C2) >= thr;
+  return __umul24(rowseed ^ kc1, DROP_C2) >= thr;
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; x <= ~0 here
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
           for (int r = 0; r < 4; ++r) {
             float pv = fast_exp2(st[qb][kb][r] - mn);
             rs += pv;
-            if (DROP) pv = drop_keep(rseed, kc + (uint32_t)r * DROP_C1, thr) ? pv * p.inv_keep : 0.f;
+            if (DROP) pv = drop_keep(rseed, kc + (uint32_t)r * DROP_C1, thr) ? pv : 0.f;      // 1/(1-p) is applied once, to the output row
             st[qb][kb][r] = pv;
           }
         }
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (q < p.Nq) {
-      const float inv = 1.0f / l;
+      const float inv = (DROP ? p.inv_keep : 1.0f) / l;
       bf16_t* op = p.o + (long)b * p.o_bs + (long)q * p.o_rs + h * HD;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {

@@ -644,11 +644,12 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(const GemmP p) {
 // owns 16 output columns: its 4 waves split K four ways, each streaming its [16][K/4] weight slab straight from HBM into MFMA
 // B-fragments (16 B per lane, no LDS) against the L2-resident activations, then the four partial 64x16 tiles are summed through
 // LDS and the usual epilogue runs on 8-wide chunks.  Grid = N/16 blocks (48..200 for the decoder projections, 2013 for the LM head).
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
-  __shared__ float part[4][64][17];
+template <int WAVES, int STEPS>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) {
+  __shared__ float part[WAVES][64][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 16;
-  const int kq = p.K >> 2;                       // K % 128 == 0
+  const int kq = p.K / WAVES;                    // multiple of 32 * STEPS (checked by the dispatcher)
   const int kbeg = wave * kq;
   const int r = lane & 15, kc = (lane >> 4) * 8;
   int brow = n0 + r; brow = brow < p.N ? brow : p.N - 1;
@@ -662,22 +663,20 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
   f32x4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // one K-step (32) of fragments is always in flight underneath the MFMAs of the previous one
-  uint4 bq = *reinterpret_cast<const uint4*>(bp);
-  uint4 aq[4];
+  // STEPS K-steps (of 32) are loaded back to back before their MFMAs: 5 x STEPS 16-byte loads in flight per lane
+  for (int k = 0; k < kq; k += 32 * STEPS) {
+    uint4 bq[STEPS], aq[STEPS][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) aq[i] = *reinterpret_cast<const uint4*>(ap[i]);
-  for (int k = 0; k < kq; k += 32) {
-    const bf16x8 bfr = __builtin_bit_cast(bf16x8, bq);
-    bf16x8 af[4];
+    for (int t = 0; t < STEPS; ++t) {
+      bq[t] = *reinterpret_cast<const uint4*>(bp + k + t * 32);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8, aq[i]);
-    const int kn = (k + 32 < kq) ? k + 32 : k;
-    bq = *reinterpret_cast<const uint4*>(bp + kn);
+      for (int i = 0; i < 4; ++i) aq[t][i] = *reinterpret_cast<const uint4*>(ap[i] + k + t * 32);
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) aq[i] = *reinterpret_cast<const uint4*>(ap[i] + kn);
+    for (int t = 0; t < STEPS; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[t][i]), __builtin_bit_cast(bf16x8, bq[t]), acc[i], 0, 0, 0);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -690,7 +689,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
     if (m < p.M && gn < p.N) {
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = part[0][m][c + j] + part[1][m][c + j] + part[2][m][c + j] + part[3][m][c + j];
+      for (int j = 0; j < 8; ++j) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) t += part[w][m][c + j];
+        v[j] = t;
+      }
       epilogue_chunk(p, v, m, gn, 0);
     }
   }
@@ -791,7 +795,16 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   if (a->M <= 64 && !a->transA && !a->transB && (a->K % 128) == 0 && v2s_opt_gemm_skinny() != 0) {
     p.tilesM = 1; p.tilesN = (a->N + 15) / 16; p.splitk = 1; p.kper = a->K; p.ws = nullptr;
     g_last_gemm = "gemm_skinny_kernel";
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)p.tilesN), dim3(256), 0, s, p);
+    const int waves = (a->K % 256) == 0 ? 8 : 4;
+    const int nsteps = a->K / waves / 32;
+    const dim3 grid((unsigned)p.tilesN);
+#define V2S_SKINNY(W_, S_) hipLaunchKernelGGL((gemm_skinny_kernel<W_, S_>), grid, dim3(W_ * 64), 0, s, p)
+    if (waves == 8) {
+      if (nsteps % 4 == 0) V2S_SKINNY(8, 4); else if (nsteps % 3 == 0) V2S_SKINNY(8, 3); else if (nsteps % 2 == 0) V2S_SKINNY(8, 2); else V2S_SKINNY(8, 1);
+    } else {
+      if (nsteps % 4 == 0) V2S_SKINNY(4, 4); else if (nsteps % 3 == 0) V2S_SKINNY(4, 3); else if (nsteps % 2 == 0) V2S_SKINNY(4, 2); else V2S_SKINNY(4, 1);
+    }
+#undef V2S_SKINNY
     V2S_LAUNCH_CHECK();
     return V2S_OK;
   }
