@@ -126,7 +126,7 @@ def main():
         "frac_of_mfma_peak_whole_step": round(step_tflop / (ms_per_step / 1e3) / PEAK_BF16_TFLOPS, 4),
     }
 
-    if rank == 0 and not a.no_roofline:
+    if rank == 0 and world == 1 and not a.no_roofline:      # N=1 only: the extra step would issue collectives other ranks do not join
         eng = model.engine()
         was = eng.overlap
         eng.overlap = False                 # per-launch durations are only meaningful without concurrent kernels

@@ -339,3 +339,36 @@ def test_full_size_cfg1_vs_reference_golden(golden_dir):
             bad.append((k, r))
     print(f"  per-tensor grad-norm ratio outside [0.9,1.1]: {bad[:8]}")
     assert len(bad) <= 2
+
+
+def test_full_size_cfg2_size_independent_properties():
+    """BASELINE cfg-2 shapes (t5-base, 100 frames, 1000 ASR tokens, 256 target tokens) where the fp32 oracle is too slow to run
+    in a test: properties that hold for the reference at any size.
+      (1) token-weighted decomposition: loss(batch) * n_tokens(batch) == sum_i loss(sample i) * n_tokens(i)   (mean CE over
+          non-ignored targets, modeling_t5.py:1721);
+      (2) padding invariance: extra all-pad columns on the speech and target ids change nothing (masks = ids != 0);
+      (3) the cached video_dict (dvc.py:78-92) gives the same loss as re-encoding the frames;
+      (4) no speech (dvc.py:47-50: a single EOS token per row) runs and is finite."""
+    model = Vid2Seq("t5-base", tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
+                    init_seed=5, device=DEV).eval()
+    B = 4
+    b = synth.make_batch(B, 100, 1000, 256, 32200, 77, 768)
+    video, ids, out = b["video"].to(DEV), b["input_ids"], b["output_ids"]
+    with torch.no_grad():
+        full, vd = model(video, tok(ids), tok(out))
+        full = full["loss"].item()
+        n_tok = [(out[i] != 0).sum().item() for i in range(B)]
+        per = [model(video[i:i + 1], tok(ids[i:i + 1]), tok(out[i:i + 1]))[0]["loss"].item() for i in range(B)]
+        recomposed = sum(l * n for l, n in zip(per, n_tok)) / sum(n_tok)
+        print(f"cfg-2 loss {full:.6f}; recomposed from per-sample losses {recomposed:.6f}")
+        assert abs(full - recomposed) <= 2e-3 * abs(full)
+        ids_p = torch.cat([ids, torch.zeros(B, 24, dtype=ids.dtype)], 1)
+        out_p = torch.cat([out, torch.zeros(B, 8, dtype=out.dtype)], 1)
+        padded = model(video, tok(ids_p), tok(out_p))[0]["loss"].item()
+        print(f"  with 24/8 extra pad columns {padded:.6f}")
+        assert abs(padded - full) <= 2e-3 * abs(full)
+        cached = model(vd, tok(ids), tok(out))[0]["loss"].item()
+        assert abs(cached - full) <= 1e-5 * abs(full)
+        eos_only = torch.ones(B, 1, dtype=ids.dtype)
+        nospeech = model(video, tok(eos_only), tok(out))[0]["loss"].item()
+        assert np.isfinite(nospeech) and abs(nospeech - full) > 0
