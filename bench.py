@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--denoising", type=float, default=0.0)
     ap.add_argument("--model", default="t5-base")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames", type=int, default=100, help="frames per video = ViT positions (cfg-5 uses 200)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream execution (A/B for the stream overlap)")
     ap.add_argument("--no-generate", action="store_true", help="skip the greedy generate() leg (cfg-4, reported as an extra field)")
@@ -72,9 +73,9 @@ def main():
     from vidchapters_amd import lib as L
     from vidchapters_amd.train import Trainer
 
-    B, T, Lx, Lo = a.batch, 100, a.asr_tokens, a.target_tokens
+    B, T, Lx, Lo = a.batch, a.frames, a.asr_tokens, a.target_tokens
     tok = SyntheticTokenizer(32100, 100)
-    model = Vid2Seq(a.model, tokenizer=tok, vis_drop=a.dropout, enc_drop=a.dropout, dec_drop=a.dropout, init_seed=1234,
+    model = Vid2Seq(a.model, num_features=T, tokenizer=tok, vis_drop=a.dropout, enc_drop=a.dropout, dec_drop=a.dropout, init_seed=1234,
                     device=dev).train()
     log(f"model built: {sum(p.numel() for p in model.parameters()) / 1e6:.1f} M parameters")
     model.engine().overlap = not a.no_overlap
@@ -117,7 +118,7 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{'cfg-2' if a.model == 't5-base' else 'cfg-5'}: Vid2Seq {a.model} train step (generative pass"
-                               f"{' + denoising pass' if a.denoising > 0 else ''}), per-GPU batch {B}, 100 frames x 768, "
+                               f"{' + denoising pass' if a.denoising > 0 else ''}), per-GPU batch {B}, {T} frames x 768, "
                                f"{Lx} ASR tokens, {Lo} target tokens, dropout {a.dropout}, fp32 master weights + fused clip/Adam/renorm",
                    "global_batch": world * B, "parallelism": f"dp{world}", "weights": "deterministic synthetic init (no checkpoints offline)"},
         "loss": round(loss_val, 5),

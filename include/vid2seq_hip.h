@@ -32,7 +32,7 @@ extern "C" {
 #define V2S_BF16 0
 #define V2S_F32 1
 
-#define V2S_ABI_VERSION 1
+#define V2S_ABI_VERSION 2
 
 int v2s_version(void);
 const char* v2s_last_error(void);
@@ -87,11 +87,17 @@ typedef struct v2s_gemm_args {
   uint32_t dropout_seed;
   void* workspace;      /* optional fp32 scratch: enables split-K for few-tile/long-K (weight-gradient) shapes */
   int64_t workspace_bytes;
+  float rms_eps;        /* > 0: fused T5 RMSNorm prologue for cached decoding (M <= 64 only): row m of the result is multiplied by
+                           rsqrt(mean_k(A[m][k]^2) + rms_eps) before alpha/bias/...; the norm's weight vector must have been folded
+                           into B's columns (v2s_scale_cols).  Replaces T5LayerNorm + Linear, modeling_t5.py:263-277 + :528-536 */
 } v2s_gemm_args;
 
 int v2s_gemm(const v2s_gemm_args* args, void* stream);
 /* symbol of the kernel variant the calling thread's last v2s_gemm dispatched (for profiling: matches rocprofv3 kernel names) */
 const char* v2s_last_gemm_kernel(void);
+
+/* out[r][c] = W[r][c] * w[c]  (bf16 [rows][cols] x fp32 [cols] -> bf16): folds a norm weight into the next projection */
+int v2s_scale_cols(const void* W, const float* w, void* out, int32_t rows, int32_t cols, void* stream);
 
 /* column sums of a bf16 matrix (bias gradients of the ViT linears: autograd of vit.py:41,53,17,20)
  * out[n] (+)= sum_m X[m][n];  out fp32 */

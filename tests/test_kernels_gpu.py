@@ -185,6 +185,25 @@ def test_gemm_skinny_decode_kernel(M, N, K):
         assert relerr(out, out2) < 1e-2
 
 
+def test_gemm_fused_rmsnorm_prologue():
+    """v2s_gemm rms_eps (decode path): RMSNorm (modeling_t5.py:263-277) + Linear as one GEMM over weights with the norm weight folded
+    into their columns (v2s_scale_cols)."""
+    M, N, K = 48, 512, 768
+    x = rnd(M, K, seed=51, scale=2.0); W = rnd(N, K, seed=52, scale=0.1)
+    w = rnd(K, seed=53, dtype=torch.float32).abs() + 0.5
+    Wf = torch.empty_like(W)
+    L.scale_cols(W, w, Wf, N, K)
+    assert relerr(Wf, W.float() * w) < 1e-2
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L.gemm(x, Wf, out, M, N, K, rms_eps=1e-6, act=L.ACT_RELU)
+    xf = x.float()
+    ref = torch.relu((xf * torch.rsqrt((xf * xf).mean(-1, keepdim=True) + 1e-6) * w) @ W.float().T)
+    assert relerr(out, ref) < 1.5e-2
+    with pytest.raises(RuntimeError, match="rms_eps"):
+        big = rnd(128, K, seed=54)
+        L.gemm(big, Wf, torch.empty(128, N, dtype=torch.bfloat16, device=DEV), 128, N, K, rms_eps=1e-6)
+
+
 def test_gemm_splitk_workspace():
     """Weight-gradient shape (few output tiles, long contraction): split-K through a caller workspace."""
     Mp, Np, Kc = 768, 256, 8000

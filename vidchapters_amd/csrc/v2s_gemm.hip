@@ -36,6 +36,7 @@ struct GemmP {
   int tilesM, tilesN;
   int splitk, kper;      // split-K (wgrad): slice z covers K range [z*kper, min(K,(z+1)*kper)) and writes ws[z][M][N]
   float* ws;
+  float rms_eps;         // > 0: fused RMSNorm row scale (skinny kernel only)
 };
 
 // swizzle of the [k][row] (transposed-operand) LDS image: XOR the 32-byte column chunk with bits of k
@@ -663,6 +664,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
   f32x4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool rms = p.rms_eps > 0.f;
+  float sq[4] = {0.f, 0.f, 0.f, 0.f};       // fused RMSNorm: sum of squares of this lane's A elements, per 16-row fragment
   // STEPS K-steps (of 32) are loaded back to back before their MFMAs: 5 x STEPS 16-byte loads in flight per lane
   for (int k = 0; k < kq; k += 32 * STEPS) {
     uint4 bq[STEPS], aq[STEPS][4];
@@ -677,6 +680,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[t][i]), __builtin_bit_cast(bf16x8, bq[t]), acc[i], 0, 0, 0);
+    if (rms) {
+#pragma unroll
+      for (int t = 0; t < STEPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float f[8];
+          unpack8(aq[t][i], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sq[i] = fmaf(f[j], f[j], sq[i]);
+        }
+    }
+  }
+  __shared__ float rowsq[WAVES][64];
+  if (rms) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = sq[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) rowsq[wave][i * 16 + lane] = v;
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -694,6 +718,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) t += part[w][m][c + j];
         v[j] = t;
+      }
+      if (rms) {
+        float ss = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) ss += rowsq[w][m];
+        const float rstd = rsqrtf(ss / (float)p.K + p.rms_eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= rstd;
       }
       epilogue_chunk(p, v, m, gn, 0);
     }
@@ -719,6 +751,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       o.x += c0.x; o.y += c0.y; o.z += c0.z; o.w += c0.w;
     }
     *reinterpret_cast<float4*>(cp) = o;
+  }
+}
+
+// out[r][c] = W[r][c] * w[c]
+__global__ __launch_bounds__(256) void scale_cols_kernel(const bf16_t* __restrict__ W, const float* __restrict__ w, bf16_t* __restrict__ out,
+                                                         long total8, int cols8) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total8; t += (long)gridDim.x * 256) {
+    const int c = (int)(t % cols8) * 8;
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(W + t * 8), f);
+    const float4 w0 = *reinterpret_cast<const float4*>(w + c), w1 = *reinterpret_cast<const float4*>(w + c + 4);
+    f[0] *= w0.x; f[1] *= w0.y; f[2] *= w0.z; f[3] *= w0.w; f[4] *= w1.x; f[5] *= w1.y; f[6] *= w1.z; f[7] *= w1.w;
+    *reinterpret_cast<uint4*>(out + t * 8) = pack8(f);
   }
 }
 
@@ -788,6 +833,7 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   p.p16 = (uint32_t)(a->dropout_p * 65536.0f + 0.5f);
   p.inv_keep = p.p16 ? 1.0f / (1.0f - (float)p.p16 / 65536.0f) : 1.0f;
   p.seed = a->dropout_seed;
+  p.rms_eps = a->rms_eps;
   hipStream_t s = (hipStream_t)stream;
   const bool tr = v2s_opt_tr_read() != 0;
   const bool plain_split = a->workspace && a->c_dtype == V2S_F32 && !a->bias && !a->act && !a->dact && !a->residual && !a->pre &&
@@ -808,6 +854,7 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
     V2S_LAUNCH_CHECK();
     return V2S_OK;
   }
+  V2S_CHECK(a->rms_eps <= 0.f, V2S_ERR_ARG, "v2s_gemm: rms_eps (fused RMSNorm) is only available on the M <= 64, K %% 128 == 0 decode path");
   // tile choice: the 256-row kernel (one 8-wave block per CU) when K % 64 == 0 and it yields enough tiles, else 128x128
   int bm = BM, bn = BN;
   const int big_mode = v2s_opt_gemm_big();
@@ -945,6 +992,17 @@ extern "C" int v2s_colsum(const void* X, int64_t ldx, int32_t M, int32_t N, floa
   const int rows_per_block = 1024;
   const dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block), block(256);
   hipLaunchKernelGGL(colsum_kernel, grid, block, 0, s, (const bf16_t*)X, (long)ldx, M, N, out, rows_per_block);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_scale_cols(const void* W, const float* w, void* out, int32_t rows, int32_t cols, void* stream) {
+  V2S_CHECK(W && w && out && rows > 0 && cols > 0 && (cols % 8) == 0, V2S_ERR_SHAPE, "v2s_scale_cols: bad shape %d x %d", rows, cols);
+  const long total8 = (long)rows * (cols / 8);
+  long blocks = (total8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W, w, (bf16_t*)out, total8,
+                     cols / 8);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

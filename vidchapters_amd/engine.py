@@ -644,6 +644,26 @@ class Engine:
         mask = torch.cat(masks, 1).contiguous() if len(masks) == 2 else masks[0]
         return mem, mask
 
+    def _decode_weights(self):
+        """Per generate() call: decoder projection weights with the preceding RMSNorm weight folded into their columns
+        (W' = W * diag(w_ln)), so that the decode step runs norm + projection as ONE skinny GEMM with the row scale
+        rsqrt(mean(x^2)+eps) computed in its prologue (v2s_gemm rms_eps).  Temporary bf16 copies (t5-base: 162 MB)."""
+        a, c = self.arena, self.cfg
+        d, inner = self.d, self.inner
+        out = {"qkv": [], "cq": [], "wi": []}
+        for i in range(c.n_dec):
+            for key, wname, shape, ln in (("qkv", self._sa("decoder", i) + "q.weight", (3 * inner, d), 0),
+                                          ("cq", self._ca(i) + "q.weight", (inner, d), 1),
+                                          ("wi", self._ffp("decoder", i) + "wi.weight", (self.ff, d), 2)):
+                t = self._bf(*shape)
+                L.scale_cols(a.w(wname, shape), a.f(self._ln("decoder", i, ln)), t, shape[0], shape[1])
+                out[key].append(t)
+        E = a.w("t5_model.shared.weight")
+        Ef = self._bf(E.shape[0], d)
+        L.scale_cols(E, a.f("t5_model.decoder.final_layer_norm.weight"), Ef, E.shape[0], d)
+        out["head"] = Ef
+        return out
+
     @torch.no_grad()
     def greedy(self, video, input_tokenized, max_new_tokens: int = 256, stop_at_eos: bool = True, use_graph: bool = True) -> torch.Tensor:
         """HF-4.28 greedy_search semantics on a static KV cache: the cross K/V of every layer are
@@ -677,28 +697,39 @@ class Engine:
         ha, hb = self._bf(B, d), self._bf(B, d)
         eos = c.eos_id if stop_at_eos else -1
 
+        fw = self._decode_weights() if (d % 128 == 0 and B <= 64) else None      # fused norm+projection: the M <= 64, K % 128 == 0 kernel
+        eps = c.eps
+
+        def proj(x, rows, key, i, wname, shape, ln_idx, out, **kw):
+            """RMSNorm + Linear of a decode step: one fused skinny GEMM (folded weights) or norm kernel + GEMM."""
+            if fw is not None:
+                L.gemm(x, fw[key][i], out, rows, shape[0], d, rms_eps=eps, **kw)
+            else:
+                L.rmsnorm_fwd(x, a.f(self._ln("decoder", i, ln_idx)), n, rstd, rows, d, eps)
+                L.gemm(n, a.w(wname, shape), out, rows, shape[0], d, **kw)
+
         def step():
             h, h2 = ha, hb
             L.embed_fwd(nxt, E, h, B, d, self.V)
             for i in range(nl):
                 sa, ca, fp = self._sa("decoder", i), self._ca(i), self._ffp("decoder", i)
-                L.rmsnorm_fwd(h, a.f(self._ln("decoder", i, 0)), n, rstd, B, d, c.eps)
-                L.gemm(n, a.w(sa + "q.weight", (3 * inner, d)), qkv, B, 3 * inner, d)
+                proj(h, B, "qkv", i, sa + "q.weight", (3 * inner, d), 0, qkv)
                 L.kv_append(qkv[:, inner:], 3 * inner, cache[i], maxlen * 2 * inner, 2 * inner, B, 2 * inner, 0, pos_dev=pos)
                 L.decode_attn(B, H, maxlen, qkv, 3 * inner, cache[i], cache[i][:, :, inner:], maxlen * 2 * inner, 2 * inner,
                               ctx, inner, bias_row=diag, bias_ld=2 * maxlen - 1, pos_dev=pos, bias_maxlen=maxlen)
                 L.gemm(ctx, a.w(sa + "o.weight"), h2, B, d, inner, residual=h)
-                L.rmsnorm_fwd(h2, a.f(self._ln("decoder", i, 1)), n, rstd, B, d, c.eps)
-                L.gemm(n, a.w(ca + "q.weight"), q, B, inner, d)
+                proj(h2, B, "cq", i, ca + "q.weight", (inner, d), 1, q)
                 L.decode_attn(B, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
                               key_mask=mem_mask, mask_ld=S)
                 L.gemm(ctx, a.w(ca + "o.weight"), h, B, d, inner, residual=h2)
-                L.rmsnorm_fwd(h, a.f(self._ln("decoder", i, 2)), n, rstd, B, d, c.eps)
-                L.gemm(n, a.w(fp + "wi.weight"), u, B, self.ff, d, act=L.ACT_RELU)
+                proj(h, B, "wi", i, fp + "wi.weight", (self.ff, d), 2, u, act=L.ACT_RELU)
                 L.gemm(u, a.w(fp + "wo.weight"), h2, B, d, self.ff, residual=h)
                 h, h2 = h2, h
-            L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, B, d, c.eps)
-            L.gemm(n, E, logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
+            if fw is not None:
+                L.gemm(h, fw["head"], logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5, rms_eps=eps)
+            else:
+                L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, B, d, eps)
+                L.gemm(n, E, logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
             L.argmax_step_seq(logits, self.ldv, B, self.V, nxt, unfinished, eos, c.pad_id, seq, maxlen + 1, pos)
             L.counter_add(pos, 1)
 
@@ -766,28 +797,38 @@ class Engine:
         ha, hb = self._bf(R, d), self._bf(R, d)
         cbs = maxlen * 2 * inner
 
+        fw = self._decode_weights() if (d % 128 == 0 and R <= 64) else None
+        eps = c.eps
+
+        def proj(x, key, i, wname, shape, ln_idx, out, **kw):
+            if fw is not None:
+                L.gemm(x, fw[key][i], out, R, shape[0], d, rms_eps=eps, **kw)
+            else:
+                L.rmsnorm_fwd(x, a.f(self._ln("decoder", i, ln_idx)), n, rstd, R, d, eps)
+                L.gemm(n, a.w(wname, shape), out, R, shape[0], d, **kw)
+
         def step(cache):
             h, h2 = ha, hb
             L.embed_fwd(nxt, E, h, R, d, self.V)
             for i in range(nl):
                 sa, ca, fp = self._sa("decoder", i), self._ca(i), self._ffp("decoder", i)
-                L.rmsnorm_fwd(h, a.f(self._ln("decoder", i, 0)), n, rstd, R, d, c.eps)
-                L.gemm(n, a.w(sa + "q.weight", (3 * inner, d)), qkv, R, 3 * inner, d)
+                proj(h, "qkv", i, sa + "q.weight", (3 * inner, d), 0, qkv)
                 L.kv_append(qkv[:, inner:], 3 * inner, cache[i], cbs, 2 * inner, R, 2 * inner, 0, pos_dev=pos)
                 L.decode_attn(R, H, maxlen, qkv, 3 * inner, cache[i], cache[i][:, :, inner:], cbs, 2 * inner,
                               ctx, inner, bias_row=diag, bias_ld=2 * maxlen - 1, pos_dev=pos, bias_maxlen=maxlen)
                 L.gemm(ctx, a.w(sa + "o.weight"), h2, R, d, inner, residual=h)
-                L.rmsnorm_fwd(h2, a.f(self._ln("decoder", i, 1)), n, rstd, R, d, c.eps)
-                L.gemm(n, a.w(ca + "q.weight"), q, R, inner, d)
+                proj(h2, "cq", i, ca + "q.weight", (inner, d), 1, q)
                 L.decode_attn(R, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
                               key_mask=mem_mask, mask_ld=S, kv_group=nb)
                 L.gemm(ctx, a.w(ca + "o.weight"), h, R, d, inner, residual=h2)
-                L.rmsnorm_fwd(h, a.f(self._ln("decoder", i, 2)), n, rstd, R, d, c.eps)
-                L.gemm(n, a.w(fp + "wi.weight"), u, R, self.ff, d, act=L.ACT_RELU)
+                proj(h, "wi", i, fp + "wi.weight", (self.ff, d), 2, u, act=L.ACT_RELU)
                 L.gemm(u, a.w(fp + "wo.weight"), h2, R, d, self.ff, residual=h)
                 h, h2 = h2, h
-            L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, R, d, c.eps)
-            L.gemm(n, E, logits, R, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
+            if fw is not None:
+                L.gemm(h, fw["head"], logits, R, self.V, d, ldc=self.ldv, alpha=d ** -0.5, rms_eps=eps)
+            else:
+                L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, R, d, eps)
+                L.gemm(n, E, logits, R, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
             L.topk_logprob(logits, self.ldv, R, self.V, K, bscore, cand_val, cand_tok, ban_token=c.eos_id, pos_dev=pos,
                            min_length=min_length)
             L.counter_add(pos, 1)

@@ -28,7 +28,8 @@ class GemmArgs(C.Structure):
                 ("A", _vp), ("B", _vp), ("lda", _i64), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
                 ("c_dtype", _i32), ("accumulate", _i32), ("alpha", _f32), ("bias", _vp), ("act", _i32),
                 ("pre", _vp), ("dact", _i32), ("z", _vp), ("ldz", _i64), ("residual", _vp), ("ldr", _i64),
-                ("dropout_p", _f32), ("dropout_seed", _u32), ("workspace", _vp), ("workspace_bytes", _i64)]
+                ("dropout_p", _f32), ("dropout_seed", _u32), ("workspace", _vp), ("workspace_bytes", _i64),
+                ("rms_eps", _f32)]
 
 
 class AttnArgs(C.Structure):
@@ -92,6 +93,7 @@ SYMBOLS = {
     "v2s_kv_append": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "v2s_counter_add": (C.c_int, [_vp, _i32, _vp]),
     "v2s_last_gemm_kernel": (C.c_char_p, []),
+    "v2s_scale_cols": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "v2s_span_corrupt": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "v2s_topk_logprob": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "v2s_kv_gather": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
@@ -185,7 +187,7 @@ class KernelTimer:
 # --------------------------------------------------------------------------------------------- GEMM
 def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, K: int, *, transA=False, transB=False,
          lda=None, ldb=None, ldc=None, accumulate=False, alpha=1.0, bias=None, act=ACT_NONE, pre=None, dact=ACT_NONE,
-         z=None, ldz=None, residual=None, ldr=None, dropout_p=0.0, dropout_seed=0, workspace=None) -> None:
+         z=None, ldz=None, residual=None, ldr=None, dropout_p=0.0, dropout_seed=0, workspace=None, rms_eps=0.0) -> None:
     """C[M,N] (+)= epilogue(alpha * A(m,k) B(n,k)); see include/vid2seq_hip.h for layouts."""
     _need(A, torch.bfloat16, "gemm A"); _need(B, torch.bfloat16, "gemm B")
     a = GemmArgs()
@@ -209,6 +211,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, 
     a.ldr = ldr if ldr is not None else N
     a.dropout_p = dropout_p
     a.dropout_seed = dropout_seed & 0xFFFFFFFF
+    a.rms_eps = rms_eps
     if workspace is not None:
         a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     kt = KernelTimer.active
@@ -427,3 +430,8 @@ def span_corrupt(ids, lens, noise, max_len, num_text_tokens, eos, den_in, den_ou
     _check(lib().v2s_span_corrupt(ids.data_ptr(), ids.stride(0), lens.data_ptr(), noise.data_ptr(), noise.stride(0), ids.shape[0], max_len,
                                   num_text_tokens, eos, den_in.data_ptr(), den_in.stride(0), den_out.data_ptr(), den_out.stride(0),
                                   out_lens.data_ptr(), stream_ptr()), "v2s_span_corrupt")
+
+
+def scale_cols(W, w, out, rows, cols):
+    _need(W, torch.bfloat16, "scale_cols W"); _need(w, torch.float32, "scale_cols w")
+    _check(lib().v2s_scale_cols(W.data_ptr(), w.data_ptr(), out.data_ptr(), rows, cols, stream_ptr()), "v2s_scale_cols")
