@@ -41,6 +41,8 @@ const char* v2s_last_error(void);
  *   "gemm_dma"      1: LDS-DMA 128x128 main loop for transposed-operand GEMMs (default), 2: for every variant, 0: register-staged
  *   "gemm_big"      1: tile-size heuristics (default), 0: 128x128 only, 2: 256x128 8-wave only, 3: force the 4-wave 256x128x32 kernel
  *   "gemm_skinny"   1: dedicated weight-streaming kernel for M <= 64 (cached decoding; default), 0: general tiles
+ *   "gemm_order"    GM > 0: grouped tile walk, GM tile rows deep, K slices tile-major (default 4: the blocks an XCD runs together share
+ *                   operand slabs in its L2; +20..40 % on the split-K weight gradients), 0: row-major with adjacent K slices
  *   "gemm_split"    1: split-K slice count from the rounds x length cost model (default), 0: fixed block-count target
  *   "attn_bwd_part" 0: v2s_attn_bwd launches dQ and dK/dV kernels (default), 1: dQ only, 2: dK/dV only (per-kernel timing) */
 int v2s_set_option(const char* name, int value);

@@ -45,9 +45,22 @@ vitw = [("vit wgrad qkv", 2304, 768, 3200), ("vit wgrad fc1", 2048, 768, 3200), 
 import sys as _s
 if len(_s.argv) > 1 and _s.argv[1] == "wgrad":
     allw = [("wgrad qkv", 2304, 768, 32000), ("wgrad wi", 3072, 768, 32000), ("wgrad o", 768, 768, 32000), ("wgrad wo", 768, 3072, 32000)] + vitw + [("vit wgrad fc2b", 768, 2048, 3200)]
-    for big, split in ((1, 1), (1, 0), (3, 1), (0, 1), (0, 0)):
+    L.set_option("gemm_order", int(_s.argv[2]) if len(_s.argv) > 2 else 0)
+    for big, split in ((1, 1), (3, 1), (0, 1), (2, 1), (1, 1), (3, 1), (0, 1), (2, 1)):
         L.set_option("gemm_big", big); L.set_option("gemm_split", split)
         print(f"--- gemm_big={big} gemm_split={split}")
+        for name, M, N, K in allw:
+            tf, us = bench(M, N, K, True, True, f32=True, acc=True, ws=ws)
+            print(f"{name:16s} M={M:6d} N={N:6d} K={K:6d}: {tf:7.1f} TF/s  {us:8.1f} us (split-K)")
+    _s.exit(0)
+if len(_s.argv) > 1 and _s.argv[1] == "order":
+    allw = [("wgrad qkv", 2304, 768, 32000), ("wgrad wi", 3072, 768, 32000), ("wgrad o", 768, 768, 32000), ("wgrad wo", 768, 3072, 32000)] + vitw
+    for order in (0, 4, 8, 0, 4, 8):
+        L.set_option("gemm_order", order)
+        print(f"--- gemm_order={order}")
+        for name, M, N, K, ta, tb in shapes:
+            tf, us = bench(M, N, K, bool(ta), bool(tb), f32=(name == "lm head fwd"))
+            print(f"{name:16s} M={M:6d} N={N:6d} K={K:6d}: {tf:7.1f} TF/s  {us:8.1f} us")
         for name, M, N, K in allw:
             tf, us = bench(M, N, K, True, True, f32=True, acc=True, ws=ws)
             print(f"{name:16s} M={M:6d} N={N:6d} K={K:6d}: {tf:7.1f} TF/s  {us:8.1f} us (split-K)")

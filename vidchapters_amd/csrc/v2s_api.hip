@@ -10,6 +10,7 @@ static std::atomic<int> g_tr_read{1};
 static std::atomic<int> g_gemm_dma{1};
 static std::atomic<int> g_gemm_big{1};
 static std::atomic<int> g_gemm_split{1};
+static std::atomic<int> g_gemm_order{4};
 static std::atomic<int> g_gemm_skinny{1};
 static std::atomic<int> g_attn_bwd_part{0};
 
@@ -24,6 +25,7 @@ int v2s_opt_tr_read() { return g_tr_read.load(std::memory_order_relaxed); }
 int v2s_opt_gemm_dma() { return g_gemm_dma.load(std::memory_order_relaxed); }
 int v2s_opt_gemm_big() { return g_gemm_big.load(std::memory_order_relaxed); }
 int v2s_opt_gemm_split() { return g_gemm_split.load(std::memory_order_relaxed); }
+int v2s_opt_gemm_order() { return g_gemm_order.load(std::memory_order_relaxed); }
 int v2s_opt_gemm_skinny() { return g_gemm_skinny.load(std::memory_order_relaxed); }
 int v2s_opt_attn_bwd_part() { return g_attn_bwd_part.load(std::memory_order_relaxed); }
 
@@ -35,6 +37,7 @@ extern "C" int v2s_set_option(const char* name, int value) {
   if (name && strcmp(name, "gemm_dma") == 0) { g_gemm_dma.store(value); return V2S_OK; }
   if (name && strcmp(name, "gemm_big") == 0) { g_gemm_big.store(value); return V2S_OK; }
   if (name && strcmp(name, "gemm_split") == 0) { g_gemm_split.store(value); return V2S_OK; }
+  if (name && strcmp(name, "gemm_order") == 0) { g_gemm_order.store(value); return V2S_OK; }
   if (name && strcmp(name, "gemm_skinny") == 0) { g_gemm_skinny.store(value); return V2S_OK; }
   if (name && strcmp(name, "attn_bwd_part") == 0) { g_attn_bwd_part.store(value); return V2S_OK; }
   v2s_set_error("v2s_set_option: unknown option '%s'", name ? name : "(null)");
@@ -45,6 +48,7 @@ extern "C" int v2s_get_option(const char* name) {
   if (name && strcmp(name, "gemm_dma") == 0) return g_gemm_dma.load();
   if (name && strcmp(name, "gemm_big") == 0) return g_gemm_big.load();
   if (name && strcmp(name, "gemm_split") == 0) return g_gemm_split.load();
+  if (name && strcmp(name, "gemm_order") == 0) return g_gemm_order.load();
   if (name && strcmp(name, "gemm_skinny") == 0) return g_gemm_skinny.load();
   if (name && strcmp(name, "attn_bwd_part") == 0) return g_attn_bwd_part.load();
   v2s_set_error("v2s_get_option: unknown option '%s'", name ? name : "(null)");

@@ -37,6 +37,7 @@ int v2s_opt_tr_read();   // 1 = use ds_read_b64_tr_b16 for transposed operand fr
 int v2s_opt_gemm_dma();  // 1 = LDS-DMA (global_load_lds) GEMM main loop where K % 64 == 0
 int v2s_opt_attn_bwd_part(); // profiling aid for v2s_attn_bwd: 0 = both kernels (default), 1 = dQ only, 2 = dK/dV only
 int v2s_opt_gemm_skinny(); // 1 = dedicated M <= 64 kernel for cached decoding (default), 0 = general tiles
+int v2s_opt_gemm_order(); // tile walk of the tiled GEMM kernels: GM > 0 = grouped GM tile rows deep with tile-major split-K (default 4), 0 = row-major
 int v2s_opt_gemm_split(); // 1 = split-K slice count from the rounds x length cost model (default), 0 = fixed block-count target
 int v2s_opt_gemm_big();  // 0 = never, 1 = 256x256/256x128 tiles where they fill the chip, 2 = 256x128 only
 

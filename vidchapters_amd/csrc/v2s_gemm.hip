@@ -37,10 +37,33 @@ struct GemmP {
   int splitk, kper;      // split-K (wgrad): slice z covers K range [z*kper, min(K,(z+1)*kper)) and writes ws[z][M][N]
   float* ws;
   float rms_eps;         // > 0: fused RMSNorm row scale (skinny kernel only)
+  int order;             // tile walk: 0 = row-major with adjacent K slices, GM > 0 = grouped (tile_coords)
 };
 
 // swizzle of the [k][row] (transposed-operand) LDS image: XOR the 32-byte column chunk with bits of k
 __device__ __forceinline__ int tr_g(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+
+// work-item id -> (tile row, tile column, K slice).  order 0: slices of one tile adjacent, tiles row-major.  order 1: all tiles of one
+// K slice adjacent, and inside a slice a grouped walk (GM tile rows deep, column by column), so that the ~32 blocks an XCD runs at
+// any time share a few A row-slabs and B column-slabs in its L2 instead of touching 32 different ones.
+__device__ __forceinline__ void tile_coords(const GemmP& p, int id0, int& tm, int& tn, int& slice) {
+  if (p.order == 0) {
+    slice = id0 % p.splitk;
+    const int id = id0 / p.splitk;
+    tm = id / p.tilesN; tn = id - tm * p.tilesN;
+  } else {
+    const int tiles = p.tilesM * p.tilesN;
+    slice = id0 / tiles;
+    const int t = id0 - slice * tiles;
+    const int GM = p.order;
+    const int gsz = GM * p.tilesN;
+    const int grp = t / gsz, first = grp * GM;
+    const int gm = min(p.tilesM - first, GM);
+    const int r = t - grp * gsz;
+    tm = first + r % gm; tn = r / gm;
+  }
+}
 
 // ---- global -> register staging -------------------------------------------------------------------
 template <bool T>
@@ -215,8 +238,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmP p) {
 
   const int nwg = p.tilesM * p.tilesN * p.splitk;
   const int id0 = xcd_remap(blockIdx.x, nwg);
-  const int slice = id0 % p.splitk, id = id0 / p.splitk;   // slices of one tile are neighbours (same XCD)
-  const int tm = id / p.tilesN, tn = id - tm * p.tilesN;
+  int tm, tn, slice;
+  tile_coords(p, id0, tm, tn, slice);
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = slice * p.kper, kend = min(p.K, kbeg + p.kper);
 
@@ -317,8 +340,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const GemmP p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int nwg = p.tilesM * p.tilesN * p.splitk;
   const int id0 = xcd_remap(blockIdx.x, nwg);
-  const int slice = id0 % p.splitk, id = id0 / p.splitk;
-  const int tm = id / p.tilesN, tn = id - tm * p.tilesN;
+  int tm, tn, slice;
+  tile_coords(p, id0, tm, tn, slice);
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = slice * p.kper, kend = min(p.K, kbeg + p.kper);
   const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
@@ -427,8 +450,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmP p) {
   const int wm = wave / WN, wn = wave % WN;
   const int nwg = p.tilesM * p.tilesN * p.splitk;
   const int id0 = xcd_remap(blockIdx.x, nwg);
-  const int slice = id0 % p.splitk, id = id0 / p.splitk;
-  const int tm = id / p.tilesN, tn = id - tm * p.tilesN;
+  int tm, tn, slice;
+  tile_coords(p, id0, tm, tn, slice);
   const int m0 = tm * BM2, n0 = tn * BN2;
   const int kbeg = slice * p.kper, kend = min(p.K, kbeg + p.kper);
   const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
@@ -562,8 +585,8 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(const GemmP p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int nwg = p.tilesM * p.tilesN * p.splitk;
   const int id0 = xcd_remap(blockIdx.x, nwg);
-  const int slice = id0 % p.splitk, id = id0 / p.splitk;
-  const int tm = id / p.tilesN, tn = id - tm * p.tilesN;
+  int tm, tn, slice;
+  tile_coords(p, id0, tm, tn, slice);
   const int m0 = tm * BM2, n0 = tn * BN2;
   const int kbeg = slice * p.kper, kend = min(p.K, kbeg + p.kper);
   const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
@@ -834,6 +857,7 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   p.inv_keep = p.p16 ? 1.0f / (1.0f - (float)p.p16 / 65536.0f) : 1.0f;
   p.seed = a->dropout_seed;
   p.rms_eps = a->rms_eps;
+  p.order = v2s_opt_gemm_order();
   hipStream_t s = (hipStream_t)stream;
   const bool tr = v2s_opt_tr_read() != 0;
   const bool plain_split = a->workspace && a->c_dtype == V2S_F32 && !a->bias && !a->act && !a->dact && !a->residual && !a->pre &&
@@ -862,7 +886,8 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   // wo dgrad 856 vs 753, wo wgrad 922 vs 684, LM head 754 vs 571); N < 1024 -> 256x128 for plain NT (o fwd 727 vs 667,
   // wo fwd 1032 vs 885) but the 128x128 DMA kernel for the transposed variants (dgrad 1000-1040 vs 931-953)
   if (big_mode && tr && (a->K % BK) == 0 && a->M >= 256 && a->N >= 128) {
-    const bool wide = a->N >= 1024 && big_mode != 2;
+    // weight gradients with a short contraction keep the 128x128 tiles even for wide outputs (768x2048x3200: 359 vs 270 TF/s)
+    const bool wide = a->N >= 1024 && big_mode != 2 && !(a->transA && a->K < 8192);
     const int bn2 = wide ? 256 : 128;
     const long t2 = (long)((a->M + 255) / 256) * ((a->N + bn2 - 1) / bn2);
     const bool transposed = a->transA || a->transB;
