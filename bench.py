@@ -258,9 +258,9 @@ def input_leg(dev, B, Lx, Lo, frames=300):
             "note": f"{frames} source frames/sample -> 100, single host thread incl. numpy span-mask RNG"}
 
 
-def cpu_baseline(model, tok, Lx, Lo, threads=32, batch=4):
+def cpu_baseline(model, tok, Lx, Lo, threads=32, batch=8):
     """The CPU oracle (fp32 torch port of the reference path, pinned against the reference in the build container)
-    timed on this box's host cores on a bounded sample: ONE optimizer step at B=4 of the same workload.
+    timed on this box's host cores on a bounded sample: ONE optimizer step at B=8 of the same workload (about 15 s).
     32 threads: on the 2 x 64-core GPU host more threads are slower for these matrix sizes (measured: B=1 step
     3.4 s at 32 threads, 13.7 s at 128)."""
     from oracle import vid2seq_ref as R
