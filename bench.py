@@ -113,7 +113,7 @@ def main():
     fps = flops_per_sample(T, Lx, Lo, cfgm.vocab, cfgm.d_model, cfgm.d_ff, cfgm.n_enc, cfgm.n_dec)
     step_tflop = 3.0 * fps * B / 1e12
     out = {
-        "metric": "Vid2Seq train-step samples/sec (100f x 768 vis, 1000 ASR tok)",
+        "metric": "Vid2Seq train-step samples/sec (100f\u00d7768 vis, 1000 ASR tok)",
         "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
