@@ -162,6 +162,12 @@ typedef struct v2s_attn_args {
    * resolution and deposited on the diagonals bias_far_lo / bias_far_hi themselves, i.e. dbias_diag is exact after
    * bucket reduction (v2s_bias_bucket_bwd) but not per diagonal.  Disabled when bias_far_lo >= bias_far_hi (0,0). */
   int32_t bias_far_lo, bias_far_hi;
+  /* optional packed ("varlen") SELF-attention: B+1 int32 row offsets on the device.  Sequence b then occupies rows
+   * [seq_off[b], seq_off[b+1]) of q/k/v/o (and d_o/dq/dk/dv): the *_bs batch strides are ignored, Nq = Nk = the nominal
+   * (maximum) length that sizes the grid, the bias diagonal table, ml and delta ([B][H][Nq] as before); key_mask must be NULL.
+   * Rows of pad tokens simply do not exist -- the reference computes them and masks them as keys (modeling_t5.py:996), so the
+   * rows that remain are identical */
+  const int32_t* seq_off;
 } v2s_attn_args;
 
 int v2s_attn_fwd(const v2s_attn_args* a, void* stream);

@@ -371,6 +371,46 @@ def test_attention_fwd_bwd(B, H, Nq, Nk, scale, use_bias, use_mask, causal, tr_m
         assert c > 0.999 and e < 3e-2
 
 
+@pytest.mark.parametrize("N,H,drop", [(200, 3, 0.0), (1000, 4, 0.1), (70, 2, 0.1)])
+def test_attention_packed_equals_padded(N, H, drop):
+    """Packed ("varlen", seq_off) self-attention == the padded + key-masked call on every row that exists: forward output,
+    dQ/dK/dV and the bias gradient, bit for bit (same tiles, same arithmetic; the pad keys the padded call masks do not exist)."""
+    B = 4
+    W = H * 64
+    lens = [N, max(1, N - 37), max(1, N // 2 + 3), 1]
+    off = [0]
+    for n in lens:
+        off.append(off[-1] + n)
+    T = off[-1]
+    qkv_pad = rnd(B, N, 3 * W, seed=1, scale=0.5)
+    do_pad = rnd(B, N, W, seed=2)
+    for b_, n_ in enumerate(lens):
+        do_pad[b_, n_:] = 0          # the gradient reaching pad rows is exactly zero in the model (their keys are masked downstream)
+    diag = rnd(H, 2 * N - 1, seed=3, dtype=torch.float32)
+    mask = (torch.arange(N, device=DEV)[None, :] < torch.tensor(lens, device=DEV)[:, None]).to(torch.uint8).contiguous()
+    # padded reference call
+    o_pad = torch.zeros(B, N, W, dtype=torch.bfloat16, device=DEV); ml = torch.zeros(B, H, N, 2, device=DEV)
+    st3, st1 = (N * 3 * W, 3 * W), (N * W, W)
+    a = L.attn_args(B, H, N, N, qkv_pad, qkv_pad[..., W:], qkv_pad[..., 2 * W:], o_pad, st3, st3, st3, st1, ml=ml, bias_diag=diag,
+                    key_mask=mask, dropout_p=drop, dropout_seed=9)
+    L.attn_fwd(a)
+    dqkv_pad = torch.zeros_like(qkv_pad); delta = torch.zeros(B, H, N, device=DEV); dd_pad = torch.zeros_like(diag)
+    L.attn_bwd(a, do_pad, st1, delta, dqkv_pad, dqkv_pad[..., W:], dqkv_pad[..., 2 * W:], st3, st3, st3, dbias_diag=dd_pad, far=(-60, 60))
+    # packed call on the rows that exist
+    rows = torch.cat([torch.arange(n, device=DEV) + b * N for b, n in enumerate(lens)])
+    qkv = qkv_pad.view(B * N, 3 * W)[rows].contiguous(); d_o = do_pad.view(B * N, W)[rows].contiguous()
+    o = torch.zeros(T, W, dtype=torch.bfloat16, device=DEV); ml2 = torch.zeros(B, H, N, 2, device=DEV)
+    so = torch.tensor(off, dtype=torch.int32, device=DEV)
+    a2 = L.attn_args(B, H, N, N, qkv, qkv[:, W:], qkv[:, 2 * W:], o, (0, 3 * W), (0, 3 * W), (0, 3 * W), (0, W), ml=ml2, bias_diag=diag,
+                     dropout_p=drop, dropout_seed=9, seq_off=so)
+    L.attn_fwd(a2)
+    dqkv = torch.zeros_like(qkv); delta2 = torch.zeros(B, H, N, device=DEV); dd = torch.zeros_like(diag)
+    L.attn_bwd(a2, d_o, (0, W), delta2, dqkv, dqkv[:, W:], dqkv[:, 2 * W:], (0, 3 * W), (0, 3 * W), (0, 3 * W), dbias_diag=dd, far=(-60, 60))
+    assert torch.equal(o, o_pad.view(B * N, W)[rows])
+    assert torch.equal(dqkv, dqkv_pad.view(B * N, 3 * W)[rows])
+    assert relerr(dd, dd_pad) < 1e-5
+
+
 def test_attention_fully_masked_row_is_uniform():
     B, H, N = 1, 1, 70
     W = 64

@@ -48,6 +48,7 @@ struct AttnP {
   long dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
   float* dbias_diag;
   int far_lo, far_hi;   // all relative positions <= far_lo (>= far_hi) share one bias bucket
+  const int* seq_off;   // packed self-attention: sequence b = rows [seq_off[b], seq_off[b+1]) of every operand (batch strides unused)
 };
 
 // byte offset of element (row, d) inside a [rows][64] bf16 LDS tile
@@ -164,10 +165,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int qblk = id % nqb, bh = id / nqb, h = bh % p.H, b = bh / p.H;
   const int Q0 = qblk * 128, wq0 = wave * 32;
+  const int row0_ = p.seq_off ? p.seq_off[b] : 0;                          // packed (varlen) self-attention: first row of sequence b
+  const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq, nk_ = p.seq_off ? nq_ : p.Nk;
+  if (Q0 >= nq_) return;                                                   // block beyond the end of a short sequence
 
-  const bf16_t* qp = p.q + (long)b * p.q_bs + h * HD;
-  const bf16_t* kp = p.k + (long)b * p.k_bs + h * HD;
-  const bf16_t* vp = p.v + (long)b * p.v_bs + h * HD;
+  const bf16_t* qp = p.q + (p.seq_off ? (long)row0_ * p.q_rs : (long)b * p.q_bs) + h * HD;
+  const bf16_t* kp = p.k + (p.seq_off ? (long)row0_ * p.k_rs : (long)b * p.k_bs) + h * HD;
+  const bf16_t* vp = p.v + (p.seq_off ? (long)row0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
 
   bf16x8 qf[2][2];
 #pragma unroll
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (q < p.Nq) v = *reinterpret_cast<const uint4*>(qp + (long)q * p.q_rs + ks * 32 + g * 8);
+      if (q < nq_) v = *reinterpret_cast<const uint4*>(qp + (long)q * p.q_rs + ks * 32 + g * 8);
       qf[qb][ks] = __builtin_bit_cast(bf16x8, v);
     }
   }
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
     for (int db = 0; db < 4; ++db) ot[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int ntiles = (p.Nk + 63) >> 6;
+  const int ntiles = (nk_ + 63) >> 6;
   const float sc2 = p.scale * LOG2E;
   const int qmin = Q0 + wq0, qmax = qmin + 31;
   uint4 rk[2], rv[2];
@@ -196,15 +200,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
 
   auto prefetch = [&](int t) {
     const int k0 = t * 64;
-    tile_load(kp, p.k_rs, k0, p.Nk, tid, rk);
-    tile_load(vp, p.v_rs, k0, p.Nk, tid, rv);
+    tile_load(kp, p.k_rs, k0, nk_, tid, rk);
+    tile_load(vp, p.v_rs, k0, nk_, tid, rv);
     if (BIAS && tid < 192) {
       const int idx = k0 - Q0 - 127 + tid + p.Nq - 1;
       rbias = (idx >= 0 && idx < p.Nq + p.Nk - 1) ? p.bias_diag[(long)h * (p.Nq + p.Nk - 1) + idx] * LOG2E : 0.f;
     }
     if (tid < 64) {
       const int k = k0 + tid;
-      rflag = (k >= p.Nk) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
+      rflag = (k >= nk_) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
     }
   };
   auto commit = [&](int s) {
@@ -331,9 +335,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
     float l = lsum[qb];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    if (q < p.Nq) {
+    if (q < nq_) {
       const float inv = (DROP ? p.inv_keep : 1.0f) / l;
-      bf16_t* op = p.o + (long)b * p.o_bs + (long)q * p.o_rs + h * HD;
+      bf16_t* op = p.o + (p.seq_off ? (long)row0_ * p.o_rs : (long)b * p.o_bs) + (long)q * p.o_rs + h * HD;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         uint2 w;
@@ -361,14 +365,20 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p, float* _
     long r = t >> 3;
     h = (int)(r % p.H); r /= p.H;
     q = (int)(r % p.Nq); b = (int)(r / p.Nq);
+    const int row0_ = p.seq_off ? p.seq_off[b] : 0;
+    if (p.seq_off && q >= p.seq_off[b + 1] - row0_) q = -1;         // row beyond the end of a packed sequence: delta stays unwritten
+  }
+  if (t < total && q >= 0) {
+    const int c = (int)(t & 7);
+    const int row0_ = p.seq_off ? p.seq_off[b] : 0;
     float a[8], d[8];
-    unpack8(*reinterpret_cast<const uint4*>(p.o + (long)b * p.o_bs + (long)q * p.o_rs + h * HD + c * 8), a);
-    unpack8(*reinterpret_cast<const uint4*>(p.d_o + (long)b * p.do_bs + (long)q * p.do_rs + h * HD + c * 8), d);
+    unpack8(*reinterpret_cast<const uint4*>(p.o + (p.seq_off ? (long)row0_ * p.o_rs : (long)b * p.o_bs) + (long)q * p.o_rs + h * HD + c * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(p.d_o + (p.seq_off ? (long)row0_ * p.do_rs : (long)b * p.do_bs) + (long)q * p.do_rs + h * HD + c * 8), d);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += a[j] * d[j];
   }
   s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-  if (t < total && (t & 7) == 0) delta[((long)(b * p.H + h)) * p.Nq + q] = s;
+  if (t < total && q >= 0 && (t & 7) == 0) delta[((long)(b * p.H + h)) * p.Nq + q] = s;
 }
 
 // ====================================================================================== backward: dQ (+ dbias)
@@ -383,6 +393,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int qblk = id % nqb, bh = id / nqb, h = bh % p.H, b = bh / p.H;
   const int Q0 = qblk * 128, wq0 = wave * 32;
+  const int row0_ = p.seq_off ? p.seq_off[b] : 0;                          // packed (varlen) self-attention: first row of sequence b
+  const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq, nk_ = p.seq_off ? nq_ : p.Nk;
+  if (Q0 >= nq_) return;                                                   // block beyond the end of a short sequence
   const bool want_dbias = BIAS && p.dbias_diag != nullptr;
   // per-diagonal bias-gradient window of this block, index (k - q) + (Q0 + 127) in [0, Nk+127), accumulated in 64-bit
   // fixed point (2^-40 units): LDS float atomics run at ~0.33 lane-ops/clk/CU on gfx950, 64-bit integer ones at ~8
@@ -394,10 +407,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   }
   float acc_lo = 0.f, acc_hi = 0.f;    // bias-gradient mass of the two "far" buckets (no per-diagonal resolution needed)
 
-  const bf16_t* qp = p.q + (long)b * p.q_bs + h * HD;
-  const bf16_t* dop = p.d_o + (long)b * p.do_bs + h * HD;
-  const bf16_t* kp = p.k + (long)b * p.k_bs + h * HD;
-  const bf16_t* vp = p.v + (long)b * p.v_bs + h * HD;
+  const bf16_t* qp = p.q + (p.seq_off ? (long)row0_ * p.q_rs : (long)b * p.q_bs) + h * HD;
+  const bf16_t* dop = p.d_o + (p.seq_off ? (long)row0_ * p.do_rs : (long)b * p.do_bs) + h * HD;
+  const bf16_t* kp = p.k + (p.seq_off ? (long)row0_ * p.k_rs : (long)b * p.k_bs) + h * HD;
+  const bf16_t* vp = p.v + (p.seq_off ? (long)row0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
 
   bf16x8 qf[2][2], dof[2][2];
   float m2[2], linv[2], dl[2];
@@ -407,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
-      if (q < p.Nq) {
+      if (q < nq_) {
         v = *reinterpret_cast<const uint4*>(qp + (long)q * p.q_rs + ks * 32 + g * 8);
         w = *reinterpret_cast<const uint4*>(dop + (long)q * p.do_rs + ks * 32 + g * 8);
       }
@@ -415,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
       dof[qb][ks] = __builtin_bit_cast(bf16x8, w);
     }
     m2[qb] = 0.f; linv[qb] = 0.f; dl[qb] = 0.f;     // rows >= Nq: linv = 0 => P = 0 => dS = 0
-    if (q < p.Nq) {
+    if (q < nq_) {
       const long r = ((long)(b * p.H + h)) * p.Nq + q;
       m2[qb] = p.ml[r * 2];
       linv[qb] = 1.0f / p.ml[r * 2 + 1];
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
     for (int db = 0; db < 4; ++db) dqt[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int ntiles = (p.Nk + 63) >> 6;
+  const int ntiles = (nk_ + 63) >> 6;
   const float sc2 = p.scale * LOG2E;
   const int qmin = Q0 + wq0, qmax = qmin + 31;
   uint4 rk[2], rv[2];
@@ -439,15 +452,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   uint32_t rflag = 0;
   auto prefetch = [&](int t) {
     const int k0 = t * 64;
-    tile_load(kp, p.k_rs, k0, p.Nk, tid, rk);
-    tile_load(vp, p.v_rs, k0, p.Nk, tid, rv);
+    tile_load(kp, p.k_rs, k0, nk_, tid, rk);
+    tile_load(vp, p.v_rs, k0, nk_, tid, rv);
     if (BIAS && tid < 192) {
       const int idx = k0 - Q0 - 127 + tid + p.Nq - 1;
       rbias = (idx >= 0 && idx < p.Nq + p.Nk - 1) ? p.bias_diag[(long)h * (p.Nq + p.Nk - 1) + idx] * LOG2E : 0.f;
     }
     if (tid < 64) {
       const int k = k0 + tid;
-      rflag = (k >= p.Nk) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
+      rflag = (k >= nk_) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
     }
   };
   auto commit = [&](int s) {
@@ -573,8 +586,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int q = Q0 + wq0 + qb * 16 + li;
-    if (q < p.Nq) {
-      bf16_t* op = p.dq + (long)b * p.dq_bs + (long)q * p.dq_rs + h * HD;
+    if (q < nq_) {
+      bf16_t* op = p.dq + (p.seq_off ? (long)row0_ * p.dq_rs : (long)b * p.dq_bs) + (long)q * p.dq_rs + h * HD;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         uint2 w;
@@ -613,11 +626,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int kblk = id % nkb, bh = id / nkb, h = bh % p.H, b = bh / p.H;
   const int K0 = kblk * 128, wk0 = wave * 32;
+  const int row0_ = p.seq_off ? p.seq_off[b] : 0;
+  const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq, nk_ = p.seq_off ? nq_ : p.Nk;
+  if (K0 >= nk_) return;
 
-  const bf16_t* qp = p.q + (long)b * p.q_bs + h * HD;
-  const bf16_t* dop = p.d_o + (long)b * p.do_bs + h * HD;
-  const bf16_t* kp = p.k + (long)b * p.k_bs + h * HD;
-  const bf16_t* vp = p.v + (long)b * p.v_bs + h * HD;
+  const bf16_t* qp = p.q + (p.seq_off ? (long)row0_ * p.q_rs : (long)b * p.q_bs) + h * HD;
+  const bf16_t* dop = p.d_o + (p.seq_off ? (long)row0_ * p.do_rs : (long)b * p.do_bs) + h * HD;
+  const bf16_t* kp = p.k + (p.seq_off ? (long)row0_ * p.k_rs : (long)b * p.k_bs) + h * HD;
+  const bf16_t* vp = p.v + (p.seq_off ? (long)row0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
 
   bf16x8 kf[2][2], vf[2][2];
   uint32_t kflag[2];
@@ -627,14 +643,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       uint4 a = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
-      if (k < p.Nk) {
+      if (k < nk_) {
         a = *reinterpret_cast<const uint4*>(kp + (long)k * p.k_rs + ks * 32 + g * 8);
         c = *reinterpret_cast<const uint4*>(vp + (long)k * p.v_rs + ks * 32 + g * 8);
       }
       kf[kb][ks] = __builtin_bit_cast(bf16x8, a);
       vf[kb][ks] = __builtin_bit_cast(bf16x8, c);
     }
-    kflag[kb] = (k >= p.Nk) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
+    kflag[kb] = (k >= nk_) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
   }
   const bool keys_clean = __all(kflag[0] == 0u && kflag[1] == 0u);
   const int kmin = K0 + wk0, kmax = kmin + 31;
@@ -644,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 #pragma unroll
     for (int db = 0; db < 4; ++db) { dkt[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  const int ntiles = (p.Nq + 63) >> 6;
+  const int ntiles = (nq_ + 63) >> 6;
   const float sc2 = p.scale * LOG2E, isc2 = 1.0f / sc2;
   const uint32_t thr = p.p16 << 16;
   uint4 rq[2], rdo[2];
@@ -654,8 +670,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   // bias window for this (128-key block, 64-query tile): index (k - q) - dmin, dmin = K0 - (q0 + 63); 191 entries
   auto prefetch = [&](int t) {
     const int q0 = t * 64;
-    tile_load(qp, p.q_rs, q0, p.Nq, tid, rq);
-    tile_load(dop, p.do_rs, q0, p.Nq, tid, rdo);
+    tile_load(qp, p.q_rs, q0, nq_, tid, rq);
+    tile_load(dop, p.do_rs, q0, nq_, tid, rdo);
     if (BIAS && tid < 192) {
       const int idx = K0 - q0 - 63 + tid + p.Nq - 1;
       rbias = (idx >= 0 && idx < p.Nq + p.Nk - 1) ? p.bias_diag[(long)h * (p.Nq + p.Nk - 1) + idx] * LOG2E : 0.f;
@@ -664,7 +680,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       const int q = q0 + tid;
       if (DROP) rseed = drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q));
       rm = 0.f; rl = 0.f; rd = 0.f;                 // rows >= Nq: 1/l = 0 => P = 0
-      if (q < p.Nq) {
+      if (q < nq_) {
         const long r = ((long)(b * p.H + h)) * p.Nq + q;
         rm = p.ml[r * 2]; rl = 1.0f / p.ml[r * 2 + 1]; rd = p.delta[r];
       }
@@ -702,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     const bool skip = (keys_all_masked || future) && rows_real;
 
     if (!skip) {
-      const bool clean = keys_clean && !edge && (q0 + 63 < p.Nq);
+      const bool clean = keys_clean && !edge && (q0 + 63 < nq_);
       // two halves of 32 query rows each (keeps the live score registers at 2x2 fragments)
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh) {
@@ -803,9 +819,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     const int k = K0 + wk0 + kb * 16 + li;
-    if (k < p.Nk) {
-      bf16_t* dkp = p.dk + (long)b * p.dk_bs + (long)k * p.dk_rs + h * HD;
-      bf16_t* dvp = p.dv + (long)b * p.dv_bs + (long)k * p.dv_rs + h * HD;
+    if (k < nk_) {
+      bf16_t* dkp = p.dk + (p.seq_off ? (long)row0_ * p.dk_rs : (long)b * p.dk_bs) + (long)k * p.dk_rs + h * HD;
+      bf16_t* dvp = p.dv + (p.seq_off ? (long)row0_ * p.dv_rs : (long)b * p.dv_bs) + (long)k * p.dv_rs + h * HD;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         uint2 w;
@@ -865,6 +881,8 @@ int fill(AttnP& p, const v2s_attn_args* a, const char* who, bool bwd) {
   p.dq = (bf16_t*)a->dq; p.dk = (bf16_t*)a->dk; p.dv = (bf16_t*)a->dv;
   p.dq_bs = a->dq_bs; p.dq_rs = a->dq_rs; p.dk_bs = a->dk_bs; p.dk_rs = a->dk_rs; p.dv_bs = a->dv_bs; p.dv_rs = a->dv_rs;
   p.dbias_diag = a->dbias_diag;
+  p.seq_off = a->seq_off;
+  V2S_CHECK(!a->seq_off || (a->Nq == a->Nk && !a->key_mask), V2S_ERR_ARG, "%s: seq_off (packed self-attention) needs Nq == Nk and no key_mask", who);
   // far buckets: disabled (every diagonal resolved) unless the caller states lo < hi
   if (a->bias_far_lo < a->bias_far_hi) { p.far_lo = a->bias_far_lo; p.far_hi = a->bias_far_hi; }
   else { p.far_lo = -(1 << 30); p.far_hi = (1 << 30); }
