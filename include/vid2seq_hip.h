@@ -164,7 +164,8 @@ typedef struct v2s_attn_args {
   int32_t bias_far_lo, bias_far_hi;
   /* optional packed ("varlen") SELF-attention: B+1 int32 row offsets on the device.  Sequence b then occupies rows
    * [seq_off[b], seq_off[b+1]) of q/k/v/o (and d_o/dq/dk/dv): the *_bs batch strides are ignored, Nq = Nk = the nominal
-   * (maximum) length that sizes the grid, the bias diagonal table, ml and delta ([B][H][Nq] as before); key_mask must be NULL.
+   * (maximum) length that sizes the grid, the bias diagonal table, ml and delta ([B][H][Nq] as before) -- no sequence may be longer;
+   * key_mask must be NULL.
    * Rows of pad tokens simply do not exist -- the reference computes them and masks them as keys (modeling_t5.py:996), so the
    * rows that remain are identical */
   const int32_t* seq_off;

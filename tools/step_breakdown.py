@@ -11,6 +11,10 @@ model = Vid2Seq("t5-base", tokenizer=tok, vis_drop=p, enc_drop=p, dec_drop=p, de
 tr = Trainer(model, denoising=0.0)
 batch = {k: v.to(dev) for k, v in synth.make_batch(32, 100, 1000, 256, len(tok), 1234, 768).items()}
 batch["video"] = batch["video"].to(torch.bfloat16)
+batch["input_lens"] = (batch["input_ids"] != 0).sum(1).tolist()
+print("valid encoder tokens:", sum(batch["input_lens"]), "of", batch["input_ids"].numel())
+if len(sys.argv) > 2 and sys.argv[2] == "dense":
+    model.engine().pack = False
 for _ in range(2): tr.step(batch)
 model.engine().overlap = False      # per-launch durations only mean something without concurrent kernels
 with L.KernelTimer(detail=True) as kt:

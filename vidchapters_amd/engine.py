@@ -71,6 +71,7 @@ class Engine:
         # CUs those leave idle (tails, epilogues, small decoder/ViT launches).  `vstream` lets the temporal ViT (small
         # launches, independent of the T5 encoder) run beside the encoder in both directions (train.Trainer).
         self.overlap = True
+        self.pack = True          # run the text encoder on the valid (non-pad) tokens only: exact, see _pack_plan
         self.wstream = torch.cuda.Stream(device=device)
         self.vstream = torch.cuda.Stream(device=device)
         self.arena.refresh_shadow(force=True)
@@ -197,9 +198,11 @@ class Engine:
         return dx
 
     # ========================================================================================== T5 sublayers (forward)
-    def _self_attn(self, stack: str, i: int, h, B: int, N: int, bias_diag, key_mask, causal: bool, p: float, tape):
+    def _self_attn(self, stack: str, i: int, h, B: int, N: int, bias_diag, key_mask, causal: bool, p: float, tape, pack=None):
+        """``pack`` = (seq_off int32 [B+1] on the device, total rows): the rows of ``h`` are the valid tokens only
+        (sequence b = rows seq_off[b]..seq_off[b+1]), N stays the nominal length."""
         a = self.arena
-        M, d, inner = B * N, self.d, self.inner
+        M, d, inner = (pack[1] if pack is not None else B * N), self.d, self.inner
         n = self._bf(M, d); rstd = self._f32(M)
         lnw = a.f(self._ln(stack, i, 0))
         L.rmsnorm_fwd(h, lnw, n, rstd, M, d, self.cfg.eps)
@@ -210,15 +213,15 @@ class Engine:
         seed_a = self._next_seed()
         st = (N * 3 * inner, 3 * inner)
         args = L.attn_args(B, self.H, N, N, qkv, qkv[:, inner:], qkv[:, 2 * inner:], ctx, st, st, st, (N * inner, inner),
-                           ml=ml, scale=1.0, bias_diag=bias_diag, key_mask=key_mask, causal=causal, dropout_p=p,
-                           dropout_seed=seed_a)
+                           ml=ml, scale=1.0, bias_diag=bias_diag, key_mask=None if pack is not None else key_mask, causal=causal,
+                           dropout_p=p, dropout_seed=seed_a, seq_off=pack[0] if pack is not None else None)
         L.attn_fwd(args)
         out = self._bf(M, d)
         seed_o = self._next_seed()
         L.gemm(ctx, a.w(self._sa(stack, i) + "o.weight"), out, M, d, inner, residual=h, dropout_p=p, dropout_seed=seed_o)
         if tape is not None:
             tape.append(_Rec(kind="self", stack=stack, i=i, h=h, n=n, rstd=rstd, qkv=qkv, ctx=ctx, ml=ml, args=args,
-                             B=B, N=N, p=p, seed_o=seed_o))
+                             B=B, N=N, M=M, p=p, seed_o=seed_o))
         return out
 
     def _cross_attn(self, i: int, h, B: int, Nq: int, mem, S: int, mem_mask, p: float, tape, kv=None):
@@ -283,7 +286,7 @@ class Engine:
     # ========================================================================================== T5 sublayers (backward)
     def _self_attn_bwd(self, r, dh, dbias_diag):
         a = self.arena
-        B, N, M, d, inner = r.B, r.N, r.B * r.N, self.d, self.inner
+        B, N, M, d, inner = r.B, r.N, r.M, self.d, self.inner
         sa = self._sa(r.stack, r.i)
         df = self._drop(dh, r.p, r.seed_o)
         self._wgrad(df, r.ctx, sa + "o.weight", d, inner, M)
@@ -357,14 +360,58 @@ class Engine:
                         self.cfg.buckets)
         return diag, lut
 
-    def encoder_forward(self, ids: torch.Tensor, mask_u8: torch.Tensor, p: float, tape):
-        B, Lx = ids.shape
+    def encoder_forward(self, ids: torch.Tensor, mask_u8: torch.Tensor, p: float, tape, pack=None):
+        """``pack`` = (seq_off, rows, tok_rows, n_seq, Lx, n_valid) from _pack_plan: run the stack on the valid tokens only (``ids``
+        is then the 1-D packed id vector); returns [rows, d] (the first n_valid rows are the tokens) instead of [B*Lx, d]."""
+        if pack is not None:
+            B, Lx, M = pack[3], pack[4], pack[1]
+        else:
+            B, Lx = ids.shape
+            M = B * Lx
         h = self._embed(ids, p, tape)
         diag, _ = self._bias_diag("encoder", Lx, Lx)
         for i in range(self.cfg.n_enc):
-            h = self._self_attn("encoder", i, h, B, Lx, diag, mask_u8, False, p, tape)
-            h = self._ffn("encoder", i, h, B * Lx, p, tape)
-        return self._final_norm("encoder", h, B * Lx, p, tape)
+            h = self._self_attn("encoder", i, h, B, Lx, diag, mask_u8, False, p, tape, pack=pack[:2] if pack is not None else None)
+            h = self._ffn("encoder", i, h, M, p, tape)
+        return self._final_norm("encoder", h, M, p, tape)
+
+    # ---- padding-free encoder ------------------------------------------------------------------------------------------
+    def _pack_plan(self, input_ids: torch.Tensor, input_mask: torch.Tensor, lens=None):
+        """Row bookkeeping for running the text encoder on the valid tokens only.  The reference computes the rows of pad tokens and
+        then masks them as keys everywhere (modeling_t5.py:996,1005), so nothing downstream depends on them: dropping them is exact
+        for the loss and every gradient.  Needs the usual right-padded batch (mask = a prefix per row, dvc.py:44-53 + the collate
+        of dataset/dvc_dataset.py:179-226); anything else -> None (dense path).  ``lens``: per-row valid lengths if the caller has
+        them on the host (DeviceBatcher / bench), else they are read back from the mask (one small device->host sync)."""
+        B, Lx = input_ids.shape
+        if lens is None:
+            m = input_mask.to(torch.bool)
+            prefix = bool((m[:, 1:] <= m[:, :-1]).all().item()) if Lx > 1 else True
+            if not prefix:
+                return None
+            lens = m.sum(1).tolist()
+        lens = [int(x) for x in lens]
+        if min(lens) < 1 or sum(lens) == B * Lx:
+            return None                                   # nothing to drop (or an empty row: keep the reference's dense semantics)
+        key = (B, Lx, tuple(lens))
+        plans = self._ws.setdefault("pack_plans", {})
+        plan = plans.get(key)
+        if plan is None:
+            if len(plans) >= 8:
+                plans.clear()
+            total = int(sum(lens))
+            padded = (total + 63) // 64 * 64          # row count a multiple of 64: the weight-gradient GEMMs contract over it (K % 64)
+            # the < 64 filler rows form extra dummy sequences (each no longer than the nominal length Lx that sizes the attention
+            # grid and its bias window): they attend among themselves, stay finite, receive a zero gradient and are never
+            # scattered into the memory
+            seqs, fill = list(lens), padded - total
+            while fill > 0:
+                seqs.append(min(fill, Lx)); fill -= seqs[-1]
+            off = np.zeros(len(seqs) + 1, dtype=np.int32)
+            off[1:] = np.cumsum(seqs)
+            rows = np.concatenate([np.arange(n, dtype=np.int64) + b * Lx for b, n in enumerate(lens)] +
+                                  [np.zeros(padded - total, dtype=np.int64)])
+            plan = plans[key] = (torch.from_numpy(off).to(self.device), padded, torch.from_numpy(rows).to(self.device), len(seqs), total)
+        return (plan[0], plan[1], plan[2], plan[3], Lx, plan[4])
 
     def decoder_forward(self, dec_ids, dec_mask_u8, mem, S: int, mem_mask_u8, p: float, tape):
         B, Lo = dec_ids.shape
@@ -509,7 +556,7 @@ class Engine:
             gpos.index_add_(0, tape["idx"], tmp)
 
     # ========================================================================================== loss head
-    def t5_loss_forward(self, vis, input_ids, input_mask, output_ids, output_mask, tape, vis_ready=None):
+    def t5_loss_forward(self, vis, input_ids, input_mask, output_ids, output_mask, tape, vis_ready=None, input_lens=None):
         """Encoder on the ASR tokens, [video ; text] memory, decoder on the shifted targets, tied LM head and
         label-smoothed CE (vid2seq.py:63-98 -> modeling_t5.py:1587-1738).  ``vis``: bf16 [B, T, d] or None."""
         m, c = self.model, self.cfg
@@ -524,17 +571,32 @@ class Engine:
             parts.append(vis.view(B, T, self.d))
             masks.append(torch.ones(B, T, dtype=torch.uint8, device=self.device))
         Lx = 0
+        plan = None
         if m.use_speech:
             Lx = input_ids.shape[1]
             in_mask = input_mask.to(torch.uint8).contiguous()
-            enc = self.encoder_forward(input_ids, in_mask, pe, enc_tape)
-            parts.append(enc.view(B, Lx, self.d))
+            plan = self._pack_plan(input_ids, input_mask, input_lens) if self.pack else None
+            if plan is not None:
+                enc = self.encoder_forward(input_ids.reshape(-1).index_select(0, plan[2]), None, pe, enc_tape, pack=plan)
+            else:
+                enc = self.encoder_forward(input_ids, in_mask, pe, enc_tape)
+                parts.append(enc.view(B, Lx, self.d))
             masks.append(in_mask)
         S = T + Lx
         if vis_ready is not None:           # the ViT ran on its own stream beside the encoder
             torch.cuda.current_stream().wait_event(vis_ready)
             vis.record_stream(torch.cuda.current_stream())
-        if len(parts) == 2:                 # torch.cat of vid2seq.py:78-79 (pure data movement)
+        mem_rows = None
+        if plan is not None:                # [video ; text] memory with the packed encoder rows scattered back; pad rows = 0
+            mem3 = torch.zeros(B, S, self.d, dtype=torch.bfloat16, device=self.device)
+            if T:
+                mem3[:, :T] = parts[0]
+            tr = plan[2][:plan[5]]
+            mem_rows = tr + (torch.div(tr, Lx, rounding_mode="floor") * T + T) if T else tr
+            mem = mem3.view(B * S, self.d)
+            mem.index_copy_(0, mem_rows, enc[:plan[5]])
+            mem_mask = torch.cat(masks, 1).contiguous() if len(masks) == 2 else masks[0]
+        elif len(parts) == 2:               # torch.cat of vid2seq.py:78-79 (pure data movement)
             mem = torch.cat(parts, 1).view(B * S, self.d)
             mem_mask = torch.cat(masks, 1).contiguous()
         else:
@@ -558,7 +620,7 @@ class Engine:
         loss = acc[0] / acc[1]
         if tape is not None:
             tape.update(enc=enc_tape, dec=dec_tape, B=B, T=T, Lx=Lx, Lo=Lo, S=S, hs=hs, logits=logits, labels=labels, row=row,
-                        acc=acc, alpha=alpha)
+                        acc=acc, alpha=alpha, mem_rows=mem_rows, enc_rows=plan[1] if plan is not None else 0)
         return loss
 
     def t5_loss_backward(self, tape, gloss: torch.Tensor, after_decoder=None, after_encoder=None) -> Optional[torch.Tensor]:
@@ -585,7 +647,12 @@ class Engine:
         if after_decoder is not None:
             after_decoder(dvis)               # DP hook / ViT backward may start now, beside the encoder backward
         if m.use_speech:
-            denc = dmem3[:, T:].contiguous().view(B * Lx, d) if T else dmem
+            if tape.get("mem_rows") is not None:          # packed encoder: gather the gradient rows of the valid tokens
+                mr = tape["mem_rows"]
+                denc = torch.zeros(tape["enc_rows"], d, dtype=torch.bfloat16, device=self.device)     # filler rows: zero gradient
+                torch.index_select(dmem, 0, mr, out=denc[:mr.numel()])
+            else:
+                denc = dmem3[:, T:].contiguous().view(B * Lx, d) if T else dmem
             self._stack_backward(tape["enc"], denc, "encoder", Lx)
         if after_encoder is not None:
             after_encoder()
@@ -638,8 +705,21 @@ class Engine:
         if m.use_speech:
             ids = input_tokenized["input_ids"]
             im = input_tokenized["attention_mask"].to(torch.uint8).contiguous()
-            parts.append(self.encoder_forward(ids, im, 0.0, None).view(B, ids.shape[1], self.d))
+            Lx = ids.shape[1]
+            plan = self._pack_plan(ids, input_tokenized["attention_mask"]) if self.pack else None
             masks.append(im)
+            if plan is not None:                   # padding-free encoder, rows scattered back into the zero-filled memory
+                T = parts[0].shape[1] if parts else 0
+                enc = self.encoder_forward(ids.reshape(-1).index_select(0, plan[2]), None, 0.0, None, pack=plan)
+                mem = torch.zeros(B, T + Lx, self.d, dtype=torch.bfloat16, device=self.device)
+                if T:
+                    mem[:, :T] = parts[0]
+                tr = plan[2][:plan[5]]
+                rows = tr + (torch.div(tr, Lx, rounding_mode="floor") * T + T) if T else tr
+                mem.view(B * (T + Lx), self.d).index_copy_(0, rows, enc[:plan[5]])
+                mask = torch.cat(masks, 1).contiguous() if len(masks) == 2 else masks[0]
+                return mem, mask
+            parts.append(self.encoder_forward(ids, im, 0.0, None).view(B, Lx, self.d))
         mem = torch.cat(parts, 1).contiguous() if len(parts) == 2 else parts[0].contiguous()
         mask = torch.cat(masks, 1).contiguous() if len(masks) == 2 else masks[0]
         return mem, mask
