@@ -55,7 +55,8 @@ def main():
     ap.add_argument("--model", default="t5-base")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames", type=int, default=100, help="frames per video = ViT positions (cfg-5 uses 200)")
-    ap.add_argument("--no-packing", action="store_true", help="compute the encoder rows of pad tokens too (dense, like the reference)")
+    ap.add_argument("--packing", action="store_true", help="measure `value` with the padding-free text encoder (the engine's default; exact). "
+                    "Off here: `value` computes the pad rows like the reference does, the padding-free rate is reported beside it")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream execution (A/B for the stream overlap)")
     ap.add_argument("--no-generate", action="store_true", help="skip the greedy generate() leg (cfg-4, reported as an extra field)")
@@ -86,7 +87,7 @@ def main():
     batch["input_lens"] = (batch["input_ids"] != 0).sum(1).tolist()      # host-side lengths, as a data loader knows them
     if "den_input_ids" in batch:
         batch["den_input_lens"] = (batch["den_input_ids"] != 0).sum(1).tolist()
-    model.engine().pack = not a.no_packing
+    model.engine().pack = a.packing
 
     def barrier():
         if world > 1:
@@ -117,7 +118,7 @@ def main():
     cfgm = model.cfg
     fps = flops_per_sample(T, Lx, Lo, cfgm.vocab, cfgm.d_model, cfgm.d_ff, cfgm.n_enc, cfgm.n_dec)
     step_tflop = 3.0 * fps * B / 1e12                     # nominal: the dense-padded algorithmic count of SURVEY 8d
-    if a.no_packing:
+    if not a.packing:
         exec_tflop = step_tflop
     else:                                                 # executed: encoder terms at each sample's valid length
         d_, ff_, ne = cfgm.d_model, cfgm.d_ff, cfgm.n_enc
@@ -132,7 +133,7 @@ def main():
         "config": {"workload": f"{'cfg-2' if a.model == 't5-base' else 'cfg-5'}: Vid2Seq {a.model} train step (generative pass"
                                f"{' + denoising pass' if a.denoising > 0 else ''}), per-GPU batch {B}, {T} frames x 768, "
                                f"{Lx} ASR tokens, {Lo} target tokens, dropout {a.dropout}, fp32 master weights + fused clip/Adam/renorm"
-                               f"{'' if a.no_packing else ', encoder rows of pad tokens not computed (exact)'}",
+                               f"{', encoder rows of pad tokens not computed (exact)' if a.packing else ', pad rows computed like the reference'}",
                    "global_batch": world * B, "parallelism": f"dp{world}", "weights": "deterministic synthetic init (no checkpoints offline)"},
         "loss": round(loss_val, 5),
         "model_tflops_per_step_per_gpu": round(step_tflop, 2),
@@ -141,23 +142,23 @@ def main():
         "frac_of_mfma_peak_whole_step": round(exec_tflop / (ms_per_step / 1e3) / PEAK_BF16_TFLOPS, 4),
     }
 
-    if rank == 0 and world == 1 and not a.no_packing:
-        # the same step with the pad rows of the encoder computed as the reference does (dense): reported beside `value`
+    if rank == 0 and world == 1 and not a.packing:
+        # the same step with the engine's default padding-free text encoder (pad-token rows are not computed; exact, see
+        # DESIGN.md): reported beside `value`, which computes them like the reference does
         eng = model.engine()
-        eng.pack = False
+        eng.pack = True
         trainer.step(batch)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3):
             trainer.step(batch)
         torch.cuda.synchronize()
-        dtd = (time.perf_counter() - t0) / 3
-        eng.pack = True
-        valid = int(sum(batch["input_lens"]))
-        out["padding_free_encoder"] = {"valid_encoder_tokens": valid, "padded_encoder_tokens": int(B * Lx),
-                                       "dense_ms_per_step": round(dtd * 1e3, 3), "dense_samples_per_s": round(B / dtd, 2),
-                                       "note": "value is measured with the text encoder run on the non-pad tokens only (exact: the reference "
-                                               "computes the pad rows and masks them as keys); dense_* = same step with the pad rows computed"}
+        dtp = (time.perf_counter() - t0) / 3
+        eng.pack = False
+        out["padding_free_encoder"] = {"valid_encoder_tokens": int(sum(batch["input_lens"])), "padded_encoder_tokens": int(B * Lx),
+                                       "ms_per_step": round(dtp * 1e3, 3), "samples_per_s": round(B / dtp, 2),
+                                       "note": "engine default (Engine.pack): the text encoder runs on the non-pad tokens only; exact because the "
+                                               "reference masks those rows as keys everywhere.  `value` above does NOT use it"}
     if rank == 0 and world == 1 and not a.no_roofline:      # N=1 only: the extra step would issue collectives other ranks do not join
         eng = model.engine()
         was = eng.overlap
