@@ -142,7 +142,7 @@ def main():
         "frac_of_mfma_peak_whole_step": round(exec_tflop / (ms_per_step / 1e3) / PEAK_BF16_TFLOPS, 4),
     }
 
-    if rank == 0 and world == 1 and not a.packing:
+    if rank == 0 and world == 1 and not a.packing and not a.no_generate:
         # the same step with the engine's default padding-free text encoder (pad-token rows are not computed; exact, see
         # DESIGN.md): reported beside `value`, which computes them like the reference does
         eng = model.engine()
