@@ -65,11 +65,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = local % max(1, torch.cuda.device_count())      # (several ranks on one GPU only in the gloo control-flow check below)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" == RCCL on ROCm
+        backend = os.environ.get("V2S_DIST_BACKEND", "nccl")   # "nccl" == RCCL on ROCm; "gloo" lets two ranks share one GPU to
+        if backend == "nccl":                                  # exercise the multi-rank control flow where only one GPU exists
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from vidchapters_amd import SyntheticTokenizer, Vid2Seq, synth
     from vidchapters_amd import lib as L
