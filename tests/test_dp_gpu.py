@@ -1,0 +1,74 @@
+"""Data-parallel step on the real engine: two ranks (gloo backend, both on the one visible GPU) x per-rank batch b must produce
+the same updated weights as a single process on the concatenated batch when every rank has the same number of target tokens
+(SURVEY 8e).  Exercises Trainer's hooks, GradSync's side-stream slices and the 1/world scaling in the fused Adam kernel."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    solo = dist.new_group([0])                     # a one-rank group for the single-process reference run on rank 0
+    from oracle import vid2seq_ref as R
+    from vidchapters_amd import SyntheticTokenizer, Vid2Seq, synth
+    from vidchapters_amd.train import Trainer
+    torch.cuda.set_device(0)
+    cfg = R.RefConfig.small()
+
+    def build():
+        t5 = dict(d_model=cfg.d_model, d_kv=cfg.d_kv, heads=cfg.heads, d_ff=cfg.d_ff, n_enc=cfg.n_enc, n_dec=cfg.n_dec)
+        return Vid2Seq(t5, num_features=cfg.num_features, embed_dim=cfg.vit_dim, depth=cfg.vit_depth, heads=cfg.vit_heads,
+                       mlp_dim=cfg.vit_mlp, tokenizer=SyntheticTokenizer(cfg.vocab - cfg.num_bins, cfg.num_bins), vis_drop=0.0,
+                       enc_drop=0.0, dec_drop=0.0, num_bins=cfg.num_bins, init_seed=17).to("cuda").train()
+
+    full = synth.make_batch(4, 10, 40, 12, cfg.vocab, 21, cfg.vit_dim, denoising=True)
+    for k in ("output_ids", "den_output_ids"):     # no target padding => equal token counts per rank
+        full[k] = torch.where(full[k] == 0, torch.full_like(full[k], 5), full[k])
+    sl = slice(rank * 2, rank * 2 + 2)
+    mine = {k: v[sl].cuda() for k, v in full.items()}
+    model = build()
+    tr = Trainer(model, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=1.0)
+    assert tr.world == 2
+    for _ in range(2):
+        losses = tr.step(mine)
+    torch.cuda.synchronize()
+    if rank == 0:
+        ref = build()
+        tr1 = Trainer(ref, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=1.0, group=solo)
+        assert tr1.world == 1
+        allb = {k: v.cuda() for k, v in full.items()}
+        for _ in range(2):
+            tr1.step(allb)
+        torch.cuda.synchronize()
+        worst, worst_k, maxdiff = 1.0, "", 0.0
+        for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            init = synth.init_tensor(k, tuple(q.shape), 17, cfg.d_model, cfg.inner, cfg.d_ff, device="cuda")
+            u1, u2 = (p.detach() - init).double().flatten(), (q.detach() - init).double().flatten()
+            if float(u2.norm()) == 0.0:
+                continue
+            c = float(u1 @ u2 / (u1.norm() * u2.norm() + 1e-30))
+            if c < worst:
+                worst, worst_k = c, k
+            maxdiff = max(maxdiff, float((u1 - u2).abs().max()))
+        ret["worst"], ret["worst_k"], ret["maxdiff"] = worst, worst_k, maxdiff
+        ret["loss"] = float(losses["loss"].item())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_large_batch():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    print(f"DP (2 ranks) vs single process after 2 steps: worst update cosine {ret['worst']:.4f} ({ret['worst_k']}), max |dw| diff {ret['maxdiff']:.2e}")
+    # Adam turns every gradient element into a step of ~lr whatever its size, so elements whose gradient is bf16/atomics-order noise
+    # may step in different directions: compare update DIRECTIONS per tensor (as test_dropin_optimizer_path_matches_trainer does)
+    assert ret["worst"] > 0.9 and ret["maxdiff"] <= 2 * 2.1 * 1e-3
