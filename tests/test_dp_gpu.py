@@ -19,7 +19,7 @@ def _worker(rank, world, port, ret):
     from vidchapters_amd import SyntheticTokenizer, Vid2Seq, synth
     from vidchapters_amd.train import Trainer
     torch.cuda.set_device(0)
-    cfg = R.RefConfig.small()
+    cfg = R.RefConfig.small(n_enc=5)          # 5 encoder blocks: the per-4-layers gradient hand-off of Trainer fires at block 4
 
     def build():
         t5 = dict(d_model=cfg.d_model, d_kv=cfg.d_kv, heads=cfg.heads, d_ff=cfg.d_ff, n_enc=cfg.n_enc, n_dec=cfg.n_dec)
@@ -50,6 +50,9 @@ def _worker(rank, world, port, ret):
         for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
             init = synth.init_tensor(k, tuple(q.shape), 17, cfg.d_model, cfg.inner, cfg.d_ff, device="cuda")
             u1, u2 = (p.detach() - init).double().flatten(), (q.detach() - init).double().flatten()
+            if k.endswith("attn.qkv.bias"):        # the key third has a true gradient of exactly 0 (softmax shift invariance): pure noise
+                n3 = u1.numel() // 3
+                u1, u2 = torch.cat([u1[:n3], u1[2 * n3:]]), torch.cat([u2[:n3], u2[2 * n3:]])
             if float(u2.norm()) == 0.0:
                 continue
             c = float(u1 @ u2 / (u1.norm() * u2.norm() + 1e-30))

@@ -423,7 +423,7 @@ class Engine:
             h = self._ffn("decoder", i, h, B * Lo, p, tape)
         return self._final_norm("decoder", h, B * Lo, p, tape)
 
-    def _stack_backward(self, tape: List[_Rec], dout, stack: str, nq: int, dmem=None):
+    def _stack_backward(self, tape: List[_Rec], dout, stack: str, nq: int, dmem=None, layer_done=None):
         """Replays ``tape`` (records of one stack) in reverse.  Returns nothing: parameter gradients go to the arena,
         the cross-attention memory gradient to ``dmem``."""
         a = self.arena
@@ -441,6 +441,8 @@ class Engine:
                 first_cross = False
             elif r.kind == "self":
                 dh = self._self_attn_bwd(r, dh, ddiag)
+                if layer_done is not None:        # all parameter gradients of block r.i are enqueued (except block 0's bias table)
+                    layer_done(r.i)
             elif r.kind == "embed":
                 self._embed_bwd(r, dh)
         L.bias_bucket_bwd(ddiag, lut, a.g(self._sa(stack, 0) + "relative_attention_bias.weight"), self.H, 2 * nq - 1,
@@ -623,7 +625,8 @@ class Engine:
                         acc=acc, alpha=alpha, mem_rows=mem_rows, enc_rows=plan[1] if plan is not None else 0)
         return loss
 
-    def t5_loss_backward(self, tape, gloss: torch.Tensor, after_decoder=None, after_encoder=None) -> Optional[torch.Tensor]:
+    def t5_loss_backward(self, tape, gloss: torch.Tensor, after_decoder=None, after_encoder=None,
+                         encoder_layer_done=None) -> Optional[torch.Tensor]:
         """Returns d(loss)/d(vis) (bf16 [B, T, d]) or None.  ``after_decoder`` / ``after_encoder`` are called once the
         gradients of that stack are complete (data-parallel all-reduce hooks)."""
         m = self.model
@@ -653,7 +656,7 @@ class Engine:
                 torch.index_select(dmem, 0, mr, out=denc[:mr.numel()])
             else:
                 denc = dmem3[:, T:].contiguous().view(B * Lx, d) if T else dmem
-            self._stack_backward(tape["enc"], denc, "encoder", Lx)
+            self._stack_backward(tape["enc"], denc, "encoder", Lx, layer_done=encoder_layer_done)
         if after_encoder is not None:
             after_encoder()
         return dvis
