@@ -184,6 +184,9 @@ class Trainer:
                         eng.join_wgrads()
                         self.sync.ready(*self._r_dec)
                     launch_vit_backward()
+                    if self.world > 1 and m.use_video:     # the (short) ViT backward is fully enqueued: reduce its slice beside the
+                        self.sync.ready(*self._r_vis, also=(eng.vstream, eng.wstream) if overlap else ())   # encoder backward
+                        state["vis_sent"] = True
 
             enc_sent = [self._r_enc[0]]          # encoder gradients up to this arena offset are already being reduced
 
@@ -208,7 +211,7 @@ class Trainer:
         if m.use_video and overlap:
             main.wait_stream(eng.vstream)
         eng.join_wgrads()
-        if m.use_video:
+        if m.use_video and not state.get("vis_sent"):
             self.sync.ready(*self._r_vis)
         self.sync.finish()
         self._optimizer_step()
