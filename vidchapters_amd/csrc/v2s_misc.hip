@@ -35,23 +35,24 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__
   }
 }
 
+// one ELEMENT per lane: a wave's atomic instruction then covers 64 consecutive floats of one table row (4 full 64-byte lines).
+// With an 8-element chunk per lane each of the 8 atomic instructions touched 64 lines two floats at a time and the scatter ran at a
+// quarter of the atomic rate (tools/ubench/atomic_rate.hip: 1.3 TB/s of operand bytes).
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const long* __restrict__ ids, const bf16_t* __restrict__ dy,
                                                         float* __restrict__ dtable, long n, int d, int vocab, uint32_t p16,
                                                         float inv_keep, uint32_t seed) {
-  const int cpr = d >> 3;
-  const long total = n * cpr;
+  const long total = n * d;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-    const long row = t / cpr;
-    const int c = (int)(t - row * cpr);
+    const long row = t / d;
+    const int e = (int)(t - row * d);
     long id = ids[row];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    float f[8];
-    unpack8(*reinterpret_cast<const uint4*>(dy + row * d + c * 8), f);
-    float* dst = dtable + id * d + c * 8;
-    if (p16) v2s_drop8(f, (unsigned long long)row * d + c * 8, seed, p16, inv_keep);
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (f[j] != 0.f) atomicAdd(dst + j, f[j]);
+    float f = bf2f(dy[t]);
+    if (p16) {          // same mask as the forward: bit (e & 7) of the keep byte of the element's 8-chunk
+      const uint32_t keep = v2s_keep8((unsigned long long)(t & ~7L), seed, p16);
+      f = ((keep >> (e & 7)) & 1u) ? f * inv_keep : 0.f;
+    }
+    if (f != 0.f) atomicAdd(dtable + id * d + e, f);
   }
 }
 
@@ -218,7 +219,7 @@ extern "C" int v2s_embed_bwd(const int64_t* ids, const void* dy, float* dtable, 
   V2S_CHECK(n > 0 && d > 0 && (d % 8) == 0 && vocab > 0, V2S_ERR_SHAPE, "v2s_embed_bwd: bad shape n=%ld d=%d", (long)n, d);
   const uint32_t p16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
   const float inv = p16 ? 1.0f / (1.0f - p16 / 65536.0f) : 1.f;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(n * (d / 8))), dim3(256), 0, (hipStream_t)stream, (const long*)ids,
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(n * d)), dim3(256), 0, (hipStream_t)stream, (const long*)ids,
                      (const bf16_t*)dy, dtable, (long)n, d, vocab, p16, inv, dropout_seed);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
