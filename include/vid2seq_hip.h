@@ -271,10 +271,18 @@ int v2s_kv_append(const void* src, int64_t src_bs, void* cache, int64_t cache_bs
                   int32_t B, int32_t width, int32_t pos, const int32_t* pos_dev, void* stream);
 /* beam search (HF 4.28 beam_search, call site vid2seq.py:150-162): per row the K best of log_softmax(logits) + beam_scores[row],
  * sorted descending (K in {2,4,8,16}); ban_token >= 0 is excluded from the candidates (not from the softmax) while
- * *pos_dev + 1 < min_length (HF's MinLengthLogitsProcessor on EOS, applied to log-probs; pos_dev = device step counter); and the beam reorder of the self-attention cache (modeling_t5.py:1771-1793):
+ * *pos_dev + 1 < min_length (HF's MinLengthLogitsProcessor on EOS, applied to log-probs; pos_dev = device step counter);
+ * row_lse != NULL: use these row log-sum-exps instead of recomputing them (after v2s_repetition_penalty); and the beam reorder of the self-attention cache (modeling_t5.py:1771-1793):
  * dst[b, 0:len, :] = src[idx[b], 0:len, :] for [B][*][width] bf16 caches with batch stride bs and row stride rs */
 int v2s_topk_logprob(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const float* beam_scores,
-                     float* out_val, int32_t* out_idx, int32_t ban_token, const int32_t* pos_dev, int32_t min_length, void* stream);
+                     float* out_val, int32_t* out_idx, int32_t ban_token, const int32_t* pos_dev, int32_t min_length, const float* row_lse,
+                     void* stream);
+/* HF 4.28 RepetitionPenaltyLogitsProcessor (vid2seq.py:159, dvc.py:182), in place, one row per block: tokens in hist[row][0..n), n =
+ * *pos_dev + 1 (or n_static), are penalised once each.  row_lse == NULL: scores are raw logits (greedy_search).  row_lse != NULL:
+ * beam_search semantics -- the penalty acts on log-probabilities; the row log-sum-exp is stored there and v2s_topk_logprob must be
+ * given the same row_lse */
+int v2s_repetition_penalty(float* scores, int64_t ld, int32_t rows, int32_t V, const int64_t* hist, int64_t hist_ld,
+                           const int32_t* pos_dev, int32_t n_static, float penalty, float* row_lse, void* stream);
 int v2s_kv_gather(const void* src, void* dst, const int32_t* idx, int64_t bs, int64_t rs, int32_t B, int32_t len,
                   int32_t width, void* stream);
 /* T5 span corruption of a 0-padded id batch on the device (util/t5.py:3-32 as used by dataset/dvc_dataset.py:127-145).

@@ -419,6 +419,51 @@ def case_data():
     npz("data_pipeline.npz", **arrs)
 
 
+
+def case_repetition_penalty(cfg, penalty=1.3, max_new=14):
+    """repetition_penalty (dvc.py:182 passes args.repetition_penalty; un-vendored HF 4.28 processor): oracle vs the installed
+    transformers' generate for greedy and beam search; outputs stored (parity unpinned w.r.t. 4.28 itself)."""
+    import transformers
+    from transformers.modeling_outputs import BaseModelOutput
+    print(f"[small repetition_penalty={penalty}] installed transformers {transformers.__version__}")
+    arrs = {}
+    for i, (seed, fac) in enumerate(((40, 0.9), (47, 1.05))):
+        P, b, fav = beam_case_params(cfg, seed, fac)
+        hf = transformers.T5ForConditionalGeneration(transformers.T5Config(
+            vocab_size=cfg.vocab, d_model=cfg.d_model, d_kv=cfg.d_kv, d_ff=cfg.d_ff, num_layers=cfg.n_enc,
+            num_decoder_layers=cfg.n_dec, num_heads=cfg.heads, feed_forward_proj="relu", dropout_rate=0.0,
+            tie_word_embeddings=True, pad_token_id=0, eos_token_id=1, decoder_start_token_id=0))
+        sd = {k[len("t5_model."):]: v for k, v in P.items() if k.startswith("t5_model.")}
+        for a in ("encoder.embed_tokens.weight", "decoder.embed_tokens.weight", "lm_head.weight"):
+            sd[a] = sd["shared.weight"]
+        hf.load_state_dict(sd, strict=False); hf.eval()
+        mem, mm, _ = R.encode(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0)
+
+        def norm(x):
+            x = x.tolist()
+            x = x[:x.index(1) + 1] if 1 in x else x
+            while x and x[-1] == 0:
+                x.pop()
+            return x
+        for nb in (1, 4):
+            if nb == 1:
+                out = R.greedy_generate(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, max_new, repetition_penalty=penalty)
+            else:
+                out = R.beam_generate(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, nb, max_new, 1.0, repetition_penalty=penalty)
+            with torch.no_grad():
+                ref = hf.generate(encoder_outputs=BaseModelOutput(last_hidden_state=mem), attention_mask=mm, num_beams=nb, do_sample=False,
+                                  max_new_tokens=max_new, min_length=1, length_penalty=1.0, early_stopping=False, repetition_penalty=penalty)
+            for r in range(out.shape[0]):
+                assert norm(out[r]) == norm(ref[r]), (seed, fac, nb, r, norm(out[r]), norm(ref[r]))
+            pad = torch.zeros(out.shape[0], max_new + 1, dtype=torch.long)
+            pad[:, :out.shape[1]] = out
+            arrs[f"tok_{i}_{nb}"] = pad
+        arrs[f"video_{i}"], arrs[f"ids_{i}"] = b["video"], b["input_ids"]
+        arrs[f"meta_{i}"] = np.array([seed, fav], dtype=np.int64); arrs[f"fac_{i}"] = np.float32(fac)
+    print("  OK  oracle == installed-HF generate (greedy and 4 beams) with the repetition penalty on 2 cases x 4 rows")
+    npz("small_repetition_penalty.npz", penalty=np.float32(penalty), max_new=max_new, n=2, **arrs)
+
+
 def case_train_recipe(v2s, cfg, seed=5):
     """dvc.py:train_one_epoch (the real one) for 2 steps on a fake loader vs oracle train_step."""
     print("[train recipe: reference dvc.train_one_epoch x2 steps]")
@@ -549,6 +594,7 @@ def main():
     case_tiny(v2s, "small_resize_proj", cfg2, B=2, T=7, L=16, Lo=9, seed=9)
     case_train_recipe(v2s, cfg)
     case_beam(cfg)
+    case_repetition_penalty(cfg)
     case_data()
     if not a.skip_full:
         case_full(v2s)

@@ -345,7 +345,17 @@ def vid2seq_forward(P: Params, cfg: RefConfig, video, input_ids, input_mask, out
 
 
 @torch.no_grad()
-def greedy_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, max_new_tokens: int = 256):
+def repetition_penalty_(scores: torch.Tensor, seq: torch.Tensor, penalty: float) -> None:
+    """transformers 4.28 RepetitionPenaltyLogitsProcessor (in place): every token that occurs in ``seq`` (decoder ids so far, start
+    token included) has its score multiplied by ``penalty`` if negative, divided by it otherwise; gather-then-scatter, so a token is
+    penalised once however often it occurs."""
+    sc = torch.gather(scores, 1, seq)
+    sc = torch.where(sc < 0, sc * penalty, sc / penalty)
+    scores.scatter_(1, seq, sc)
+
+
+def greedy_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, max_new_tokens: int = 256,
+                    repetition_penalty: float = 1.0):
     """vid2seq.py:100-167 with num_beams=1, do_sample=False: HF 4.28 GenerationMixin.greedy_search
     rules: start token 0, argmax of the last-position logits, rows that already
     emitted EOS emit pad, stop when every row is finished or after max_new_tokens new tokens
@@ -359,7 +369,10 @@ def greedy_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, max
         step_in = seq if past is None else seq[:, -1:]
         dec_mask = torch.ones(B, seq.shape[1], dtype=torch.long)      # HF passes no decoder mask => ones
         h, past = t5_decoder(P, cfg, step_in, dec_mask, memory, mem_mask, past=past, use_cache=True)
-        nxt = lm_logits(P, cfg, h[:, -1:]).squeeze(1).argmax(-1)
+        logits = lm_logits(P, cfg, h[:, -1:]).squeeze(1).float()
+        if repetition_penalty != 1.0:                                 # greedy_search: processors run on the raw logits
+            repetition_penalty_(logits, seq, repetition_penalty)
+        nxt = logits.argmax(-1)
         nxt = nxt * unfinished + cfg.pad_id * (1 - unfinished)
         seq = torch.cat([seq, nxt[:, None]], 1)
         unfinished = unfinished * (nxt != cfg.eos_id).long()
@@ -395,7 +408,7 @@ class _BeamHyps:
 
 @torch.no_grad()
 def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_beams: int = 4, max_new_tokens: int = 256,
-                  length_penalty: float = 1.0, min_length: int = 1):
+                  length_penalty: float = 1.0, min_length: int = 1, repetition_penalty: float = 1.0):
     """vid2seq.py:150-162 with num_beams>1, do_sample=False, early_stopping=False, num_return_sequences=1:
     transformers==4.28.0 GenerationMixin.beam_search + BeamSearchScorer (un-vendored dependency -> restated from the
     published algorithm; *parity unpinned by reference tests*, cross-checked against the installed transformers'
@@ -417,6 +430,8 @@ def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_b
         step_in = seq if past is None else seq[:, -1:]
         h, past = t5_decoder(P, cfg, step_in, torch.ones(B * nb, seq.shape[1], dtype=torch.long), mem, mmask, past=past, use_cache=True)
         logp = torch.log_softmax(lm_logits(P, cfg, h[:, -1:]).squeeze(1).float(), dim=-1)
+        if repetition_penalty != 1.0:                                 # beam_search: processors run on the log-probabilities
+            repetition_penalty_(logp, seq, repetition_penalty)
         if seq.shape[-1] < min_length:                         # MinLengthLogitsProcessor (applied to the log-probs in 4.28 beam_search)
             logp[:, cfg.eos_id] = -float("inf")
         logp = logp + beam_scores[:, None]

@@ -401,3 +401,31 @@ def test_padding_free_encoder_is_exact():
     t2 = model.engine().greedy(args[0], args[1], max_new_tokens=8).cpu()
     n = min(t1.shape[1], t2.shape[1])
     assert torch.equal(t1[:, :n], t2[:, :n])
+
+
+def test_repetition_penalty_vs_golden(golden_dir):
+    """generate(repetition_penalty=1.3) for greedy and 4 beams; fixture = oracle outputs that agree with the installed transformers'
+    generate (the 4.28 processor is un-vendored: parity unpinned)."""
+    g = np.load(os.path.join(golden_dir, "small_repetition_penalty.npz"))
+    cfg = R.RefConfig.small()
+    pen, max_new = float(g["penalty"]), int(g["max_new"])
+    rows = same = 0
+    for i in range(int(g["n"])):
+        seed, fav = (int(x) for x in g[f"meta_{i}"])
+        model = build(cfg, seed).eval()
+        with torch.no_grad():
+            E = model.t5_model.shared.weight
+            E.mul_(6.0)
+            E[1] = E[fav] * float(g[f"fac_{i}"])
+        video, ids = torch.from_numpy(g[f"video_{i}"]).to(DEV), torch.from_numpy(g[f"ids_{i}"])
+        for nb in (1, 4):
+            want = torch.from_numpy(g[f"tok_{i}_{nb}"])
+            if nb == 1:
+                out = model.engine().greedy(video, tok(ids), max_new_tokens=max_new, repetition_penalty=pen).cpu()
+            else:
+                out = model.engine().beam_search(video, tok(ids), num_beams=nb, max_new_tokens=max_new, repetition_penalty=pen).cpu()
+            for r in range(out.shape[0]):
+                rows += 1
+                same += (out[r].tolist() == want[r, :out.shape[1]].tolist() and int(want[r, out.shape[1]:].abs().sum()) == 0)
+    print(f"repetition penalty: rows identical to the fp32 fixture: {same}/{rows}")
+    assert same * 4 >= rows * 3

@@ -90,6 +90,26 @@ def test_oracle_beam_search_vs_golden(golden_dir):
         assert torch.equal(out, want[:, :out.shape[1]]) and int(want[:, out.shape[1]:].abs().sum()) == 0
 
 
+def test_oracle_repetition_penalty_vs_golden(golden_dir):
+    """oracle greedy / beam search with HF's repetition penalty reproduce the fixture (which agreed with the installed transformers'
+    generate when it was written; the 4.28 processor itself is un-vendored: parity unpinned)."""
+    g = np.load(os.path.join(golden_dir, "small_repetition_penalty.npz"))
+    cfg = R.RefConfig.small()
+    pen, max_new = float(g["penalty"]), int(g["max_new"])
+    for i in range(int(g["n"])):
+        seed, fav = (int(x) for x in g[f"meta_{i}"])
+        P = synth.init_params(R.param_shapes(cfg), seed, cfg.d_model, cfg.inner, cfg.d_ff)
+        E = P["t5_model.shared.weight"] * 6.0
+        E[1] = E[fav] * float(g[f"fac_{i}"])
+        P["t5_model.shared.weight"] = E
+        video, ids = torch.from_numpy(g[f"video_{i}"]), torch.from_numpy(g[f"ids_{i}"])
+        out1 = R.greedy_generate(P, cfg, video, ids, ids != 0, max_new, repetition_penalty=pen)
+        out4 = R.beam_generate(P, cfg, video, ids, ids != 0, 4, max_new, 1.0, repetition_penalty=pen)
+        for out, key in ((out1, f"tok_{i}_1"), (out4, f"tok_{i}_4")):
+            want = torch.from_numpy(g[key])
+            assert torch.equal(out, want[:, :out.shape[1]]) and int(want[:, out.shape[1]:].abs().sum()) == 0
+
+
 def test_host_beam_scorer_matches_oracle(golden_dir):
     """vidchapters_amd.beam.BeamScorer (the product's host bookkeeping) driven by the oracle's decoder through the same
     per-beam top-2nb interface the device kernel provides."""

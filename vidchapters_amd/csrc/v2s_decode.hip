@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict
 template <int K>
 __global__ __launch_bounds__(256) void topk_logprob_kernel(const float* __restrict__ logits, long ld, int V,
                                                            const float* __restrict__ beam_scores, float* __restrict__ out_val,
-                                                           int* __restrict__ out_idx, int ban_tok, const int* __restrict__ pos_dev, int min_length) {
+                                                           int* __restrict__ out_idx, int ban_tok, const int* __restrict__ pos_dev, int min_length, const float* __restrict__ row_lse) {
   __shared__ float sv[256 * K];
   __shared__ int si[256 * K];
   __shared__ float red_m[4], red_s[4], best_v[4];
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void topk_logprob_kernel(const float* __restri
   float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
   float S = 0.f;
   for (int w = 0; w < 4; ++w) S += red_s[w] * __expf(red_m[w] - M);
-  const float lse = M + logf(S);
+  const float lse = row_lse ? row_lse[row] : M + logf(S);      // a processor may have rewritten logits against a stored lse
   const float base = beam_scores ? beam_scores[row] : 0.f;
   // K rounds of block-wide argmax over the heads of the 256 sorted lists
   int head = 0;
@@ -245,6 +245,60 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(const bf16_t* __restrict
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     const long r = t / width8; const int c = (int)(t - r * width8);
     *reinterpret_cast<uint4*>(dst + (long)b * bs + r * rs + c * 8) = *reinterpret_cast<const uint4*>(src + sb * bs + r * rs + c * 8);
+  }
+}
+
+
+// HF 4.28 RepetitionPenaltyLogitsProcessor on one row per block, in place.  hist[row][0..n) = decoder ids so far (start token
+// included), n = *pos_dev + 1 (or n_static).  Gather first, scatter after a barrier: a token that occurs several times is penalised once.
+// row_lse == NULL: the scores are raw logits (greedy_search): v < 0 ? v * pen : v / pen.
+// row_lse != NULL: beam_search applies the processor to log-probabilities: the row's log-sum-exp is computed and stored, and the logit
+// is rewritten so that logit' - lse equals the penalised log-probability (v2s_topk_logprob then takes the stored lse).
+__global__ __launch_bounds__(256) void rep_penalty_kernel(float* __restrict__ scores, long ld, int V, const long* __restrict__ hist, long hist_ld,
+                                                          const int* __restrict__ pos_dev, int n_static, float pen, float* __restrict__ row_lse) {
+  __shared__ float red_m[4], red_s[4];
+  __shared__ float gathered[1024];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* z = scores + (long)row * ld;
+  const long* hs = hist + (long)row * hist_ld;
+  int n = pos_dev ? *pos_dev + 1 : n_static;
+  n = n < 1024 ? n : 1024;
+  float lse = 0.f;
+  if (row_lse) {
+    float m = -INFINITY, ssum = 0.f;
+    for (int i = tid; i < V; i += 256) {
+      const float v = z[i];
+      const float mn = fmaxf(m, v);
+      ssum = ssum * __expf(m - mn) + __expf(v - mn);
+      m = mn;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(ssum, o, 64);
+      const float mn = fmaxf(m, m2);
+      ssum = (m == -INFINITY ? 0.f : ssum * __expf(m - mn)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mn));
+      m = mn;
+    }
+    if (lane == 0) { red_m[wave] = m; red_s[wave] = ssum; }
+    __syncthreads();
+    const float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    float S = 0.f;
+    for (int w = 0; w < 4; ++w) S += red_s[w] * __expf(red_m[w] - M);
+    lse = M + logf(S);
+    if (tid == 0) row_lse[row] = lse;
+  }
+  for (int j = tid; j < n; j += 256) {
+    long t = hs[j];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    gathered[j] = z[t];
+  }
+  __syncthreads();
+  for (int j = tid; j < n; j += 256) {
+    long t = hs[j];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    float v = gathered[j] - lse;
+    v = v < 0.f ? v * pen : v / pen;
+    z[t] = v + lse;
   }
 }
 
@@ -301,14 +355,15 @@ extern "C" int v2s_kv_append(const void* src, int64_t src_bs, void* cache, int64
 }
 
 extern "C" int v2s_topk_logprob(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const float* beam_scores,
-                                float* out_val, int32_t* out_idx, int32_t ban_token, const int32_t* pos_dev, int32_t min_length, void* stream) {
+                                float* out_val, int32_t* out_idx, int32_t ban_token, const int32_t* pos_dev, int32_t min_length, const float* row_lse,
+                                void* stream) {
   V2S_CHECK(logits && out_val && out_idx && rows > 0 && V > 0, V2S_ERR_ARG, "v2s_topk_logprob: bad args");
   V2S_CHECK(K == 2 || K == 4 || K == 8 || K == 16, V2S_ERR_ARG, "v2s_topk_logprob: K must be 2, 4, 8 or 16 (got %d)", K);
   hipStream_t s = (hipStream_t)stream;
-  if (K == 2) hipLaunchKernelGGL((topk_logprob_kernel<2>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length);
-  else if (K == 4) hipLaunchKernelGGL((topk_logprob_kernel<4>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length);
-  else if (K == 8) hipLaunchKernelGGL((topk_logprob_kernel<8>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length);
-  else hipLaunchKernelGGL((topk_logprob_kernel<16>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length);
+  if (K == 2) hipLaunchKernelGGL((topk_logprob_kernel<2>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
+  else if (K == 4) hipLaunchKernelGGL((topk_logprob_kernel<4>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
+  else if (K == 8) hipLaunchKernelGGL((topk_logprob_kernel<8>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
+  else hipLaunchKernelGGL((topk_logprob_kernel<16>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
@@ -321,6 +376,15 @@ extern "C" int v2s_kv_gather(const void* src, void* dst, const int32_t* idx, int
   if (blocks > 64) blocks = 64;
   hipLaunchKernelGGL(kv_gather_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, idx,
                      (long)bs, (long)rs, len, width / 8);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_repetition_penalty(float* scores, int64_t ld, int32_t rows, int32_t V, const int64_t* hist, int64_t hist_ld,
+                                      const int32_t* pos_dev, int32_t n_static, float penalty, float* row_lse, void* stream) {
+  V2S_CHECK(scores && hist && rows > 0 && V > 0 && penalty > 0.f && (pos_dev || n_static > 0), V2S_ERR_ARG, "v2s_repetition_penalty: bad args");
+  hipLaunchKernelGGL(rep_penalty_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, scores, (long)ld, V, (const long*)hist, (long)hist_ld,
+                     pos_dev, n_static, penalty, row_lse);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

@@ -748,7 +748,8 @@ class Engine:
         return out
 
     @torch.no_grad()
-    def greedy(self, video, input_tokenized, max_new_tokens: int = 256, stop_at_eos: bool = True, use_graph: bool = True) -> torch.Tensor:
+    def greedy(self, video, input_tokenized, max_new_tokens: int = 256, stop_at_eos: bool = True, use_graph: bool = True,
+               repetition_penalty: float = 1.0) -> torch.Tensor:
         """HF-4.28 greedy_search semantics on a static KV cache: the cross K/V of every layer are
         projected once; the self K/V grow in place (no torch.cat, no cache reorder).  One decode step is ~150 small
         launches, so it is captured ONCE into a hipGraph (through torch.cuda.CUDAGraph) and replayed: every
@@ -813,6 +814,8 @@ class Engine:
             else:
                 L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, B, d, eps)
                 L.gemm(n, E, logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
+            if repetition_penalty != 1.0:           # HF RepetitionPenaltyLogitsProcessor on the raw logits (greedy_search)
+                L.repetition_penalty(logits, self.ldv, B, self.V, seq, repetition_penalty, pos_dev=pos)
             L.argmax_step_seq(logits, self.ldv, B, self.V, nxt, unfinished, eos, c.pad_id, seq, maxlen + 1, pos)
             L.counter_add(pos, 1)
 
@@ -842,7 +845,7 @@ class Engine:
 
     @torch.no_grad()
     def beam_search(self, video, input_tokenized, num_beams: int, max_new_tokens: int, length_penalty: float = 1.0,
-                    use_graph: bool = True, min_length: int = 1) -> torch.Tensor:
+                    use_graph: bool = True, min_length: int = 1, repetition_penalty: float = 1.0) -> torch.Tensor:
         """HF-4.28 beam_search + BeamSearchScorer semantics (call site vid2seq.py:150-162) on static caches.
         The encoder memory is NOT replicated per beam: cross K/V are projected once per batch entry and the nb beams of an
         entry read the same rows (``kv_group``).  A step = decoder forward for B*nb rows -> ``v2s_topk_logprob`` (log-softmax +
@@ -879,6 +882,9 @@ class Engine:
         qkv = self._bf(R, 3 * inner); q = self._bf(R, inner); ctx = self._bf(R, inner); u = self._bf(R, self.ff)
         ha, hb = self._bf(R, d), self._bf(R, d)
         cbs = maxlen * 2 * inner
+        rp = repetition_penalty != 1.0
+        hist = torch.zeros(R, maxlen + 1, dtype=torch.long, device=self.device) if rp else None     # decoder ids so far, per beam
+        row_lse = self._f32(R) if rp else None
 
         fw = self._decode_weights() if (d % 128 == 0 and R <= 64) else None
         eps = c.eps
@@ -912,11 +918,15 @@ class Engine:
             else:
                 L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, R, d, eps)
                 L.gemm(n, E, logits, R, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
+            if rp:          # processor on the log-probabilities (beam_search): rewrites the logits against the stored row lse
+                L.repetition_penalty(logits, self.ldv, R, self.V, hist, repetition_penalty, pos_dev=pos, row_lse=row_lse)
             L.topk_logprob(logits, self.ldv, R, self.V, K, bscore, cand_val, cand_tok, ban_token=c.eos_id, pos_dev=pos,
-                           min_length=min_length)
+                           min_length=min_length, row_lse=row_lse if rp else None)
             L.counter_add(pos, 1)
 
         scorer = BeamScorer(B, nb, length_penalty, c.eos_id, c.pad_id, c.dec_start_id, max_new_tokens + 1)
+        if rp:
+            hist.copy_(torch.from_numpy(scorer.seqs))
         bscore.copy_(torch.from_numpy(scorer.scores.reshape(-1)))
         identity = np.arange(R, dtype=np.int32)
         graphs = [None, None]
@@ -939,6 +949,8 @@ class Engine:
                 break
             nxt.copy_(torch.from_numpy(tok))
             bscore.copy_(torch.from_numpy(scorer.scores.reshape(-1)))
+            if rp:
+                hist.copy_(torch.from_numpy(scorer.seqs))
             if not np.array_equal(src, identity):
                 src_dev.copy_(torch.from_numpy(src))
                 for i in range(nl):

@@ -95,7 +95,8 @@ SYMBOLS = {
     "v2s_last_gemm_kernel": (C.c_char_p, []),
     "v2s_scale_cols": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "v2s_span_corrupt": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
-    "v2s_topk_logprob": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
+    "v2s_topk_logprob": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
+    "v2s_repetition_penalty": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),
     "v2s_kv_gather": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
 }
 
@@ -417,9 +418,15 @@ def counter_add(ctr, delta):
     _check(lib().v2s_counter_add(ctr.data_ptr(), delta, stream_ptr()), "v2s_counter_add")
 
 
-def topk_logprob(logits, ld, rows, V, K, beam_scores, out_val, out_idx, ban_token=-1, pos_dev=None, min_length=0):
+def topk_logprob(logits, ld, rows, V, K, beam_scores, out_val, out_idx, ban_token=-1, pos_dev=None, min_length=0, row_lse=None):
     _check(lib().v2s_topk_logprob(logits.data_ptr(), ld, rows, V, K, ptr(beam_scores), out_val.data_ptr(), out_idx.data_ptr(),
-                                  ban_token, ptr(pos_dev), min_length, stream_ptr()), "v2s_topk_logprob")
+                                  ban_token, ptr(pos_dev), min_length, ptr(row_lse), stream_ptr()), "v2s_topk_logprob")
+
+
+def repetition_penalty(scores, ld, rows, V, hist, penalty, pos_dev=None, n_static=0, row_lse=None):
+    _need(hist, torch.int64, "repetition_penalty hist")
+    _check(lib().v2s_repetition_penalty(scores.data_ptr(), ld, rows, V, hist.data_ptr(), hist.stride(0), ptr(pos_dev), n_static, penalty,
+                                        ptr(row_lse), stream_ptr()), "v2s_repetition_penalty")
 
 
 def kv_gather(src, dst, idx, bs, rs, B, length, width):

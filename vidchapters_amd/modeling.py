@@ -258,13 +258,13 @@ class Vid2Seq(nn.Module):
         eng = self.engine()
         if use_nucleus_sampling:
             raise NotImplementedError("nucleus sampling is not implemented in the HIP decoder")
-        if repetition_penalty != 1.0 or num_captions != 1:
-            raise NotImplementedError("repetition_penalty != 1 / num_captions != 1 are not implemented")
+        if num_captions != 1:
+            raise NotImplementedError("num_captions != 1 is not implemented")
         if num_beams > 1:
             toks = eng.beam_search(video, input_tokenized, num_beams=num_beams, max_new_tokens=max_length,
-                                   length_penalty=length_penalty, min_length=min_length)
+                                   length_penalty=length_penalty, min_length=min_length, repetition_penalty=repetition_penalty)
         else:
-            toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length)
+            toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length, repetition_penalty=repetition_penalty)
         return self.t5_tokenizer.batch_decode(toks, skip_special_tokens=True)
 
 
