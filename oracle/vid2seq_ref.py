@@ -408,7 +408,7 @@ class _BeamHyps:
 
 @torch.no_grad()
 def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_beams: int = 4, max_new_tokens: int = 256,
-                  length_penalty: float = 1.0, min_length: int = 1, repetition_penalty: float = 1.0):
+                  length_penalty: float = 1.0, min_length: int = 1, repetition_penalty: float = 1.0, num_return_sequences: int = 1):
     """vid2seq.py:150-162 with num_beams>1, do_sample=False, early_stopping=False, num_return_sequences=1:
     transformers==4.28.0 GenerationMixin.beam_search + BeamSearchScorer (un-vendored dependency -> restated from the
     published algorithm; *parity unpinned by reference tests*, cross-checked against the installed transformers'
@@ -466,10 +466,13 @@ def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_b
             continue
         for j in range(nb):
             hyps[b].add(seq[b * nb + j], float(beam_scores[b * nb + j]))
-    best = [sorted(hb.beams, key=lambda x: x[0])[-1][1] for hb in hyps]
+    best = []                                                                       # num_return_sequences best hypotheses per entry,
+    for hb in hyps:                                                                 # best first (BeamSearchScorer.finalize pops the sorted list)
+        srt = sorted(hb.beams, key=lambda x: x[0])
+        best += [srt.pop()[1] for _ in range(num_return_sequences)]
     lens = [len(x) for x in best]
     out_len = min(max(lens) + 1, max_length)
-    out = torch.full((B, out_len), cfg.pad_id, dtype=torch.long)
+    out = torch.full((len(best), out_len), cfg.pad_id, dtype=torch.long)
     for b, hyp in enumerate(best):
         out[b, :lens[b]] = hyp
         if lens[b] < out_len:

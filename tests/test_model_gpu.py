@@ -269,6 +269,8 @@ def test_beam_search_vs_golden(golden_dir):
     assert same * 4 >= rows * 3
     text = model.generate(video, tok(ids), num_beams=nb, max_length=max_new)
     assert isinstance(text, list) and len(text) == out.shape[0]
+    text2 = model.generate(video, tok(ids), num_beams=nb, max_length=max_new, num_captions=2)     # num_return_sequences = 2
+    assert len(text2) == 2 * out.shape[0] and text2[0::2] == text
 
 
 

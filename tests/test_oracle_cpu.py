@@ -133,8 +133,13 @@ def test_host_beam_scorer_matches_oracle(golden_dir):
                 v, t = torch.topk(logp, 2 * nb, dim=1)
                 _, src, finished = sc.advance(v.numpy(), t.numpy().astype(np.int32))
                 past = [tuple(x.index_select(0, torch.from_numpy(src).long()) for x in layer) for layer in past]
-            out = torch.from_numpy(sc.finalize())
-        assert torch.equal(out, want[:, :out.shape[1]]) and int(want[:, out.shape[1]:].abs().sum()) == 0
+            out3 = torch.from_numpy(sc.finalize(3))          # num_captions = 3 (num_return_sequences): the 3 best per entry, best first
+            want3 = R.beam_generate(P, cfg, video, ids, ids != 0, nb, max_new, 1.0, num_return_sequences=3)
+            assert torch.equal(out3, want3)
+            out = out3[0::3]
+            out = out[:, :max(int((row != cfg.pad_id).nonzero().max()) + 1 if (row != cfg.pad_id).any() else 1 for row in out)]
+        n = min(out.shape[1], want.shape[1])
+        assert torch.equal(out[:, :n], want[:, :n]) and int(want[:, n:].abs().sum()) == 0 and int(out[:, n:].abs().sum()) == 0
 
 
 

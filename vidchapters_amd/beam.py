@@ -31,12 +31,11 @@ class _Heap:
     def full_and_unbeatable(self, best_sum_logprobs: float, cur_len: int) -> bool:
         return len(self.items) >= self.cap and self.worst >= best_sum_logprobs / cur_len ** self.lp
 
-    def best(self) -> np.ndarray:
-        top = 0
-        for i in range(1, len(self.items)):
-            if self.items[i][0] >= self.items[top][0]:
-                top = i
-        return self.items[top][1]
+    def best(self, n: int = 1):
+        """The n best hypotheses, best first; among equal scores the one added later wins (a stable ascending sort popped from
+        the end, like BeamSearchScorer.finalize)."""
+        order = sorted(range(len(self.items)), key=lambda i: self.items[i][0])
+        return [self.items[order.pop()][1] for _ in range(n)]
 
 
 class BeamScorer:
@@ -86,15 +85,15 @@ class BeamScorer:
         self.cur_len += 1
         return new_tok.reshape(-1), src, bool(self.done.all()) or self.cur_len >= self.max_length
 
-    def finalize(self) -> np.ndarray:
+    def finalize(self, num_return: int = 1) -> np.ndarray:
         for b in range(self.B):
             if self.done[b]:
                 continue
             for j in range(self.nb):
                 self.heaps[b].push(self.seqs[b * self.nb + j, :self.cur_len].copy(), float(self.scores[b, j]))
-        best = [h.best() for h in self.heaps]
+        best = [hyp for h in self.heaps for hyp in h.best(num_return)]
         out_len = min(max(len(x) for x in best) + 1, self.max_length)
-        out = np.full((self.B, out_len), self.pad, dtype=np.int64)
+        out = np.full((len(best), out_len), self.pad, dtype=np.int64)
         for b, hyp in enumerate(best):
             out[b, :len(hyp)] = hyp
             if len(hyp) < out_len:

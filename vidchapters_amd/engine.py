@@ -845,7 +845,7 @@ class Engine:
 
     @torch.no_grad()
     def beam_search(self, video, input_tokenized, num_beams: int, max_new_tokens: int, length_penalty: float = 1.0,
-                    use_graph: bool = True, min_length: int = 1, repetition_penalty: float = 1.0) -> torch.Tensor:
+                    use_graph: bool = True, min_length: int = 1, repetition_penalty: float = 1.0, num_return: int = 1) -> torch.Tensor:
         """HF-4.28 beam_search + BeamSearchScorer semantics (call site vid2seq.py:150-162) on static caches.
         The encoder memory is NOT replicated per beam: cross K/V are projected once per batch entry and the nb beams of an
         entry read the same rows (``kv_group``).  A step = decoder forward for B*nb rows -> ``v2s_topk_logprob`` (log-softmax +
@@ -956,7 +956,9 @@ class Engine:
                 for i in range(nl):
                     L.kv_gather(caches[cur][i], caches[cur ^ 1][i], src_dev, cbs, 2 * inner, R, t + 1, 2 * inner)
                 cur ^= 1
-        return torch.from_numpy(scorer.finalize()).to(self.device)
+        if not 1 <= num_return <= nb:
+            raise ValueError(f"num_captions must be in [1, num_beams] (got {num_return})")
+        return torch.from_numpy(scorer.finalize(num_return)).to(self.device)
 
 
 # ==============================================================================================================

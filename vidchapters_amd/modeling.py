@@ -258,11 +258,12 @@ class Vid2Seq(nn.Module):
         eng = self.engine()
         if use_nucleus_sampling:
             raise NotImplementedError("nucleus sampling is not implemented in the HIP decoder")
-        if num_captions != 1:
-            raise NotImplementedError("num_captions != 1 is not implemented")
+        if num_captions != 1 and num_beams <= 1:
+            raise ValueError("num_captions > 1 needs beam search (HF: greedy search returns one sequence)")
         if num_beams > 1:
             toks = eng.beam_search(video, input_tokenized, num_beams=num_beams, max_new_tokens=max_length,
-                                   length_penalty=length_penalty, min_length=min_length, repetition_penalty=repetition_penalty)
+                                   length_penalty=length_penalty, min_length=min_length, repetition_penalty=repetition_penalty,
+                                   num_return=num_captions)
         else:
             toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length, repetition_penalty=repetition_penalty)
         return self.t5_tokenizer.batch_decode(toks, skip_special_tokens=True)
