@@ -38,7 +38,8 @@ int v2s_version(void);
 const char* v2s_last_error(void);
 /* runtime switches (tuning / profiling aids; defaults are what the product path uses):
  *   "tr_read"       1: ds_read_b64_tr_b16 operand transposes (default), 0: scalar LDS gathers
- *   "gemm_dma"      1: LDS-DMA 128x128 main loop for transposed-operand GEMMs (default), 2: for every variant, 0: register-staged
+ *   "gemm_dma"      2: LDS-DMA 128x128 main loop for every variant with K % 64 == 0 (default), 1: transposed-operand variants only,
+ *                   0: register-staged loop everywhere
  *   "gemm_big"      1: tile-size heuristics (default), 0: 128x128 only, 2: 256x128 8-wave only, 3: force the 4-wave 256x128x32 kernel
  *   "gemm_skinny"   1: dedicated weight-streaming kernel for M <= 64 (cached decoding; default), 0: general tiles
  *   "gemm_order"    GM > 0: grouped tile walk, GM tile rows deep, K slices tile-major (default 4: the blocks an XCD runs together share

@@ -13,8 +13,12 @@ batch = {k: v.to(dev) for k, v in synth.make_batch(32, 100, 1000, 256, len(tok),
 batch["video"] = batch["video"].to(torch.bfloat16)
 batch["input_lens"] = (batch["input_ids"] != 0).sum(1).tolist()
 print("valid encoder tokens:", sum(batch["input_lens"]), "of", batch["input_ids"].numel())
-if len(sys.argv) > 2 and sys.argv[2] == "dense":
+if len(sys.argv) > 2 and "dense" in sys.argv[2]:
     model.engine().pack = False
+for kv in sys.argv[3:]:          # extra library options, e.g. gemm_dma=2
+    k, v = kv.split("=")
+    L.set_option(k, int(v))
+    print("option", k, v)
 for _ in range(2): tr.step(batch)
 model.engine().overlap = False      # per-launch durations only mean something without concurrent kernels
 with L.KernelTimer(detail=True) as kt:

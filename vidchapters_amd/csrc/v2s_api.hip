@@ -7,7 +7,7 @@
 
 static thread_local char g_err[512] = "";
 static std::atomic<int> g_tr_read{1};
-static std::atomic<int> g_gemm_dma{1};
+static std::atomic<int> g_gemm_dma{2};
 static std::atomic<int> g_gemm_big{1};
 static std::atomic<int> g_gemm_split{1};
 static std::atomic<int> g_gemm_order{4};

@@ -882,16 +882,22 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   // tile choice: the 256-row kernel (one 8-wave block per CU) when K % 64 == 0 and it yields enough tiles, else 128x128
   int bm = BM, bn = BN;
   const int big_mode = v2s_opt_gemm_big();
-  // measured on the step's shapes (tools/gemm_bench.py, TF/s): N >= 1024 -> 256x256 for every variant (wi fwd 801 vs 711,
-  // wo dgrad 856 vs 753, wo wgrad 922 vs 684, LM head 754 vs 571); N < 1024 -> 256x128 for plain NT (o fwd 727 vs 667,
-  // wo fwd 1032 vs 885) but the 128x128 DMA kernel for the transposed variants (dgrad 1000-1040 vs 931-953)
+  // measured on the step's shapes with every kernel on the LDS-DMA loop (tools/gemm_tile_ab.py, us, 256-row tiles vs 128x128 DMA):
+  // NT 32000x3072x768 190 vs 199, LM head 8192x32200x768 498 vs 530 -> 256x256; but 32000x768x3072 203 vs 179, 32000x768x768 63 vs 59,
+  // 35200x1536x768 109 vs 101, 8192x2304x768 54 vs 43, 8192x3072x768 63 vs 53, 32000x2304x768 137 vs 139 -> 128x128 (two blocks per
+  // CU, twice as many tiles: far less tail quantisation).  So plain NT takes the 256x256 tile only for wide outputs with >= 1200 tiles
+  // (>= 4.7 rounds of the chip), dgrad (transB) likewise (32000x3072x768 261 vs 268, but 8192x3072x768 74 vs 60); wide long-K weight
+  // gradients keep it.
   if (big_mode && tr && (a->K % BK) == 0 && a->M >= 256 && a->N >= 128) {
     // weight gradients with a short contraction keep the 128x128 tiles even for wide outputs (768x2048x3200: 359 vs 270 TF/s)
     const bool wide = a->N >= 1024 && big_mode != 2 && !(a->transA && a->K < 8192);
     const int bn2 = wide ? 256 : 128;
     const long t2 = (long)((a->M + 255) / 256) * ((a->N + bn2 - 1) / bn2);
     const bool transposed = a->transA || a->transB;
-    if ((wide || !transposed || big_mode == 2) && (t2 >= 240 || (plain_split && t2 >= 8))) { bm = 256; bn = bn2; }
+    // forward and dgrad: wide output AND enough 256x256 tiles (dgrad 8192x3072x768: 74 vs 60 us -> 128x128); weight gradients: wide
+    const bool use256 = a->transA ? wide : (wide && t2 >= 1200);
+    if (big_mode == 2) { if (t2 >= 240) { bm = 256; bn = bn2; } }
+    else if (use256 && (t2 >= 240 || (plain_split && t2 >= 8))) { bm = 256; bn = bn2; }
   }
   // 4-wave 256x128x32 kernel, two blocks per CU.  With the split-K cost model below, measured (tools/gemm_bench.py wgrad, TF/s,
   // w4 / 128x128 DMA / 8-wave 256-row): qkv 2304x768x32000 756/678/-, wi 3072x768x32000 798/761/-, o 768x768x32000 476/545/-,
@@ -975,10 +981,10 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
 #undef V2S_BIG
   } else {
   const dim3 grid(nblocks), block(NTHREADS);
-  // measured (tools/gemm_bench.py): the DMA loop wins for the transposed-operand variants (dgrad +5..18 %, wgrad +2..9 %),
-  // the register-staged loop for plain NT (forward) shapes
+  // measured: the DMA loop wins for the transposed-operand variants (dgrad +5..18 %, wgrad +2..9 %) and, since the grouped tile walk,
+  // for plain NT shapes too (tools/gemm_dma_ab.py: 8192x768x3072 61 -> 49 us, 3200x768x2048 35 -> 30 us, 8192x768x768 24 -> 21 us)
   const bool dma = v2s_opt_gemm_dma() != 0 && tr && (a->transA || a->transB || v2s_opt_gemm_dma() == 2) && (a->K % BK) == 0 && (p.kper % BK) == 0 &&
-                   a->M >= 8 && a->N >= 8;
+                   a->M >= 8 && a->N >= 8;      // gemm_dma: 2 (default) = every variant, 1 = transposed-operand variants only
   if (dma) g_last_gemm = !a->transB ? "gemm_dma_kernel<false, false>" : (!a->transA ? "gemm_dma_kernel<false, true>" : "gemm_dma_kernel<true, true>");
   else g_last_gemm = !a->transB ? "gemm_kernel<false, false, true>" : (!a->transA ? (tr ? "gemm_kernel<false, true, true>" : "gemm_kernel<false, true, false>")
                                                                                     : (tr ? "gemm_kernel<true, true, true>" : "gemm_kernel<true, true, false>"));
