@@ -6,19 +6,26 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vidchapters_amd import lib as L
 
-# (M, N, K, launches per step)  -- dx = dy @ W  (transB)
-SHAPES = [(32000, 768, 3072, 12), (32000, 768, 2304, 12), (35200, 768, 1536, 12), (32000, 768, 768, 12), (8192, 768, 768, 36),
-          (8192, 768, 3072, 12), (8192, 768, 2304, 12), (3200, 768, 2304, 12), (3200, 768, 2048, 12), (3200, 2048, 768, 12),
-          (3200, 768, 768, 12)]
+# (M, N, K, launches per step) of the two dominant kernel variants in the cfg-2 step
+# gemm_dma_kernel<false, true>: dx = dy @ W (transB), N < 1024 or fewer than 1200 256x256 tiles
+SHAPES_DGRAD = [(32000, 768, 3072, 12), (32000, 768, 2304, 12), (35200, 768, 1536, 12), (32000, 768, 768, 12), (8192, 768, 768, 36),
+                (8192, 768, 3072, 12), (8192, 768, 2304, 12), (8192, 3072, 768, 12), (3200, 768, 2304, 12), (3200, 768, 2048, 12),
+                (3200, 2048, 768, 12), (3200, 768, 768, 12)]
+# gemm_dma_kernel<false, false>: y = x @ W^T (forward): encoder qkv/o/wo, every decoder and ViT projection, cross K/V
+SHAPES_NT = [(32000, 2304, 768, 12), (32000, 768, 768, 12), (32000, 768, 3072, 12), (35200, 1536, 768, 12), (8192, 2304, 768, 12),
+             (8192, 768, 768, 36), (8192, 3072, 768, 12), (8192, 768, 3072, 12), (3200, 2304, 768, 12), (3200, 768, 768, 12),
+             (3200, 2048, 768, 12), (3200, 768, 2048, 12)]
+VARIANT = sys.argv[1] if len(sys.argv) > 1 else "nt"
+SHAPES = SHAPES_NT if VARIANT == "nt" else SHAPES_DGRAD
 if __name__ == "__main__":
     dev = "cuda"
     names = []
     for M, N, K, _ in SHAPES:
         A = torch.randn(M, K, device=dev).to(torch.bfloat16)
-        B = torch.randn(K, N, device=dev).to(torch.bfloat16)
+        B = torch.randn((N, K) if VARIANT == "nt" else (K, N), device=dev).to(torch.bfloat16)
         C = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
         for _ in range(3):
-            L.gemm(A, B, C, M, N, K, transB=True)
+            L.gemm(A, B, C, M, N, K, transB=(VARIANT != "nt"))
         names.append(L.lib().v2s_last_gemm_kernel().decode())
     torch.cuda.synchronize()
     print(json.dumps(names))

@@ -3,8 +3,9 @@ dominant GEMM kernel.  Corrections as MI355X_MICROARCH.md (HBM section) prescrib
 16-B/lane reads at half their bytes -> doubled; WRITE_SIZE is taken as is (it reproduces the C matrix size exactly here)."""
 import csv, json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gemm_mix import SHAPES
 src, out = sys.argv[1], sys.argv[2]
+sys.argv = [sys.argv[0]] + sys.argv[3:]          # variant (nt | dgrad) is read by gemm_mix
+from gemm_mix import SHAPES
 def per_dispatch(counter):
     rows = list(csv.DictReader(open(f"{src}/{counter}/p_counter_collection.csv")))
     rows = [r for r in rows if "gemm" in r["Kernel_Name"] and r["Counter_Name"] == counter]
