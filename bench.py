@@ -196,6 +196,8 @@ def main():
                         out["roofline"]["algorithmic_bytes_per_launch"] = round(pj["algorithmic"])
         except OSError:
             pass
+        out["kernel_breakdown_note"] = ("HIP-event pairs around each launch on the launch stream; at ~2500 launches per step this leg is host-bound, so "
+                                        "short kernels carry launch gaps (see profiles/ for the rocprofv3 durations)")
         out["kernel_breakdown_ms_per_step"] = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] / 1e3) / 1e12, 1)}
                                                for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}
 
