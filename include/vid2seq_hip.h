@@ -294,6 +294,15 @@ int v2s_kv_gather(const void* src, void* dst, const int32_t* idx, int64_t bs, in
 int v2s_span_corrupt(const int64_t* ids, int64_t ld_ids, const int32_t* lens, const uint8_t* noise, int64_t ld_noise, int32_t B,
                      int32_t max_len, int64_t num_text_tokens, int64_t eos, int64_t* den_in, int64_t ld_in, int64_t* den_out,
                      int64_t ld_out, int32_t* out_lens, void* stream);
+/* one nucleus-sampling step (HF 4.28 sample(): temperature + top-p warpers + multinomial; call site vid2seq.py:150-162 with
+ * do_sample=use_nucleus_sampling): per row, softmax(logits / temperature), keep the most probable tokens whose preceding mass is
+ * < top_p, draw from the renormalised kept set with a counter-based uniform number (seed, row, *pos_dev) -- torch's RNG stream is not
+ * reproducible, so parity is distributional.  Finished rows emit pad; the token is also written to seq_out[row][*pos_dev + 1] when
+ * seq_out != NULL.  EOS has probability 0 while *pos_dev + 1 < min_length (MinLengthLogitsProcessor).  probs_out (optional,
+ * [rows][V]) receives the filtered, renormalised distribution (tests). */
+int v2s_topp_sample_step(const float* logits, int64_t ld, int32_t rows, int32_t V, float top_p, float temperature, uint32_t seed,
+                         int64_t* next_tok, int32_t* unfinished, int32_t eos_id, int32_t pad_id, int64_t* seq_out, int64_t seq_ld,
+                         const int32_t* pos_dev, float* probs_out, int32_t min_length, void* stream);
 /* *ctr += delta (one thread; closes a captured decode step) */
 int v2s_counter_add(int32_t* ctr, int32_t delta, void* stream);
 

@@ -345,6 +345,16 @@ def vid2seq_forward(P: Params, cfg: RefConfig, video, input_ids, input_mask, out
 
 
 @torch.no_grad()
+def top_p_probs(logits: torch.Tensor, top_p: float, temperature: float = 1.0) -> torch.Tensor:
+    """The distribution HF 4.28 sample() draws from: TemperatureLogitsWarper then TopPLogitsWarper (min_tokens_to_keep=1), softmax."""
+    scores = logits.float() / temperature
+    sl, si = torch.sort(scores, descending=False, dim=-1)
+    remove = sl.softmax(-1).cumsum(-1) <= (1 - top_p)
+    remove[..., -1:] = False
+    scores = scores.masked_fill(remove.scatter(-1, si, remove), -float("inf"))
+    return scores.softmax(-1)
+
+
 def repetition_penalty_(scores: torch.Tensor, seq: torch.Tensor, penalty: float) -> None:
     """transformers 4.28 RepetitionPenaltyLogitsProcessor (in place): every token that occurs in ``seq`` (decoder ids so far, start
     token included) has its score multiplied by ``penalty`` if negative, divided by it otherwise; gather-then-scatter, so a token is

@@ -612,6 +612,43 @@ def test_device_batcher_vs_oracle():
     assert np.array_equal(b["den_output_ids"].cpu().numpy(), D.collate([p[1] for p in pairs]))
 
 
+def test_topp_sampling_step_distribution():
+    """v2s_topp_sample_step: (1) the filtered, renormalised distribution equals HF's temperature + top-p warpers (oracle.top_p_probs,
+    itself identical to the installed transformers' warpers); (2) draws only ever hit kept tokens and their frequencies follow that
+    distribution; (3) finished rows emit pad; (4) min_length bans EOS."""
+    from oracle import vid2seq_ref as R
+    rows, V, ld = 6, 612, 616
+    g = torch.Generator().manual_seed(3)
+    logits = torch.zeros(rows, ld); logits[:, :V] = torch.randn(rows, V, generator=g) * 2.5; logits[:, V:] = 50.0
+    for top_p, temp in ((0.9, 1.0), (0.5, 0.7)):
+        want = R.top_p_probs(logits[:, :V], top_p, temp)
+        probs = torch.zeros(rows, V, device=DEV)
+        nxt = torch.zeros(rows, dtype=torch.long, device=DEV); unf = torch.ones(rows, dtype=torch.int32, device=DEV)
+        L.topp_sample_step(logits.to(DEV), ld, rows, V, top_p, temp, 1, nxt, unf, -1, 0, probs_out=probs)
+        got = probs.cpu()
+        edge = ((got > 0) != (want > 0)).sum().item()          # ties at the nucleus boundary may fall either way
+        assert edge <= rows and (got - want).abs().max() < 2e-3
+        counts = torch.zeros(rows, V)
+        n_draw = 3000
+        lg = logits.to(DEV)
+        for sd in range(n_draw):
+            unf.fill_(1)
+            L.topp_sample_step(lg, ld, rows, V, top_p, temp, 1000 + sd, nxt, unf, -1, 0)
+            counts[torch.arange(rows), nxt.cpu()] += 1
+        assert (counts[got == 0] == 0).all()                  # never outside the nucleus
+        freq = counts / n_draw
+        assert (freq - got).abs().max() < 0.04, float((freq - got).abs().max())
+    # finished rows emit pad; EOS banned below min_length
+    unf = torch.tensor([1, 0, 1, 0, 1, 1], dtype=torch.int32, device=DEV)
+    big = logits.clone(); big[:, 1] = 40.0                         # EOS overwhelmingly likely
+    pos = torch.tensor([2], dtype=torch.int32, device=DEV); seq = torch.zeros(rows, 8, dtype=torch.long, device=DEV)
+    L.topp_sample_step(big.to(DEV), ld, rows, V, 0.9, 1.0, 7, nxt, unf, 1, 0, seq_out=seq, seq_ld=8, pos_dev=pos, min_length=1)
+    assert nxt.cpu().tolist() == [1, 0, 1, 0, 1, 1] and unf.cpu().tolist() == [0, 0, 0, 0, 0, 0] and seq[:, 3].cpu().tolist() == [1, 0, 1, 0, 1, 1]
+    unf.fill_(1)
+    L.topp_sample_step(big.to(DEV), ld, rows, V, 0.9, 1.0, 7, nxt, unf, 1, 0, seq_out=seq, seq_ld=8, pos_dev=pos, min_length=5)
+    assert (nxt.cpu() != 1).all()
+
+
 def test_decode_kernels():
     B, H, Nk = 3, 4, 333
     W = H * 64

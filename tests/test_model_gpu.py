@@ -431,3 +431,19 @@ def test_repetition_penalty_vs_golden(golden_dir):
                 same += (out[r].tolist() == want[r, :out.shape[1]].tolist() and int(want[r, out.shape[1]:].abs().sum()) == 0)
     print(f"repetition penalty: rows identical to the fp32 fixture: {same}/{rows}")
     assert same * 4 >= rows * 3
+
+
+def test_generate_with_nucleus_sampling_runs():
+    """generate(use_nucleus_sampling=True) (dvc.py:177 with --num_beams 0): valid sequences, different draws for different calls, and with
+    a near-deterministic distribution (top_p tiny) the same tokens as greedy decoding."""
+    cfg = R.RefConfig.small()
+    model = build(cfg, 7).eval()
+    b = synth.make_batch(3, 10, 24, 12, cfg.vocab, 7, cfg.vit_dim)
+    video, ids = b["video"].to(DEV), tok(b["input_ids"])
+    t1 = model.generate(video, ids, use_nucleus_sampling=True, num_beams=0, max_length=12, top_p=0.9)
+    t2 = model.generate(video, ids, use_nucleus_sampling=True, num_beams=0, max_length=12, top_p=0.9)
+    assert len(t1) == len(t2) == 3 and all(isinstance(x, str) for x in t1) and t1 != t2
+    greedy = model.engine().greedy(video, ids, max_new_tokens=12).cpu()
+    samp = model.engine().greedy(video, ids, max_new_tokens=12, sample=(1e-6, 1.0, 5)).cpu()      # nucleus = the argmax token only
+    n = min(greedy.shape[1], samp.shape[1])
+    assert torch.equal(greedy[:, :n], samp[:, :n])

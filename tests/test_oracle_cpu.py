@@ -110,6 +110,18 @@ def test_oracle_repetition_penalty_vs_golden(golden_dir):
             assert torch.equal(out, want[:, :out.shape[1]]) and int(want[:, out.shape[1]:].abs().sum()) == 0
 
 
+def test_oracle_top_p_filter_equals_installed_hf_warpers():
+    """oracle.top_p_probs == softmax after the installed transformers' TemperatureLogitsWarper + TopPLogitsWarper (un-vendored in the
+    reference: 4.28 itself cannot be imported here)."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopPLogitsWarper
+    g = torch.Generator().manual_seed(0)
+    for V, tp, T in ((612, 0.9, 1.0), (4000, 0.9, 1.0), (500, 0.5, 0.7), (100, 0.95, 1.3)):
+        lg = torch.randn(5, V, generator=g) * 3
+        sc = TemperatureLogitsWarper(T)(None, lg.clone()) if T != 1.0 else lg.clone()
+        ref = TopPLogitsWarper(top_p=tp)(None, sc).softmax(-1)
+        assert torch.equal(R.top_p_probs(lg, tp, T), ref)
+
+
 def test_host_beam_scorer_matches_oracle(golden_dir):
     """vidchapters_amd.beam.BeamScorer (the product's host bookkeeping) driven by the oracle's decoder through the same
     per-beam top-2nb interface the device kernel provides."""

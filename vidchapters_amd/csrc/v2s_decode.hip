@@ -302,6 +302,96 @@ __global__ __launch_bounds__(256) void rep_penalty_kernel(float* __restrict__ sc
   }
 }
 
+
+// ---- nucleus (top-p) sampling step (vid2seq.py:150-162 with do_sample=True: HF 4.28 sample() = TemperatureLogitsWarper +
+// TopPLogitsWarper + multinomial).  One block per row; the row's softmax is built once in LDS.  Kept set = the most probable tokens
+// whose preceding (larger) mass is < top_p, found by bisection on the probability threshold (no sort); the draw walks the kept
+// tokens in index order with a counter-based uniform number (torch's RNG stream cannot be reproduced: distribution parity only).
+__device__ __forceinline__ float block_sum256(float v, float* red, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void topp_sample_kernel(const float* __restrict__ logits, long ld, int V, float top_p, float inv_temp,
+                                                          uint32_t seed, long* __restrict__ next_tok, int* __restrict__ unfinished, int eos_id,
+                                                          int pad_id, long* __restrict__ seq_out, long seq_ld, const int* __restrict__ pos_dev,
+                                                          float* __restrict__ probs_out, int min_length) {
+  extern __shared__ float pr[];          // V probabilities (unnormalised), then 256 + 8 floats of scratch
+  float* part = pr + V;
+  float* red = part + 256;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* z = logits + (long)row * ld;
+  // MinLengthLogitsProcessor: EOS gets -inf (probability 0) while the decoder sequence is shorter than min_length
+  const int ban = (eos_id >= 0 && (pos_dev ? *pos_dev + 1 : 0) < min_length) ? eos_id : -1;
+  float m = -INFINITY;
+  for (int i = tid; i < V; i += 256) m = fmaxf(m, i == ban ? -INFINITY : z[i]);
+  m = wave_max(m);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int i = tid; i < V; i += 256) { const float e = i == ban ? 0.f : __expf((z[i] - m) * inv_temp); pr[i] = e; s += e; }
+  const float Z = block_sum256(s, red, tid);
+  // bisection: G(tau) = mass of tokens with p > tau; invariant G(lo) >= top_p > G(hi)
+  float lo = -1.f, hi = 1.f;             // p_max = exp(0)/Z <= 1
+  const float goal = top_p * Z;
+  for (int it = 0; it < 40; ++it) {
+    const float mid = 0.5f * (lo + hi), thr = mid * Z;
+    float g = 0.f;
+    for (int i = tid; i < V; i += 256) g += pr[i] > thr ? pr[i] : 0.f;
+    g = block_sum256(g, red, tid);
+    if (g < goal) hi = mid; else lo = mid;
+  }
+  const float thr = lo * Z;
+  // kept mass per thread over a CONTIGUOUS chunk (the draw walks the tokens in index order)
+  const int C = (V + 255) / 256, beg = min(V, tid * C), end = min(V, beg + C);
+  float loc = 0.f;
+  for (int i = beg; i < end; ++i) loc += pr[i] > thr ? pr[i] : 0.f;
+  __syncthreads();
+  part[tid] = loc;
+  __syncthreads();
+  if (tid == 0) {                         // exclusive scan of 256 partials (serial: trivial next to the passes above)
+    float run = 0.f;
+    for (int t = 0; t < 256; ++t) { const float v = part[t]; part[t] = run; run += v; }
+    red[4] = run;                         // kept mass
+    const int step = pos_dev ? *pos_dev : 0;
+    const uint32_t h = v2s_hash32(seed ^ v2s_hash32((uint32_t)row * 0x9E3779B1u + (uint32_t)step * 0x85EBCA6Bu + 0x1234567u));
+    red[5] = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f) * run;       // target in (0, kept mass)
+    red[6] = __int_as_float(-1);
+  }
+  __syncthreads();
+  const float Zk = red[4], target = red[5];
+  if (probs_out) {
+    for (int i = tid; i < V; i += 256) probs_out[(long)row * V + i] = pr[i] > thr ? pr[i] / Zk : 0.f;
+  }
+  const float pre = part[tid];
+  if (target >= pre && target < pre + loc) {
+    float run = pre;
+    int pick = -1;
+    for (int i = beg; i < end; ++i) {
+      if (pr[i] > thr) { pick = i; run += pr[i]; if (target < run) break; }
+    }
+    red[6] = __int_as_float(pick);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int pick = __float_as_int(red[6]);
+    if (pick < 0) {                        // rounding left the target on a chunk boundary: take the most probable token
+      float best = -1.f;
+      for (int i = 0; i < V; ++i) if (pr[i] > best) { best = pr[i]; pick = i; }
+    }
+    const int un = unfinished[row];
+    const long tok = un ? (long)pick : (long)pad_id;
+    next_tok[row] = tok;
+    unfinished[row] = un && (tok != eos_id);
+    if (seq_out) seq_out[(long)row * seq_ld + *pos_dev + 1] = tok;
+  }
+}
+
 }  // namespace
 
 extern "C" int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream) {
@@ -385,6 +475,22 @@ extern "C" int v2s_repetition_penalty(float* scores, int64_t ld, int32_t rows, i
   V2S_CHECK(scores && hist && rows > 0 && V > 0 && penalty > 0.f && (pos_dev || n_static > 0), V2S_ERR_ARG, "v2s_repetition_penalty: bad args");
   hipLaunchKernelGGL(rep_penalty_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, scores, (long)ld, V, (const long*)hist, (long)hist_ld,
                      pos_dev, n_static, penalty, row_lse);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_topp_sample_step(const float* logits, int64_t ld, int32_t rows, int32_t V, float top_p, float temperature, uint32_t seed,
+                                    int64_t* next_tok, int32_t* unfinished, int32_t eos_id, int32_t pad_id, int64_t* seq_out, int64_t seq_ld,
+                                    const int32_t* pos_dev, float* probs_out, int32_t min_length, void* stream) {
+  V2S_CHECK(logits && next_tok && unfinished && rows > 0 && V > 0, V2S_ERR_ARG, "v2s_topp_sample_step: bad args");
+  V2S_CHECK(top_p > 0.f && top_p <= 1.f && temperature > 0.f, V2S_ERR_ARG, "v2s_topp_sample_step: top_p in (0,1], temperature > 0");
+  V2S_CHECK(!seq_out || pos_dev, V2S_ERR_ARG, "v2s_topp_sample_step: seq_out needs pos_dev");
+  const size_t dyn = ((size_t)V + 256 + 8) * sizeof(float);
+  V2S_CHECK(dyn <= 160 * 1024, V2S_ERR_SHAPE, "v2s_topp_sample_step: vocabulary %d too large for the LDS row buffer", V);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)topp_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(topp_sample_kernel, dim3(rows), dim3(256), dyn, (hipStream_t)stream, logits, (long)ld, V, top_p, 1.0f / temperature, seed,
+                     (long*)next_tok, unfinished, eos_id, pad_id, (long*)seq_out, (long)seq_ld, pos_dev, probs_out, min_length);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

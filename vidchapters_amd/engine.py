@@ -749,13 +749,15 @@ class Engine:
 
     @torch.no_grad()
     def greedy(self, video, input_tokenized, max_new_tokens: int = 256, stop_at_eos: bool = True, use_graph: bool = True,
-               repetition_penalty: float = 1.0) -> torch.Tensor:
+               repetition_penalty: float = 1.0, sample=None, min_length: int = 1) -> torch.Tensor:
         """HF-4.28 greedy_search semantics on a static KV cache: the cross K/V of every layer are
         projected once; the self K/V grow in place (no torch.cat, no cache reorder).  One decode step is ~150 small
         launches, so it is captured ONCE into a hipGraph (through torch.cuda.CUDAGraph) and replayed: every
         step-dependent quantity (cache position, number of keys, bias row, output column) is read by the kernels from a
         device-resident step counter, so the same graph serves all steps.  The all-rows-finished test of HF is evaluated
-        every 8 replays; the returned tensor is trimmed to exactly the length HF would have produced."""
+        every 8 replays; the returned tensor is trimmed to exactly the length HF would have produced.
+        ``sample=(top_p, temperature, seed)`` switches the token choice from argmax to nucleus sampling (same loop and stopping
+        rule as HF's sample()); ``min_length`` bans EOS while the sequence is shorter (sampling only; a no-op at HF's default 1)."""
         a, c = self.arena, self.cfg
         mem, mem_mask = self.encode(video, input_tokenized)
         B, S, d = mem.shape
@@ -816,7 +818,11 @@ class Engine:
                 L.gemm(n, E, logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
             if repetition_penalty != 1.0:           # HF RepetitionPenaltyLogitsProcessor on the raw logits (greedy_search)
                 L.repetition_penalty(logits, self.ldv, B, self.V, seq, repetition_penalty, pos_dev=pos)
-            L.argmax_step_seq(logits, self.ldv, B, self.V, nxt, unfinished, eos, c.pad_id, seq, maxlen + 1, pos)
+            if sample is not None:                  # nucleus sampling (HF sample(): processors, then temperature / top-p warpers, multinomial)
+                L.topp_sample_step(logits, self.ldv, B, self.V, sample[0], sample[1], sample[2], nxt, unfinished, eos, c.pad_id,
+                                   seq_out=seq, seq_ld=maxlen + 1, pos_dev=pos, min_length=min_length)
+            else:
+                L.argmax_step_seq(logits, self.ldv, B, self.V, nxt, unfinished, eos, c.pad_id, seq, maxlen + 1, pos)
             L.counter_add(pos, 1)
 
         step()                                   # step 0 eagerly (also warms every code path before capture)

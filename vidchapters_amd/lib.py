@@ -96,6 +96,7 @@ SYMBOLS = {
     "v2s_scale_cols": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "v2s_span_corrupt": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "v2s_topk_logprob": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
+    "v2s_topp_sample_step": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _f32, _u32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
     "v2s_repetition_penalty": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),
     "v2s_kv_gather": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
 }
@@ -445,3 +446,10 @@ def span_corrupt(ids, lens, noise, max_len, num_text_tokens, eos, den_in, den_ou
 def scale_cols(W, w, out, rows, cols):
     _need(W, torch.bfloat16, "scale_cols W"); _need(w, torch.float32, "scale_cols w")
     _check(lib().v2s_scale_cols(W.data_ptr(), w.data_ptr(), out.data_ptr(), rows, cols, stream_ptr()), "v2s_scale_cols")
+
+
+def topp_sample_step(logits, ld, rows, V, top_p, temperature, seed, next_tok, unfinished, eos_id, pad_id, seq_out=None, seq_ld=0, pos_dev=None,
+                     probs_out=None, min_length=0):
+    _check(lib().v2s_topp_sample_step(logits.data_ptr(), ld, rows, V, top_p, temperature, seed & 0xFFFFFFFF, next_tok.data_ptr(),
+                                      unfinished.data_ptr(), eos_id, pad_id, ptr(seq_out), seq_ld, ptr(pos_dev), ptr(probs_out), min_length, stream_ptr()),
+           "v2s_topp_sample_step")

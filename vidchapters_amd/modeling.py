@@ -257,7 +257,14 @@ class Vid2Seq(nn.Module):
                  top_p=0.9, repetition_penalty=1.0, length_penalty=1.0, num_captions=1, temperature=1):
         eng = self.engine()
         if use_nucleus_sampling:
-            raise NotImplementedError("nucleus sampling is not implemented in the HIP decoder")
+            # HF sample(): multinomial draws from the top-p filtered softmax.  The draws use a counter-based generator keyed on
+            # self.sampling_seed (torch's global RNG stream cannot be reproduced): same distribution, different samples.
+            if num_captions != 1:
+                raise NotImplementedError("num_captions > 1 with nucleus sampling is not implemented")
+            self.sampling_seed = (getattr(self, "sampling_seed", 0) + 1) & 0xFFFFFFFF
+            toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length, repetition_penalty=repetition_penalty,
+                              sample=(float(top_p), float(temperature), self.sampling_seed), min_length=min_length)
+            return self.t5_tokenizer.batch_decode(toks, skip_special_tokens=True)
         if num_captions != 1 and num_beams <= 1:
             raise ValueError("num_captions > 1 needs beam search (HF: greedy search returns one sequence)")
         if num_beams > 1:
