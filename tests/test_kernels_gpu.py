@@ -421,6 +421,20 @@ def test_attention_fully_masked_row_is_uniform():
     L.attn_fwd(a)
     want = v.float().mean(1, keepdim=True).expand(B, N, W)
     assert relerr(o, want) < 2e-2
+    # backward of the same degenerate rows: P = 1/N everywhere (1/l is folded into the exponent inside the kernels; all-masked rows
+    # take the masked-element value -log2 l instead)
+    ml = torch.empty(B, H, N, 2, dtype=torch.float32, device=DEV)
+    a = L.attn_args(B, H, N, N, q, k, v, o, (N * W, W), (N * W, W), (N * W, W), (N * W, W), key_mask=mk, ml=ml)
+    L.attn_fwd(a)
+    d_o = rnd(B, N, W, seed=4)
+    dq, dk, dv = (torch.zeros(B, N, W, dtype=torch.bfloat16, device=DEV) for _ in range(3))
+    delta = torch.empty(B, H, N, dtype=torch.float32, device=DEV)
+    L.attn_bwd(a, d_o, (N * W, W), delta, dq, dk, dv, (N * W, W), (N * W, W), (N * W, W))
+    P = torch.full((B, N, N), 1.0 / N, device=DEV)
+    dP = d_o.float() @ v.float().transpose(1, 2)
+    dS = P * (dP - (dP * P).sum(-1, keepdim=True))
+    assert relerr(dv, P.transpose(1, 2) @ d_o.float()) < 2e-2
+    assert relerr(dq, dS @ k.float()) < 3e-2 and relerr(dk, dS.transpose(1, 2) @ q.float()) < 3e-2
 
 
 def test_attention_dropout_consistency():
@@ -445,6 +459,39 @@ def test_attention_dropout_consistency():
     lhs = (d_o.float() * oD.float()).sum().item(); rhs = (dv.float() * D.float()).sum().item()
     print(f"dropout linearity: {lhs:.4f} vs {rhs:.4f}")
     assert abs(lhs - rhs) < 2e-2 * (abs(lhs) + abs(rhs) + 1.0)
+
+
+def test_attention_dropout_backward_with_extracted_mask():
+    """All three kernels must use ONE dropout mask: the forward kernel's mask is read back exactly (V = one-hot rows, one 64-key
+    chunk at a time, so O = dropped probabilities), then dQ / dK / dV are compared with the closed-form backward under that mask."""
+    B, H, Nq, Nk, W, pdrop, scale = 2, 1, 128, 192, 64, 0.25, 0.5
+    q, k, v = rnd(B, Nq, W, seed=1, scale=0.5), rnd(B, Nk, W, seed=2, scale=0.5), rnd(B, Nk, W, seed=3)
+    st = ((Nq * W, W), (Nk * W, W), (Nk * W, W), (Nq * W, W))
+    ml = torch.empty(B, H, Nq, 2, dtype=torch.float32, device=DEV)
+    pd = torch.zeros(B, Nq, Nk, device=DEV)
+    for c in range(Nk // 64):
+        onehot = torch.zeros(B, Nk, W, dtype=torch.bfloat16, device=DEV)
+        onehot[:, c * 64:(c + 1) * 64] = torch.eye(64, dtype=torch.bfloat16, device=DEV)
+        oc = torch.empty(B, Nq, W, dtype=torch.bfloat16, device=DEV)
+        L.attn_fwd(L.attn_args(B, H, Nq, Nk, q, k, onehot, oc, *st, scale=scale, dropout_p=pdrop, dropout_seed=123))
+        pd[:, :, c * 64:(c + 1) * 64] = oc.float()
+    keep = (pd > 0).float()
+    assert abs(keep.mean().item() - (1 - pdrop)) < 0.02
+    P = torch.softmax(scale * q.float() @ k.float().transpose(1, 2), -1)
+    assert relerr(pd, P * keep / (1 - pdrop)) < 1e-2
+    o = torch.empty(B, Nq, W, dtype=torch.bfloat16, device=DEV)
+    a = L.attn_args(B, H, Nq, Nk, q, k, v, o, *st, ml=ml, scale=scale, dropout_p=pdrop, dropout_seed=123)
+    L.attn_fwd(a)
+    d_o = rnd(B, Nq, W, seed=5)
+    dq, dk, dv = (torch.zeros(B, n, W, dtype=torch.bfloat16, device=DEV) for n in (Nq, Nk, Nk))
+    delta = torch.empty(B, H, Nq, dtype=torch.float32, device=DEV)
+    L.attn_bwd(a, d_o, (Nq * W, W), delta, dq, dk, dv, (Nq * W, W), (Nk * W, W), (Nk * W, W))
+    Pd = P * keep / (1 - pdrop)
+    dP = (d_o.float() @ v.float().transpose(1, 2)) * keep / (1 - pdrop)
+    dS = P * (dP - (dP * P).sum(-1, keepdim=True))
+    for name, got, want in (("dv", dv, Pd.transpose(1, 2) @ d_o.float()), ("dq", dq, scale * dS @ k.float()),
+                            ("dk", dk, scale * dS.transpose(1, 2) @ q.float())):
+        assert relerr(got, want) < 2e-2, (name, relerr(got, want))
 
 
 def test_bias_diag_roundtrip():

@@ -103,20 +103,36 @@ __device__ __forceinline__ void tile_store(char* tile, int tid, const uint4 (&r)
   for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(tile + tile_off(rr + i * 32, chunk * 8)) = r[i];
 }
 
+// two fp32 -> one packed bf16 pair with a single v_cvt_pk_bf16_f32 (element-wise casts compile to one conversion per element
+// plus a v_perm to merge them)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// a + b on two fp32 lanes per instruction (the compiler splits a <2 x float> add that feeds scalar transcendental ops)
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
-  bf16x8 f;
-  f[0] = (__bf16)a[0]; f[1] = (__bf16)a[1]; f[2] = (__bf16)a[2]; f[3] = (__bf16)a[3];
-  f[4] = (__bf16)b[0]; f[5] = (__bf16)b[1]; f[6] = (__bf16)b[2]; f[7] = (__bf16)b[3];
-  return f;
+  const uint4 w = make_uint4(cvt_pk(a[0], a[1]), cvt_pk(a[2], a[3]), cvt_pk(b[0], b[1]), cvt_pk(b[2], b[3]));
+  return __builtin_bit_cast(bf16x8, w);
 }
 
-// attention-probability dropout: keep(b,h,q,k) <=> mul24(rowseed(b,h,q) ^ (k * C1), C2) >= (p16 << 16): a per-row seed (one
+// attention-probability dropout: keep(b,h,q,k) <=> mul24(rowseed(b,h,q) ^ keyhash(k), C2) >= (p16 << 16): a per-row seed (one
 // full hash per row) and one xor-multiply per element, decided on the top 16 bits of the low product word.  The multiply is the
-// 24-bit one (v_mul_u32_u24, full rate; v_mul_lo_u32 is quarter rate and was ~1/6 of the VALU time of a tile).  Same definition
-// in all three kernels (forward mask == backward mask).
+// 24-bit one (v_mul_u32_u24, full rate; v_mul_lo_u32 is quarter rate and was ~1/6 of the VALU time of a tile).  keyhash(k) =
+// ((k & ~63) * C1) ^ ((k & 0xC) * C1) ^ ((k & 0x33) * C1): in the forward / dQ kernels a lane's 16 keys of a tile are
+// k = k0 + 4g + (16 kb + r), so the 4g term is folded into the row seed once per kernel, the k0 term once per tile (scalar
+// multiply), and the last term is an instruction literal -- one v_xor per element, no address arithmetic.  Same definition in
+// all three kernels (forward mask == backward mask).
 constexpr uint32_t DROP_C1 = 0x9E3779B1u, DROP_C2 = 0x00EBCA77u;
 __device__ __forceinline__ uint32_t drop_rowseed(uint32_t seed, uint32_t rowid) { return v2s_hash32(seed ^ (rowid * 0x9E3779B1u)); }
-__device__ __forceinline__ bool drop_keep(uint32_t rowseed, uint32_t kc1, uint32_t thr) {   // kc1 = k * DROP_C1, thr = p16 << 16
+__device__ __forceinline__ uint32_t drop_keyhash(uint32_t k) { return ((k & ~63u) * DROP_C1) ^ ((k & 0xCu) * DROP_C1) ^ ((k & 0x33u) * DROP_C1); }
+__device__ __forceinline__ bool drop_keep(uint32_t rowseed, uint32_t kc1, uint32_t thr) {   // kc1 = (part of) keyhash(k), thr = p16 << 16
   return __umul24(rowseed ^ kc1, DROP_C2) >= thr;
 }
 
@@ -128,7 +144,7 @@ constexpr int OFF_BIAS = 2 * KV_TILE;         // 4 x 192 floats: copy s holds w[
 constexpr int BIAS_COPY = 192;                // floats per copy
 constexpr int OFF_FLAG = OFF_BIAS + 4 * BIAS_COPY * 4;   // 64 key flags (0 keep, 1 masked, 2 out of range)
 constexpr int OFF_STATE = OFF_FLAG + 64;      // int[2]: OR of flags, AND of (flag != 0)
-constexpr int OFF_MS = OFF_STATE + 16;        // dkv kernel: m[64], 1/l[64], delta[64], dropout row seed[64]
+constexpr int OFF_MS = OFF_STATE + 16;        // dkv kernel: (m + log2 l)[64], masked-element exponent[64], delta[64], dropout row seed[64]
 constexpr int STAGE = OFF_MS + 4 * 64 * 4;    // + 64 dropout row seeds (dkv kernel)
 static_assert(STAGE % 16 == 0 && OFF_MS % 16 == 0 && OFF_BIAS % 16 == 0, "LDS carve alignment");
 
@@ -185,6 +201,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
     }
   }
   float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+  uint32_t rowseed[2] = {0u, 0u};
+  if (DROP) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) rowseed[qb] = drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + Q0 + wq0 + qb * 16 + li)) ^ ((uint32_t)(4 * g) * DROP_C1);
+  }
   f32x4 ot[2][4];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
@@ -296,20 +317,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
         const float mn = fmaxf(m[qb], mx);
         const float alpha = fast_exp2(m[qb] - mn);
         m[qb] = mn;
-        float rs = 0.f;
-        const uint32_t rseed = DROP ? drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q)) : 0u;
+        f32x4 rs4 = f32x4{0.f, 0.f, 0.f, 0.f};     // subtraction and row sum as 4-vectors: v_pk_add_f32 handles two elements each
+        const uint32_t rseed = rowseed[qb] ^ ((uint32_t)k0 * DROP_C1);
         const uint32_t thr = p.p16 << 16;
+        const f32x2 nmn2 = f32x2{-mn, -mn};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-          const uint32_t kc = (uint32_t)(k0 + kb * 16 + 4 * g) * DROP_C1;
+          const f32x2 x01 = pk_add(f32x2{st[qb][kb][0], st[qb][kb][1]}, nmn2), x23 = pk_add(f32x2{st[qb][kb][2], st[qb][kb][3]}, nmn2);
+          const f32x4 pv4 = f32x4{fast_exp2(x01[0]), fast_exp2(x01[1]), fast_exp2(x23[0]), fast_exp2(x23[1])};
+          rs4 += pv4;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float pv = fast_exp2(st[qb][kb][r] - mn);
-            rs += pv;
-            if (DROP) pv = drop_keep(rseed, kc + (uint32_t)r * DROP_C1, thr) ? pv : 0.f;      // 1/(1-p) is applied once, to the output row
-            st[qb][kb][r] = pv;
-          }
+          for (int r = 0; r < 4; ++r)
+            st[qb][kb][r] = (!DROP || drop_keep(rseed, (uint32_t)(kb * 16 + r) * DROP_C1, thr)) ? pv4[r] : 0.f;   // 1/(1-p) is applied once, to the output row
         }
+        const float rs = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
         lsum[qb] = lsum[qb] * alpha + rs;
 #pragma unroll
         for (int db = 0; db < 4; ++db) ot[qb][db] *= alpha;
@@ -388,7 +409,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p, float* _
 template <bool TR, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2*STAGE + (Nk+128)*8 (dbias window) bytes
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // scalar: the per-block bias-gradient routing below branches on it
   const int nqb = (p.Nq + 127) >> 7;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int qblk = id % nqb, bh = id / nqb, h = bh % p.H, b = bh / p.H;
@@ -413,7 +435,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   const bf16_t* vp = p.v + (p.seq_off ? (long)row0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
 
   bf16x8 qf[2][2], dof[2][2];
-  float m2[2], linv[2], dl[2];
+  float m2[2], xmask[2], dl[2];
+  uint32_t rowseed[2] = {0u, 0u};
+  bool rows_real = true;
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int q = Q0 + wq0 + qb * 16 + li;
@@ -427,15 +451,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
       qf[qb][ks] = __builtin_bit_cast(bf16x8, v);
       dof[qb][ks] = __builtin_bit_cast(bf16x8, w);
     }
-    m2[qb] = 0.f; linv[qb] = 0.f; dl[qb] = 0.f;     // rows >= Nq: linv = 0 => P = 0 => dS = 0
+    // 1/l is folded into the exponent: P = exp2(s - (m + log2 l)).  Rows >= Nq: huge offset => P = 0 => dS = 0.  A row whose
+    // keys are ALL masked (m <= REAL_MIN) keeps the reference's uniform distribution: its masked elements evaluate to
+    // exp2(-log2 l) = 1/l (xmask), every other row's masked elements to 0.
+    m2[qb] = 1.0e30f; xmask[qb] = -3.0e38f; dl[qb] = 0.f;
+    bool real = true;
     if (q < nq_) {
       const long r = ((long)(b * p.H + h)) * p.Nq + q;
-      m2[qb] = p.ml[r * 2];
-      linv[qb] = 1.0f / p.ml[r * 2 + 1];
+      const float mm = p.ml[r * 2], l2 = __log2f(p.ml[r * 2 + 1]);
+      real = mm > REAL_MIN;
+      m2[qb] = real ? mm + l2 : 0.f;
+      xmask[qb] = real ? -3.0e38f : -l2;
       dl[qb] = p.delta[r];
     }
+    rows_real = rows_real && real;
+    if (DROP) rowseed[qb] = drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q)) ^ ((uint32_t)(4 * g) * DROP_C1);
   }
-  const bool seen = __all((m2[0] > REAL_MIN) && (m2[1] > REAL_MIN));
+  const bool seen = __all(rows_real);
   const float isc2 = 1.0f / (p.scale * LOG2E);
   const float ninit[2] = {-m2[0] * isc2, -m2[1] * isc2};
   f32x4 dqt[2][4];
@@ -516,19 +548,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
       for (int qb = 0; qb < 2; ++qb) {
         const int qq = wq0 + qb * 16 + li, q = Q0 + qq;
         const uint8_t* fl = reinterpret_cast<const uint8_t*>(sK + OFF_FLAG);
-        const uint32_t rseed = DROP ? drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q)) : 0u;
+        const uint32_t rseed = rowseed[qb] ^ ((uint32_t)k0 * DROP_C1);
         const uint32_t thr = p.p16 << 16;
-        const float li_q = linv[qb], dl_q = dl[qb];
+        const float dl_q = dl[qb], ndl_q = -dl_q, xm_q = xmask[qb];
         const int qlo = Q0 + wq0 + qb * 16;            // rows of this block: qlo .. qlo+15
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-          float lsum_ds = 0.f;
           const int klo = k0 + kb * 16;
           const int route = !want_dbias ? 0 : ((klo + 15 - qlo) <= p.far_lo ? 1 : ((klo - (qlo + 15)) >= p.far_hi ? 2 : 3));
           float4 bw = make_float4(0.f, 0.f, 0.f, 0.f);
           if (BIAS) bw = bias_read4(sK, kb * 16 + 4 * g + 127 - qq);
           const float bwv[4] = {bw.x, bw.y, bw.z, bw.w};
-          const uint32_t kc = (uint32_t)(k0 + kb * 16 + 4 * g) * DROP_C1;
           float x[4];
           if (clean) {
 #pragma unroll
@@ -539,32 +569,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
             for (int r = 0; r < 4; ++r) {
               uint32_t f = (f4 >> (8 * r)) & 0xffu;
               if (CAUSAL && (k0 + kb * 16 + 4 * g + r) > q + p.causal_off) f |= 1u;
-              x[r] = (f & 2u) ? -INFINITY : ((f & 1u) ? (MASKED2 - m2[qb]) : fmaf(st[qb][kb][r], sc2, bwv[r]));
+              x[r] = (f & 2u) ? -INFINITY : ((f & 1u) ? xm_q : fmaf(st[qb][kb][r], sc2, bwv[r]));
             }
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pr = fast_exp2(x[r]) * li_q;
-            float dpv = dp[qb][kb][r];
-            if (DROP) dpv = drop_keep(rseed, kc + (uint32_t)r * DROP_C1, thr) ? dpv * p.inv_keep : 0.f;
-            const float ds = pr * (dpv - dl_q);
-            st[qb][kb][r] = ds;
-            if (BIAS) {
-              if (route == 3) {     // near-diagonal block: branch-free per element (no exec-mask juggling in the hot loop)
-                const int kk = kb * 16 + 4 * g + r;
-                const int d = (k0 + kk) - q;
-                const bool lo = d <= p.far_lo, hi = d >= p.far_hi;
-                acc_lo += lo ? ds : 0.f;
-                acc_hi += hi ? ds : 0.f;
-                atomicAdd(&dbw[(k0 + kk) + 127 - qq], (unsigned long long)(long long)(((lo || hi) ? 0.f : ds) * 1099511627776.0f));
-              } else {
-                lsum_ds += ds;
-              }
-            }
+            const float pr = fast_exp2(x[r]);                       // already divided by l
+            float u = fmaf(dp[qb][kb][r], DROP ? p.inv_keep : 1.0f, ndl_q);      // dP/(1-p) - delta on kept elements
+            if (DROP) u = drop_keep(rseed, (uint32_t)(kb * 16 + r) * DROP_C1, thr) ? u : ndl_q;
+            st[qb][kb][r] = pr * u;
           }
-          if (BIAS) {
-            if (route == 1) acc_lo += lsum_ds;
-            else if (route == 2) acc_hi += lsum_ds;
+          if (BIAS && route != 0) {      // route is wave-uniform: one scalar branch per 16x16 block, none per element
+            if (route == 3) {            // near-diagonal block: every element goes to its own diagonal of the window
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                // float -> 2^-40 fixed point without the (emulated, ~11 instruction) float->int64 conversion: adding
+                // 1.5 * 2^12 in double leaves round(ds * 2^40) (two's complement, |ds| < 2048) in the low 51 mantissa bits;
+                // the magic number's bit pattern has a zero low word, so subtracting its high word yields the integer.
+                const double md = (double)st[qb][kb][r] + 6144.0;
+                const unsigned long long bits = __builtin_bit_cast(unsigned long long, md) - 0x40B8000000000000ull;
+                atomicAdd(&dbw[(k0 + kb * 16 + 4 * g + r) + 127 - qq], bits);
+              }
+            } else {
+              const float lsum_ds = (st[qb][kb][0] + st[qb][kb][1]) + (st[qb][kb][2] + st[qb][kb][3]);
+              if (route == 1) acc_lo += lsum_ds;
+              else acc_hi += lsum_ds;
+            }
           }
         }
         dsf[qb][0] = pack_frag(st[qb][0], st[qb][1]);
@@ -666,6 +696,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   uint4 rq[2], rdo[2];
   float rbias = 0.f;
   float rm = 0.f, rl = 0.f, rd = 0.f;
+  int rreal = 1;
   uint32_t rseed = 0;
   // bias window for this (128-key block, 64-query tile): index (k - q) - dmin, dmin = K0 - (q0 + 63); 191 entries
   auto prefetch = [&](int t) {
@@ -679,10 +710,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     if (tid < 64) {
       const int q = q0 + tid;
       if (DROP) rseed = drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q));
-      rm = 0.f; rl = 0.f; rd = 0.f;                 // rows >= Nq: 1/l = 0 => P = 0
+      // rm = m + log2 l (1/l folded into the exponent), rl = value of a MASKED element's exponent: -log2 l for a row whose keys
+      // are all masked (uniform distribution, like the reference), -huge otherwise; rows >= Nq: P = 0.  See the dQ kernel.
+      rm = 1.0e30f; rl = -3.0e38f; rd = 0.f; rreal = 1;
       if (q < nq_) {
         const long r = ((long)(b * p.H + h)) * p.Nq + q;
-        rm = p.ml[r * 2]; rl = 1.0f / p.ml[r * 2 + 1]; rd = p.delta[r];
+        const float mm = p.ml[r * 2], l2 = __log2f(p.ml[r * 2 + 1]);
+        rreal = mm > REAL_MIN;
+        rm = rreal ? mm + l2 : 0.f; rl = rreal ? -3.0e38f : -l2; rd = p.delta[r];
       }
     }
   };
@@ -696,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       ms[tid] = rm; ms[64 + tid] = rl; ms[128 + tid] = rd;
       if (DROP) reinterpret_cast<uint32_t*>(ms)[192 + tid] = rseed;
       // "every query row of this tile has real statistics": lets all-masked / all-future key blocks skip the tile
-      const unsigned long long real = __ballot(rm > REAL_MIN || rl == 0.f);
+      const unsigned long long real = __ballot(rreal != 0);
       if (tid == 0) reinterpret_cast<int*>(st + OFF_STATE)[0] = (real == ~0ull);
     }
   };
@@ -748,17 +783,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
           const int qb = 2 * qh + qi;
-          const float4 mv = *reinterpret_cast<const float4*>(ms + qb * 16 + 4 * g);
           const float4 lv = *reinterpret_cast<const float4*>(ms + 64 + qb * 16 + 4 * g);
           const float4 dv4 = *reinterpret_cast<const float4*>(ms + 128 + qb * 16 + 4 * g);
-          const float mr[4] = {mv.x, mv.y, mv.z, mv.w}, lr[4] = {lv.x, lv.y, lv.z, lv.w}, dr[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+          const float lr[4] = {lv.x, lv.y, lv.z, lv.w}, dr[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
           uint4 sd4 = make_uint4(0, 0, 0, 0);
           if (DROP) sd4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(ms) + 192 + qb * 16 + 4 * g);
           const uint32_t sdr[4] = {sd4.x, sd4.y, sd4.z, sd4.w};
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb) {
             const int kk = wk0 + kb * 16 + li, k = K0 + kk;
-            const uint32_t kc = (uint32_t)k * DROP_C1;
+            const uint32_t kc = drop_keyhash((uint32_t)k);
             // window entries for r = 0..3 sit at decreasing indices i0 - r with i0 = kk + 63 - (qb*16 + 4g)
             float bwv[4] = {0.f, 0.f, 0.f, 0.f};
             if (BIAS) {
@@ -775,20 +809,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
                 const int q = q0 + qb * 16 + 4 * g + r;
                 uint32_t f = kflag[kb];
                 if (CAUSAL && k > q + p.causal_off) f |= 1u;
-                x[r] = (f & 2u) ? -INFINITY : ((f & 1u) ? (MASKED2 - mr[r]) : fmaf(st[qi][kb][r], sc2, bwv[r]));
+                x[r] = (f & 2u) ? -INFINITY : ((f & 1u) ? lr[r] : fmaf(st[qi][kb][r], sc2, bwv[r]));
               }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float pr = fast_exp2(x[r]) * lr[r];
-              float dpv = dp[qi][kb][r];
+              const float pr = fast_exp2(x[r]);                    // already divided by l
               float pd = pr;
-              if (DROP) {
-                const bool keep = drop_keep(sdr[r], kc, thr);
-                dpv = keep ? dpv * p.inv_keep : 0.f;
-                pd = keep ? pr * p.inv_keep : 0.f;
-              }
-              st[qi][kb][r] = pr * (dpv - dr[r]);
+              if (DROP) pd = drop_keep(sdr[r], kc, thr) ? pr * p.inv_keep : 0.f;
+              st[qi][kb][r] = fmaf(pd, dp[qi][kb][r], -(pr * dr[r]));   // dS = P * (dP_dropped - delta)
               dp[qi][kb][r] = pd;
             }
           }
