@@ -332,6 +332,62 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long l
   }
 }
 
+// Per-lane SOURCE byte offset of 1 KiB chunk c of a tile, relative to (matrix base + the K offset of the tile): constant over the
+// K loop, so the loop only advances a scalar base (saddr form of the DMA: address = SGPR pair + 32-bit VGPR offset).
+template <bool T>
+__device__ __forceinline__ uint32_t dma_lane_off(long ld, int row0, int R, int R8, int c, int lane) {
+  if (!T) {                             // [128 rows][64 k]: chunk = 8 rows x 128 B
+    const int row = c * 8 + (lane >> 3), pos = lane & 7;
+    const int chunk = pos ^ ((row >> 1) & 7);
+    int grow = row0 + row;
+    grow = grow < R ? grow : R - 1;
+    return (uint32_t)(((long)grow * ld + chunk * 8) * 2);
+  } else {                              // [64 k][128 rows]: chunk = 4 k-rows x 256 B
+    const int k = c * 4 + (lane >> 4), pos16 = lane & 15;
+    const int c16 = ((((pos16 >> 1) ^ tr_g(k)) << 1) | (pos16 & 1));
+    int grow = row0 + c16 * 8;
+    grow = grow <= R8 - 8 ? grow : R8 - 8;
+    return (uint32_t)(((long)k * ld + grow) * 2);
+  }
+}
+// One wave's share of a stage: 4 x 1 KiB of A and 4 x 1 KiB of B, consecutive chunks (lds = stage base + wave * 4 KiB).  M0 (the
+// wave-uniform LDS destination) is saved once, stepped with s_add between the loads and restored once; one wait state is needed
+// between an M0 write and the LDS-DMA instruction that reads it.
+__device__ __forceinline__ void dma_issue8(const uint32_t (&oa)[4], const uint32_t (&ob)[4], const void* ga, const void* gb, uint32_t lds) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %[keep], m0\n\t"
+      "s_mov_b32 m0, %[lds]\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[a0], %[ga]\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[a1], %[ga]\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[a2], %[ga]\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[a3], %[ga]\n\t"
+      "s_add_u32 m0, m0, %[skip]\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[b0], %[gb]\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[b1], %[gb]\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[b2], %[gb]\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[b3], %[gb]\n\t"
+      "s_mov_b32 m0, %[keep]"
+      : [keep] "=&s"(keep)
+      : [lds] "s"(lds), [ga] "s"(ga), [gb] "s"(gb), [a0] "v"(oa[0]), [a1] "v"(oa[1]), [a2] "v"(oa[2]), [a3] "v"(oa[3]),
+        [b0] "v"(ob[0]), [b1] "v"(ob[1]), [b2] "v"(ob[2]), [b3] "v"(ob[3]), [skip] "n"(A_BYTES - 3 * 1024)
+      : "memory", "scc");
+}
+
 template <bool TA, bool TB>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const GemmP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
@@ -353,9 +409,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const GemmP p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (kend - kbeg) / BK;
-  const uint32_t sbase = lds_addr(smem);
-  dma_tile<TA>(p.A, p.lda, m0, p.M, M8, kbeg, sbase, wave, lane);
-  dma_tile<TB>(p.B, p.ldb, n0, p.N, N8, kbeg, sbase + A_BYTES, wave, lane);
+  const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 4096);   // this wave's 4 chunks of the A tile of stage 0
+  uint32_t oa[4], ob[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    oa[i] = dma_lane_off<TA>(p.lda, m0, p.M, M8, wave * 4 + i, lane);
+    ob[i] = dma_lane_off<TB>(p.ldb, n0, p.N, N8, wave * 4 + i, lane);
+  }
+  const long stepA = TA ? (long)BK * p.lda * 2 : (long)BK * 2, stepB = TB ? (long)BK * p.ldb * 2 : (long)BK * 2;   // bytes per K-step
+  const char* ga = reinterpret_cast<const char*>(p.A) + (long)(kbeg / BK) * stepA;
+  const char* gb = reinterpret_cast<const char*>(p.B) + (long)(kbeg / BK) * stepB;
+  dma_issue8(oa, ob, ga, gb, sbase);
   dma_wait();
   __syncthreads();
 
@@ -363,9 +427,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const GemmP p) {
     const char* sa = smem + (t & 1) * STAGE_BYTES;
     const char* sb = sa + A_BYTES;
     if (t + 1 < nk) {
-      const uint32_t da = sbase + ((t + 1) & 1) * STAGE_BYTES;
-      dma_tile<TA>(p.A, p.lda, m0, p.M, M8, kbeg + (t + 1) * BK, da, wave, lane);
-      dma_tile<TB>(p.B, p.ldb, n0, p.N, N8, kbeg + (t + 1) * BK, da + A_BYTES, wave, lane);
+      ga += stepA; gb += stepB;
+      dma_issue8(oa, ob, ga, gb, sbase + ((t + 1) & 1) * STAGE_BYTES);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -984,7 +1047,9 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   // measured: the DMA loop wins for the transposed-operand variants (dgrad +5..18 %, wgrad +2..9 %) and, since the grouped tile walk,
   // for plain NT shapes too (tools/gemm_dma_ab.py: 8192x768x3072 61 -> 49 us, 3200x768x2048 35 -> 30 us, 8192x768x768 24 -> 21 us)
   const bool dma = v2s_opt_gemm_dma() != 0 && tr && (a->transA || a->transB || v2s_opt_gemm_dma() == 2) && (a->K % BK) == 0 && (p.kper % BK) == 0 &&
-                   a->M >= 8 && a->N >= 8;      // gemm_dma: 2 (default) = every variant, 1 = transposed-operand variants only
+                   a->M >= 8 && a->N >= 8 &&    // gemm_dma: 2 (default) = every variant, 1 = transposed-operand variants only
+                   (a->transA ? 64 * a->lda + a->M : (long)a->M * a->lda) < (1L << 31) &&     // per-lane source offsets are 32-bit byte offsets
+                   (a->transB ? 64 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 31);
   if (dma) g_last_gemm = !a->transB ? "gemm_dma_kernel<false, false>" : (!a->transA ? "gemm_dma_kernel<false, true>" : "gemm_dma_kernel<true, true>");
   else g_last_gemm = !a->transB ? "gemm_kernel<false, false, true>" : (!a->transA ? (tr ? "gemm_kernel<false, true, true>" : "gemm_kernel<false, true, false>")
                                                                                     : (tr ? "gemm_kernel<true, true, true>" : "gemm_kernel<true, true, false>"));
