@@ -172,9 +172,12 @@ __device__ __forceinline__ void state_store(char* stage, int tid, uint32_t flag)
 }
 
 // ====================================================================================== forward
-// block = 4 waves x 32 query rows; loop over 64-key tiles.
+// block = 4 waves x 32 query rows; loop over 64-key tiles.  Three blocks per CU (<= 168 VGPRs; a dozen cold spills in the bias
+// variants) instead of two: inside a wave the score MFMAs, the softmax VALU work and the PV MFMAs are serial, and only waves in
+// different phases overlap them, so a third wave per SIMD is worth 8-13 % (encoder layer 308 -> 284 us, tools/attn_ab.py).  The
+// causal variants spill into their hot path at that budget (28 -> 32 us) and stay at two.
 template <bool TR, bool BIAS, bool CAUSAL, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const AttnP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int nqb = (p.Nq + 127) >> 7;

@@ -308,30 +308,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst_unifor
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <bool T>
-__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ base, long ld, int row0, int R, int R8, int k0,
-                                         uint32_t tile_addr, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = wave * 4 + i;           // 1 KiB chunk of the 16 KiB tile
-    const bf16_t* src;
-    if (!T) {                             // [128 rows][64 k]: chunk = 8 rows x 128 B
-      const int row = c * 8 + (lane >> 3), pos = lane & 7;
-      const int chunk = pos ^ ((row >> 1) & 7);
-      int grow = row0 + row;
-      grow = grow < R ? grow : R - 1;
-      src = base + (long)grow * ld + k0 + chunk * 8;
-    } else {                              // [64 k][128 rows]: chunk = 4 k-rows x 256 B
-      const int k = c * 4 + (lane >> 4), pos16 = lane & 15;
-      const int c16 = ((((pos16 >> 1) ^ tr_g(k)) << 1) | (pos16 & 1));
-      int grow = row0 + c16 * 8;
-      grow = grow <= R8 - 8 ? grow : R8 - 8;
-      src = base + (long)(k0 + k) * ld + grow;
-    }
-    glds16(src, __builtin_amdgcn_readfirstlane(tile_addr + c * 1024));
-  }
-}
-
 // Per-lane SOURCE byte offset of 1 KiB chunk c of a tile, relative to (matrix base + the K offset of the tile): constant over the
 // K loop, so the loop only advances a scalar base (saddr form of the DMA: address = SGPR pair + 32-bit VGPR offset).
 template <bool T>
