@@ -141,7 +141,9 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // ---- LDS stage layout ---------------------------------------------------------------------------------
 constexpr int KV_TILE = 8192;                 // one [64][64] bf16 tile
 constexpr int OFF_BIAS = 2 * KV_TILE;         // 4 x 192 floats: copy s holds w[i+s] at index i
-constexpr int BIAS_COPY = 192;                // floats per copy
+constexpr int BIAS_COPY = 208;                // floats per copy: 192 used; 208 = 3 * 64 + 16 puts copy s 16 banks after copy s-1, so the
+                                              // four copies that lanes with consecutive diagonals read (same 4-float group, different shift)
+                                              // fall on different banks (at 192 they shared one 4-bank window: 4-way conflict on every read)
 constexpr int OFF_FLAG = OFF_BIAS + 4 * BIAS_COPY * 4;   // 64 key flags (0 keep, 1 masked, 2 out of range)
 constexpr int OFF_STATE = OFF_FLAG + 64;      // int[2]: OR of flags, AND of (flag != 0)
 constexpr int OFF_MS = OFF_STATE + 16;        // dkv kernel: (m + log2 l)[64], masked-element exponent[64], delta[64], dropout row seed[64]
