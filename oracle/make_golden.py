@@ -544,6 +544,148 @@ def case_parse():
     print(f"  OK  {len(cases)} cases; wrote tests/golden/parse_chapters.json")
 
 
+def load_reference_eval():
+    """Import the reference's dvc_eval package.  Its Java-backed pieces are absent (`.MISSING_LARGE_BLOBS`: meteor-1.5.jar, the Stanford
+    tokenizer jar) and pycocoevalcap is only vendored for cider/ and meteor/, so stand-ins are registered for exactly those imports:
+    a whitespace PTBTokenizer, and Meteor / Bleu / Rouge scorers that return zeros (their numbers are not used).  CIDEr, the
+    tIoU matching, the precision / recall code and all of SODA run from the reference's own files."""
+    if "dvc_eval" in sys.modules:
+        return sys.modules["dvc_eval"]
+    pkg = types.ModuleType("pycocoevalcap"); pkg.__path__ = [REF + "/dvc_eval/pycocoevalcap"]
+    sys.modules["pycocoevalcap"] = pkg
+    cpk = types.ModuleType("pycocoevalcap.cider"); cpk.__path__ = [REF + "/dvc_eval/pycocoevalcap/cider"]
+    sys.modules["pycocoevalcap.cider"] = cpk
+
+    class PTBTokenizer:                      # stand-in: the goldens are taken on text that is already tokenised
+        def tokenize(self, d):
+            return {k: [" ".join(c["caption"].split()) for c in v] for k, v in d.items()}
+
+    class _Zero:
+        def __init__(self, n=None): self.n = n
+        def method(self): return "stub"
+        def compute_score(self, gts, res):
+            if self.n:
+                return [0.0] * self.n, [[0.0] * len(gts)] * self.n
+            return 0.0, [0.0] * len(gts)
+
+    for name, attrs in (("tokenizer", None), ("tokenizer.ptbtokenizer", {"PTBTokenizer": PTBTokenizer}), ("meteor", None),
+                        ("meteor.meteor", {"Meteor": _Zero}), ("bleu", None), ("bleu.bleu", {"Bleu": _Zero}), ("rouge", None),
+                        ("rouge.rouge", {"Rouge": _Zero})):
+        m = types.ModuleType("pycocoevalcap." + name)
+        if attrs is None:
+            m.__path__ = []
+        else:
+            m.__dict__.update(attrs)
+        sys.modules["pycocoevalcap." + name] = m
+    sys.path.insert(0, REF)
+    return importlib.import_module("dvc_eval")
+
+
+def synth_eval_set(seed, n_videos=7):
+    """Seeded synthetic predictions / references in the json layout of dvc.py:218-233: sentences over a small vocabulary (so that
+    n-grams recur and the tf-idf weights are non-trivial), near-miss and far-off timestamps, a video without predictions, a video
+    without ground truth, unsorted predictions, a prediction without any overlap, identical sentences."""
+    rng = np.random.RandomState(seed)
+    vocab = ["add", "the", "flour", "mix", "eggs", "in", "a", "bowl", "pour", "batter", "pan", "cook", "until", "golden", "serve",
+             "with", "syrup", "intro", "outro", "chop", "onions", "and", "garlic", "stir", "sauce"]
+    def sent(n):
+        return " ".join(vocab[i] for i in rng.randint(0, len(vocab), n))
+    refs = [{}, {}]
+    preds = {}
+    for v in range(n_videos):
+        vid = f"vid{v}"
+        dur = float(rng.randint(60, 600))
+        ng = int(rng.randint(1, 7))
+        cuts = np.sort(rng.uniform(0, dur, ng + 1))
+        gts_t = [[float(cuts[i]), float(cuts[i + 1])] for i in range(ng)]
+        gts_s = [sent(rng.randint(2, 9)) for _ in range(ng)]
+        order = rng.permutation(ng)
+        refs[0][vid] = {"duration": dur, "timestamps": [gts_t[i] for i in order], "sentences": [gts_s[i] for i in order]}
+        if v % 3 == 0:                       # a second annotation file covers some of the videos
+            refs[1][vid] = {"duration": dur, "timestamps": [[t[0] * 0.9, min(dur, t[1] * 1.05)] for t in gts_t],
+                            "sentences": [sent(rng.randint(2, 9)) for _ in range(ng)]}
+        if v == 2:
+            preds[vid] = []                  # video with an empty prediction list
+            continue
+        if v == 5:
+            continue                         # video missing from the predictions
+        pr = []
+        for i in range(ng):
+            if rng.rand() < 0.8:
+                jit = rng.uniform(-0.2, 0.2, 2) * (gts_t[i][1] - gts_t[i][0])
+                s = gts_s[i] if rng.rand() < 0.4 else (gts_s[i] + " " + sent(2) if rng.rand() < 0.5 else sent(rng.randint(2, 9)))
+                st, en = max(0.0, gts_t[i][0] + jit[0]), min(dur, gts_t[i][1] + jit[1])
+                if en > st:
+                    pr.append({"sentence": s, "timestamp": [float(st), float(en)]})
+        pr.append({"sentence": sent(4), "timestamp": [dur + 5.0, dur + 9.0]})       # overlaps nothing
+        pr.append({"sentence": "caf\u00e9 " + sent(3), "timestamp": [0.0, dur]})      # non-ascii character, covers everything
+        rng.shuffle(pr)
+        preds[vid] = pr
+    preds["extra_video_without_gt"] = [{"sentence": sent(3), "timestamp": [0.0, 10.0]}]
+    return {"results": preds}, refs
+
+
+def case_eval():
+    print("[eval metrics] reference dvc_eval (CIDEr, tIoU matching, precision/recall, SODA_c with the Cider scorer)")
+    from oracle import eval_ref as E
+    de = load_reference_eval()
+    from dvc_eval.SODA.soda import SODA
+    from dvc_eval.SODA.dataset import ANETCaptions
+    from pycocoevalcap.cider.cider import Cider
+    tok = lambda s: " ".join(s.split())
+    out = {"cases": [], "cider": [], "dp": []}
+    # (1) the scorer alone
+    rng = np.random.RandomState(3)
+    for _ in range(4):
+        n = int(rng.randint(1, 6))
+        sub, _ = synth_eval_set(int(rng.randint(1 << 30)), 3)
+        sents = [p["sentence"] for v in sub["results"].values() for p in v][: 2 * n + 2]
+        hyps = sents[:n]
+        refs = [[sents[(i + 1 + k) % len(sents)] for k in range(1 + i % 2)] for i in range(n)]
+        mean, per = Cider().compute_score({i: r for i, r in enumerate(refs)}, {i: [h] for i, h in enumerate(hyps)})
+        m2, p2 = E.cider(hyps, refs)
+        assert abs(mean - m2) < 1e-12 and np.allclose(per, p2, atol=1e-12), (mean, m2)
+        out["cider"].append({"hyps": hyps, "refs": refs, "mean": float(mean), "scores": [float(x) for x in per]})
+    # (2) the DP alone (soda.py:156-191 through a bare instance)
+    soda = SODA.__new__(SODA)
+    for shape in ((1, 1), (1, 5), (4, 1), (3, 3), (5, 8), (9, 4)):
+        mat = rng.rand(*shape) * (rng.rand(*shape) < 0.6)
+        best, _ = soda.chased_dp_assignment(mat)
+        assert abs(best - E.dp_assignment(mat.tolist())) < 1e-12
+        out["dp"].append({"scores": mat.tolist(), "best": float(best)})
+    # (3) end to end
+    for seed in (11, 12, 13):
+        sub, refs = synth_eval_set(seed)
+        files = []
+        for r in refs:
+            f = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False); json.dump(r, f); f.close(); files.append(f.name)
+        import copy, io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref_dvc = de.eval_dvc(copy.deepcopy(sub), files, tious=[0.3, 0.5, 0.7, 0.9], max_proposals_per_video=1000, verbose=False, no_lang_eval=False)
+            ref_soda = []
+            for f in files:
+                data = ANETCaptions.from_load_files([f], copy.deepcopy(sub), multi_reference=False, verbose=False)
+                data.preprocess()
+                ref_soda.append(SODA(data, soda_type="c", tious=None, scorer="Cider", verbose=False).evaluate()["Cider"])
+        ref_dvc = {k: float(v) for k, v in ref_dvc.items() if k not in ("METEOR", "Rouge-L", "Bleu_1", "Bleu_2", "Bleu_3", "Bleu_4")}
+        got = E.eval_dvc(sub, refs, tok)
+        assert set(got) == set(ref_dvc), (sorted(got), sorted(ref_dvc))
+        for k in ref_dvc:
+            assert abs(got[k] - ref_dvc[k]) < 1e-9, (k, got[k], ref_dvc[k])
+        for r, want in zip(refs, ref_soda):
+            g = E.soda_c(sub, r, tok)
+            assert np.allclose(g, want, atol=1e-9), (g, want)
+        soda_c = float(np.mean([w[2] for w in ref_soda]))
+        assert abs(E.eval_soda(sub, refs, tok)["soda_c"] - soda_c) < 1e-9
+        print(f"  seed {seed}: CIDEr {ref_dvc['CIDEr']:.4f}  F1 {ref_dvc['F1']:.4f}  soda_c(Cider) {soda_c:.4f}  -- oracle == reference")
+        out["cases"].append({"submission": sub, "references": refs, "eval_dvc": ref_dvc, "soda_prf_per_reference": [[float(x) for x in w] for w in ref_soda],
+                             "soda_c": soda_c})
+        for f in files:
+            os.unlink(f)
+    json.dump(out, open(os.path.join(OUT, "eval_metrics.json"), "w"))
+    print("  OK  wrote tests/golden/eval_metrics.json")
+
+
 def case_full(v2s, B=2, L=256, Lo=256, seed=1234):
     print(f"[full-size cfg-1] t5-base, B={B} T=100 L={L} Lo={Lo}  (reference fp32 CPU)")
     cfg = R.RefConfig()
@@ -580,7 +722,11 @@ def case_full(v2s, B=2, L=256, Lo=256, seed=1234):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--only-eval", action="store_true", help="regenerate tests/golden/eval_metrics.json only")
     a = ap.parse_args()
+    if a.only_eval:
+        case_eval()
+        return
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
     mt5, v2s, vit = load_reference()
@@ -596,6 +742,7 @@ def main():
     case_beam(cfg)
     case_repetition_penalty(cfg)
     case_data()
+    case_eval()
     if not a.skip_full:
         case_full(v2s)
     print("ALL GOLDEN CASES OK")

@@ -321,3 +321,103 @@ def test_c_abi_exports_every_declared_symbol():
     # argument validation happens on the host before any launch: exercisable without a GPU
     a = L.GemmArgs()
     assert l.v2s_gemm(ctypes.byref(a), None) != 0 and b"v2s_gemm" in l.v2s_last_error()
+
+
+# ---------------------------------------------------------------------------------------------- evaluation metrics (§8f N4)
+def _eval_golden(golden_dir):
+    import json
+    return json.load(open(os.path.join(golden_dir, "eval_metrics.json")))
+
+
+_ws_tok = lambda s: " ".join(s.split())      # the goldens were taken on pre-tokenised text (PTB tokenizer jar absent everywhere)
+
+
+def test_eval_oracle_matches_reference_golden(golden_dir):
+    """oracle/eval_ref.py == the reference's own dvc_eval modules (CIDEr scorer, DP, eval_dvc, SODA with the Cider scorer)."""
+    from oracle import eval_ref as E
+    g = _eval_golden(golden_dir)
+    for c in g["cider"]:
+        mean, per = E.cider(c["hyps"], c["refs"])
+        assert abs(mean - c["mean"]) < 1e-12 and np.allclose(per, c["scores"], atol=1e-12)
+    for d in g["dp"]:
+        assert abs(E.dp_assignment(d["scores"]) - d["best"]) < 1e-12
+    for c in g["cases"]:
+        got = E.eval_dvc(c["submission"], c["references"], _ws_tok)
+        assert set(got) == set(c["eval_dvc"])
+        for k, v in c["eval_dvc"].items():
+            assert abs(got[k] - v) < 1e-9, k
+        assert abs(E.eval_soda(c["submission"], c["references"], _ws_tok)["soda_c"] - c["soda_c"]) < 1e-9
+
+
+def test_evalmetrics_matches_reference_golden(golden_dir, tmp_path):
+    """vidchapters_amd.evalmetrics (numpy) == reference goldens: every key of eval_dvc, SODA P/R/F per annotation file, scorer, DP;
+    json paths and dicts are both accepted like the reference's loaders."""
+    import json
+    from vidchapters_amd import evalmetrics as M
+    g = _eval_golden(golden_dir)
+    for c in g["cider"]:
+        mean, per = M.Cider().compute_score({i: r for i, r in enumerate(c["refs"])}, {i: [h] for i, h in enumerate(c["hyps"])})
+        assert abs(mean - c["mean"]) < 1e-12 and np.allclose(per, c["scores"], atol=1e-12)
+    for d in g["dp"]:
+        assert abs(M.dp_assignment(np.array(d["scores"])) - d["best"]) < 1e-12
+    for n, c in enumerate(g["cases"]):
+        sub, refs = c["submission"], c["references"]
+        if n == 0:                                   # file-based call, as dvc.py:218-233 does with --save_dir
+            sp = tmp_path / "pred.json"; sp.write_text(json.dumps(sub)); sub = str(sp)
+            rp = []
+            for i, r in enumerate(refs):
+                f = tmp_path / f"ref{i}.json"; f.write_text(json.dumps(r)); rp.append(str(f))
+            refs = rp
+        got = M.eval_dvc(sub, refs, tokenize=_ws_tok)
+        assert set(got) == set(c["eval_dvc"])
+        for k, v in c["eval_dvc"].items():
+            assert abs(got[k] - v) < 1e-9, (k, got[k], v)
+        for r, want in zip(refs, c["soda_prf_per_reference"]):
+            assert np.allclose(M.soda_c(sub, r, _ws_tok), want, atol=1e-9)
+        assert abs(M.eval_soda(sub, refs, tokenize=_ws_tok)["soda_c_cider"] - c["soda_c"]) < 1e-9
+        loc = M.eval_dvc(sub, refs, tokenize=_ws_tok, no_lang_eval=True)
+        assert "CIDEr" not in loc and all(abs(loc[k] - c["eval_dvc"][k]) < 1e-12 for k in loc)
+
+
+def test_evalmetrics_properties():
+    """Size-independent properties on a larger random set: DP == brute force over order-preserving matchings; the corpus-level scorer with
+    several references per item == the oracle; a scorer object passed to SODA goes through the reference's call convention and agrees
+    with the built-in matrix path; a perfect submission has precision = recall = 1 at every tIoU; error behaviour."""
+    import itertools
+    from vidchapters_amd import evalmetrics as M
+    from oracle import eval_ref as E
+    rng = np.random.RandomState(0)
+    for _ in range(30):
+        m, n = rng.randint(1, 6), rng.randint(1, 6)
+        s = rng.rand(m, n) * (rng.rand(m, n) < 0.7)
+        best = 0.0
+        for k in range(1, min(m, n) + 1):
+            for rows in itertools.combinations(range(m), k):
+                for cols in itertools.combinations(range(n), k):
+                    best = max(best, sum(s[r, c] for r, c in zip(rows, cols)))
+        assert abs(M.dp_assignment(s) - best) < 1e-12 and abs(E.dp_assignment(s.tolist()) - best) < 1e-12
+    vocab = [f"w{i}" for i in range(40)]
+    sent = lambda: " ".join(vocab[i] for i in rng.randint(0, 40, rng.randint(1, 12)))
+    gts = {i: [sent() for _ in range(1 + i % 3)] for i in range(200)}
+    res = {i: [gts[i][0] if i % 4 == 0 else sent()] for i in range(200)}
+    dense = M.Cider().compute_score(gts, res)
+    want = E.cider([res[i][0] for i in range(200)], [gts[i] for i in range(200)])
+    assert abs(dense[0] - want[0]) < 1e-10 and np.allclose(dense[1], want[1], atol=1e-10)
+    ref = {f"v{v}": {"timestamps": [[10.0 * i, 10.0 * i + 8] for i in range(5)], "sentences": [sent() for _ in range(5)]} for v in range(6)}
+    sub = {"results": {v: [{"sentence": s, "timestamp": list(t)} for t, s in zip(r["timestamps"], r["sentences"])] for v, r in ref.items()}}
+    out = M.eval_dvc(sub, [ref], tokenize=_ws_tok)
+    assert all(abs(out[f"{k}@{t}"] - 1.0) < 1e-12 for k in ("Recall", "Precision", "F1") for t in (0.3, 0.5, 0.7, 0.9))
+    a = M.soda_c(sub, ref, _ws_tok)
+    b = M.soda_c(sub, ref, _ws_tok, scorer=M.Cider())
+    assert np.allclose(a, b, atol=1e-10) and a[0] == pytest.approx(a[1])
+    assert "soda_c" in M.eval_soda(sub, [ref], tokenize=_ws_tok, scorer=M.Cider())
+    with pytest.raises(IOError):
+        M.eval_dvc(sub, [ref], tious=[])
+    with pytest.raises(IOError):
+        M.eval_dvc(sub, [])
+    with pytest.raises(ZeroDivisionError):
+        M.eval_dvc({"results": {"other": []}}, [ref], tokenize=_ws_tok)
+    vc = M.COCOEvalCap({i: {"sentence": res[i][0], "gt": gts[i][0]} for i in range(50)}, tokenize=_ws_tok)
+    r = vc.evaluate()
+    want = E.cider([gts[i][0] for i in range(50)], [[res[i][0]] for i in range(50)])[0]      # eval_vc.py:16-23: prediction is the reference side
+    assert abs(r["CIDEr"] - want) < 1e-10 and len(vc.evalImgs) == 50
