@@ -1,6 +1,6 @@
 """CPU restatement of the reference's dense-captioning evaluation: TEST INFRASTRUCTURE ONLY.
 
-Only tests/, oracle/make_golden.py and tools/eval_bench.py may import this module; the product implementation is
+Only tests/, oracle/make_golden.py and tests/tools/eval_bench.py may import this module; the product implementation is
 vidchapters_amd/evalmetrics.py.  Plain-Python loops over dicts, written to follow the reference's arithmetic step by step:
 
   * temporal IoU                      dvc_eval/eval_dvc.py:99-105, dvc_eval/SODA/utils.py:3-15

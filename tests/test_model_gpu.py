@@ -6,7 +6,7 @@ Stated tolerances: loss rel <= 2e-2; greedy tokens equal up to a 
 >= 0.975 per tensor on the reduced ("small") shapes and gradient-norm ratio within [0.9, 1.1].  Why 0.975 and not 0.99:
 on these tiny shapes (3 sequences x 24 tokens) the attention q/k/bias gradients are cancellation-dominated, and the
 reference math itself run under torch's bf16 autocast scores 0.977-0.990 against its own fp32 gradients on exactly
-these inputs (tools/bf16_noise.py); the HIP path measures 0.980-0.995.  At full size (t5-base, cfg-1) the per-tensor
+these inputs (tests/tools/bf16_noise.py); the HIP path measures 0.980-0.995.  At full size (t5-base, cfg-1) the per-tensor
 gradient norms are within 10 % and the total norm within 5 % of the reference.
 """
 import os

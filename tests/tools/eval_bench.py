@@ -1,8 +1,8 @@
 """Throughput of the evaluation post-processing (eval_dvc + eval_soda) on a synthetic test-set-sized job: numpy implementation
 (vidchapters_amd/evalmetrics.py) next to the plain-Python oracle port of the reference (oracle/eval_ref.py).  CPU only.
-usage: python tools/eval_bench.py [n_videos] [oracle_videos]"""
+usage: python tests/tools/eval_bench.py [n_videos] [oracle_videos]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from vidchapters_amd import evalmetrics as M
 from oracle import eval_ref as E
