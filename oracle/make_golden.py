@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import argparse
 import importlib
+import importlib.util
 import json
 import os
 import sys
@@ -544,6 +545,28 @@ def case_parse():
     print(f"  OK  {len(cases)} cases; wrote tests/golden/parse_chapters.json")
 
 
+def case_schedule():
+    """util/misc.py:15-42 adjust_learning_rate, run from the reference file itself: LR of every step for the three schedules."""
+    print("[LR schedule]")
+    spec = importlib.util.spec_from_file_location("ref_util_misc", REF + "/util/misc.py")
+    misc = importlib.util.module_from_spec(spec); spec.loader.exec_module(misc)
+    from vidchapters_amd.train import lr_at as prod_lr
+    out = []
+    for sched in ("", "linear_with_warmup", "cosine_with_warmup"):
+        for total, frac, lr in ((100, 0.1, 3e-4), (7, 0.1, 3e-4), (1, 0.1, 1e-3), (1000, 0.0, 3e-4), (33, 0.5, 7e-5)):
+            args = types.SimpleNamespace(fraction_warmup_steps=frac, schedule=sched, lr=lr)
+            opt = types.SimpleNamespace(param_groups=[{"lr": None}])
+            lrs = []
+            for step in range(total + 2):
+                misc.adjust_learning_rate(opt, step, total, args)
+                lrs.append(float(opt.param_groups[0]["lr"]))
+                assert R.lr_at(step, total, lr, sched, frac) == lrs[-1], (sched, total, frac, step, R.lr_at(step, total, lr, sched, frac), lrs[-1])
+                assert prod_lr(step, total, lr, sched, frac) == lrs[-1]
+            out.append({"schedule": sched, "total": total, "fraction_warmup_steps": frac, "lr": lr, "lrs": lrs})
+    json.dump(out, open(os.path.join(OUT, "lr_schedule.json"), "w"))
+    print(f"  OK  {len(out)} (schedule, length) cases bit-identical; wrote tests/golden/lr_schedule.json")
+
+
 def load_reference_eval():
     """Import the reference's dvc_eval package.  Its Java-backed pieces are absent (`.MISSING_LARGE_BLOBS`: meteor-1.5.jar, the Stanford
     tokenizer jar) and pycocoevalcap is only vendored for cider/ and meteor/, so stand-ins are registered for exactly those imports:
@@ -725,6 +748,7 @@ def main():
     ap.add_argument("--only-eval", action="store_true", help="regenerate tests/golden/eval_metrics.json only")
     a = ap.parse_args()
     if a.only_eval:
+        case_schedule()
         case_eval()
         return
     torch.manual_seed(0)
@@ -742,6 +766,7 @@ def main():
     case_beam(cfg)
     case_repetition_penalty(cfg)
     case_data()
+    case_schedule()
     case_eval()
     if not a.skip_full:
         case_full(v2s)

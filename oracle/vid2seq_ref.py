@@ -506,8 +506,10 @@ def lr_at(step: int, total: int, base_lr: float, schedule: str = "", warmup_frac
     warm = round(warmup_frac * total)
     if schedule == "":
         return base_lr
+    if schedule not in ("linear_with_warmup", "cosine_with_warmup"):
+        raise NotImplementedError(schedule)
     if step < warm:
-        return base_lr * float(step) / float(max(1, warm))
+        return base_lr * (float(step) / float(max(1, warm)))        # gamma first, like the reference: bit-identical LR
     if schedule == "linear_with_warmup":
         return base_lr * max(0.0, float(total - step) / float(max(1, total - warm)))
     if schedule == "cosine_with_warmup":

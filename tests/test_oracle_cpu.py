@@ -221,11 +221,16 @@ def test_parse_chapters_vs_reference(golden_dir):
         assert R.parse_chapters(case["text"], case["duration"], case["num_bins"]) == case["expected"]
 
 
-def test_lr_schedule_matches_oracle():
+def test_lr_schedule_vs_reference_golden(golden_dir):
+    """util/misc.py:15-42: the LR of every step, bit-identical to the reference function's (tests/golden/lr_schedule.json)."""
     from vidchapters_amd.train import lr_at
-    for sched in ("", "linear_with_warmup", "cosine_with_warmup"):
-        for step in (0, 1, 9, 10, 11, 57, 99, 100):
-            assert lr_at(step, 100, 3e-4, sched, 0.1) == R.lr_at(step, 100, 3e-4, sched, 0.1)
+    for c in json.load(open(os.path.join(golden_dir, "lr_schedule.json"))):
+        for step, want in enumerate(c["lrs"]):
+            a = (step, c["total"], c["lr"], c["schedule"], c["fraction_warmup_steps"])
+            assert lr_at(*a) == want and R.lr_at(*a) == want, (a, lr_at(*a), want)
+    for f in (lr_at, R.lr_at):
+        with pytest.raises(NotImplementedError):
+            f(0, 100, 3e-4, "step_decay", 0.1)
 
 
 def test_bucket_lut_matches_oracle():
