@@ -261,6 +261,8 @@ class Vid2Seq(nn.Module):
             # self.sampling_seed (torch's global RNG stream cannot be reproduced): same distribution, different samples.
             if num_captions != 1:
                 raise NotImplementedError("num_captions > 1 with nucleus sampling is not implemented")
+            if num_beams > 1:       # HF 4.28 would run beam-sample (multinomial beam search) for do_sample with num_beams > 1
+                raise NotImplementedError("nucleus sampling with num_beams > 1 (HF beam-sample) is not implemented; use num_beams <= 1")
             self.sampling_seed = (getattr(self, "sampling_seed", 0) + 1) & 0xFFFFFFFF
             toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length, repetition_penalty=repetition_penalty,
                               sample=(float(top_p), float(temperature), self.sampling_seed), min_length=min_length)
