@@ -274,6 +274,8 @@ class Vid2Seq(nn.Module):
                                    length_penalty=length_penalty, min_length=min_length, repetition_penalty=repetition_penalty,
                                    num_return=num_captions)
         else:
+            if min_length > 1:     # every caller passes 1 (a no-op); the argmax step kernel has no EOS ban
+                raise NotImplementedError("min_length > 1 with greedy decoding is not implemented (beam search and sampling honour it)")
             toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length, repetition_penalty=repetition_penalty)
         return self.t5_tokenizer.batch_decode(toks, skip_special_tokens=True)
 
