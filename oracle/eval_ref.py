@@ -12,7 +12,8 @@ vidchapters_amd/evalmetrics.py.  Plain-Python loops over dicts, written to follo
                                       data preparation dvc_eval/SODA/dataset.py:27-85; driver dvc_eval/eval_soda.py:5-43
 
 Pinned by tests/golden/eval_metrics.json, produced by running the reference's own modules (oracle/make_golden.py:case_eval) on seeded
-synthetic predictions.  NOT pinned: tokenisation and METEOR.  The reference tokenises with the Stanford PTBTokenizer jar and scores SODA
+synthetic predictions.  NOT pinned: tokenisation, METEOR, and the BLEU / ROUGE-L restatements (pycocoevalcap.bleu / .rouge are imported
+by the reference but not vendored in it).  The reference tokenises with the Stanford PTBTokenizer jar and scores SODA
 with the METEOR jar (pycocoevalcap, Java); neither jar is in the reference tree (`.MISSING_LARGE_BLOBS`) nor in this image, so the
 goldens are taken with a whitespace tokenizer stub and with the reference's own `Cider` choice of SODA scorer (soda.py:224).
 """
@@ -87,6 +88,62 @@ def cider(hyps: List[str], refs: List[List[str]], n: int = 4, sigma: float = 6.0
     return sum(scores) / len(scores), scores
 
 
+# ------------------------------------------------------------------------------------------- BLEU / ROUGE-L (UNPINNED)
+# The reference imports pycocoevalcap.bleu / .rouge (eval_dvc.py:21-22, eval_vc.py:2-4) but vendors neither; the two functions below restate
+# the published pycocoevalcap package (BleuScorer.compute_score(option='closest'), Rouge.calc_score with beta = 1.2).  No golden pins them.
+def bleu(hyps: List[str], refs: List[List[str]], n: int = 4) -> Tuple[List[float], List[List[float]]]:
+    small, tiny = 1e-9, 1e-15
+    tot_guess, tot_correct = [0] * n, [0] * n
+    tot_test = tot_ref = 0
+    per_item = [[] for _ in range(n)]
+    for h, rs in zip(hyps, refs):
+        hc, hl = _ngrams(h, n), len(h.split())
+        maxc: Dict[tuple, int] = {}
+        for r in rs:
+            for g, c in _ngrams(r, n).items():
+                maxc[g] = max(maxc.get(g, 0), c)
+        reflen = min((abs(len(r.split()) - hl), len(r.split())) for r in rs)[1]
+        guess = [max(0, hl - k) for k in range(n)]
+        correct = [0] * n
+        for g, c in hc.items():
+            correct[len(g) - 1] += min(maxc.get(g, 0), c)
+        tot_test += hl; tot_ref += reflen
+        b = 1.0
+        for k in range(n):
+            tot_guess[k] += guess[k]; tot_correct[k] += correct[k]
+            b *= (float(correct[k]) + tiny) / (float(guess[k]) + small)
+            per_item[k].append(b ** (1.0 / (k + 1)))
+        ratio = (hl + tiny) / (reflen + small)
+        if ratio < 1:
+            for k in range(n):
+                per_item[k][-1] *= math.exp(1 - 1 / ratio)
+    out, b = [], 1.0
+    for k in range(n):
+        b *= float(tot_correct[k] + tiny) / (tot_guess[k] + small)
+        out.append(b ** (1.0 / (k + 1)))
+    ratio = (tot_test + tiny) / (tot_ref + small)
+    if ratio < 1:
+        out = [x * math.exp(1 - 1 / ratio) for x in out]
+    return out, per_item
+
+
+def rouge_l(hyps: List[str], refs: List[List[str]], beta: float = 1.2) -> Tuple[float, List[float]]:
+    def lcs(a, b):
+        dp = [[0] * (len(b) + 1) for _ in range(len(a) + 1)]
+        for i in range(1, len(a) + 1):
+            for j in range(1, len(b) + 1):
+                dp[i][j] = dp[i - 1][j - 1] + 1 if a[i - 1] == b[j - 1] else max(dp[i - 1][j], dp[i][j - 1])
+        return dp[len(a)][len(b)]
+    scores = []
+    for h, rs in zip(hyps, refs):
+        tc = h.split(" ")
+        prec = [lcs(r.split(" "), tc) / float(len(tc)) for r in rs]
+        rec = [lcs(r.split(" "), tc) / float(len(r.split(" "))) for r in rs]
+        p, r = max(prec), max(rec)
+        scores.append((1 + beta ** 2) * p * r / float(r + beta ** 2 * p) if p != 0 and r != 0 else 0.0)
+    return sum(scores) / len(scores), scores
+
+
 # ------------------------------------------------------------------------------------------------- eval_dvc restated
 def _gt_video_ids(gts: List[dict]) -> List[str]:
     ids = set()
@@ -117,7 +174,7 @@ def detection(pred: Dict[str, list], gts: List[dict], thr: float, by_distance: b
     return sum(precision) / len(precision), sum(recall) / len(recall)
 
 
-def caption_score_at_tiou(pred: Dict[str, list], gts: List[dict], tiou: float, tokenize: Callable[[str], str]) -> float:
+def caption_score_at_tiou(pred: Dict[str, list], gts: List[dict], tiou: float, tokenize: Callable[[str], str], scorer=None):
     """eval_dvc.py:214-302 with the CIDEr scorer: every (prediction, ground-truth) pair with IoU >= tiou is one item; a prediction
     without any match is scored against a garbage reference (a random 10-20 letter word in the reference; here a unique token);
     CIDEr is computed PER VIDEO over its items (document frequencies from that video's items only) and averaged over videos."""
@@ -139,7 +196,12 @@ def caption_score_at_tiou(pred: Dict[str, list], gts: List[dict], tiou: float, t
             if not added:
                 hyps.append(tokenize(remove_nonascii(p["sentence"])))
                 refs.append([f"zzgarbage{pi}qq"])
-        per_video.append(cider(hyps, refs)[0] if hyps else 0.0)
+        if scorer is None:
+            per_video.append(cider(hyps, refs)[0] if hyps else 0.0)
+        else:                                   # unpinned scorers (BLEU: list of 4, ROUGE-L: float), eval_dvc.py:283-301
+            per_video.append(scorer(hyps, refs)[0] if hyps else ([0.0] * 4 if scorer is bleu else 0.0))
+    if scorer is bleu:
+        return [sum(v[k] for v in per_video) / len(per_video) for k in range(4)]
     return sum(per_video) / len(per_video)
 
 
@@ -150,6 +212,11 @@ def eval_dvc(submission: dict, references: List[dict], tokenize: Callable[[str],
     out: Dict[str, float] = {}
     cid = [caption_score_at_tiou(pred, references, t, tokenize) for t in tious]
     out["CIDEr"] = sum(cid) / len(cid)
+    bl = [caption_score_at_tiou(pred, references, t, tokenize, bleu) for t in tious]
+    for k in range(4):
+        out[f"Bleu_{k + 1}"] = sum(b[k] for b in bl) / len(bl)
+    rg = [caption_score_at_tiou(pred, references, t, tokenize, rouge_l) for t in tious]
+    out["Rouge-L"] = sum(rg) / len(rg)
     P, Rc, F = [], [], []
     for t, by_distance in [(t, False) for t in tious] + [(d, True) for d in distances]:
         p, r = detection(pred, references, t, by_distance)

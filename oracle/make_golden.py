@@ -692,7 +692,7 @@ def case_eval():
                 ref_soda.append(SODA(data, soda_type="c", tious=None, scorer="Cider", verbose=False).evaluate()["Cider"])
         ref_dvc = {k: float(v) for k, v in ref_dvc.items() if k not in ("METEOR", "Rouge-L", "Bleu_1", "Bleu_2", "Bleu_3", "Bleu_4")}
         got = E.eval_dvc(sub, refs, tok)
-        assert set(got) == set(ref_dvc), (sorted(got), sorted(ref_dvc))
+        assert set(got) - {"Bleu_1", "Bleu_2", "Bleu_3", "Bleu_4", "Rouge-L"} == set(ref_dvc), (sorted(got), sorted(ref_dvc))
         for k in ref_dvc:
             assert abs(got[k] - ref_dvc[k]) < 1e-9, (k, got[k], ref_dvc[k])
         for r, want in zip(refs, ref_soda):

@@ -334,6 +334,7 @@ def _eval_golden(golden_dir):
     return json.load(open(os.path.join(golden_dir, "eval_metrics.json")))
 
 
+_UNPINNED = {"Bleu_1", "Bleu_2", "Bleu_3", "Bleu_4", "Rouge-L"}      # pycocoevalcap.bleu / .rouge are not vendored in the reference
 _ws_tok = lambda s: " ".join(s.split())      # the goldens were taken on pre-tokenised text (PTB tokenizer jar absent everywhere)
 
 
@@ -348,7 +349,7 @@ def test_eval_oracle_matches_reference_golden(golden_dir):
         assert abs(E.dp_assignment(d["scores"]) - d["best"]) < 1e-12
     for c in g["cases"]:
         got = E.eval_dvc(c["submission"], c["references"], _ws_tok)
-        assert set(got) == set(c["eval_dvc"])
+        assert set(got) - _UNPINNED == set(c["eval_dvc"])
         for k, v in c["eval_dvc"].items():
             assert abs(got[k] - v) < 1e-9, k
         assert abs(E.eval_soda(c["submission"], c["references"], _ws_tok)["soda_c"] - c["soda_c"]) < 1e-9
@@ -374,9 +375,13 @@ def test_evalmetrics_matches_reference_golden(golden_dir, tmp_path):
                 f = tmp_path / f"ref{i}.json"; f.write_text(json.dumps(r)); rp.append(str(f))
             refs = rp
         got = M.eval_dvc(sub, refs, tokenize=_ws_tok)
-        assert set(got) == set(c["eval_dvc"])
+        assert set(got) - _UNPINNED == set(c["eval_dvc"])
         for k, v in c["eval_dvc"].items():
             assert abs(got[k] - v) < 1e-9, (k, got[k], v)
+        from oracle import eval_ref as E
+        want = E.eval_dvc(c["submission"], c["references"], _ws_tok)        # BLEU / ROUGE-L: product == plain-Python restatement (unpinned)
+        for k in _UNPINNED:
+            assert abs(got[k] - want[k]) < 1e-9, (k, got[k], want[k])
         for r, want in zip(refs, c["soda_prf_per_reference"]):
             assert np.allclose(M.soda_c(sub, r, _ws_tok), want, atol=1e-9)
         assert abs(M.eval_soda(sub, refs, tokenize=_ws_tok)["soda_c_cider"] - c["soda_c"]) < 1e-9
@@ -424,5 +429,19 @@ def test_evalmetrics_properties():
         M.eval_dvc({"results": {"other": []}}, [ref], tokenize=_ws_tok)
     vc = M.COCOEvalCap({i: {"sentence": res[i][0], "gt": gts[i][0]} for i in range(50)}, tokenize=_ws_tok)
     r = vc.evaluate()
-    want = E.cider([gts[i][0] for i in range(50)], [[res[i][0]] for i in range(50)])[0]      # eval_vc.py:16-23: prediction is the reference side
-    assert abs(r["CIDEr"] - want) < 1e-10 and len(vc.evalImgs) == 50
+    hy, rf = [gts[i][0] for i in range(50)], [[res[i][0]] for i in range(50)]                 # eval_vc.py:16-23: prediction is the reference side
+    assert abs(r["CIDEr"] - E.cider(hy, rf)[0]) < 1e-10 and len(vc.evalImgs) == 50
+    bl, bls = E.bleu(hy, rf)
+    assert all(abs(r[f"Bleu_{k + 1}"] - bl[k]) < 1e-10 for k in range(4)) and abs(r["ROUGE_L"] - E.rouge_l(hy, rf)[0]) < 1e-10
+    # BLEU / ROUGE-L scorer objects: per-item values == the plain-Python restatement; hand-checked values of the published definitions
+    hyps = ["the cat sat on the mat", "a dog runs", "", "x y z w", "same same"]
+    refs = [["the cat sat on the mat"], ["a dog barks loudly"], ["hello world"], ["w z y x"], ["same"]]
+    g2, r2 = {i: r for i, r in enumerate(refs)}, {i: [h] for i, h in enumerate(hyps)}
+    b, bi = M.Bleu(4).compute_score(g2, r2)
+    wb, wbi = E.bleu(hyps, refs)
+    assert np.allclose(b, wb, atol=1e-12) and np.allclose(bi, wbi, atol=1e-12)
+    assert bi[0][1] == pytest.approx(2 / 3 * np.exp(1 - 4 / 3), abs=1e-6) and bi[1][1] == pytest.approx(np.sqrt(2 / 3 * 1 / 2) * np.exp(1 - 4 / 3), abs=1e-6)
+    rg, ri = M.Rouge().compute_score(g2, r2)
+    wr, wri = E.rouge_l(hyps, refs)
+    assert abs(rg - wr) < 1e-12 and np.allclose(ri, wri, atol=1e-12)
+    assert ri[0] == pytest.approx(1.0) and ri[1] == pytest.approx(2.44 * (2 / 3) * 0.5 / (0.5 + 1.44 * 2 / 3)) and ri[2] == 0.0

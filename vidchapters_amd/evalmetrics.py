@@ -18,7 +18,9 @@ What is NOT reproduced, because the reference itself shells out to Java for it a
 (`.MISSING_LARGE_BLOBS`) nor in this image: METEOR, and the Stanford PTB tokenizer.  `ptb_tokenize` below is an approximation of the
 latter (lower-casing, punctuation split off and dropped like pycocoevalcap's PUNCTUATIONS list); pass `tokenize=` to use another one.
 SODA_c is therefore computed with the reference's own alternative scorer choice `Cider` (soda.py:224) and reported under the key
-`soda_c_cider`; METEOR, BLEU and ROUGE-L are absent from the `eval_dvc` result.  Parity with the reference's modules (run on
+`soda_c_cider`; METEOR is absent from the results.  BLEU-1..4 and ROUGE-L are computed, but pycocoevalcap's bleu/ and rouge/ are not
+vendored in the reference either: they are restated from the published package and their parity is UNPINNED (hand-checked cases and
+the plain-Python restatement in the oracle only).  Parity with the reference's modules (run on
 pre-tokenised text): tests/golden/eval_metrics.json, tests/test_oracle_cpu.py.
 """
 from __future__ import annotations
@@ -74,6 +76,7 @@ def _ngram_csr(sentences: Sequence[str], n: int = 4):
         rank = np.zeros(len(flat), np.int64)
         rank[idx] = inv
         mats.append(sp.coo_matrix((np.ones(len(idx)), (sid[idx], inv)), shape=(S + 1, max(len(uniq), 1))).tocsr())   # duplicates are summed
+    _ngram_csr.words = (flat, np.cumsum(lens) - lens, lens)        # word ids of the last corpus, for the LCS of ROUGE-L
     return mats, np.concatenate((np.maximum(lens - 1, 0), [0])).astype(np.float64)
 
 
@@ -117,6 +120,62 @@ def _group_df(dkey: np.ndarray, NC: int, doc_id: np.ndarray, doc_group: np.ndarr
     return np.unique(group_of_doc[dkey // NC] * NC + dkey % NC, return_counts=True)
 
 
+def _bleu_batch(mats, words, h_rows: np.ndarray, r_rows: np.ndarray, item_group: np.ndarray, n_groups: int) -> np.ndarray:
+    """Corpus-level BLEU-1..n of every group over its (hypothesis, single reference) items, [n_groups, n]: clipped n-gram matches and
+    guesses summed per group, brevity penalty on the summed lengths -- pycocoevalcap's BleuScorer.compute_score(option='closest') as
+    called through Bleu(4).compute_score at eval_dvc.py:286 / eval_vc.py:60 (the scorer itself is not vendored in the reference:
+    restated from the published package, parity unpinned).  A garbage reference (row = last) is one word long and matches nothing."""
+    n = len(mats)
+    lens = np.concatenate((words[2], [1])).astype(np.float64)
+    N = len(h_rows)
+    correct = np.zeros((n_groups, n)); guess = np.zeros((n_groups, n))
+    for k, S in enumerate(mats):
+        NC = S.shape[1]
+        H, R = S[h_rows].tocoo(), S[r_rows].tocoo()
+        _, ih, ir = np.intersect1d(H.row.astype(np.int64) * NC + H.col, R.row.astype(np.int64) * NC + R.col, assume_unique=True, return_indices=True)
+        correct[:, k] = np.bincount(item_group[H.row[ih]], np.minimum(H.data[ih], R.data[ir]), n_groups)
+        guess[:, k] = np.bincount(item_group, np.maximum(0.0, lens[h_rows] - k), n_groups)
+    testlen = np.bincount(item_group, lens[h_rows], n_groups)
+    reflen = np.bincount(item_group, lens[r_rows], n_groups)
+    bleus = np.cumprod((correct + 1e-15) / (guess + 1e-9), axis=1) ** (1.0 / np.arange(1, n + 1))
+    ratio = (testlen + 1e-15) / (reflen + 1e-9)
+    return bleus * np.where(ratio < 1, np.exp(1 - 1 / ratio), 1.0)[:, None]
+
+
+def _rouge_batch(words, h_rows: np.ndarray, r_rows: np.ndarray, beta: float = 1.2) -> np.ndarray:
+    """ROUGE-L F-score (beta = 1.2) of N (hypothesis, single reference) items: LCS by a dynamic program that advances all items
+    together (one vector step per hypothesis position; the dependence along the reference is a running maximum).  pycocoevalcap's
+    Rouge.calc_score (not vendored in the reference: restated from the published package, parity unpinned), incl. its
+    `split(" ")`: an empty sentence is one empty token."""
+    flat, starts, lens = words
+    S = len(lens)
+
+    def padded(rows, fill):
+        ln = np.where(rows < S, lens[np.minimum(rows, S - 1)], 1)             # garbage row: one word that matches nothing
+        L = max(int(ln.max()) if len(ln) else 1, 1)
+        out = np.full((len(rows), L), fill, np.int64)
+        j = np.arange(L)[None, :]
+        ok = (j < ln[:, None]) & (rows < S)[:, None]
+        src = np.minimum(starts[np.minimum(rows, S - 1)][:, None] + j, max(len(flat) - 1, 0))
+        if len(flat):
+            out[ok] = flat[src[ok]]
+        empty = (rows < S) & (ln == 0)
+        out[empty, 0] = -3                                                      # '' == '' (split(" ") of an empty string)
+        out[rows >= S, 0] = -4
+        return out, np.maximum(ln, 1).astype(np.float64)
+
+    Hs, lh = padded(h_rows, -1)
+    Rs, lr = padded(r_rows, -2)
+    dp = np.zeros((len(h_rows), Rs.shape[1] + 1))
+    for i in range(Hs.shape[1]):
+        eq = Hs[:, i:i + 1] == Rs
+        dp[:, 1:] = np.maximum.accumulate(np.maximum(dp[:, 1:], np.where(eq, dp[:, :-1] + 1, 0.0)), axis=1)
+    lcs = dp[:, -1]
+    p, r = lcs / lh, lcs / lr
+    den = r + beta ** 2 * p
+    return np.where((p != 0) & (r != 0), (1 + beta ** 2) * p * r / np.where(den != 0, den, 1.0), 0.0)
+
+
 class Cider:
     """pycocoevalcap-compatible scorer object (dvc_eval/pycocoevalcap/cider/cider.py:12-53): compute_score(gts, res) with
     gts[id] = list of tokenised reference strings, res[id] = [tokenised hypothesis]; one corpus, any number of references per item."""
@@ -142,6 +201,46 @@ class Cider:
         pair = _cider_batch(mats, bigrams, owner, r_rows, zeros, r_rows, owner, zeros, np.array([H]), self._sigma)
         scores = np.bincount(owner, pair, H) / np.bincount(owner, minlength=H)
         return float(scores.mean()), scores
+
+
+def _single_ref_corpus(gts: Dict, res: Dict):
+    ids = list(gts.keys())
+    assert gts.keys() == res.keys()
+    for i in ids:
+        assert type(res[i]) is list and len(res[i]) == 1
+        assert type(gts[i]) is list and len(gts[i]) == 1, "the batched BLEU / ROUGE-L scorers take one reference per item (all call sites of the reference do)"
+    H = len(ids)
+    mats, _ = _ngram_csr([res[i][0] for i in ids] + [gts[i][0] for i in ids])
+    return H, mats, _ngram_csr.words
+
+
+class Bleu:
+    """pycocoevalcap-compatible Bleu(n).compute_score(gts, res) -> ([BLEU-1..n], per-item lists); one reference per item."""
+
+    def __init__(self, n: int = 4):
+        self._n = n
+
+    def method(self) -> str:
+        return "Bleu"
+
+    def compute_score(self, gts: Dict, res: Dict):
+        H, mats, words = _single_ref_corpus(gts, res)
+        h, r = np.arange(H), H + np.arange(H)
+        corpus = _bleu_batch(mats[:self._n], words, h, r, np.zeros(H, np.int64), 1)[0]
+        per_item = _bleu_batch(mats[:self._n], words, h, r, h, H)
+        return [float(x) for x in corpus], [per_item[:, k].tolist() for k in range(self._n)]
+
+
+class Rouge:
+    """pycocoevalcap-compatible Rouge().compute_score(gts, res) -> (mean ROUGE-L, per-item array); one reference per item."""
+
+    def method(self) -> str:
+        return "Rouge"
+
+    def compute_score(self, gts: Dict, res: Dict):
+        H, _, words = _single_ref_corpus(gts, res)
+        sc = _rouge_batch(words, np.arange(H), H + np.arange(H))
+        return float(sc.mean()), sc
 
 
 # ------------------------------------------------------------------------------------------------------------ localisation
@@ -262,6 +361,12 @@ def eval_dvc(submission, references, tious=[0.3, 0.5, 0.7, 0.9], distances=[1, 3
         sc = _cider_batch(mats, bigrams, h, r, grp, r, np.arange(len(r)), grp, n_items)
         per_group = np.bincount(grp, sc, len(tious) * NV) / np.maximum(n_items, 1)          # videos without predictions score 0
         out["CIDEr"] = float(per_group.reshape(len(tious), NV).mean(1).mean())
+        # BLEU-1..4 (corpus-level per video) and ROUGE-L (mean per video), averaged like CIDEr (eval_dvc.py:283-301); unpinned restatements
+        bl = _bleu_batch(mats, _ngram_csr.words, h, r, grp, len(tious) * NV) * (n_items > 0)[:, None]
+        for k in range(4):
+            out[f"Bleu_{k + 1}"] = float(bl[:, k].reshape(len(tious), NV).mean(1).mean())
+        rg = np.bincount(grp, _rouge_batch(_ngram_csr.words, h, r), len(tious) * NV) / np.maximum(n_items, 1)
+        out["Rouge-L"] = float(rg.reshape(len(tious), NV).mean(1).mean())
     for i, x in enumerate(tious):
         out[f"Recall@{x}"], out[f"Precision@{x}"], out[f"F1@{x}"] = float(R[i]), float(P[i]), float(F[i])
     out["Recall"], out["Precision"], out["F1"] = float(R[:4].mean()), float(P[:4].mean()), float(F[:4].mean())
@@ -347,10 +452,18 @@ class COCOEvalCap:
         self.evalImgs: List = []
 
     def evaluate(self) -> Dict[str, float]:
-        score, scores = Cider().compute_score(self.gts, self.res)
-        self.eval["CIDEr"] = score
-        # eval_vc.py:67-72 pairs the scores with sorted(ids) although they were computed in dict order; kept
-        for k, s in zip(sorted(self.gts.keys()), scores):
-            self.imgToEval.setdefault(k, {"image_id": k})["CIDEr"] = float(s)
+        out: Dict[str, float] = {}
+
+        def put(name, score, scores):
+            out[name] = self.eval[name] = score
+            # eval_vc.py:67-72 pairs the scores with sorted(ids) although they were computed in dict order; kept
+            for k, s in zip(sorted(self.gts.keys()), scores):
+                self.imgToEval.setdefault(k, {"image_id": k})[name] = float(s)
+
+        bl, bls = Bleu(4).compute_score(self.gts, self.res)
+        for k in range(4):
+            put(f"Bleu_{k + 1}", bl[k], bls[k])
+        put("ROUGE_L", *Rouge().compute_score(self.gts, self.res))
+        put("CIDEr", *Cider().compute_score(self.gts, self.res))
         self.evalImgs = [self.imgToEval[k] for k in sorted(self.imgToEval.keys())]
-        return {"CIDEr": score}
+        return out
