@@ -55,7 +55,7 @@ def ptb_tokenize(text: str) -> str:
 
 # ------------------------------------------------------------------------------------------------------------ CIDEr-D
 def _ngram_csr(sentences: Sequence[str], n: int = 4):
-    """sentences: tokenised strings.  Returns (mats, bigrams): mats[k-1] = CSR count matrix [len(sentences) + 1, V_k] of the k-grams
+    """sentences: tokenised strings.  Returns (mats, bigrams, words): mats[k-1] = CSR count matrix [len(sentences) + 1, V_k] of the k-grams
     (the extra last row is empty: the 'garbage' reference of eval_dvc.py:253-259), bigrams[s] = number of 2-grams of sentence s, which is
     what the reference uses as the sentence length (cider_scorer.py:127-128).  No per-n-gram Python work: word ids -> k-gram keys
     rank(k-1 gram) * V + next word, re-ranked by np.unique at every order so that the keys stay below 2^62."""
@@ -76,8 +76,8 @@ def _ngram_csr(sentences: Sequence[str], n: int = 4):
         rank = np.zeros(len(flat), np.int64)
         rank[idx] = inv
         mats.append(sp.coo_matrix((np.ones(len(idx)), (sid[idx], inv)), shape=(S + 1, max(len(uniq), 1))).tocsr())   # duplicates are summed
-    _ngram_csr.words = (flat, np.cumsum(lens) - lens, lens)        # word ids of the last corpus, for the LCS of ROUGE-L
-    return mats, np.concatenate((np.maximum(lens - 1, 0), [0])).astype(np.float64)
+    words = (flat, np.cumsum(lens) - lens, lens)                    # word ids, sentence starts and lengths (BLEU lengths, LCS of ROUGE-L)
+    return mats, np.concatenate((np.maximum(lens - 1, 0), [0])).astype(np.float64), words
 
 
 def _cider_batch(mats, bigrams: np.ndarray, h_rows: np.ndarray, r_rows: np.ndarray, item_group: np.ndarray, doc_rows: np.ndarray,
@@ -195,7 +195,7 @@ class Cider:
         H = len(ids)
         flat = [r for i in ids for r in gts[i]]
         owner = np.repeat(np.arange(H), [len(gts[i]) for i in ids])
-        mats, bigrams = _ngram_csr([res[i][0] for i in ids] + flat, self._n)
+        mats, bigrams, _ = _ngram_csr([res[i][0] for i in ids] + flat, self._n)
         r_rows = H + np.arange(len(flat))
         zeros = np.zeros(len(flat), np.int64)
         pair = _cider_batch(mats, bigrams, owner, r_rows, zeros, r_rows, owner, zeros, np.array([H]), self._sigma)
@@ -210,8 +210,8 @@ def _single_ref_corpus(gts: Dict, res: Dict):
         assert type(res[i]) is list and len(res[i]) == 1
         assert type(gts[i]) is list and len(gts[i]) == 1, "the batched BLEU / ROUGE-L scorers take one reference per item (all call sites of the reference do)"
     H = len(ids)
-    mats, _ = _ngram_csr([res[i][0] for i in ids] + [gts[i][0] for i in ids])
-    return H, mats, _ngram_csr.words
+    mats, _, words = _ngram_csr([res[i][0] for i in ids] + [gts[i][0] for i in ids])
+    return H, mats, words
 
 
 class Bleu:
@@ -357,15 +357,15 @@ def eval_dvc(submission, references, tious=[0.3, 0.5, 0.7, 0.9], distances=[1, 3
             grp += [ti * NV + p_vid[pi[m]], ti * NV + p_vid[lone]]
         h, r, grp = np.concatenate(h), np.concatenate(r), np.concatenate(grp)
         n_items = np.bincount(grp, minlength=len(tious) * NV)
-        mats, bigrams = _ngram_csr(sents.rows)
+        mats, bigrams, words = _ngram_csr(sents.rows)
         sc = _cider_batch(mats, bigrams, h, r, grp, r, np.arange(len(r)), grp, n_items)
         per_group = np.bincount(grp, sc, len(tious) * NV) / np.maximum(n_items, 1)          # videos without predictions score 0
         out["CIDEr"] = float(per_group.reshape(len(tious), NV).mean(1).mean())
         # BLEU-1..4 (corpus-level per video) and ROUGE-L (mean per video), averaged like CIDEr (eval_dvc.py:283-301); unpinned restatements
-        bl = _bleu_batch(mats, _ngram_csr.words, h, r, grp, len(tious) * NV) * (n_items > 0)[:, None]
+        bl = _bleu_batch(mats, words, h, r, grp, len(tious) * NV) * (n_items > 0)[:, None]
         for k in range(4):
             out[f"Bleu_{k + 1}"] = float(bl[:, k].reshape(len(tious), NV).mean(1).mean())
-        rg = np.bincount(grp, _rouge_batch(_ngram_csr.words, h, r), len(tious) * NV) / np.maximum(n_items, 1)
+        rg = np.bincount(grp, _rouge_batch(words, h, r), len(tious) * NV) / np.maximum(n_items, 1)
         out["Rouge-L"] = float(rg.reshape(len(tious), NV).mean(1).mean())
     for i, x in enumerate(tious):
         out[f"Recall@{x}"], out[f"Precision@{x}"], out[f"F1@{x}"] = float(R[i]), float(P[i]), float(F[i])
@@ -411,7 +411,7 @@ def soda_c(submission, reference, tokenize: Optional[Callable[[str], str]] = Non
     gi, pi = g_off[blk] + ga, p_off[blk] + pb
     weight = _iou(p_ts[pi], g_ts[gi])
     if scorer is None:
-        mats, bigrams = _ngram_csr(sents.rows)
+        mats, bigrams, _ = _ngram_csr(sents.rows)
         p_vid = np.repeat(np.arange(NV), p_cnt)
         weight = weight * _cider_batch(mats, bigrams, g_row[gi], p_row[pi], blk, p_row, np.arange(len(p_row)), p_vid, p_cnt)
     pair_off = np.cumsum(g_cnt * p_cnt) - g_cnt * p_cnt
