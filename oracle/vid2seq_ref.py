@@ -417,33 +417,24 @@ class _BeamHyps:
 
 
 @torch.no_grad()
-def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_beams: int = 4, max_new_tokens: int = 256,
-                  length_penalty: float = 1.0, min_length: int = 1, repetition_penalty: float = 1.0, num_return_sequences: int = 1):
-    """vid2seq.py:150-162 with num_beams>1, do_sample=False, early_stopping=False, num_return_sequences=1:
-    transformers==4.28.0 GenerationMixin.beam_search + BeamSearchScorer (un-vendored dependency -> restated from the
-    published algorithm; *parity unpinned by reference tests*, cross-checked against the installed transformers'
-    generate in oracle/make_golden.py).  Returns int64 [B, <= 1+max_new_tokens] (start token first, pad after EOS)."""
-    memory, mem_mask, _ = encode(P, cfg, video, input_ids, input_mask)
-    B, nb = memory.shape[0], num_beams
-    V = P["t5_model.shared.weight"].shape[0]
-    max_length = max_new_tokens + 1
-    mem = memory.repeat_interleave(nb, 0)
-    mmask = mem_mask.repeat_interleave(nb, 0)
-    seq = torch.full((B * nb, 1), cfg.dec_start_id, dtype=torch.long)
+def beam_search_core(step_logp, B: int, nb: int, V: int, eos_id: int, pad_id: int, start_id: int, max_length: int,
+                     length_penalty: float = 1.0, min_length: int = 1, repetition_penalty: float = 1.0, num_return_sequences: int = 1):
+    """transformers==4.28.0 GenerationMixin.beam_search + BeamSearchScorer (early_stopping=False) over an arbitrary next-token model:
+    ``step_logp(seq, beam_idx)`` returns log-softmax scores [B*nb, V] for the sequences ``seq`` ([B*nb, len]); ``beam_idx`` (None at the
+    first call) is the row permutation that produced ``seq`` from the previous call's rows (for reordering a cache)."""
+    seq = torch.full((B * nb, 1), start_id, dtype=torch.long)
     beam_scores = torch.zeros(B, nb)
     beam_scores[:, 1:] = -1e9
     beam_scores = beam_scores.view(-1)
     hyps = [_BeamHyps(nb, length_penalty) for _ in range(B)]
     done = [False] * B
-    past = None
+    bidx = None
     while True:
-        step_in = seq if past is None else seq[:, -1:]
-        h, past = t5_decoder(P, cfg, step_in, torch.ones(B * nb, seq.shape[1], dtype=torch.long), mem, mmask, past=past, use_cache=True)
-        logp = torch.log_softmax(lm_logits(P, cfg, h[:, -1:]).squeeze(1).float(), dim=-1)
+        logp = step_logp(seq, bidx)
         if repetition_penalty != 1.0:                                 # beam_search: processors run on the log-probabilities
             repetition_penalty_(logp, seq, repetition_penalty)
         if seq.shape[-1] < min_length:                         # MinLengthLogitsProcessor (applied to the log-probs in 4.28 beam_search)
-            logp[:, cfg.eos_id] = -float("inf")
+            logp[:, eos_id] = -float("inf")
         logp = logp + beam_scores[:, None]
         top_s, top_i = torch.topk(logp.view(B, nb * V), 2 * nb, dim=1, largest=True, sorted=True)
         nidx, ntok = top_i // V, top_i % V
@@ -451,12 +442,12 @@ def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_b
         new_scores = torch.zeros(B, nb); new_tok = torch.zeros(B, nb, dtype=torch.long); new_idx = torch.zeros(B, nb, dtype=torch.long)
         for b in range(B):
             if done[b]:
-                new_tok[b] = cfg.pad_id
+                new_tok[b] = pad_id
                 continue
             k = 0
             for rank in range(2 * nb):
                 t, sc, bi = int(ntok[b, rank]), float(top_s[b, rank]), b * nb + int(nidx[b, rank])
-                if t == cfg.eos_id:
+                if t == eos_id:
                     if rank >= nb:
                         continue
                     hyps[b].add(seq[bi].clone(), sc)
@@ -468,7 +459,6 @@ def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_b
             done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len)
         beam_scores, bt, bidx = new_scores.view(-1), new_tok.view(-1), new_idx.view(-1)
         seq = torch.cat([seq[bidx], bt[:, None]], -1)
-        past = [tuple(x.index_select(0, bidx) for x in layer) for layer in past]      # modeling_t5.py:1771-1793
         if all(done) or seq.shape[-1] >= max_length:
             break
     for b in range(B):                                                              # BeamSearchScorer.finalize
@@ -482,12 +472,37 @@ def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_b
         best += [srt.pop()[1] for _ in range(num_return_sequences)]
     lens = [len(x) for x in best]
     out_len = min(max(lens) + 1, max_length)
-    out = torch.full((len(best), out_len), cfg.pad_id, dtype=torch.long)
+    out = torch.full((len(best), out_len), pad_id, dtype=torch.long)
     for b, hyp in enumerate(best):
         out[b, :lens[b]] = hyp
         if lens[b] < out_len:
-            out[b, lens[b]] = cfg.eos_id
+            out[b, lens[b]] = eos_id
     return out
+
+
+def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_beams: int = 4, max_new_tokens: int = 256,
+                  length_penalty: float = 1.0, min_length: int = 1, repetition_penalty: float = 1.0, num_return_sequences: int = 1):
+    """vid2seq.py:150-162 with num_beams>1, do_sample=False, early_stopping=False, num_return_sequences=1:
+    transformers==4.28.0 GenerationMixin.beam_search + BeamSearchScorer (un-vendored dependency -> restated from the
+    published algorithm; *parity unpinned by reference tests*, cross-checked against the installed transformers'
+    generate in oracle/make_golden.py).  Returns int64 [B, <= 1+max_new_tokens] (start token first, pad after EOS)."""
+    memory, mem_mask, _ = encode(P, cfg, video, input_ids, input_mask)
+    B, nb = memory.shape[0], num_beams
+    V = P["t5_model.shared.weight"].shape[0]
+    mem = memory.repeat_interleave(nb, 0)
+    mmask = mem_mask.repeat_interleave(nb, 0)
+    state = {"past": None}
+
+    def step_logp(seq, bidx):
+        past = state["past"]
+        if past is not None:
+            past = [tuple(x.index_select(0, bidx) for x in layer) for layer in past]      # modeling_t5.py:1771-1793
+        step_in = seq if past is None else seq[:, -1:]
+        h, state["past"] = t5_decoder(P, cfg, step_in, torch.ones(B * nb, seq.shape[1], dtype=torch.long), mem, mmask, past=past, use_cache=True)
+        return torch.log_softmax(lm_logits(P, cfg, h[:, -1:]).squeeze(1).float(), dim=-1)
+
+    return beam_search_core(step_logp, B, nb, V, cfg.eos_id, cfg.pad_id, cfg.dec_start_id, max_new_tokens + 1, length_penalty,
+                            min_length, repetition_penalty, num_return_sequences)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -155,6 +155,43 @@ def test_host_beam_scorer_matches_oracle(golden_dir):
 
 
 
+def test_host_beam_scorer_matches_oracle_on_random_markov_models():
+    """200 random next-token models (EOS-heavy, short and long runs, 2-5 beams, several length penalties, 1..nb returned hypotheses,
+    min_length): the product's host BeamScorer, fed per-beam top-2nb candidates like the device kernel provides them, returns exactly
+    the hypotheses of the oracle's HF-4.28 restatement (oracle.beam_search_core)."""
+    from vidchapters_amd.beam import BeamScorer
+    rng = np.random.RandomState(0)
+    eos, pad, start = 1, 0, 0
+    for case in range(200):
+        V, nb, B = int(rng.randint(6, 14)), int(rng.randint(2, 6)), int(rng.randint(1, 4))
+        max_new = int(rng.randint(2, 12))
+        lp = float(rng.choice([1.0, 0.6, 2.0, 0.0]))
+        n_ret = int(rng.randint(1, nb + 1))
+        min_len = int(rng.choice([1, 1, 3]))
+        table = torch.from_numpy(rng.randn(B, V, V).astype(np.float32) * 2.0)
+        table[:, :, eos] += float(rng.choice([-1.0, 1.0, 3.0]))                         # how eager the model is to stop
+        drift = torch.from_numpy(rng.randn(max_new + 2, V).astype(np.float32))
+        row_b = torch.arange(B).repeat_interleave(nb)
+
+        def logp_of(seq):
+            return torch.log_softmax(table[row_b, seq[:, -1]] + drift[seq.shape[1]], -1)
+
+        want = R.beam_search_core(lambda seq, bidx: logp_of(seq), B, nb, V, eos, pad, start, max_new + 1, lp, min_len, 1.0, n_ret)
+        sc = BeamScorer(B, nb, lp, eos, pad, start, max_new + 1)
+        finished = False
+        while not finished:
+            seq = torch.from_numpy(sc.seqs[:, :sc.cur_len])
+            lg = logp_of(seq)
+            if sc.cur_len < min_len:
+                lg[:, eos] = -float("inf")
+            lg = lg + torch.from_numpy(sc.scores.reshape(-1))[:, None]
+            v, t = torch.topk(lg, min(2 * nb, V), dim=1)
+            _, _, finished = sc.advance(v.numpy(), t.numpy().astype(np.int32))
+        got = torch.from_numpy(sc.finalize(n_ret))
+        assert got.shape == want.shape and torch.equal(got, want), (case, V, nb, B, max_new, lp, n_ret, got.tolist(), want.tolist())
+
+
+
 def test_oracle_train_recipe_vs_reference(golden_dir):
     """Two steps of the reference's own dvc.train_one_epoch (captured) vs oracle.train_step."""
     g = np.load(os.path.join(golden_dir, "small_train_recipe.npz"))
