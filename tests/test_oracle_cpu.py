@@ -252,6 +252,42 @@ def test_data_oracle_and_host_pipeline_vs_reference_golden(golden_dir):
     assert seq.tolist() == [32100, 32124, 11, 12, 13, 32124, 32189, 1]
 
 
+def test_data_host_helpers_match_oracle_on_random_inputs():
+    """Randomised sweep (300 cases) of the host side of the input pipeline against oracle/data_ref.py (itself pinned against the
+    reference's functions by tests/golden/data_pipeline.npz): frame subsampling / padding incl. n == max_feats and n == 1, time
+    tokens at the edges, sequence assembly with truncation and the empty case, noise masks under the same numpy RNG state, and the
+    closed-form corrupted lengths against the actual span corruption."""
+    from vidchapters_amd import data as D
+    from oracle import data_ref as O
+    rng = np.random.RandomState(1)
+    for case in range(300):
+        n, mf, dim = int(rng.randint(1, 400)), int(rng.choice([1, 7, 100, 128])), 6
+        fr = rng.randn(n, dim).astype(np.float32 if case % 2 else np.float64)
+        assert np.array_equal(D.subsample_or_pad(fr, mf), O.get_video(fr, mf))
+        dur, nb, ntt = float(rng.uniform(1, 4000)), int(rng.choice([2, 50, 100])), 32100
+        x = float(rng.choice([0.0, dur, rng.uniform(0, dur)]))
+        assert D.time_tokenize(x, dur, nb, ntt) == O.time_tokenize(x, dur, nb, ntt)
+        nseg = int(rng.randint(0, 6))
+        times = [tuple(sorted(rng.uniform(0, dur, 2))) for _ in range(nseg)]
+        texts = [rng.randint(2, 32100, rng.randint(0, 9)).tolist() for _ in range(nseg)]
+        mt = int(rng.choice([2, 8, 1000]))
+        assert np.array_equal(D.assemble_sequence(times, texts, dur, nb, ntt, mt, 1), O.assemble(times, texts, dur, nb, ntt, mt, 1))
+        L_ = int(rng.randint(2, 300))
+        seed = int(rng.randint(1 << 30))
+        np.random.seed(seed); a = D.random_spans_noise_mask(L_, 0.25, 5.0)
+        np.random.seed(seed); b = O.random_spans_noise_mask(L_, 0.25, 5.0)
+        assert np.array_equal(a, b)
+        toks = rng.randint(2, 32100, L_).astype(np.int64)
+        den_in, den_out = O.span_corrupt(toks, a, ntt, 1)
+        assert D.corrupted_lengths(a) == (len(den_in), len(den_out))
+    assert D.corrupted_lengths(np.zeros(1, bool)) == (1, 1)
+    with pytest.raises(ValueError):
+        D.time_tokenize(250.0, 1.0, 100, 32100)            # dvc_dataset.py:92 asserts; here a ValueError
+    seqs = [rng.randint(1, 9, rng.randint(1, 12)) for _ in range(5)]
+    assert np.array_equal(D.pad_ids(seqs).numpy(), O.collate(seqs))
+
+
+
 def test_parse_chapters_vs_reference(golden_dir):
     for case in json.load(open(os.path.join(golden_dir, "parse_chapters.json"))):
         assert parse_chapters(case["text"], case["duration"], case["num_bins"]) == case["expected"]
