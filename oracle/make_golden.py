@@ -525,6 +525,12 @@ def case_parse():
         ("<time=3> <time=4> a  b   c <time=", 10.0, 100),
         ("", 10.0, 100),
     ]
+    rng = np.random.RandomState(4)                              # + 80 random strings over the pieces that matter to the regex / pairing
+    pieces = ["<time=%d>" % k for k in (0, 1, 5, 17, 50, 98, 99)] + ["intro", "how", "to", "mix", "eggs", "<time=", "<", ">", "a<b", "x>y", " ", "  "]
+    for _ in range(80):
+        n = int(rng.randint(0, 14))
+        toks = [pieces[i] if rng.rand() < 0.6 else pieces[int(rng.randint(0, 7))] for i in rng.randint(0, len(pieces), n)]
+        cases.append((" ".join(toks), float(rng.choice([10.0, 123.4, 3600.0])), int(rng.choice([100, 50]))))
     # the reference has no function for this (inline loop dvc.py:186-212); run that loop body verbatim-in-spirit by
     # exec'ing it from the reference source so expected values come from reference code, not from the restatement
     src = open(REF + "/dvc.py").read().splitlines()
@@ -535,9 +541,15 @@ def case_parse():
     for text, dur, nb in cases:
         env = {"re": re, "output": [text], "i": 0, "vid": "v", "res": {}, "duration": [dur],
                "args": types.SimpleNamespace(num_bins=nb)}
-        exec(code, env)
-        exp = env["res"]["v"]
-        got = R.parse_chapters(text, dur, nb)
+        try:
+            exec(code, env)
+            exp = env["res"]["v"]
+        except AssertionError:                                  # dvc.py:197-200 asserts that both time tokens parse ("<time=" alone does not)
+            exp = "AssertionError"
+        try:
+            got = R.parse_chapters(text, dur, nb)
+        except AssertionError:
+            got = "AssertionError"
         assert got == exp, (text, got, exp)
         out.append({"text": text, "duration": dur, "num_bins": nb, "expected": exp})
     os.makedirs(OUT, exist_ok=True)

@@ -289,9 +289,17 @@ def test_data_host_helpers_match_oracle_on_random_inputs():
 
 
 def test_parse_chapters_vs_reference(golden_dir):
-    for case in json.load(open(os.path.join(golden_dir, "parse_chapters.json"))):
-        assert parse_chapters(case["text"], case["duration"], case["num_bins"]) == case["expected"]
-        assert R.parse_chapters(case["text"], case["duration"], case["num_bins"]) == case["expected"]
+    """dvc.py:186-212 (the golden is produced by running that loop body from the reference source): 8 hand-written and 80 random strings,
+    incl. the malformed ones on which the reference's own asserts fire."""
+    cases = json.load(open(os.path.join(golden_dir, "parse_chapters.json")))
+    assert len(cases) >= 80
+    for case in cases:
+        for f in (parse_chapters, R.parse_chapters):
+            if case["expected"] == "AssertionError":
+                with pytest.raises(AssertionError):
+                    f(case["text"], case["duration"], case["num_bins"])
+            else:
+                assert f(case["text"], case["duration"], case["num_bins"]) == case["expected"]
 
 
 def test_lr_schedule_vs_reference_golden(golden_dir):
