@@ -288,6 +288,41 @@ def test_data_host_helpers_match_oracle_on_random_inputs():
 
 
 
+def test_real_sentencepiece_tokenizer_roundtrip_to_chapters(tmp_path):
+    """_get_tokenizer (vid2seq.py:10-18) on a REAL sentencepiece model (trained here in a second; the t5-base spiece.model is not
+    available offline): vocabulary = pieces + 100 sentinels + num_bins time tokens with the time tokens last, like t5-base's 32100 +
+    100; and the decode used by generate() gives the 4.28-style spaced text the chapter parser needs, whatever transformers is installed."""
+    import random
+    import sentencepiece as spm
+    from vidchapters_amd import _get_tokenizer
+    from vidchapters_amd.tokenizer import batch_decode_spaced
+    words = "intro how to mix eggs and flour in a bowl pour the batter into pan cook until golden serve with syrup outro".split()
+    random.seed(0)
+    corpus = tmp_path / "corpus.txt"
+    corpus.write_text("\n".join(" ".join(random.choice(words) for _ in range(random.randint(3, 12))) for _ in range(2000)))
+    d = tmp_path / "t5-tiny"; d.mkdir()
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(d / "spiece"), vocab_size=64, model_type="unigram", pad_id=0, eos_id=1,
+                                   unk_id=2, bos_id=-1, hard_vocab_limit=False, minloglevel=2)
+    tok = _get_tokenizer(str(d), 100)
+    base = len(tok) - 100
+    assert tok.pad_token_id == 0 and tok.eos_token_id == 1
+    assert tok.convert_tokens_to_ids([f"<time={i}>" for i in (0, 57, 99)]) == [base, base + 57, base + 99]
+    text = "<time=5> <time=7> how to mix eggs <time=7> <time=99> pour the batter"
+    ids = tok(text, return_tensors="pt")["input_ids"]
+    assert ids[0, -1] == 1 and ids[0, 0] == base + 5 and ids[0, 1] == base + 7
+    out = batch_decode_spaced(tok, torch.cat([ids, torch.zeros(1, 3, dtype=torch.long)], 1))          # EOS + pad tail like generate() returns
+    assert out == [text]
+    ch = parse_chapters(out[0], 100.0, 100)
+    assert [c["sentence"] for c in ch] == ["how to mix eggs", "pour the batter"]
+    assert ch[0]["timestamp"] == [5 * 100.0 / 99, 7 * 100.0 / 99] and ch[1]["timestamp"] == [7 * 100.0 / 99, 100.0]
+    with pytest.raises(NotImplementedError):
+        _get_tokenizer(str(tmp_path / "bert-base"), 100)
+    from vidchapters_amd import SyntheticTokenizer
+    st = SyntheticTokenizer(32100, 100)
+    assert batch_decode_spaced(st, [[32105, 32107, 17, 1, 0]]) == st.batch_decode([[32105, 32107, 17, 1, 0]]) == ["<time=5> <time=7> w17"]
+
+
+
 def test_parse_chapters_vs_reference(golden_dir):
     """dvc.py:186-212 (the golden is produced by running that loop body from the reference source): 8 hand-written and 80 random strings,
     incl. the malformed ones on which the reference's own asserts fire."""

@@ -23,6 +23,7 @@ import torch
 from torch import nn
 
 from . import synth
+from .tokenizer import batch_decode_spaced
 
 T5_CONFIGS = {   # HF hub config.json values (not shipped with the reference)
     "t5-small": dict(d_model=512, d_kv=64, heads=8, d_ff=2048, n_enc=6, n_dec=6),
@@ -266,7 +267,7 @@ class Vid2Seq(nn.Module):
             self.sampling_seed = (getattr(self, "sampling_seed", 0) + 1) & 0xFFFFFFFF
             toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length, repetition_penalty=repetition_penalty,
                               sample=(float(top_p), float(temperature), self.sampling_seed), min_length=min_length)
-            return self.t5_tokenizer.batch_decode(toks, skip_special_tokens=True)
+            return batch_decode_spaced(self.t5_tokenizer, toks, skip_special_tokens=True)
         if num_captions != 1 and num_beams <= 1:
             raise ValueError("num_captions > 1 needs beam search (HF: greedy search returns one sequence)")
         if num_beams > 1:
@@ -277,7 +278,7 @@ class Vid2Seq(nn.Module):
             if min_length > 1:     # every caller passes 1 (a no-op); the argmax step kernel has no EOS ban
                 raise NotImplementedError("min_length > 1 with greedy decoding is not implemented (beam search and sampling honour it)")
             toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length, repetition_penalty=repetition_penalty)
-        return self.t5_tokenizer.batch_decode(toks, skip_special_tokens=True)
+        return batch_decode_spaced(self.t5_tokenizer, toks, skip_special_tokens=True)
 
 
 def build_vid2seq_model(args, tokenizer) -> Vid2Seq:
