@@ -45,9 +45,16 @@ const char* v2s_last_error(void);
  *   "gemm_order"    GM > 0: grouped tile walk, GM tile rows deep, K slices tile-major (default 4: the blocks an XCD runs together share
  *                   operand slabs in its L2; +20..40 % on the split-K weight gradients), 0: row-major with adjacent K slices
  *   "gemm_split"    1: split-K slice count from the rounds x length cost model (default), 0: fixed block-count target
+ *   "gemm_p8"       8-phase ping-pong kernel (256-row tiles, counted vmcnt LDS-DMA ring): 1: where it measured faster (default),
+ *                   0: never, 2: 256x256 tiles wherever legal, 3: 256x128 tiles wherever legal
  *   "attn_bwd_part" 0: v2s_attn_bwd launches dQ and dK/dV kernels (default), 1: dQ only, 2: dK/dV only (per-kernel timing) */
 int v2s_set_option(const char* name, int value);
 int v2s_get_option(const char* name);
+
+/* sizeof() of an argument struct ("v2s_gemm_args", "v2s_attn_args", "v2s_adam_args", "v2s_decode_attn_args") as this library was
+ * compiled, -1 for an unknown name.  A binding compares it with the size of its own struct definition before the first call: a
+ * definition that is one field short would make the library read past the caller's buffer. */
+int64_t v2s_sizeof(const char* struct_name);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM:  C[M,N] (+)= epilogue( alpha * sum_k A(m,k) * B(n,k) )

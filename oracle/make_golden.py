@@ -16,6 +16,7 @@ import importlib
 import importlib.util
 import json
 import os
+import re
 import sys
 import tempfile
 import types
@@ -67,6 +68,10 @@ def load_reference_dvc():
         return importlib.import_module("dvc")
     finally:
         sys.path.remove(REF)
+        # the path-less stand-ins must not outlive this import: case_data / case_eval import the real packages
+        for name in ("dataset", "dvc_eval"):
+            if getattr(sys.modules.get(name), "__file__", None) is None and not hasattr(sys.modules.get(name), "__path__"):
+                sys.modules.pop(name, None)
 
 
 class StubTokenizer:
@@ -754,10 +759,87 @@ def case_full(v2s, B=2, L=256, Lo=256, seed=1234):
         grad_norm_keys=np.array(list(gn.keys())), grad_norm_vals=np.array(list(gn.values())))
 
 
+def grad_sample(name: str, g: torch.Tensor) -> torch.Tensor:
+    """Deterministic strided sample of a gradient tensor (<= ~130k elements) -- the SAME rule is applied by the GPU tests
+    (tests/test_configs_gpu.py:grad_sample), so that a fixture of a few hundred kB pins the direction of 289 M / 737 M gradients."""
+    if g.dim() <= 1 or g.numel() <= 65536:
+        return g.clone()
+    if g.dim() == 3:                                    # pos_embed [1, T, C]
+        return g[:, :, ::6].clone()
+    if name.endswith("shared.weight"):
+        return g[::32, ::6].clone()
+    r = max(1, g.shape[0] // 128)
+    c = max(1, g.shape[1] // 128)
+    return g[::r, ::c].clone()
+
+
+SLICE_KEYS = ("SelfAttention.q.weight", "SelfAttention.v.weight", "SelfAttention.o.weight", "EncDecAttention.k.weight", "EncDecAttention.q.weight",
+              "DenseReluDense.wi.weight", "DenseReluDense.wo.weight", "attn.qkv.weight", "mlp.fc2.weight", "attn.proj.weight")
+
+
+def wants_slice(name: str, n_layers: int) -> bool:
+    """Gradient tensors whose sampled VALUES go into the big-shape fixtures: every 1-D tensor and bias table, the embedding, the
+    position embedding, proj_v2t, and the 2-D weights of the first / middle / last block of each stack."""
+    if name.endswith(("layer_norm.weight", "relative_attention_bias.weight", ".bias", "norm.weight", "norm1.weight", "norm2.weight",
+                      "shared.weight", "pos_embed", "proj_v2t.weight")):
+        return True
+    m = re.search(r"\.(block|blocks)\.(\d+)\.", name)
+    if m is None:
+        return False
+    i = int(m.group(2))
+    nl = 12 if "visual_encoder" in name else n_layers
+    return i in (0, nl // 2, nl - 1) and name.endswith(SLICE_KEYS)
+
+
+def case_shape(v2s, tag, cfg, B, T, L, Lo, seed, check_oracle=True):
+    """Big-shape goldens straight from the reference (fp32 CPU): loss, total and per-tensor gradient norms and strided gradient samples.
+    cfg-2 shape (t5-base, 100 frames, 1000 ASR tokens, 256 targets) and the t5-large / cfg-5 shape (200 frames x 2000 tokens: the
+    proj_v2t branch at d_model 1024, 24+24 layers)."""
+    import re as _re  # noqa: F401
+    print(f"[{tag}] d_model={cfg.d_model} layers={cfg.n_enc}+{cfg.n_dec} B={B} T={T} L={L} Lo={Lo}  (reference fp32 CPU)")
+    P = oracle_params(cfg, seed, grad=False)
+    m = build_ref_model(v2s, cfg, P)
+    batch = synth.make_batch(B, T, L, Lo, cfg.vocab, seed, cfg.vit_dim)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    loss_ref, vd = ref_forward(m, batch)
+    if check_oracle:
+        with torch.no_grad():
+            lg, tgt, _ = R.vid2seq_logits(P, cfg, batch["video"], batch["input_ids"], batch["input_ids"] != 0,
+                                          batch["output_ids"], batch["output_ids"] != 0)
+            loss = R.smoothed_ce(lg, tgt, cfg.label_smoothing)
+        print(f"  loss oracle={loss.item():.7f} ref={loss_ref.item():.7f}")
+        assert abs(loss.item() - loss_ref.item()) <= 5e-6 * abs(loss_ref.item())
+        del lg
+    loss_ref.backward()
+    named = dict(m.named_parameters())
+    arrs = {"seed": seed, "B": B, "T": T, "L": L, "Lo": Lo, "loss": loss_ref.detach(),
+            "memory_slice": vd["video"][:, ::max(1, T // 8), :32].detach()}
+    keys, vals, tot = [], [], 0.0
+    for k in P:
+        rk = k if k in named else next(n for n in named if named[n] is m.t5_model.shared.weight)
+        g = named[rk].grad
+        g = g if g is not None else torch.zeros_like(P[k])
+        keys.append(k); vals.append(float(g.norm())); tot += vals[-1] ** 2
+        if wants_slice(k, cfg.n_enc):
+            arrs["gs:" + k] = grad_sample(k, g)
+    arrs["grad_norm"] = tot ** 0.5
+    arrs["grad_norm_keys"], arrs["grad_norm_vals"] = np.array(keys), np.array(vals)
+    print(f"  total grad norm = {tot ** 0.5:.6f}; {sum(1 for k in arrs if k.startswith('gs:'))} sampled gradient tensors")
+    npz(f"{tag}_scalars.npz", **arrs)
+
+
+def case_shapes(v2s):
+    case_shape(v2s, "full_cfg2", R.RefConfig(), B=2, T=100, L=1000, Lo=256, seed=2024)
+    large = R.RefConfig(d_model=1024, d_kv=64, heads=16, d_ff=4096, n_enc=24, n_dec=24, num_features=200)
+    case_shape(v2s, "large_cfg5", large, B=1, T=200, L=2000, Lo=256, seed=2025)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-eval", action="store_true", help="regenerate tests/golden/eval_metrics.json only")
+    ap.add_argument("--only-shapes", action="store_true", help="regenerate the big-shape goldens (cfg-2 shape, t5-large / cfg-5 shape) only")
     a = ap.parse_args()
     if a.only_eval:
         case_schedule()
@@ -766,6 +848,9 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
     mt5, v2s, vit = load_reference()
+    if a.only_shapes:
+        case_shapes(v2s)
+        return
     case_functions(mt5)
     case_parse()
     cfg = R.RefConfig.small()
@@ -782,6 +867,7 @@ def main():
     case_eval()
     if not a.skip_full:
         case_full(v2s)
+        case_shapes(v2s)
     print("ALL GOLDEN CASES OK")
 
 

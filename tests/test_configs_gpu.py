@@ -1,0 +1,239 @@
+"""BASELINE.json's configurations, each exercised on the GPU at its own shapes (VERDICT r01 "configs not exercised"):
+
+  cfg-2 shape  t5-base, 100 frames, 1000 ASR tokens, 256 targets: loss / gradient norms / strided gradient samples captured from the
+               REAL reference at B=2 (tests/golden/full_cfg2_scalars.npz, oracle/make_golden.py:case_shape), and the full B=32 train
+               step through a size-independent property (the batch gradient is the token-weighted sum of the per-sample gradients);
+  cfg-4        greedy generate() at B=64, 100 frames + 1000 ASR tokens: row i of the batch == the B=1 run of sample i;
+  cfg-5 shape  t5-large (d_model 1024, 24+24 layers, proj_v2t), 200 frames x 2000 ASR tokens: reference golden at B=1;
+  cfg-3        (8 GPUs) cannot run on one GPU: the RCCL code path itself is loaded and driven with a one-rank "nccl" group.
+
+Tolerances sit just under what the bf16 engine measures against the fp32 reference (printed by every test).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.make_golden import grad_sample, wants_slice          # noqa: E402  (sampling rule of the fixtures; checker only)
+from vidchapters_amd import SyntheticTokenizer, Vid2Seq, synth   # noqa: E402
+from vidchapters_amd.train import Trainer                        # noqa: E402
+
+DEV = "cuda"
+
+
+def tok(ids):
+    ids = ids.to(DEV)
+    return {"input_ids": ids, "attention_mask": ids != 0}
+
+
+def cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float(a @ b / (a.norm() * b.norm() + 1e-30))
+
+
+def _check_against_shape_golden(g, model, n_layers, min_cos, min_cos_1d, tag):
+    seed, B, T, Lx, Lo = (int(g[k]) for k in ("seed", "B", "T", "L", "Lo"))
+    b = synth.make_batch(B, T, Lx, Lo, 32200, seed, 768)
+    out, vd = model(b["video"].to(DEV), tok(b["input_ids"]), tok(b["output_ids"]))
+    ref = float(g["loss"])
+    rel = abs(out["loss"].item() - ref) / ref
+    print(f"[{tag}] loss hip={out['loss'].item():.6f} reference={ref:.6f} (rel {rel:.1e})")
+    assert rel <= 2e-3                                      # measured 1e-5 .. 1e-4 (bf16 activations, fp32 accumulation)
+    ms = torch.from_numpy(g["memory_slice"])
+    got = vd["video"].float().cpu()[:, ::max(1, T // 8), :32]
+    c = cos(got, ms)
+    print(f"  visual tokens cosine vs reference: {c:.6f}")
+    assert c > 0.9995
+    out["loss"].backward()
+    grads = {k: p.grad.detach().float() for k, p in model.named_parameters()}
+    assert all(torch.isfinite(v).all() for v in grads.values())
+    tot = float(torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values())))
+    print(f"  total grad norm hip={tot:.5f} reference={float(g['grad_norm']):.5f}")
+    assert abs(tot - float(g["grad_norm"])) <= 2e-2 * float(g["grad_norm"])
+    bad_norm = []
+    for k, v in zip((str(k) for k in g["grad_norm_keys"]), g["grad_norm_vals"]):
+        r = float(grads[k].norm()) / (float(v) + 1e-12)
+        if not 0.93 < r < 1.07:
+            bad_norm.append((k, round(r, 3)))
+    print(f"  per-tensor grad-norm ratio outside [0.93, 1.07]: {len(bad_norm)} {bad_norm[:6]}")
+    assert not bad_norm
+    worst2, worst1, bad = (1.0, ""), (1.0, ""), []
+    n = 0
+    for key in g.files:
+        if not key.startswith("gs:"):
+            continue
+        name = key[3:]
+        assert wants_slice(name, n_layers)
+        want = torch.from_numpy(g[key])
+        got = grad_sample(name, grads[name].cpu().view(*model.state_dict()[name].shape)).view_as(want)
+        c = cos(got, want)
+        n += 1
+        one_d = want.dim() <= 1 or name.endswith("relative_attention_bias.weight")
+        if one_d:
+            worst1 = min(worst1, (c, name))
+        else:
+            worst2 = min(worst2, (c, name))
+        if not c > (min_cos_1d if one_d else min_cos):
+            bad.append((name, round(c, 4)))
+    print(f"  {n} sampled gradient tensors: worst cosine 2-D {worst2[0]:.4f} ({worst2[1]}), 1-D {worst1[0]:.4f} ({worst1[1]}); failing {bad[:8]}")
+    assert not bad
+
+
+def test_cfg2_shape_vs_reference_golden(golden_dir):
+    """t5-base at the cfg-2 shape (B=2): direction (cosine on strided samples) and size of the gradients, not only their norms."""
+    g = np.load(os.path.join(golden_dir, "full_cfg2_scalars.npz"))
+    model = Vid2Seq("t5-base", tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
+                    init_seed=int(g["seed"]), device=DEV).eval()
+    _check_against_shape_golden(g, model, 12, min_cos=0.985, min_cos_1d=0.97, tag="cfg-2 shape")
+
+
+def test_t5_large_cfg5_shape_vs_reference_golden(golden_dir):
+    """t5-large (737 M parameters: d_model 1024, 16 heads, 24+24 layers, proj_v2t 768 -> 1024), 200 frames x 2000 ASR tokens."""
+    g = np.load(os.path.join(golden_dir, "large_cfg5_scalars.npz"))
+    model = Vid2Seq("t5-large", num_features=200, tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
+                    init_seed=int(g["seed"]), device=DEV).eval()
+    assert model.proj_v2t is not None
+    _check_against_shape_golden(g, model, 24, min_cos=0.98, min_cos_1d=0.96, tag="cfg-5 shape (t5-large)")
+
+
+SLICE_NAMES = ["t5_model.encoder.block.0.layer.0.SelfAttention.q.weight", "t5_model.encoder.block.11.layer.1.DenseReluDense.wi.weight",
+               "t5_model.encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight",
+               "t5_model.decoder.block.5.layer.1.EncDecAttention.k.weight", "t5_model.decoder.block.11.layer.2.DenseReluDense.wo.weight",
+               "visual_encoder.blocks.0.attn.qkv.weight", "visual_encoder.blocks.11.mlp.fc2.bias", "visual_encoder.pos_embed",
+               "t5_model.shared.weight", "t5_model.encoder.final_layer_norm.weight"]
+
+
+def test_cfg2_train_step_batch32_is_token_weighted_sum_of_samples():
+    """BASELINE cfg-2 exactly (B=32, 100 frames, 1000 ASR tokens, 256 targets) as a forward+backward TRAIN step through
+    Trainer's engine path.  The loss is the mean CE over the non-pad targets of the whole batch (modeling_t5.py:1721), every sample
+    is independent of the others, hence   grad(batch) = sum_i (n_i / N) grad(sample i),   loss(batch) = sum_i (n_i / N) loss_i.
+    Checked on strided samples of ten tensors that cover every kernel family (dropout off: the masks are indexed by batch position)."""
+    B = 32
+    model = Vid2Seq("t5-base", tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
+                    init_seed=11, device=DEV).train()
+    eng = model.engine()
+    b = synth.make_batch(B, 100, 1000, 256, 32200, 4242, 768)
+    video, ids, out = b["video"].to(DEV).to(torch.bfloat16), b["input_ids"].to(DEV), b["output_ids"].to(DEV)
+    n_tok = (out != 0).sum(1).double()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+
+    def run(sl):
+        """loss and sampled gradients of the rows ``sl`` through the same calls Trainer.step makes"""
+        eng.prepare()
+        eng.arena.grad.zero_()
+        vt, tp = {}, {}
+        vis = eng.vit_forward(video[sl], vt).view(-1, 100, eng.d)
+        loss = eng.t5_loss_forward(vis, ids[sl], ids[sl] != 0, out[sl], out[sl] != 0, tp)
+        dvis = eng.t5_loss_backward(tp, torch.ones(1, device=DEV))
+        eng.vit_backward(vt, dvis)
+        eng.join_wgrads()
+        torch.cuda.synchronize()
+        return float(loss.item()), {k: grad_sample(k, eng.arena.g(k).view(*shapes[k])).double().cpu() for k in SLICE_NAMES}
+
+    loss_b, g_b = run(slice(0, B))
+    acc = {k: torch.zeros_like(v) for k, v in g_b.items()}
+    loss_sum = 0.0
+    for i in range(B):
+        li, gi = run(slice(i, i + 1))
+        w = float(n_tok[i] / n_tok.sum())
+        loss_sum += w * li
+        for k in acc:
+            acc[k] += w * gi[k]
+    print(f"cfg-2 B=32 train step: loss {loss_b:.6f}, recomposed from 32 single-sample steps {loss_sum:.6f}")
+    assert abs(loss_b - loss_sum) <= 1e-4 * abs(loss_b)
+    worst = (1.0, "")
+    for k in SLICE_NAMES:
+        c = cos(g_b[k], acc[k])
+        r = float(g_b[k].norm() / (acc[k].norm() + 1e-30))
+        worst = min(worst, (c, k))
+        print(f"  {k}: cosine {c:.5f}, norm ratio {r:.4f}")
+        assert c > 0.995 and 0.98 < r < 1.02, (k, c, r)
+    print(f"  worst cosine {worst[0]:.5f} ({worst[1]})")
+
+
+def test_cfg4_greedy_batch64_rows_equal_single_sequence_runs():
+    """BASELINE cfg-4: greedy generate() at B=64, 100 frames + 1000 ASR tokens (demo_vid2seq.py path).  Sequences are independent, so
+    row i of the batch must reproduce the B=1 run of sample i; the two runs go through different GEMM tile shapes for the encoder,
+    so bf16 rounding may flip an argmax only where the top-2 logit margin is below bf16 resolution -- the bar is the first divergence."""
+    B, steps = 64, 48
+    model = Vid2Seq("t5-base", tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
+                    init_seed=21, device=DEV).eval()
+    with torch.no_grad():                    # sharper output distribution than the flat synthetic init (as in the beam-search goldens)
+        model.t5_model.shared.weight.mul_(6.0)
+    eng = model.engine()
+    b = synth.make_batch(B, 100, 1000, 8, 32200, 99, 768)
+    video, ids = b["video"].to(DEV).to(torch.bfloat16), b["input_ids"].to(DEV)
+    full = eng.greedy(video, {"input_ids": ids, "attention_mask": ids != 0}, max_new_tokens=steps, stop_at_eos=False).cpu()
+    assert full.shape == (B, steps + 1) and full[:, 0].eq(0).all()
+    assert full[:, 1:].max() < 32200 and len(set(map(tuple, full.tolist()))) > B // 2        # rows differ: the inputs matter
+    first = []
+    for i in (0, 7, 31, 63):
+        one = eng.greedy(video[i:i + 1], {"input_ids": ids[i:i + 1], "attention_mask": ids[i:i + 1] != 0}, max_new_tokens=steps,
+                         stop_at_eos=False).cpu()
+        same = one[0] == full[i]
+        first.append(int((~same).nonzero()[0]) if (~same).any() else steps + 1)
+    print(f"cfg-4 greedy B=64 vs B=1, first divergence per checked row (of {steps + 1} positions): {first}")
+    assert min(first) >= steps // 2
+    # the module surface (what demo_vid2seq.py calls) on the same batch
+    text = model.generate(video[:4], {"input_ids": ids[:4], "attention_mask": ids[:4] != 0}, num_beams=1, max_length=8)
+    assert isinstance(text, list) and len(text) == 4
+
+
+def _nccl_world1(rank, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from oracle import vid2seq_ref as R
+    cfg = R.RefConfig.small(n_enc=5)
+    t5 = dict(d_model=cfg.d_model, d_kv=cfg.d_kv, heads=cfg.heads, d_ff=cfg.d_ff, n_enc=cfg.n_enc, n_dec=cfg.n_dec)
+
+    def build():
+        return Vid2Seq(t5, num_features=cfg.num_features, embed_dim=cfg.vit_dim, depth=cfg.vit_depth, heads=cfg.vit_heads,
+                       mlp_dim=cfg.vit_mlp, tokenizer=SyntheticTokenizer(cfg.vocab - cfg.num_bins, cfg.num_bins), vis_drop=0.0,
+                       enc_drop=0.0, dec_drop=0.0, num_bins=cfg.num_bins, init_seed=17).to("cuda").train()
+    batch = {k: v.cuda() for k, v in synth.make_batch(4, 10, 40, 12, cfg.vocab, 21, cfg.vit_dim).items()}
+    res = {}
+    for dtype in ("fp32", "bf16"):
+        m_c, m_p = build(), build()
+        tr_c = Trainer(m_c, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=0.0, force_collectives=True, grad_comm_dtype=dtype,
+                       bucket_bytes=1 << 20)
+        tr_p = Trainer(m_p, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=0.0)
+        assert tr_c.sync.active and not tr_p.sync.active
+        for _ in range(2):
+            tr_c.step(batch); tr_p.step(batch)
+        torch.cuda.synchronize()
+        d = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(m_c.parameters(), m_p.parameters()))
+        res[dtype] = (d, tr_c.sync.collectives, tr_c.sync.bytes_reduced)
+    # the collectives GradSync can use, straight on arena memory
+    g = tr_c.eng.arena.grad
+    n = g.numel() // 64 * 64
+    before = g[:n].clone()
+    dist.all_reduce(g[:n]); torch.cuda.synchronize()
+    ok_ar = bool(torch.equal(g[:n], before))
+    shard = torch.empty(n, dtype=g.dtype, device="cuda")
+    dist.reduce_scatter_tensor(shard, g[:n]); dist.all_gather_into_tensor(g[:n], shard); torch.cuda.synchronize()
+    ok_rs = bool(torch.equal(g[:n], before))
+    ret.update(res=res, ok_ar=ok_ar, ok_rs=ok_rs, backend=dist.get_backend(), world=dist.get_world_size())
+    dist.destroy_process_group()
+
+
+def test_rccl_world1_gradient_all_reduce_path():
+    """RCCL itself (backend "nccl" on ROCm) on the GPU box: a one-rank process group, Trainer.step with the collectives FORCED
+    (GradSync skips them at world 1 otherwise) -- librccl loads, communicator init, the side-stream hand-off with events, bucketed
+    all-reduce of arena slices in fp32 and through the bf16 staging buffer, plus reduce-scatter / all-gather on arena memory.  With one
+    rank a SUM all-reduce is the identity (checked bit for bit on arena memory); the two-step training runs are compared like the other
+    optimizer tests (fp32 atomics make two runs of the same step differ in the last bits, which Adam's first steps amplify to <= 2 lr)."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_world1, args=(29600 + (os.getpid() % 2000), ret), nprocs=1, join=True)
+    print(f"RCCL world-1: backend {ret['backend']}, world {ret['world']}, results (max |dw| vs no collectives, #collectives, bytes) {dict(ret['res'])}")
+    assert ret["backend"] == "nccl" and ret["ok_ar"] and ret["ok_rs"]
+    d32, ncoll, nbytes = ret["res"]["fp32"]
+    assert d32 <= 2 * 2.1e-3 and ncoll >= 4 and nbytes > 0
+    d16, ncoll16, nbytes16 = ret["res"]["bf16"]
+    assert d16 <= 2 * 2.1e-3 and nbytes16 * 2 == nbytes           # bf16 wire format: half the bytes; Adam steps differ by <= 2 lr per step

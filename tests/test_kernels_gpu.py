@@ -147,6 +147,43 @@ def test_gemm_w4_kernel(M, N, K, ta, tb):
         L.set_option("gemm_big", 1)
 
 
+@pytest.mark.parametrize("mode", [2, 3], ids=["p8_256", "p8_128"])
+@pytest.mark.parametrize("M,N,K,ta,tb", [(512, 512, 128, False, False), (300, 200, 160, False, False), (1000, 520, 224, False, True),
+                                          (2304, 768, 2048, True, True), (520, 1032, 192, True, True), (4096, 2304, 768, False, False),
+                                          (3000, 776, 3072, False, True), (256, 128, 256, False, False), (777, 264, 352, False, False)])
+def test_gemm_p8_kernel(M, N, K, ta, tb, mode):
+    """The 8-phase ping-pong kernel (counted-vmcnt LDS-DMA ring, staggered halves, transposed accumulators) forced on every operand
+    layout: 4..96 stages (the prologue, the steady state and every tail length of the counted waits), ragged edges in M and N, an
+    epilogue chain, fp32 accumulate and split-K.  Repeated launches must be bit-identical (a race in the ring would not be)."""
+    A = rnd(*((K, M) if ta else (M, K)), seed=41, scale=0.25)
+    B = rnd(*((K, N) if tb else (N, K)), seed=42, scale=0.25)
+    ref = (A.float().T if ta else A.float()) @ (B.float() if tb else B.float().T)
+    L.set_option("gemm_p8", mode)
+    try:
+        C = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+        L.gemm(A, B, C, M, N, K, transA=ta, transB=tb)
+        assert "gemm_p8_kernel" in L.lib().v2s_last_gemm_kernel().decode()
+        e = relerr(C, ref)
+        print(f"p8 mode {mode} {M}x{N}x{K} ta={ta} tb={tb}: relerr {e:.2e}")
+        assert e < 2e-5
+        for _ in range(5):
+            C2 = torch.empty_like(C)
+            L.gemm(A, B, C2, M, N, K, transA=ta, transB=tb)
+            assert torch.equal(C, C2)
+        if not ta:
+            bias = rnd(N, seed=43, dtype=torch.float32); res = rnd(M, N, seed=44)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            L.gemm(A, B, out, M, N, K, transB=tb, bias=bias, act=L.ACT_RELU, residual=res)
+            assert relerr(out, torch.relu(ref + bias) + res.float()) < 1e-2
+        else:
+            ws = torch.empty(16 * M * N, dtype=torch.float32, device=DEV)
+            dW = torch.ones(M, N, dtype=torch.float32, device=DEV)
+            L.gemm(A, B, dW, M, N, K, transA=True, transB=True, accumulate=True, alpha=0.5, workspace=ws)
+            assert relerr(dW, 1.0 + 0.5 * ref) < 2e-5
+    finally:
+        L.set_option("gemm_p8", 1)
+
+
 @pytest.mark.parametrize("split", [0, 1])
 def test_gemm_splitk_policies_agree(split):
     Mp, Np, Kc = 768, 768, 8192

@@ -1,4 +1,4 @@
-// Library plumbing: version, thread-local error text, runtime options.
+// Library plumbing: version, thread-local error text, runtime options, struct-size handshake.
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -6,13 +6,23 @@
 #include "v2s_common.h"
 
 static thread_local char g_err[512] = "";
-static std::atomic<int> g_tr_read{1};
-static std::atomic<int> g_gemm_dma{2};
-static std::atomic<int> g_gemm_big{1};
-static std::atomic<int> g_gemm_split{1};
-static std::atomic<int> g_gemm_order{4};
-static std::atomic<int> g_gemm_skinny{1};
-static std::atomic<int> g_attn_bwd_part{0};
+
+namespace {
+struct Opt { const char* name; std::atomic<int> v; };
+// index order = the V2S_OPT_* enumerators below
+Opt g_opts[] = {
+    {"tr_read", {1}}, {"gemm_dma", {2}}, {"gemm_big", {1}}, {"gemm_split", {1}}, {"gemm_order", {4}}, {"gemm_skinny", {1}},
+    {"attn_bwd_part", {0}}, {"gemm_p8", {1}}, {"ce_fused", {1}}, {"gemm_dbg", {0}},
+};
+enum { O_TR_READ, O_GEMM_DMA, O_GEMM_BIG, O_GEMM_SPLIT, O_GEMM_ORDER, O_GEMM_SKINNY, O_ATTN_BWD_PART, O_GEMM_P8, O_CE_FUSED, O_GEMM_DBG };
+inline int opt(int i) { return g_opts[i].v.load(std::memory_order_relaxed); }
+Opt* find_opt(const char* name) {
+  if (!name) return nullptr;
+  for (auto& o : g_opts)
+    if (strcmp(name, o.name) == 0) return &o;
+  return nullptr;
+}
+}  // namespace
 
 void v2s_set_error(const char* fmt, ...) {
   va_list ap;
@@ -21,36 +31,47 @@ void v2s_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-int v2s_opt_tr_read() { return g_tr_read.load(std::memory_order_relaxed); }
-int v2s_opt_gemm_dma() { return g_gemm_dma.load(std::memory_order_relaxed); }
-int v2s_opt_gemm_big() { return g_gemm_big.load(std::memory_order_relaxed); }
-int v2s_opt_gemm_split() { return g_gemm_split.load(std::memory_order_relaxed); }
-int v2s_opt_gemm_order() { return g_gemm_order.load(std::memory_order_relaxed); }
-int v2s_opt_gemm_skinny() { return g_gemm_skinny.load(std::memory_order_relaxed); }
-int v2s_opt_attn_bwd_part() { return g_attn_bwd_part.load(std::memory_order_relaxed); }
+int v2s_opt_tr_read() { return opt(O_TR_READ); }
+int v2s_opt_gemm_dma() { return opt(O_GEMM_DMA); }
+int v2s_opt_gemm_big() { return opt(O_GEMM_BIG); }
+int v2s_opt_gemm_split() { return opt(O_GEMM_SPLIT); }
+int v2s_opt_gemm_order() { return opt(O_GEMM_ORDER); }
+int v2s_opt_gemm_skinny() { return opt(O_GEMM_SKINNY); }
+int v2s_opt_attn_bwd_part() { return opt(O_ATTN_BWD_PART); }
+int v2s_opt_gemm_p8() { return opt(O_GEMM_P8); }
+int v2s_opt_ce_fused() { return opt(O_CE_FUSED); }
+int v2s_opt_gemm_dbg() { return opt(O_GEMM_DBG); }
 
 extern "C" int v2s_version(void) { return V2S_ABI_VERSION; }
 extern "C" const char* v2s_last_error(void) { return g_err; }
 
 extern "C" int v2s_set_option(const char* name, int value) {
-  if (name && strcmp(name, "tr_read") == 0) { g_tr_read.store(value ? 1 : 0); return V2S_OK; }
-  if (name && strcmp(name, "gemm_dma") == 0) { g_gemm_dma.store(value); return V2S_OK; }
-  if (name && strcmp(name, "gemm_big") == 0) { g_gemm_big.store(value); return V2S_OK; }
-  if (name && strcmp(name, "gemm_split") == 0) { g_gemm_split.store(value); return V2S_OK; }
-  if (name && strcmp(name, "gemm_order") == 0) { g_gemm_order.store(value); return V2S_OK; }
-  if (name && strcmp(name, "gemm_skinny") == 0) { g_gemm_skinny.store(value); return V2S_OK; }
-  if (name && strcmp(name, "attn_bwd_part") == 0) { g_attn_bwd_part.store(value); return V2S_OK; }
-  v2s_set_error("v2s_set_option: unknown option '%s'", name ? name : "(null)");
-  return V2S_ERR_ARG;
+  Opt* o = find_opt(name);
+  if (!o) {
+    v2s_set_error("v2s_set_option: unknown option '%s'", name ? name : "(null)");
+    return V2S_ERR_ARG;
+  }
+  o->v.store(o == &g_opts[O_TR_READ] ? (value ? 1 : 0) : value);
+  return V2S_OK;
 }
 extern "C" int v2s_get_option(const char* name) {
-  if (name && strcmp(name, "tr_read") == 0) return g_tr_read.load();
-  if (name && strcmp(name, "gemm_dma") == 0) return g_gemm_dma.load();
-  if (name && strcmp(name, "gemm_big") == 0) return g_gemm_big.load();
-  if (name && strcmp(name, "gemm_split") == 0) return g_gemm_split.load();
-  if (name && strcmp(name, "gemm_order") == 0) return g_gemm_order.load();
-  if (name && strcmp(name, "gemm_skinny") == 0) return g_gemm_skinny.load();
-  if (name && strcmp(name, "attn_bwd_part") == 0) return g_attn_bwd_part.load();
-  v2s_set_error("v2s_get_option: unknown option '%s'", name ? name : "(null)");
-  return V2S_ERR_ARG;
+  Opt* o = find_opt(name);
+  if (!o) {
+    v2s_set_error("v2s_get_option: unknown option '%s'", name ? name : "(null)");
+    return V2S_ERR_ARG;
+  }
+  return o->v.load();
+}
+
+// sizeof() of the argument structs as THIS library was compiled: a binding checks its own struct definitions against these
+// before the first call (a struct that is short by one field makes the library read past the caller's buffer).
+extern "C" int64_t v2s_sizeof(const char* name) {
+  if (name) {
+    if (strcmp(name, "v2s_gemm_args") == 0) return (int64_t)sizeof(v2s_gemm_args);
+    if (strcmp(name, "v2s_attn_args") == 0) return (int64_t)sizeof(v2s_attn_args);
+    if (strcmp(name, "v2s_adam_args") == 0) return (int64_t)sizeof(v2s_adam_args);
+    if (strcmp(name, "v2s_decode_attn_args") == 0) return (int64_t)sizeof(v2s_decode_attn_args);
+  }
+  v2s_set_error("v2s_sizeof: unknown struct '%s'", name ? name : "(null)");
+  return -1;
 }

@@ -39,6 +39,9 @@ int v2s_opt_attn_bwd_part(); // profiling aid for v2s_attn_bwd: 0 = both kernels
 int v2s_opt_gemm_skinny(); // 1 = dedicated M <= 64 kernel for cached decoding (default), 0 = general tiles
 int v2s_opt_gemm_order(); // tile walk of the tiled GEMM kernels: GM > 0 = grouped GM tile rows deep with tile-major split-K (default 4), 0 = row-major
 int v2s_opt_gemm_split(); // 1 = split-K slice count from the rounds x length cost model (default), 0 = fixed block-count target
+int v2s_opt_gemm_p8();   // 8-phase ping-pong 256-row kernel: 0 = never, 1 = where it measured faster (default), 2 = 256x256 wherever legal, 3 = 256x128 wherever legal
+int v2s_opt_ce_fused();  // reserved
+int v2s_opt_gemm_dbg();  // profiling aid for the 8-phase kernel: 1 = epilogue without the global store, 2 = no epilogue (results invalid)
 int v2s_opt_gemm_big();  // 0 = never, 1 = 256x256/256x128 tiles where they pay (default), 2 = 256x128 only, 3 = 4-wave 256x128x32 ring kernel for every variant
 
 // ---------------------------------------------------------------- device helpers

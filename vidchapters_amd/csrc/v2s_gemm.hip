@@ -38,6 +38,7 @@ struct GemmP {
   float* ws;
   float rms_eps;         // > 0: fused RMSNorm row scale (skinny kernel only)
   int order;             // tile walk: 0 = row-major with adjacent K slices, GM > 0 = grouped (tile_coords)
+  int dbg;               // profiling aid (option "gemm_dbg"): 1 = p8 epilogue without the global store, 2 = p8 without epilogue
 };
 
 // swizzle of the [k][row] (transposed-operand) LDS image: XOR the 32-byte column chunk with bits of k
@@ -702,6 +703,227 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(const GemmP p) {
 
 
 // =====================================================================================================================
+// 8-phase "ping-pong" kernel: 256 x BN2 output tile (BN2 = 256 | 128), 8 waves, K walked in stages of 32 through an LDS-DMA ring
+// (4 x 32 KiB | 6 x 24 KiB) with COUNTED s_waitcnt vmcnt(N) -- loads stay in flight across barriers -- and the two halves of the
+// block (waves 0-3 / 4-7: the two waves every SIMD holds) running half a phase apart: while one half issues its 16 MFMAs
+// (s_setprio 1) the other half reads its fragments from LDS and issues the DMA of a later stage, so the matrix pipe of every SIMD
+// always has a wave that is in its MFMA half-phase.  The one-barrier-per-K-step kernels above leave the pipe idle while both waves
+// of a SIMD wait for the same barrier / the same vmcnt(0) (PMC r01: MFMA busy 36-59 %).
+//
+// Schedule (phase p = 1, 2, ..., "mem" = ds_reads + DMA issue + counted wait, "mfma" = 16 MFMAs; B0, B1, ... = s_barrier events):
+//   half 0:        mem(1) B0 mfma(1) B1 mem(2) B2 mfma(2) B3 ...
+//   half 1:  (B0)  mem(1) B1 mfma(1) B2 mem(2) B3 mfma(2) ...         one extra barrier up front, half 0 has one extra at the end
+// LDS hazards under that stagger (derivation in DESIGN.md):
+//   WAR  a ring slot last READ in phase q may be re-filled by a DMA issued in phase >= q + 2
+//   RAW  a stage whose counted wait sits in mem(p') may be read in phase >= p' + 1
+// BN2 = 256: wave tile 128 x 64 (8 x 4 fragments), 2 phases per stage; phase 2s+1 issues B(s+2), phase 2s+2 issues A(s+3) and
+//            waits for stage s+1 with vmcnt(6) (A(s+2), B(s+2), A(s+3) stay in flight: four phases of flight time per stage).
+// BN2 = 128: wave tile 64 x 64 (4 x 4 fragments), 1 phase per stage; phase s+1 issues stage s+4 and waits for stage s+1 with vmcnt(9).
+// The accumulators are kept TRANSPOSED (mfma(B fragment, A fragment)): a lane then owns 4 consecutive columns of one row per
+// fragment, so the epilogue stages through LDS with one ds_write_b128 per fragment instead of four ds_write_b32.
+template <int BN2>
+struct P8 {
+  static constexpr int BM2 = 256, KT = 32;
+  static constexpr int WN = BN2 / 64, WM = 8 / WN;          // 2 x 4 | 4 x 2 waves
+  static constexpr int MI = BM2 / WM / 16;                  // 16-row fragments per wave: 8 | 4
+  static constexpr int PPS = MI / 4;                        // phases per stage: 2 | 1
+  static constexpr int A_B = BM2 * KT * 2, B_B = BN2 * KT * 2, STG = A_B + B_B;
+  static constexpr int NST = BN2 == 256 ? 4 : 6;            // ring depth: 128 | 144 KiB
+  static constexpr int DA = A_B / 1024 / 8, DB = B_B / 1024 / 8;      // DMA instructions per wave: A part 2, B part 2 | 1
+  static constexpr int LDS_BYTES = NST * STG;
+};
+
+// per-lane SOURCE byte offset of 1 KiB chunk c of a [ROWS][32 k] stage image (same image as dma_tile_w4 / read_frag_w4), relative
+// to (matrix base + the K offset of the stage): constant over the K loop, the loop advances a scalar base (saddr DMA form)
+template <int ROWS, bool T>
+__device__ __forceinline__ uint32_t p8_lane_off(long ld, int row0, int R, int R8, int c, int lane) {
+  if (!T) {                             // chunk = 16 rows x 64 B
+    const int row = c * 16 + (lane >> 2), pos = lane & 3;
+    const int g = pos ^ (((row >> 2) & 1) << 1);
+    int grow = row0 + row;
+    grow = grow < R ? grow : R - 1;
+    return (uint32_t)(((long)grow * ld + g * 8) * 2);
+  } else {                              // [32 k][ROWS]: k-row pitch ROWS*2 bytes
+    constexpr int SLOTS = ROWS / 8, KPC = 64 / SLOTS;
+    const int k = c * KPC + lane / SLOTS, pos16 = lane % SLOTS;
+    const int c16 = ((((pos16 >> 1) ^ tr_g(k)) << 1) | (pos16 & 1));
+    int grow = row0 + c16 * 8;
+    grow = grow <= R8 - 8 ? grow : R8 - 8;
+    return (uint32_t)(((long)k * ld + grow) * 2);
+  }
+}
+__device__ __forceinline__ void p8_dma2(uint32_t o0, uint32_t o1, const void* g, uint32_t lds) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[g]\n\t"
+               "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o1], %[g]\n\ts_mov_b32 m0, %[keep]"
+               : [keep] "=&s"(keep) : [lds] "s"(lds), [g] "s"(g), [o0] "v"(o0), [o1] "v"(o1) : "memory", "scc");
+}
+__device__ __forceinline__ void p8_dma1(uint32_t o0, const void* g, uint32_t lds) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[g]\n\ts_mov_b32 m0, %[keep]"
+               : [keep] "=&s"(keep) : [lds] "s"(lds), [g] "s"(g), [o0] "v"(o0) : "memory", "scc");
+}
+#define P8_BARRIER()                      \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+template <bool TA, bool TB, int BN2>
+__global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmP p) {
+  using G = P8<BN2>;
+  constexpr int BM2 = G::BM2, WN = G::WN, MI = G::MI, PPS = G::PPS, A_B = G::A_B, STG = G::STG, NST = G::NST, DA = G::DA, DB = G::DB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = wave >> 2;                     // waves w and w + 4 share a SIMD: they must be in different halves
+  const int nwg = p.tilesM * p.tilesN * p.splitk;
+  const int id0 = xcd_remap(blockIdx.x, nwg);
+  int tm, tn, slice;
+  tile_coords(p, id0, tm, tn, slice);
+  const int m0 = tm * BM2, n0 = tn * BN2;
+  const int kbeg = slice * p.kper, kend = min(p.K, kbeg + p.kper);
+  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
+  const int nst = (kend - kbeg) / 32;             // >= 4 (dispatcher)
+
+  f32x4 acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint32_t oa[DA], ob[DB];
+#pragma unroll
+  for (int i = 0; i < DA; ++i) oa[i] = p8_lane_off<BM2, TA>(p.lda, m0, p.M, M8, wave * DA + i, lane);
+#pragma unroll
+  for (int i = 0; i < DB; ++i) ob[i] = p8_lane_off<BN2, TB>(p.ldb, n0, p.N, N8, wave * DB + i, lane);
+  const long stepA = TA ? 32L * p.lda * 2 : 64L, stepB = TB ? 32L * p.ldb * 2 : 64L;        // bytes per stage
+  const char* ga = reinterpret_cast<const char*>(p.A) + (long)(kbeg / 32) * stepA;          // source of the next A part to issue
+  const char* gb = reinterpret_cast<const char*>(p.B) + (long)(kbeg / 32) * stepB;
+  const uint32_t sbase = lds_addr(smem);
+  const uint32_t dstA = __builtin_amdgcn_readfirstlane(sbase + wave * DA * 1024);
+  const uint32_t dstB = __builtin_amdgcn_readfirstlane(sbase + A_B + wave * DB * 1024);
+  int slotA = 0, slotB = 0;                       // ring slot (byte offset) of the next A / B part to issue
+  auto issueA = [&]() {
+    p8_dma2(oa[0], oa[1], ga, dstA + slotA);
+    ga += stepA; slotA = slotA + STG == NST * STG ? 0 : slotA + STG;
+  };
+  auto issueB = [&]() {
+    if constexpr (DB == 2) p8_dma2(ob[0], ob[1], gb, dstB + slotB); else p8_dma1(ob[0], gb, dstB + slotB);
+    gb += stepB; slotB = slotB + STG == NST * STG ? 0 : slotB + STG;
+  };
+
+  bf16x8 af[4], bfr[4];
+  int rslot = 0;                                  // ring slot (byte offset) of the stage being read
+  const int arow = wm * (MI * 16), brow = wn * 64;
+
+  if constexpr (PPS == 2) {
+    issueA(); issueB(); issueA(); issueB(); issueA();           // A0 B0 A1 B1 A2   (nst >= 4)
+    dma_wait_n<6>();                                            // stage 0 landed; A1 B1 A2 in flight
+  } else {
+    issueA(); issueB(); issueA(); issueB(); issueA(); issueB(); issueA(); issueB();     // stages 0..3
+    dma_wait_n<9>();
+  }
+  P8_BARRIER();
+  if (half == 1) P8_BARRIER();
+
+  for (int s = 0; s < nst; ++s) {
+    const char* sa = smem + rslot;
+    const char* sb = sa + A_B;
+    if constexpr (PPS == 2) {
+      // ---- phase 2s+1: fragments 0-3 of A, all of B; issue B(s+2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = read_frag_w4<BN2, TB>(sb, brow + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = read_frag_w4<BM2, TA>(sa, arow + i * 16, lane);
+      if (s + 2 < nst) issueB();
+      P8_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      P8_BARRIER();
+      // ---- phase 2s+2: fragments 4-7 of A; issue A(s+3); stage s+1 must have landed before the next phase reads it
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = read_frag_w4<BM2, TA>(sa, arow + 64 + i * 16, lane);
+      if (s + 3 < nst) { issueA(); dma_wait_n<6>(); }
+      else if (s + 2 < nst) dma_wait_n<4>();
+      else dma_wait_n<0>();
+      P8_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[4 + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      P8_BARRIER();
+    } else {
+      // ---- phase s+1: the whole stage; issue stage s+4; stage s+1 must have landed before the next phase reads it
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = read_frag_w4<BN2, TB>(sb, brow + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = read_frag_w4<BM2, TA>(sa, arow + i * 16, lane);
+      if (s + 4 < nst) { issueA(); issueB(); dma_wait_n<9>(); }
+      else if (s + 3 < nst) dma_wait_n<6>();
+      else if (s + 2 < nst) dma_wait_n<3>();
+      else dma_wait_n<0>();
+      P8_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      P8_BARRIER();
+    }
+    rslot = rslot + STG == NST * STG ? 0 : rslot + STG;
+  }
+  if (half == 0) P8_BARRIER();                    // re-align the two halves: every MFMA and every LDS read of the block is done
+
+  // epilogue: passes of WM*32 tile rows through an fp32 staging block [WM*32][BN2 + 4] (pitch 65 x 16 B: the eight lanes of a
+  // ds_write_b128 group hit eight different 16-byte bank slots); transposed accumulators: lane = row (lane & 15) of fragment i,
+  // columns 4*(lane >> 4) .. +3 of fragment j
+  constexpr int WMc = G::WM, PB = BN2 + 4, NPASS = MI / 2, CPR = BN2 / 8, ROWS_PASS = WMc * 32;
+  float* cs = reinterpret_cast<float*>(smem);
+  if (p.dbg == 2) {                               // ablation: main loop only (accumulators kept live)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(cs + (wm * 32 + ii * 16 + (lane & 15)) * PB + wn * 64 + j * 16 + (lane >> 4) * 4) = acc[ps * 2 + ii][j];
+    __syncthreads();
+#pragma unroll 1
+    for (int c = tid; c < ROWS_PASS * CPR; c += 512) {
+      const int lr = c / CPR, cc = (c % CPR) * 8;
+      const int gm = m0 + (lr >> 5) * (MI * 16) + ps * 32 + (lr & 31), gn = n0 + cc;
+      if (gm >= p.M || gn >= p.N) continue;
+      float v[8];
+      const float4 x0 = *reinterpret_cast<const float4*>(cs + lr * PB + cc);
+      const float4 x1 = *reinterpret_cast<const float4*>(cs + lr * PB + cc + 4);
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+      if (p.dbg == 1) {                           // ablation: everything but the global store
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        continue;
+      }
+      epilogue_chunk(p, v, gm, gn, slice);
+    }
+    if (ps + 1 < NPASS) __syncthreads();
+  }
+}
+
+// =====================================================================================================================
 // Skinny GEMM for cached decoding (M <= 64 rows: one token per live sequence / beam): C[M][N] = A[M][K] . B[N][K]^T.
 // The weight matrix B is the only real traffic (read once); the 128-wide tiles above would occupy 6..24 CUs for it.  Here a block
 // owns 16 output columns: its 4 waves split K four ways, each streaming its [16][K/4] weight slab straight from HBM into MFMA
@@ -860,6 +1082,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 
 }  // namespace
 
+// Tile width of the 8-phase kernel for this shape, 0 = keep the older kernels.  (Rules from tools/gemm_p8_ab.py, profiles/r02_gemm_p8_ab.txt.)
+static int p8_auto(const v2s_gemm_args* a, bool plain_split) {
+  (void)plain_split;
+  if (a->M < 256) return 0;
+  const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+  const long t128 = (long)((a->M + 255) / 256) * ((a->N + 127) / 128);
+  if (a->N >= 256 && (a->N % 256 == 0 || a->N >= 1024) && t256 >= 512) return 256;
+  if (a->N >= 128 && t128 >= 256) return 128;
+  return 0;
+}
+
 static thread_local const char* g_last_gemm = "";
 extern "C" const char* v2s_last_gemm_kernel(void) { return g_last_gemm; }
 
@@ -897,6 +1130,7 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   p.seed = a->dropout_seed;
   p.rms_eps = a->rms_eps;
   p.order = v2s_opt_gemm_order();
+  p.dbg = v2s_opt_gemm_dbg();
   hipStream_t s = (hipStream_t)stream;
   const bool tr = v2s_opt_tr_read() != 0;
   const bool plain_split = a->workspace && a->c_dtype == V2S_F32 && !a->bias && !a->act && !a->dact && !a->residual && !a->pre &&
@@ -946,6 +1180,19 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   const bool w4_ok = tr && (a->K % 32) == 0 && a->M >= 128 && a->N >= 64;
   if (w4_ok && (big_mode >= 3 || (big_mode == 1 && a->transA && a->transB && a->N < 1024 &&
                                   (long)a->M * a->N >= 2304L * 768L && a->K >= 16384))) { w4 = true; bm = 256; bn = 128; }
+  // 8-phase ping-pong kernel (256 x 256 | 256 x 128 tiles).  Legal: K (and the split-K slice) a multiple of 32 with >= 4 stages, the
+  // tr-read path, 32-bit per-lane source offsets.
+  int p8 = 0;                                      // 0 = no, 256 / 128 = tile width
+  const int p8_mode = v2s_opt_gemm_p8();
+  const bool p8_ok = p8_mode != 0 && tr && (a->K % 32) == 0 && a->K >= 128 && a->M >= 128 && a->N >= 64 &&
+                     (a->transA ? 32 * a->lda + a->M : (long)a->M * a->lda) < (1L << 30) &&
+                     (a->transB ? 32 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 30);
+  if (p8_ok) {
+    if (p8_mode == 2) p8 = 256;
+    else if (p8_mode == 3) p8 = 128;
+    else p8 = p8_auto(a, plain_split);
+    if (p8) { bm = 256; bn = p8; w4 = false; }
+  }
   p.tilesM = (a->M + bm - 1) / bm; p.tilesN = (a->N + bn - 1) / bn;
   // split-K: weight-gradient GEMMs have few output tiles (768x768 -> 36) but a huge contraction (all tokens);
   // slice K so that the chip is filled.  Only for fp32 outputs with a plain epilogue; partials go to the workspace.
@@ -978,7 +1225,31 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
     }
   }
   const unsigned nblocks = (unsigned)(p.tilesM * p.tilesN * p.splitk);
-  if (w4) {
+  if (p8) {
+    static bool attr8 = false;
+    if (!attr8) {
+      (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, P8<256>::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<false, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, P8<256>::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<true, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, P8<256>::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, P8<128>::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<false, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, P8<128>::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<true, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, P8<128>::LDS_BYTES);
+      attr8 = true;
+    }
+    const dim3 grid(nblocks), block(512);
+    static const char* names8[2][3] = {{"gemm_p8_kernel<false, false, 256>", "gemm_p8_kernel<false, true, 256>", "gemm_p8_kernel<true, true, 256>"},
+                                       {"gemm_p8_kernel<false, false, 128>", "gemm_p8_kernel<false, true, 128>", "gemm_p8_kernel<true, true, 128>"}};
+    g_last_gemm = names8[p8 == 256 ? 0 : 1][!a->transB ? 0 : (!a->transA ? 1 : 2)];
+#define V2S_P8(TA_, TB_)                                                                                               \
+    do {                                                                                                               \
+      if (p8 == 256) hipLaunchKernelGGL((gemm_p8_kernel<TA_, TB_, 256>), grid, block, P8<256>::LDS_BYTES, s, p);       \
+      else hipLaunchKernelGGL((gemm_p8_kernel<TA_, TB_, 128>), grid, block, P8<128>::LDS_BYTES, s, p);                 \
+    } while (0)
+    if (!a->transA && !a->transB) V2S_P8(false, false);
+    else if (!a->transA && a->transB) V2S_P8(false, true);
+    else V2S_P8(true, true);
+#undef V2S_P8
+  } else if (w4) {
     static bool attr4 = false;
     if (!attr4) {
       (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);

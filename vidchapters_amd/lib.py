@@ -64,6 +64,7 @@ SYMBOLS = {
     "v2s_last_error": (C.c_char_p, []),
     "v2s_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "v2s_get_option": (C.c_int, [C.c_char_p]),
+    "v2s_sizeof": (_i64, [C.c_char_p]),
     "v2s_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "v2s_colsum": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "v2s_rmsnorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
@@ -117,6 +118,18 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        # ABI handshake: the argument structs defined above must have the size the library was compiled with
+        for cname, ctype in (("v2s_gemm_args", GemmArgs), ("v2s_attn_args", AttnArgs), ("v2s_adam_args", AdamArgs),
+                             ("v2s_decode_attn_args", DecodeAttnArgs)):
+            want = int(l.v2s_sizeof(cname.encode()))
+            if want != C.sizeof(ctype):
+                raise RuntimeError(f"ABI mismatch: {cname} is {want} bytes in {LIB_PATH} but {C.sizeof(ctype)} in the ctypes binding "
+                                   "(rebuild the library or update vidchapters_amd/lib.py)")
+        # developer override of the runtime options (include/vid2seq_hip.h): V2S_OPTIONS="gemm_p8=2,gemm_big=0"
+        for kv in filter(None, os.environ.get("V2S_OPTIONS", "").split(",")):
+            k, v = kv.split("=")
+            if l.v2s_set_option(k.strip().encode(), int(v)) != 0:
+                raise RuntimeError(f"V2S_OPTIONS: {l.v2s_last_error().decode()}")
         _LIB = l
     return _LIB
 
