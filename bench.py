@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream execution (A/B for the stream overlap)")
     ap.add_argument("--no-generate", action="store_true", help="skip the greedy generate() leg (cfg-4, reported as an extra field)")
+    ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the data-parallel gradient all-reduce")
+    ap.add_argument("--bucket-mib", type=int, default=48, help="wire bytes per gradient all-reduce (MiB)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,7 +88,8 @@ def main():
                     device=dev).train()
     log(f"model built: {sum(p.numel() for p in model.parameters()) / 1e6:.1f} M parameters")
     model.engine().overlap = not a.no_overlap
-    trainer = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=a.denoising)
+    trainer = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=a.denoising, grad_comm_dtype=a.grad_comm_dtype,
+                      bucket_bytes=a.bucket_mib << 20)
     batch = {k: v.to(dev) for k, v in synth.make_batch(B, T, Lx, Lo, len(tok), 1234 + rank, 768, denoising=a.denoising > 0).items()}
     batch["video"] = batch["video"].to(torch.bfloat16)       # features resident in HBM as bf16 (documented in DESIGN.md)
     batch["input_lens"] = (batch["input_ids"] != 0).sum(1).tolist()      # host-side lengths, as a data loader knows them
@@ -105,11 +108,17 @@ def main():
         torch.cuda.synchronize()
         log(f"warmup step {i} done, loss {float(losses['loss'].item()):.4f}")
     barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    evs[0].record()
+    for i in range(a.steps):
         losses = trainer.step(batch)
+        evs[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))      # HIP events on the step's main stream
+    med_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    comm_ms = trainer.sync.exposed_ms() if world > 1 else 0.0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -131,7 +140,7 @@ def main():
         enc_exec = sum(ne * (n * (8 * d_ * d_ + 4 * d_ * ff_) + 4 * n * n * d_) for n in batch["input_lens"]) / B
         exec_tflop = 3.0 * (fps - enc_nom + enc_exec) * B / 1e12
     out = {
-        "metric": "Vid2Seq train-step samples/sec (100f\u00d7768 vis, 1000 ASR tok)",
+        "metric": f"Vid2Seq train-step samples/sec ({T}f\u00d7768 vis, {Lx} ASR tok)",
         "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
@@ -140,6 +149,8 @@ def main():
                                f"{Lx} ASR tokens, {Lo} target tokens, dropout {a.dropout}, fp32 master weights + fused clip/Adam/renorm"
                                f"{', encoder rows of pad tokens not computed (exact)' if a.packing else ', pad rows computed like the reference'}",
                    "global_batch": world * B, "parallelism": f"dp{world}", "weights": "deterministic synthetic init (no checkpoints offline)"},
+        "ms_per_step_hipevent_median": round(med_ms, 3), "samples_per_s_hipevent_median": round(world * B / (med_ms / 1e3), 2),
+        "timing_note": "value = steps / wall time between the two barrier+synchronize brackets (max over ranks); the median is over per-step HIP-event intervals on rank 0",
         "loss": round(loss_val, 5),
         "model_tflops_per_step_per_gpu": round(step_tflop, 2),
         "executed_tflops_per_step_per_gpu": round(exec_tflop, 2),
@@ -147,6 +158,12 @@ def main():
         "frac_of_mfma_peak_whole_step": round(exec_tflop / (ms_per_step / 1e3) / PEAK_BF16_TFLOPS, 4),
     }
 
+    if world > 1:
+        out["data_parallel"] = {"ranks_seen_by_rccl": dist.get_world_size(), "backend": dist.get_backend(),
+                                "grad_comm_dtype": trainer.sync.comm_dtype, "bucket_mib": round(trainer.sync.chunk * (4 if trainer.sync.comm_dtype == "fp32" else 2) / 2 ** 20, 1),
+                                "collectives_per_step": trainer.sync.collectives, "wire_mb_per_step": round(trainer.sync.bytes_reduced / 1e6, 1),
+                                "exposed_comm_ms_last_step_rank0": round(comm_ms, 3),
+                                "note": "exposed = time the main stream waited for the gradient reduction after backward had been enqueued"}
     if rank == 0 and world == 1 and not a.packing and not a.no_generate:
         # the same step with the engine's default padding-free text encoder (pad-token rows are not computed; exact, see
         # DESIGN.md): reported beside `value`, which computes them like the reference does
@@ -297,24 +314,53 @@ def input_leg(dev, B, Lx, Lo, frames=300):
             "note": f"{frames} source frames/sample -> 100, single host thread incl. numpy span-mask RNG"}
 
 
-def cpu_baseline(model, tok, Lx, Lo, threads=32, batch=8):
-    """The CPU oracle (fp32 torch port of the reference path, pinned against the reference in the build container)
-    timed on this box's host cores on a bounded sample: ONE optimizer step at B=8 of the same workload (about 15 s).
-    32 threads: on the 2 x 64-core GPU host more threads are slower for these matrix sizes (measured: B=1 step
-    3.4 s at 32 threads, 13.7 s at 128)."""
+def _cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(model, tok, Lx, Lo, threads=32):
+    """The CPU oracle (fp32 torch restatement of the reference path, pinned against the reference in the build container) timed on this
+    box's host cores, SURVEY 8d protocol: per leg 1 warm-up + 3 timed iterations, median.  Legs: cfg-1 exact (B=2, 100 frames, 256 ASR
+    tokens, 256 targets: forward + loss + backward + clip + Adam + renorm), the cfg-2 shapes at B=2 (1000 ASR tokens) -- the number
+    `value` is compared with -- and 32 greedy decode steps at B=2.  32 threads: on the 2 x 64-core GPU host more threads are slower for
+    these matrix sizes (measured r01: B=1 step 3.4 s at 32 threads, 13.7 s at 128)."""
     from oracle import vid2seq_ref as R
     from vidchapters_amd import synth
-    threads = min(threads, os.cpu_count() or 1)
+    ncores = os.cpu_count() or 1
+    threads = min(threads, ncores)
     torch.set_num_threads(threads)
     cfg = R.RefConfig(vocab=len(tok))
     P = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
-    b = synth.make_batch(batch, 100, Lx, Lo, len(tok), 99, 768)
-    t0 = time.perf_counter()
-    rec = R.train_step(P, {}, cfg, b, lr=3e-4, clip=1.0, generative=1.0, denoising=0.0)
-    dt = time.perf_counter() - t0
-    return {"value": round(batch / dt, 4), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"1 optimizer step (fwd+bwd+clip+Adam+renorm) at B={batch}, 100 frames, {Lx} ASR tokens, {Lo} target tokens, "
-                      f"fp32 torch CPU oracle, dropout 0; {dt:.1f} s", "loss": round(rec["losses"]["loss"], 5)}
+
+    def timed(fn, n=3):
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    legs = {}
+    for name, L_in in (("cfg1_exact_B2_L256", 256), ("cfg2_shapes_B2", Lx)):
+        b = synth.make_batch(2, 100, L_in, Lo, len(tok), 99, 768)
+        state = {}
+        dt = timed(lambda: R.train_step(P, state, cfg, b, lr=3e-4, clip=1.0, generative=1.0, denoising=0.0))
+        legs[name] = {"samples_per_s": round(2 / dt, 4), "seconds_per_step": round(dt, 3)}
+    b = synth.make_batch(2, 100, Lx, 8, len(tok), 98, 768)
+    Pd = {k: v.detach() for k, v in P.items()}
+    dtg = timed(lambda: R.greedy_generate(Pd, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, 32), n=3)
+    legs["greedy_32_steps_B2"] = {"sequences_per_s": round(2 / dtg, 4), "seconds": round(dtg, 3)}
+    main = legs["cfg2_shapes_B2"]
+    return {"value": main["samples_per_s"], "unit": "samples/s", "cores": threads, "kind": "port",
+            "host": {"cpu_model": _cpu_model_string(), "logical_cores": ncores, "threads_used": threads},
+            "sample": f"median of 3 timed optimizer steps after 1 warm-up (fwd+bwd+clip+Adam+renorm) at B=2, 100 frames, {Lx} ASR tokens, {Lo} target "
+                      f"tokens, fp32 torch CPU oracle, dropout 0; {main['seconds_per_step']} s per step",
+            "legs": legs}
 
 
 if __name__ == "__main__":

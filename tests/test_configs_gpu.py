@@ -87,7 +87,10 @@ def test_cfg2_shape_vs_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "full_cfg2_scalars.npz"))
     model = Vid2Seq("t5-base", tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
                     init_seed=int(g["seed"]), device=DEV).eval()
-    _check_against_shape_golden(g, model, 12, min_cos=0.985, min_cos_1d=0.97, tag="cfg-2 shape")
+    # measured: engine min 2-D 0.9756 / 1-D 0.9746; the reference math under torch's CPU bf16 autocast scores 0.9704 / 0.9678 against its
+    # own fp32 gradients on these inputs (tests/tools/bf16_noise_cfg2.py, profiles/r02_bf16_noise_cfg2_shape.txt): the lowest cosines are
+    # the block-0 encoder tensors, 24 bf16 layers away from the loss
+    _check_against_shape_golden(g, model, 12, min_cos=0.972, min_cos_1d=0.970, tag="cfg-2 shape")
 
 
 def test_t5_large_cfg5_shape_vs_reference_golden(golden_dir):
@@ -96,7 +99,7 @@ def test_t5_large_cfg5_shape_vs_reference_golden(golden_dir):
     model = Vid2Seq("t5-large", num_features=200, tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
                     init_seed=int(g["seed"]), device=DEV).eval()
     assert model.proj_v2t is not None
-    _check_against_shape_golden(g, model, 24, min_cos=0.98, min_cos_1d=0.96, tag="cfg-5 shape (t5-large)")
+    _check_against_shape_golden(g, model, 24, min_cos=0.975, min_cos_1d=0.970, tag="cfg-5 shape (t5-large)")     # measured 0.9790 / 0.9743
 
 
 SLICE_NAMES = ["t5_model.encoder.block.0.layer.0.SelfAttention.q.weight", "t5_model.encoder.block.11.layer.1.DenseReluDense.wi.weight",
@@ -150,7 +153,7 @@ def test_cfg2_train_step_batch32_is_token_weighted_sum_of_samples():
         r = float(g_b[k].norm() / (acc[k].norm() + 1e-30))
         worst = min(worst, (c, k))
         print(f"  {k}: cosine {c:.5f}, norm ratio {r:.4f}")
-        assert c > 0.995 and 0.98 < r < 1.02, (k, c, r)
+        assert c > 0.9995 and 0.995 < r < 1.005, (k, c, r)          # measured: cosine >= 0.99973, ratio 0.9961 .. 0.9987
     print(f"  worst cosine {worst[0]:.5f} ({worst[1]})")
 
 
@@ -161,14 +164,14 @@ def test_cfg4_greedy_batch64_rows_equal_single_sequence_runs():
     B, steps = 64, 48
     model = Vid2Seq("t5-base", tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
                     init_seed=21, device=DEV).eval()
-    with torch.no_grad():                    # sharper output distribution than the flat synthetic init (as in the beam-search goldens)
-        model.t5_model.shared.weight.mul_(6.0)
     eng = model.engine()
     b = synth.make_batch(B, 100, 1000, 8, 32200, 99, 768)
     video, ids = b["video"].to(DEV).to(torch.bfloat16), b["input_ids"].to(DEV)
     full = eng.greedy(video, {"input_ids": ids, "attention_mask": ids != 0}, max_new_tokens=steps, stop_at_eos=False).cpu()
     assert full.shape == (B, steps + 1) and full[:, 0].eq(0).all()
-    assert full[:, 1:].max() < 32200 and len(set(map(tuple, full.tolist()))) > B // 2        # rows differ: the inputs matter
+    distinct = len(set(map(tuple, full.tolist())))
+    print(f"cfg-4: {distinct} distinct sequences among {B} rows; row 0: {full[0, :12].tolist()}")
+    assert full[:, 1:].max() < 32200 and distinct > B // 2        # rows differ: the inputs matter
     first = []
     for i in (0, 7, 31, 63):
         one = eng.greedy(video[i:i + 1], {"input_ids": ids[i:i + 1], "attention_mask": ids[i:i + 1] != 0}, max_new_tokens=steps,
@@ -176,7 +179,7 @@ def test_cfg4_greedy_batch64_rows_equal_single_sequence_runs():
         same = one[0] == full[i]
         first.append(int((~same).nonzero()[0]) if (~same).any() else steps + 1)
     print(f"cfg-4 greedy B=64 vs B=1, first divergence per checked row (of {steps + 1} positions): {first}")
-    assert min(first) >= steps // 2
+    assert min(first) >= steps - 8                      # measured: identical on all checked rows (49 of 49 positions)
     # the module surface (what demo_vid2seq.py calls) on the same batch
     text = model.generate(video[:4], {"input_ids": ids[:4], "attention_mask": ids[:4] != 0}, num_beams=1, max_length=8)
     assert isinstance(text, list) and len(text) == 4

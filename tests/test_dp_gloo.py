@@ -56,7 +56,7 @@ def test_gradsync_ranges_cover_arena_once():
     cfg = R.RefConfig.small()
     m = Vid2Seq(dict(d_model=cfg.d_model, d_kv=cfg.d_kv, heads=cfg.heads, d_ff=cfg.d_ff, n_enc=cfg.n_enc, n_dec=cfg.n_dec),
                 num_features=cfg.num_features, embed_dim=cfg.vit_dim, depth=cfg.vit_depth, heads=cfg.vit_heads, mlp_dim=cfg.vit_mlp,
-                tokenizer=SyntheticTokenizer(512, 100))
+                tokenizer=SyntheticTokenizer(512, 100), init_seed=1)
     order = [n for n, _ in Engine._arena_order(type("E", (), {"model": m, "cfg": m.cfg, "_sa": staticmethod(Engine._sa), "_ca": staticmethod(Engine._ca),
                                                                "_ln": staticmethod(Engine._ln), "_ffp": staticmethod(Engine._ffp)})())]
     first_enc = next(i for i, n in enumerate(order) if n.startswith("t5_model.encoder."))

@@ -184,6 +184,44 @@ def test_gemm_p8_kernel(M, N, K, ta, tb, mode):
         L.set_option("gemm_p8", 1)
 
 
+@pytest.mark.parametrize("M,N,K,tb,epi", [(4096, 2304, 768, False, "plain"), (4096, 3072, 768, False, "relu_drop"), (3000, 776, 3072, True, "plain"),
+                                           (70000, 512, 288, False, "drop"), (1024, 256, 320, True, "relu"), (66000, 768, 768, True, "plain"),
+                                           (2048, 512, 4096, False, "relu_drop")])
+def test_gemm_p8_deferred_epilogue_kernel(M, N, K, tb, epi):
+    """The persistent 8-phase kernel whose tile output leaves the chip during the next tile's main loop (bf16 held registers -> LDS
+    staging slabs -> 16-byte stores with the dropout mask applied on the way, stores counted in the same vmcnt stream as the DMAs).
+    Must be BIT-identical to the synchronous kernels (same products, same single rounding): 1 .. 3 tiles per block, ragged M and N,
+    both operand layouts, ReLU / dropout epilogues, repeated launches."""
+    A = rnd(M, K, seed=51, scale=0.25)
+    B = rnd(*((K, N) if tb else (N, K)), seed=52, scale=0.25)
+    kw = dict(transB=tb)
+    if "relu" in epi:
+        kw.update(act=L.ACT_RELU)
+    if "drop" in epi:
+        kw.update(dropout_p=0.1, dropout_seed=77)
+    outs = {}
+    try:
+        for mode in (0, 4):
+            L.set_option("gemm_p8", mode)
+            C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            L.gemm(A, B, C, M, N, K, **kw)
+            kern = L.lib().v2s_last_gemm_kernel().decode()
+            assert ("gemm_p8d_kernel" in kern) == (mode == 4), kern
+            outs[mode] = C
+            if mode == 4:
+                for _ in range(4):
+                    C2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+                    L.gemm(A, B, C2, M, N, K, **kw)
+                    assert torch.equal(C2.view(torch.int16), C.view(torch.int16))
+    finally:
+        L.set_option("gemm_p8", 1)
+    assert torch.isfinite(outs[4].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[4].view(torch.int16))
+    if epi == "plain":
+        ref = A.float() @ (B.float() if tb else B.float().T)
+        assert relerr(outs[4], ref) < 1e-2
+
+
 @pytest.mark.parametrize("split", [0, 1])
 def test_gemm_splitk_policies_agree(split):
     Mp, Np, Kc = 768, 768, 8192

@@ -561,3 +561,43 @@ def test_evalmetrics_properties():
     wr, wri = E.rouge_l(hyps, refs)
     assert abs(rg - wr) < 1e-12 and np.allclose(ri, wri, atol=1e-12)
     assert ri[0] == pytest.approx(1.0) and ri[1] == pytest.approx(2.44 * (2 / 3) * 0.5 / (0.5 + 1.44 * 2 / 3)) and ri[2] == 0.0
+
+
+def test_constructor_requires_t5_weights_like_the_reference(tmp_path):
+    """without init_seed the constructor behaves like the reference's from_pretrained(local_files_only=True): a path without
+    weights raises instead of silently training from random T5 weights; a directory with (sharded) weights loads them, cuts the
+    embedding to len(tokenizer) - num_bins text rows and keeps the reference init for everything the checkpoint does not cover."""
+    import json
+    from safetensors.torch import save_file
+    from vidchapters_amd import SyntheticTokenizer, Vid2Seq
+    cfg = R.RefConfig.small()
+    t5 = dict(d_model=cfg.d_model, d_kv=cfg.d_kv, heads=cfg.heads, d_ff=cfg.d_ff, n_enc=cfg.n_enc, n_dec=cfg.n_dec)
+    kw = dict(num_features=cfg.num_features, embed_dim=cfg.vit_dim, depth=cfg.vit_depth, heads=cfg.vit_heads, mlp_dim=cfg.vit_mlp,
+              tokenizer=SyntheticTokenizer(512, 100))
+    with pytest.raises(FileNotFoundError):
+        Vid2Seq(str(tmp_path / "t5-small"), **{**kw, "tokenizer": SyntheticTokenizer(32100, 100)})
+    # a "checkpoint": config.json + two shards + index
+    donor = Vid2Seq(t5, init_seed=3, **kw)
+    sd = {k: v.detach().clone() for k, v in donor.t5_model.state_dict().items()}
+    sd["shared.weight"] = torch.cat([sd["shared.weight"][:512], torch.zeros(16, cfg.d_model)])      # hub checkpoints carry extra rows (32128)
+    for a in ("encoder.embed_tokens.weight", "decoder.embed_tokens.weight", "lm_head.weight"):
+        sd[a] = sd["shared.weight"]
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    json.dump(dict(d_model=cfg.d_model, d_kv=cfg.d_kv, num_heads=cfg.heads, d_ff=cfg.d_ff, num_layers=cfg.n_enc, num_decoder_layers=cfg.n_dec,
+                   feed_forward_proj="relu"), open(d / "config.json", "w"))
+    keys = sorted(sd)
+    shards = {"model-00001-of-00002.safetensors": keys[: len(keys) // 2], "model-00002-of-00002.safetensors": keys[len(keys) // 2:]}
+    for fn, ks in shards.items():
+        save_file({k: sd[k].contiguous().clone() for k in ks}, str(d / fn))
+    json.dump({"weight_map": {k: fn for fn, ks in shards.items() for k in ks}}, open(d / "model.safetensors.index.json", "w"))
+    torch.manual_seed(0)
+    m = Vid2Seq(str(d), **kw)
+    got = m.t5_model.state_dict()
+    assert torch.equal(got["shared.weight"][:512], sd["shared.weight"][:512])
+    assert got["shared.weight"].shape[0] == 612 and float(got["shared.weight"][512:].std()) > 0.5     # time-token rows: N(0, 1), not loaded
+    k = "encoder.block.1.layer.0.SelfAttention.q.weight"
+    assert torch.equal(got[k], sd[k])
+    vit = m.visual_encoder.state_dict()
+    assert float(vit["blocks.0.norm1.weight"].min()) == 1.0 and float(vit["blocks.0.attn.qkv.bias"].abs().max()) == 0.0
+    assert m.t5_model.lm_head.weight is m.t5_model.shared.weight

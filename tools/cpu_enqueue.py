@@ -7,7 +7,7 @@ from vidchapters_amd import SyntheticTokenizer, Vid2Seq, synth
 from vidchapters_amd.train import Trainer
 dev = torch.device("cuda")
 tok = SyntheticTokenizer(32100, 100)
-model = Vid2Seq("t5-base", tokenizer=tok, vis_drop=0.1, enc_drop=0.1, dec_drop=0.1, device=dev).train()
+model = Vid2Seq("t5-base", tokenizer=tok, vis_drop=0.1, enc_drop=0.1, dec_drop=0.1, init_seed=1234, device=dev).train()
 tr = Trainer(model, denoising=0.0)
 batch = {k: v.to(dev) for k, v in synth.make_batch(32, 100, 1000, 256, len(tok), 1234, 768).items()}
 batch["video"] = batch["video"].to(torch.bfloat16)

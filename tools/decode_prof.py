@@ -4,7 +4,7 @@ import torch
 from vidchapters_amd import SyntheticTokenizer, Vid2Seq, synth
 dev = torch.device("cuda")
 tok = SyntheticTokenizer(32100, 100)
-model = Vid2Seq("t5-base", tokenizer=tok, device=dev).eval()
+model = Vid2Seq("t5-base", tokenizer=tok, init_seed=1234, device=dev).eval()
 b = synth.make_batch(64, 100, 1000, 8, len(tok), 4321, 768)
 ids = b["input_ids"].to(dev)
 eng = model.engine()

@@ -1,0 +1,45 @@
+"""Interleaved A/B of library options on the full cfg-2 train step: one model / trainer / batch, the option settings alternate step
+by step, HIP-event time per step, median per setting (separate bench.py runs differ by +-2-3 % from box to box and run to run).
+usage: python tools/step_ab.py "gemm_p8=0" "gemm_p8=1" [--steps 12] [--model t5-base]"""
+import sys, os, statistics, argparse
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vidchapters_amd import SyntheticTokenizer, Vid2Seq, synth
+from vidchapters_amd import lib as L
+from vidchapters_amd.train import Trainer
+
+ap = argparse.ArgumentParser()
+ap.add_argument("settings", nargs="+")
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--model", default="t5-base")
+ap.add_argument("--frames", type=int, default=100)
+ap.add_argument("--asr", type=int, default=1000)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+tok = SyntheticTokenizer(32100, 100)
+model = Vid2Seq(a.model, num_features=a.frames, tokenizer=tok, vis_drop=0.1, enc_drop=0.1, dec_drop=0.1, init_seed=1234, device=dev).train()
+model.engine().pack = False
+tr = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=0.0)
+batch = {k: v.to(dev) for k, v in synth.make_batch(32, a.frames, a.asr, 256, len(tok), 1234, 768).items()}
+batch["video"] = batch["video"].to(torch.bfloat16)
+defaults = {}
+def apply(setting):
+    for kv in filter(None, setting.split(",")):
+        k, v = kv.split("=")
+        defaults.setdefault(k, L.get_option(k))
+        L.set_option(k, int(v))
+for s in a.settings:
+    apply(s); tr.step(batch)
+torch.cuda.synchronize()
+times = {s: [] for s in a.settings}
+for i in range(a.steps):
+    for s in a.settings:
+        apply(s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); tr.step(batch); e1.record(); torch.cuda.synchronize()
+        times[s].append(e0.elapsed_time(e1))
+for s in a.settings:
+    med = statistics.median(times[s])
+    print(f"{s:40s} median {med:7.2f} ms  min {min(times[s]):7.2f}  -> {32 / med * 1e3:6.1f} samples/s")
+for k, v in defaults.items():
+    L.set_option(k, v)

@@ -7,7 +7,7 @@ from vidchapters_amd.train import Trainer
 dev = torch.device("cuda")
 tok = SyntheticTokenizer(32100, 100)
 p = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
-model = Vid2Seq("t5-base", tokenizer=tok, vis_drop=p, enc_drop=p, dec_drop=p, device=dev).train()
+model = Vid2Seq("t5-base", tokenizer=tok, vis_drop=p, enc_drop=p, dec_drop=p, init_seed=1234, device=dev).train()
 tr = Trainer(model, denoising=0.0)
 batch = {k: v.to(dev) for k, v in synth.make_batch(32, 100, 1000, 256, len(tok), 1234, 768).items()}
 batch["video"] = batch["video"].to(torch.bfloat16)

@@ -16,6 +16,16 @@ for s in $SRCS; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
+# The persistent deferred-epilogue GEMM counts its VMEM operations by hand (s_waitcnt vmcnt(N) across barriers): a register spill would
+# add scratch loads/stores to that queue.  Fail the build if the compiler ever needs scratch for it.
+if [ build/v2s_gemm.o -nt build/v2s_gemm.usage ] || [ ! -f build/v2s_gemm.usage ]; then
+  $HIPCC $FLAGS -c v2s_gemm.hip -o /dev/null -Rpass-analysis=kernel-resource-usage 2> build/v2s_gemm.usage.raw || true
+  grep -A8 "Function Name: .*gemm_p8d_kernel" build/v2s_gemm.usage.raw | grep -E "Function Name|ScratchSize" > build/v2s_gemm.usage || true
+  if grep -E "ScratchSize \[bytes/lane\]: [1-9]" build/v2s_gemm.usage; then
+    echo "ERROR: gemm_p8d_kernel spills to scratch (see build/v2s_gemm.usage): its hand-counted vmcnt waits would be wrong" >&2
+    rm -f build/v2s_gemm.o; exit 1
+  fi
+fi
 OBJS=""; for s in $SRCS; do OBJS="$OBJS build/$s.o"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libvid2seq_hip.so $OBJS
 echo "built $(realpath ../libvid2seq_hip.so)"

@@ -11,6 +11,7 @@
 // gfx950 LDS transpose read, so no operand is ever re-laid-out in HBM.
 // The epilogue goes through LDS so that bias / activation / activation-derivative / dropout /
 // residual / accumulate all run on 8-wide row-contiguous vectors with 16-byte global accesses.
+#include <type_traits>
 #include "v2s_common.h"
 
 namespace {
@@ -38,6 +39,7 @@ struct GemmP {
   float* ws;
   float rms_eps;         // > 0: fused RMSNorm row scale (skinny kernel only)
   int order;             // tile walk: 0 = row-major with adjacent K slices, GM > 0 = grouped (tile_coords)
+  int row0;              // rows of this launch are rows row0.. of the caller's matrix (dropout mask index; v2s_gemm splits rows over two launches)
   int dbg;               // profiling aid (option "gemm_dbg"): 1 = p8 epilogue without the global store, 2 = p8 without epilogue
 };
 
@@ -176,7 +178,7 @@ __device__ __forceinline__ void epilogue_chunk(const GemmP& p, float (&v)[8], in
     }
   }
   if (p.p16) {
-    v2s_drop8(v, (unsigned long long)gm * (unsigned long long)p.N + gn, p.seed, p.p16, p.inv_keep);
+    v2s_drop8(v, (unsigned long long)(gm + p.row0) * (unsigned long long)p.N + gn, p.seed, p.p16, p.inv_keep);
   }
   if (p.residual) {
     float rf[8];
@@ -924,6 +926,244 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmP p) {
 }
 
 // =====================================================================================================================
+// Persistent form of the 8-phase kernel with a DEFERRED epilogue (256 x 256 tiles, bf16 output, epilogues without global operands).
+// Ablation of gemm_p8_kernel on the wide K = 768 shapes of the step (profiles/r02_gemm_p8_ablation_v1.txt): of 150 us, 29 us are the
+// output stores -- every CU finishes its tile at the same moment and 256 CUs x 128 KiB hit HBM as one burst -- and 22 us the LDS
+// staging in front of them; the matrix pipe idles through both.  Here a block walks its tiles in a loop and the output of tile t
+// leaves the chip DURING the main loop of tile t+1:
+//   * after the last MFMA of a tile the accumulators are rounded to bf16 (ReLU and the dropout scale applied in registers: the same
+//     single rounding as the synchronous epilogue) into 64 "held" registers, the accumulators restart at zero;
+//   * in stages 0..8 of the next tile, one 32-row slab of the held tile per stage goes through a 2 x 16 KiB LDS staging block
+//     (dumped by the four waves that own it, read back as 16-byte row chunks by all eight) and is stored with the dropout mask
+//     applied on the way;
+//   * the DMA stream does not stop at a tile edge: the first stages of the next tile are requested during the last phases of the
+//     current one (no prologue except for the block's first tile), and past the block's last tile it re-requests that tile's
+//     last stage into free ring slots so that every counted wait keeps the same constant.
+// vmcnt bookkeeping: the stores are VMEM operations of the same in-order counter as the DMAs.  Per lane, program order is
+//   ... B(s+1) | A(s+2) | st st B(s+2) | A(s+3) wait ...    (st = the two stores of an odd phase while a write-out is running)
+// so the wait that retires stage s+1 leaves 8 operations in flight while stores are interleaved (tile-local stages 1..8) and 6
+// otherwise.  Stores are issued by every wave of the block in those phases whether or not a previous tile exists (first tile: all
+// offsets out of range, dropped by the buffer bounds check), so the constants do not depend on data.
+// Measured dead ends (profiles/r02_gemm_p8d_ablation.txt): the slabs are written back to back ON PURPOSE.  A counted wait behind a
+// store also waits for that store to be acknowledged (one in-order queue); spread over the whole tile every store stalled the ring on
+// its own (+35 %), back to back their latencies overlap.  The memory half-phases have no slack -- whatever they take beyond the other
+// half's 16 MFMAs is paid twice per stage -- so the write-out steps are kept in straight-line, fully specialised code.
+// The kernel counts its VMEM operations by hand: build.sh fails the build if the compiler ever spills a register of it to scratch.
+__device__ __forceinline__ uint2 p8_pack4(const f32x4& v) {
+  uint2 r;
+  r.x = pack2bf(v[0], v[1]); r.y = pack2bf(v[2], v[3]);
+  return r;
+}
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <bool TA, bool TB, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm_p8d_kernel(const GemmP p) {
+  using G = P8<256>;
+  constexpr int BM2 = 256, BN2 = 256, A_B = G::A_B, STG = G::STG, NST = G::NST, RING = NST * STG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // ring (128 KiB) + 2 x 16 KiB write-out staging
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int half = wm;
+  const int ntiles = p.tilesM * p.tilesN;
+  const int G_ = gridDim.x;
+  const int nmy = (ntiles - (int)blockIdx.x + G_ - 1) / G_;          // tiles of this block: ids blockIdx.x + k * gridDim.x
+  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
+  const int nst = p.K / 32;                                          // >= 9 (dispatcher)
+
+  f32x4 acc[8][4];
+  uint2 held[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; held[i][j] = make_uint2(0u, 0u); }
+
+  // ---- DMA issue streams (A and B advance separately: A runs one unit ahead of B)
+  const long stepA = TA ? 32L * p.lda * 2 : 64L, stepB = TB ? 32L * p.ldb * 2 : 64L;
+  const uint32_t sbase = lds_addr(smem);
+  const uint32_t dstA = __builtin_amdgcn_readfirstlane(sbase + wave * 2048);
+  const uint32_t dstB = __builtin_amdgcn_readfirstlane(sbase + A_B + wave * 2048);
+  uint32_t oa[2], ob[2];
+  const char* ga; const char* gb;
+  long incA = stepA, incB = stepB;
+  int sA = 0, sB = 0, kA = 0, kB = 0, slotA = 0, slotB = 0;
+  auto setupA = [&](int k) {
+    int tm, tn, sl;
+    tile_coords(p, xcd_remap((int)blockIdx.x + k * G_, ntiles), tm, tn, sl);
+    oa[0] = p8_lane_off<BM2, TA>(p.lda, tm * BM2, p.M, M8, wave * 2, lane);
+    oa[1] = p8_lane_off<BM2, TA>(p.lda, tm * BM2, p.M, M8, wave * 2 + 1, lane);
+    ga = reinterpret_cast<const char*>(p.A);
+  };
+  auto setupB = [&](int k) {
+    int tm, tn, sl;
+    tile_coords(p, xcd_remap((int)blockIdx.x + k * G_, ntiles), tm, tn, sl);
+    ob[0] = p8_lane_off<BN2, TB>(p.ldb, tn * BN2, p.N, N8, wave * 2, lane);
+    ob[1] = p8_lane_off<BN2, TB>(p.ldb, tn * BN2, p.N, N8, wave * 2 + 1, lane);
+    gb = reinterpret_cast<const char*>(p.B);
+  };
+  auto issueA = [&]() {
+    p8_dma2(oa[0], oa[1], ga, dstA + slotA);
+    slotA = slotA + STG == RING ? 0 : slotA + STG;
+    ga += incA;
+    if (++sA == nst) {
+      if (kA + 1 < nmy) { ++kA; sA = 0; setupA(kA); }
+      else { ga -= stepA; incA = 0; sA = -(1 << 30); }                         // exhausted: keep re-requesting the last stage
+    }
+  };
+  auto issueB = [&]() {
+    p8_dma2(ob[0], ob[1], gb, dstB + slotB);
+    slotB = slotB + STG == RING ? 0 : slotB + STG;
+    gb += incB;
+    if (++sB == nst) {
+      if (kB + 1 < nmy) { ++kB; sB = 0; setupB(kB); }
+      else { gb -= stepB; incB = 0; sB = -(1 << 30); }
+    }
+  };
+
+  // ---- write-out of the previous tile
+  const long cbytes = (long)p.M * p.ldc * 2;
+  const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)cbytes, 0x00020000);
+  char* stg = smem + RING;
+  int pm0 = p.M, pn0 = 0;                                             // tile origin of the held tile; pm0 = M: nothing held, every store out of range
+  const int arow = wm * 128, brow = wn * 64;
+  auto dump_unit = [&](auto Uc) {                                     // the four waves of half U/4: their fragments 2(U&3), 2(U&3)+1 -> staging U&1
+    constexpr int U = decltype(Uc)::value;
+    char* buf = stg + (U & 1) * 16384;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                                      // opaque: keeps the address arithmetic out of the loop-invariant (always live) set
+    // row r = ii*16 + (ln & 15); 16-byte chunk (wn*8 + j*2 + (ln >> 5)) ^ (ln & 15); half (ln >> 4) & 1
+    const int base = (ln & 15) * 512 + (((ln >> 4) & 1) << 3);
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ch = ((wn * 8 + j * 2 + (ln >> 5)) ^ (ln & 15));
+        *reinterpret_cast<uint2*>(buf + ii * 16 * 512 + base + (ch << 4)) = held[2 * (U & 3) + ii][j];
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto store_unit = [&](auto Uc) {                                    // every thread: two 16-byte row chunks of slab U
+    constexpr int U = decltype(Uc)::value;
+    const char* buf = stg + (U & 1) * 16384;
+    int td = tid;
+    asm volatile("" : "+v"(td));                                      // opaque (see dump_unit)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = td + q * 512, r = c >> 5, cc = c & 31;
+      u32x4 x = *reinterpret_cast<const u32x4*>(buf + r * 512 + ((cc ^ (r & 15)) << 4));
+      const int gm = pm0 + U * 32 + r, gn = pn0 + cc * 8;
+      if (p.p16) {
+        const uint32_t m = v2s_keep8((unsigned long long)(gm + p.row0) * (unsigned long long)p.N + gn, p.seed, p.p16);
+        x[0] &= ((m & 1u) ? 0xffffu : 0u) | ((m & 2u) ? 0xffff0000u : 0u);
+        x[1] &= ((m & 4u) ? 0xffffu : 0u) | ((m & 8u) ? 0xffff0000u : 0u);
+        x[2] &= ((m & 16u) ? 0xffffu : 0u) | ((m & 32u) ? 0xffff0000u : 0u);
+        x[3] &= ((m & 64u) ? 0xffffu : 0u) | ((m & 128u) ? 0xffff0000u : 0u);
+      }
+      const bool ok = gm < p.M && gn < p.N;
+      const uint32_t off = ok ? (uint32_t)(((long)gm * p.ldc + gn) * 2) : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b128(x, crsrc, (int)off, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto convert = [&]() {                                              // accumulators -> held (bf16), accumulators restart at zero
+    const bool relu = p.act == V2S_ACT_RELU;
+    const float sc = p.inv_keep;                                      // 1 without dropout
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = acc[i][j];
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        v[0] *= sc; v[1] *= sc; v[2] *= sc; v[3] *= sc;
+        held[i][j] = p8_pack4(v);
+        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+
+  bf16x8 af[4], bfr[4];
+  int rslot = 0;
+  auto mfma_lo = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto mfma_hi = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[4 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // one stage = two phases; S = tile-local stage index for the write-out steps (0..8), -1 = none
+  auto stage = [&](auto Sc) {
+    constexpr int S = decltype(Sc)::value;
+    const char* sa = smem + rslot;
+    const char* sb = sa + A_B;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                  // opaque: fragment addresses are recomputed per stage instead of living in registers for the whole kernel
+    if constexpr (S >= 1 && S <= 8) store_unit(std::integral_constant<int, (S >= 1 ? S - 1 : 0)>{});
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = read_frag_w4<BN2, TB>(sb, brow + j * 16, ln);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = read_frag_w4<BM2, TA>(sa, arow + i * 16, ln);
+    if constexpr (S >= 0 && S <= 7) {
+      if (half == (S >> 2)) dump_unit(std::integral_constant<int, (S >= 0 ? S : 0)>{});
+      issueB();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the dump is in LDS before this wave reaches the barrier
+    } else {
+      issueB();
+    }
+    P8_BARRIER();
+    mfma_lo();
+    P8_BARRIER();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = read_frag_w4<BM2, TA>(sa, arow + 64 + i * 16, ln);
+    issueA();
+    if constexpr (S >= 1 && S <= 8) dma_wait_n<8>(); else dma_wait_n<6>();
+    P8_BARRIER();
+    mfma_hi();
+    P8_BARRIER();
+    rslot = rslot + STG == RING ? 0 : rslot + STG;
+  };
+
+  setupA(0); setupB(0);
+  issueA(); issueB(); issueA(); issueB(); issueA();
+  dma_wait_n<6>();
+  P8_BARRIER();
+  if (half == 1) P8_BARRIER();
+
+  for (int k = 0; k < nmy; ++k) {
+    stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{}); stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 3>{}); stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
+    stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{}); stage(std::integral_constant<int, 8>{});
+#pragma unroll 1
+    for (int s = 9; s < nst; ++s) stage(std::integral_constant<int, -1>{});
+    convert();
+    int tm, tn, sl;
+    tile_coords(p, xcd_remap((int)blockIdx.x + k * G_, ntiles), tm, tn, sl);
+    pm0 = tm * BM2; pn0 = tn * BN2;
+  }
+  // ---- drain: the block's last tile is still in the held registers
+  if (half == 0) P8_BARRIER();
+  dma_wait_n<0>();
+  __syncthreads();
+  if constexpr (ABL == 1) return;                 // ablation build (option gemm_dbg 3): no drain
+  auto drain = [&](auto Uc) {
+    constexpr int U = decltype(Uc)::value;
+    if (half == (U >> 2)) dump_unit(Uc);
+    __syncthreads();
+    store_unit(Uc);
+  };
+  drain(std::integral_constant<int, 0>{}); drain(std::integral_constant<int, 1>{}); drain(std::integral_constant<int, 2>{});
+  drain(std::integral_constant<int, 3>{}); drain(std::integral_constant<int, 4>{}); drain(std::integral_constant<int, 5>{});
+  drain(std::integral_constant<int, 6>{}); drain(std::integral_constant<int, 7>{});
+}
+
+// =====================================================================================================================
 // Skinny GEMM for cached decoding (M <= 64 rows: one token per live sequence / beam): C[M][N] = A[M][K] . B[N][K]^T.
 // The weight matrix B is the only real traffic (read once); the 128-wide tiles above would occupy 6..24 CUs for it.  Here a block
 // owns 16 output columns: its 4 waves split K four ways, each streaming its [16][K/4] weight slab straight from HBM into MFMA
@@ -1083,20 +1323,57 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 }  // namespace
 
 // Tile width of the 8-phase kernel for this shape, 0 = keep the older kernels.  (Rules from tools/gemm_p8_ab.py, profiles/r02_gemm_p8_ab.txt.)
-static int p8_auto(const v2s_gemm_args* a, bool plain_split) {
-  (void)plain_split;
-  if (a->M < 256) return 0;
+static int p8_auto(const v2s_gemm_args* a, bool deferred_ok) {
+  // measured, variants interleaved in one process (tools/gemm_p8_ablate.py, gemm_p8_ab.py; profiles/r02_gemm_p8*.txt), us old / 8-phase
+  // synchronous / deferred:  32000x2304x768 132 / 136 / 127,  32000x3072x768 relu+dropout 192 / 182 / 174,  plain 174 / 162 / 148,
+  // 65536x2048x2048 526 / 490 / 501,  8192^3 966 / 792 / 852,  t5-large 16000x3072x1024 118 / 113 / 102, 16000x1024x4096 141 / 122 / -;
+  // few-tile shapes (N = 768: 375 tiles on 256 CUs; the 8192- and 3200-row decoder / ViT shapes) stay on the 128 x 128 kernels.
+  if (a->M < 256 || a->N < 256) return 0;
   const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
-  const long t128 = (long)((a->M + 255) / 256) * ((a->N + 127) / 128);
-  if (a->N >= 256 && (a->N % 256 == 0 || a->N >= 1024) && t256 >= 512) return 256;
-  if (a->N >= 128 && t128 >= 256) return 128;
+  if (t256 < 512) return (a->transA && t256 >= 256 && a->K >= 4096) ? 256 : 0;
+  if (deferred_ok && a->K <= 1536) return 256;          // p8_decide turns deferred_ok into the deferred form
+  if (a->K >= 1024 || a->transA) return 256;
   return 0;
+}
+
+// Which form of the 8-phase kernel runs this problem: p8 = tile width (0 = none), p8d = deferred-epilogue persistent form.
+static void p8_decide(const v2s_gemm_args* a, bool tr, int& p8, bool& p8d) {
+  p8 = 0; p8d = false;
+  const int p8_mode = v2s_opt_gemm_p8();
+  // legal: K a multiple of 32 with >= 4 stages, the tr-read path, 32-bit per-lane source offsets
+  const bool p8_ok = p8_mode != 0 && tr && (a->K % 32) == 0 && a->K >= 128 && a->M >= 128 && a->N >= 64 &&
+                     (a->transA ? 32 * a->lda + a->M : (long)a->M * a->lda) < (1L << 30) &&
+                     (a->transB ? 32 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 30);
+  if (!p8_ok) return;
+  // deferred-epilogue persistent form: bf16 output, epilogue without global operands (ReLU / dropout only), no split-K
+  const bool p8d_ok = !a->transA && a->c_dtype == V2S_BF16 && !a->accumulate && !a->bias && !a->pre && !a->residual && a->dact == V2S_ACT_NONE &&
+                      (a->act == V2S_ACT_NONE || a->act == V2S_ACT_RELU) && a->alpha == 1.0f && a->K >= 288 && a->N >= 256 && a->M >= 256 &&
+                      (long)a->M * a->ldc * 2 < (1L << 31);
+  if (p8_mode == 2) p8 = 256;
+  else if (p8_mode == 3) p8 = 128;
+  else if (p8_mode == 4) { p8 = 256; p8d = p8d_ok; }
+  else { p8 = p8_auto(a, p8d_ok); p8d = p8 == 256 && p8d_ok && a->K <= 1536; }
+}
+
+static int num_cus() {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, n = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return ncu;
 }
 
 static thread_local const char* g_last_gemm = "";
 extern "C" const char* v2s_last_gemm_kernel(void) { return g_last_gemm; }
+static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_force);
 
-extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
+// Entry point.  (gemm_impl can run a row range of a larger problem -- row0 keeps the dropout mask index global; a split of the rows
+// into whole rounds of 256 x 256 tiles plus a remainder on the 128 x 128 kernels was measured and did not pay: 132.1 vs 133.1 us
+// on 32000 x 2304 x 768, nothing on the N = 768 shapes.)
+extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) { return gemm_impl(a, stream, 0, -1); }
+
+static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_force) {
   V2S_CHECK(a != nullptr, V2S_ERR_ARG, "v2s_gemm: null args");
   V2S_CHECK(a->M > 0 && a->N > 0 && a->K > 0, V2S_ERR_SHAPE, "v2s_gemm: non-positive shape %d %d %d", a->M, a->N, a->K);
   // Ragged sizes (e.g. vocab 32100 or 612): rows are always exact (predicated); a dimension that is walked in
@@ -1131,6 +1408,7 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   p.rms_eps = a->rms_eps;
   p.order = v2s_opt_gemm_order();
   p.dbg = v2s_opt_gemm_dbg();
+  p.row0 = row0;
   hipStream_t s = (hipStream_t)stream;
   const bool tr = v2s_opt_tr_read() != 0;
   const bool plain_split = a->workspace && a->c_dtype == V2S_F32 && !a->bias && !a->act && !a->dact && !a->residual && !a->pre &&
@@ -1180,19 +1458,11 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
   const bool w4_ok = tr && (a->K % 32) == 0 && a->M >= 128 && a->N >= 64;
   if (w4_ok && (big_mode >= 3 || (big_mode == 1 && a->transA && a->transB && a->N < 1024 &&
                                   (long)a->M * a->N >= 2304L * 768L && a->K >= 16384))) { w4 = true; bm = 256; bn = 128; }
-  // 8-phase ping-pong kernel (256 x 256 | 256 x 128 tiles).  Legal: K (and the split-K slice) a multiple of 32 with >= 4 stages, the
-  // tr-read path, 32-bit per-lane source offsets.
-  int p8 = 0;                                      // 0 = no, 256 / 128 = tile width
-  const int p8_mode = v2s_opt_gemm_p8();
-  const bool p8_ok = p8_mode != 0 && tr && (a->K % 32) == 0 && a->K >= 128 && a->M >= 128 && a->N >= 64 &&
-                     (a->transA ? 32 * a->lda + a->M : (long)a->M * a->lda) < (1L << 30) &&
-                     (a->transB ? 32 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 30);
-  if (p8_ok) {
-    if (p8_mode == 2) p8 = 256;
-    else if (p8_mode == 3) p8 = 128;
-    else p8 = p8_auto(a, plain_split);
-    if (p8) { bm = 256; bn = p8; w4 = false; }
-  }
+  // 8-phase ping-pong kernel (p8_decide): 256 x 256 | 256 x 128 tiles, synchronous or deferred epilogue
+  int p8 = 0;
+  bool p8d = false;
+  if (p8_force != 0) p8_decide(a, tr, p8, p8d);
+  if (p8) { bm = 256; bn = p8; w4 = false; }
   p.tilesM = (a->M + bm - 1) / bm; p.tilesN = (a->N + bn - 1) / bn;
   // split-K: weight-gradient GEMMs have few output tiles (768x768 -> 36) but a huge contraction (all tokens);
   // slice K so that the chip is filled.  Only for fp32 outputs with a plain epilogue; partials go to the workspace.
@@ -1225,7 +1495,25 @@ extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) {
     }
   }
   const unsigned nblocks = (unsigned)(p.tilesM * p.tilesN * p.splitk);
-  if (p8) {
+  if (p8d) {
+    static bool attr8d = false;
+    const int ncu = num_cus();
+    if (!attr8d) {
+      (void)hipFuncSetAttribute((const void*)gemm_p8d_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      (void)hipFuncSetAttribute((const void*)gemm_p8d_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      attr8d = true;
+    }
+    const int nt = p.tilesM * p.tilesN;
+    const dim3 grid((unsigned)(nt < ncu ? nt : ncu)), block(512);
+    g_last_gemm = a->transB ? "gemm_p8d_kernel<false, true>" : "gemm_p8d_kernel<false, false>";
+    if (p.dbg == 3 && !a->transB) {                 // ablation build of the NT variant: 3 = no drain, 4 = no write-out at all (results invalid)
+      (void)hipFuncSetAttribute((const void*)gemm_p8d_kernel<false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      (void)hipFuncSetAttribute((const void*)gemm_p8d_kernel<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      (void)hipFuncSetAttribute((const void*)gemm_p8d_kernel<false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+      hipLaunchKernelGGL((gemm_p8d_kernel<false, false, 1>), grid, block, 163840, s, p);
+    } else if (!a->transB) hipLaunchKernelGGL((gemm_p8d_kernel<false, false>), grid, block, 163840, s, p);
+    else hipLaunchKernelGGL((gemm_p8d_kernel<false, true>), grid, block, 163840, s, p);
+  } else if (p8) {
     static bool attr8 = false;
     if (!attr8) {
       (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<false, false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, P8<256>::LDS_BYTES);

@@ -60,7 +60,12 @@ class Engine:
         assert self.arena.adjacent(*[self._sa("encoder", 0) + w for w in ("q.weight", "k.weight", "v.weight")])
         self._luts: Dict[Tuple[int, int, bool], torch.Tensor] = {}
         self._far: Dict[Tuple[int, int, bool], Tuple[int, int]] = {}
-        self._seed = 0x1234
+        # dropout stream: like the reference (torch's seeded per-process generator) the masks follow torch.manual_seed() and differ
+        # between data-parallel ranks; (seed, site counter) are part of the training state (rng_state / set_rng_state)
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        self._seed = (int(torch.initial_seed()) ^ (rank * 0x9E3779B1) ^ 0x1234) & 0xFFFFFFFF
         self._site = 0
         self._ws: Dict[str, torch.Tensor] = {}
         # autograd anchor: the coarse Functions take it as an input so that their outputs get a grad_fn even though
@@ -135,6 +140,20 @@ class Engine:
         if t is None:     # 8 slices of the largest few-tile weight gradient (d_ff x d_model)
             t = self._ws["splitk"] = self._f32(8 * max(self.ff * self.d, 3 * self.inner * self.d, self.vmlp * self.vd))
         return t
+
+    def rng_state(self) -> Tuple[int, int]:
+        """(seed, site counter) of the dropout stream: save with a checkpoint, restore with :meth:`set_rng_state` to resume the
+        mask sequence where it stopped."""
+        return (self._seed, self._site)
+
+    def set_rng_state(self, state) -> None:
+        self._seed, self._site = int(state[0]) & 0xFFFFFFFF, int(state[1])
+
+    def mark_dirty(self) -> None:
+        """Force the bf16 shadow weights to be re-cast from the fp32 masters at the next forward.  Needed only after updates that
+        bypass the Parameters' version counters (``p.data.add_``, legacy optimizers, EMA swaps): updates made through the
+        Parameters themselves (optimizer.step, load_state_dict, in-place ops) are detected automatically."""
+        self.arena._seen_version = -1
 
     def _next_seed(self) -> int:
         self._site += 1
@@ -455,9 +474,9 @@ class Engine:
         B, T, C = video.shape
         assert C == self.vd, f"feature dim {C} != embed_dim {self.vd}"
         M, p = B * T, (m.vis_drop if m.training else 0.0)
-        if video.dtype == torch.float32:
+        if video.dtype != torch.bfloat16:          # fp32 (the reference's features), fp16, fp64, ...: through fp32 to bf16
             xb = self._bf(M, C)
-            L.cast_bf16(video.contiguous().view(-1), xb, M * C)
+            L.cast_bf16(video.contiguous().float().view(-1), xb, M * C)
         else:
             xb = video.contiguous().view(M, C)
         pos = a.w("visual_encoder.pos_embed", (m.num_features, C))
@@ -864,9 +883,10 @@ class Engine:
         B, S, d = mem.shape
         nb = num_beams
         R = B * nb
-        K = 2 * nb
-        if K not in (2, 4, 8, 16):
-            raise ValueError(f"num_beams must be 1, 2, 4 or 8 (got {nb})")
+        if not 1 <= nb <= 8:
+            raise ValueError(f"num_beams must be in [1, 8] on the HIP path (got {nb})")
+        K = next(k for k in (2, 4, 8, 16) if k >= 2 * nb)     # per-beam candidate lists are sorted: a longer list only adds entries
+                                                              # the merge never reaches, so any num_beams uses the next instantiated size
         inner, H, nl = self.inner, self.H, c.n_dec
         mem2 = mem.view(B * S, d)
         cross = []

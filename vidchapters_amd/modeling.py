@@ -169,11 +169,22 @@ class _ViT(nn.Module):
         self.norm = _W(dim, bias=dim)
 
 
+def _load_weight_file(f: str) -> Dict[str, torch.Tensor]:
+    if f.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(f)
+    return torch.load(f, map_location="cpu")
+
+
 # ------------------------------------------------------------------------------------------------------
 class Vid2Seq(nn.Module):
     def __init__(self, t5_path, num_features=100, embed_dim=768, depth=12, heads=12, mlp_dim=2048, vis_drop=0.,
                  tokenizer=None, enc_drop=0., dec_drop=0.1, use_speech=True, use_video=True, num_bins=100,
-                 label_smoothing=0.1, init_seed: int = 1234, device=None):
+                 label_smoothing=0.1, init_seed: Optional[int] = None, device=None):
+        """``init_seed`` (extra to the reference signature): an int selects the deterministic synthetic weights of synth.py for EVERY
+        parameter (parity tests, benchmarks: there are no checkpoints offline).  ``None`` (the default, what the reference's callers
+        get) behaves like the reference: the T5 weights MUST be loadable from ``t5_path`` (``from_pretrained(local_files_only=True)``
+        raises otherwise, and so do we), the ViT / projection / time-token rows get the reference's initialisation."""
         super().__init__()
         if tokenizer is None:
             raise ValueError("Vid2Seq needs a tokenizer (len(), pad_token_id, eos_token_id, batch_decode)")
@@ -198,8 +209,15 @@ class Vid2Seq(nn.Module):
         self._engine = None
         if device is not None:          # extra to the reference signature: build (and init) directly on the GPU
             self.to(device)
-        self.reset_parameters(init_seed)
-        self._maybe_load_pretrained(t5_path)
+        if init_seed is not None:
+            self.reset_parameters(init_seed)
+            self._maybe_load_pretrained(t5_path)
+        else:
+            self.reference_init()
+            if not self._maybe_load_pretrained(t5_path) and not isinstance(t5_path, dict):   # (a dict = explicit shapes, nothing to load)
+                raise FileNotFoundError(
+                    f"no T5 weights (model.safetensors / pytorch_model.bin, or their sharded index) under {t5_path!r}: the reference loads "
+                    "them with from_pretrained(local_files_only=True).  Pass init_seed=<int> for deterministic synthetic weights.")
 
     # -------------------------------------------------------------------------------- parameters
     def reset_parameters(self, seed: int) -> None:
@@ -209,19 +227,64 @@ class Vid2Seq(nn.Module):
                 p.copy_(synth.init_tensor(name, tuple(p.shape), seed, self.cfg.d_model, self.cfg.inner, self.cfg.d_ff,
                                           device=p.device))
 
-    def _maybe_load_pretrained(self, t5_path) -> None:
+    def reference_init(self) -> None:
+        """The initialisation the reference's constructor leaves behind for everything that does not come from the T5 checkpoint:
+        ViT (vit.py:101-115: xavier_uniform linears, zero biases, LayerNorm 1 / 0, trunc_normal(0.02) pos_embed), proj_v2t
+        (nn.Linear default), and for the T5 holder HF's ``_init_weights`` laws (embedding N(0, 1): the law the ``num_bins`` time-token
+        rows keep after ``resize_token_embeddings``, vid2seq.py:39-40; norms 1) until a checkpoint overwrites the text rows."""
+        c = self.cfg
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.startswith("visual_encoder."):
+                    if name.endswith("pos_embed"):
+                        nn.init.trunc_normal_(p, std=0.02)
+                    elif ".norm" in name or name.startswith("visual_encoder.norm."):
+                        p.fill_(1.0 if name.endswith("weight") else 0.0)
+                    elif name.endswith(".bias"):
+                        p.zero_()
+                    else:
+                        nn.init.xavier_uniform_(p)
+                elif name.startswith("proj_v2t."):
+                    bound = 1.0 / math.sqrt(self.vit_dim)
+                    if name.endswith("weight"):
+                        nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                    else:
+                        p.uniform_(-bound, bound)
+                elif "layer_norm" in name:
+                    p.fill_(1.0)
+                elif name.endswith("shared.weight"):
+                    p.normal_(0.0, 1.0)
+                elif name.endswith("relative_attention_bias.weight"):
+                    p.normal_(0.0, c.d_model ** -0.5)
+                elif name.endswith(".q.weight"):
+                    p.normal_(0.0, (c.d_model * c.d_kv) ** -0.5)
+                elif name.endswith((".k.weight", ".v.weight", ".wi.weight")):
+                    p.normal_(0.0, c.d_model ** -0.5)
+                elif name.endswith(".o.weight"):
+                    p.normal_(0.0, c.inner ** -0.5)
+                elif name.endswith(".wo.weight"):
+                    p.normal_(0.0, c.d_ff ** -0.5)
+
+    def _maybe_load_pretrained(self, t5_path) -> bool:
+        """Load HF T5 weights from a directory: model.safetensors / pytorch_model.bin or their sharded forms (*.index.json).
+        Returns False if there is nothing to load."""
         if isinstance(t5_path, dict):
-            return
+            return False
+        d = str(t5_path)
         for fn in ("model.safetensors", "pytorch_model.bin"):
-            f = os.path.join(str(t5_path), fn)
+            f = os.path.join(d, fn)
             if os.path.isfile(f):
-                if fn.endswith(".safetensors"):
-                    from safetensors.torch import load_file
-                    sd = load_file(f)
-                else:
-                    sd = torch.load(f, map_location="cpu")
+                self.load_t5_state_dict(_load_weight_file(f))
+                return True
+            idx = f + ".index.json"
+            if os.path.isfile(idx):
+                shards = sorted(set(json.load(open(idx))["weight_map"].values()))
+                sd = {}
+                for sh in shards:
+                    sd.update(_load_weight_file(os.path.join(d, sh)))
                 self.load_t5_state_dict(sd)
-                return
+                return True
+        return False
 
     def load_t5_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         """Load an HF T5 state dict; the embedding is cut to len(tokenizer)-num_bins rows and the num_bins

@@ -39,15 +39,31 @@ def lr_at(step: int, total: int, base_lr: float, schedule: str = "", warmup_frac
 
 
 class GradSync:
-    """Slice-wise asynchronous all-reduce of the gradient arena on a dedicated stream."""
+    """Bucketed asynchronous all-reduce of the gradient arena on a dedicated stream (RCCL over xGMI: backend "nccl" on ROCm).
 
-    def __init__(self, arena, group=None, chunk_elems: int = 32 * 1024 * 1024):
+    ``ready(start, end)`` hands a finished, contiguous slice of the fp32 gradient arena to the reduction: the side stream waits for
+    the producing streams through events, then issues one all-reduce per ``bucket_bytes`` of WIRE data (default 48 MiB: xGMI is
+    point to point, a ring all-reduce is bound per link, and a few tens of MB per collective keep the links streaming while the
+    first buckets of a slice overlap the rest of backward).  ``comm_dtype="bf16"`` halves the wire bytes: the slice is rounded into a
+    bf16 staging arena, reduced there and widened back into the fp32 arena (the optimizer keeps reading fp32).  ``force=True`` issues
+    the collectives even for a one-rank group (the GPU test that loads RCCL on a single-GPU box)."""
+
+    def __init__(self, arena, group=None, bucket_bytes: int = 48 << 20, comm_dtype: str = "fp32", force: bool = False):
         self.arena = arena
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.chunk = chunk_elems            # 128 MiB of fp32 per collective: few, large xGMI transfers
-        self.stream = torch.cuda.Stream() if self.world > 1 else None
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
+        if comm_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"grad_comm_dtype must be 'fp32' or 'bf16' (got {comm_dtype!r})")
+        self.comm_dtype = comm_dtype
+        esize = 4 if comm_dtype == "fp32" else 2
+        self.chunk = max(1, bucket_bytes // esize) // 64 * 64 or 64     # elements per collective
+        self.stream = torch.cuda.Stream() if self.active else None
+        self.stage = torch.empty(arena.numel, dtype=torch.bfloat16, device=arena.grad.device) if self.active and comm_dtype == "bf16" else None
         self.works: List = []
+        self.collectives = 0          # statistics of the current step (reset by Trainer.step)
+        self.bytes_reduced = 0
+        self.exposed_ms_events = None # (start, end) events around the final wait of the last step
 
     def range_of(self, first: str, last: str) -> Tuple[int, int]:
         a = self.arena
@@ -59,32 +75,56 @@ class GradSync:
     def ready(self, start: int, end: int, also=()) -> None:
         """Gradients in arena[start:end] are final on the current stream (and on the streams in ``also``, e.g. the
         weight-gradient stream): reduce them in the background."""
-        if self.world == 1 or end <= start:
+        if not self.active or end <= start:
             return
         for st in (torch.cuda.current_stream(),) + tuple(also):
             ev = torch.cuda.Event()
             ev.record(st)
             self.stream.wait_event(ev)
+        g = self.arena.grad
         with torch.cuda.stream(self.stream):
             o = start
             while o < end:
                 e = min(end, o + self.chunk)
-                self.works.append(dist.all_reduce(self.arena.grad[o:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.stage is None:
+                    self.works.append(dist.all_reduce(g[o:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self.bytes_reduced += (e - o) * 4
+                else:
+                    L.cast_bf16(g[o:e], self.stage[o:e], e - o)                      # fp32 -> bf16 (RNE) on the side stream
+                    w = dist.all_reduce(self.stage[o:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    w.wait()                                                          # stream-side dependency only (no host block with NCCL/RCCL)
+                    g[o:e].copy_(self.stage[o:e])                                     # widen back for the fp32 optimizer
+                    self.bytes_reduced += (e - o) * 2
+                self.collectives += 1
                 o = e
 
     def finish(self) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         for w in self.works:
             w.wait()
         self.works.clear()
-        torch.cuda.current_stream().wait_stream(self.stream)
+        main = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        main.wait_stream(self.stream)
+        e1.record(main)
+        self.exposed_ms_events = (e0, e1)
+
+    def exposed_ms(self) -> float:
+        """Time the main stream spent waiting for the last step's reductions after backward had finished (synchronises)."""
+        if self.exposed_ms_events is None:
+            return 0.0
+        e0, e1 = self.exposed_ms_events
+        e1.synchronize()
+        return float(e0.elapsed_time(e1))
 
 
 class Trainer:
     def __init__(self, model, lr: float = 3e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  clip_max_norm: float = 1.0, generative: float = 1.0, denoising: float = 1.0, schedule: str = "",
-                 fraction_warmup_steps: float = 0.1, num_training_steps: int = 1, group=None):
+                 fraction_warmup_steps: float = 0.1, num_training_steps: int = 1, group=None, bucket_bytes: int = 48 << 20,
+                 grad_comm_dtype: str = "fp32", force_collectives: bool = False):
         self.model = model
         self.eng = model.engine()
         a = self.eng.arena
@@ -95,7 +135,7 @@ class Trainer:
         self.m = torch.zeros(a.numel, dtype=torch.float32, device=dev)
         self.v = torch.zeros(a.numel, dtype=torch.float32, device=dev)
         self.step_count = 0
-        self.sync = GradSync(a, group)
+        self.sync = GradSync(a, group, bucket_bytes=bucket_bytes, comm_dtype=grad_comm_dtype, force=force_collectives)
         self.world = self.sync.world
         self._sq_ws = torch.empty(1024, dtype=torch.float32, device=dev)
         self._gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -121,6 +161,7 @@ class Trainer:
         overlap = eng.overlap
         eng.prepare()
         eng.arena.grad.zero_()
+        self.sync.collectives = self.sync.bytes_reduced = 0
         losses: Dict[str, torch.Tensor] = {}
         vtape: Dict = {}
         vis, vis_ready = None, None
@@ -182,11 +223,11 @@ class Trainer:
             def after_decoder(dv, last=last):
                 add_dvis(dv)
                 if last:
-                    if self.world > 1:
+                    if self.sync.active:
                         eng.join_wgrads()
                         self.sync.ready(*self._r_dec)
                     launch_vit_backward()
-                    if self.world > 1 and m.use_video:     # the (short) ViT backward is fully enqueued: reduce its slice beside the
+                    if self.sync.active and m.use_video:     # the (short) ViT backward is fully enqueued: reduce its slice beside the
                         self.sync.ready(*self._r_vis, also=(eng.vstream, eng.wstream) if overlap else ())   # encoder backward
                         state["vis_sent"] = True
 
@@ -195,13 +236,13 @@ class Trainer:
             def encoder_layer_done(i, last=last):
                 # every 4 encoder layers (backward runs 11 -> 0): hand their slice to the reduction while the next layers compute,
                 # instead of one 0.45 GB all-reduce after the whole stack
-                if last and self.world > 1 and i > 0 and i % 4 == 0:
+                if last and self.sync.active and i > 0 and i % 4 == 0:
                     end = self.sync.range_of(self._enc_first, eng._ln("encoder", i, 0))[1]
                     self.sync.ready(enc_sent[0], end, also=(eng.wstream,) if eng.overlap else ())
                     enc_sent[0] = end
 
             def after_encoder(last=last):
-                if last and self.world > 1:
+                if last and self.sync.active:
                     eng.join_wgrads()
                     self.sync.ready(enc_sent[0], self._r_enc[1])
                     self.sync.ready(*self._r_shared)
@@ -236,6 +277,19 @@ class Trainer:
             embb = a.w("t5_model.shared.weight")
             for _ in range(2):      # dvc.py:120-126 renormalises `shared` and then `lm_head` -- the same tied tensor
                 L.timetoken_renorm(emb, embb, eng.V, eng.d, self.model.num_bins, self._renorm_ws)
+
+    def state_dict(self) -> Dict:
+        """Optimizer state for checkpoint / resume (dvc.py:310-330 saves optimizer.state_dict() next to the model): Adam moments (flat,
+        arena order), step count, and the dropout stream position so that a resumed run draws the masks the uninterrupted one would."""
+        return {"step_count": self.step_count, "exp_avg": self.m, "exp_avg_sq": self.v, "dropout_rng": self.eng.rng_state(),
+                "arena_names": list(self.eng.arena.names)}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        if list(sd["arena_names"]) != list(self.eng.arena.names):
+            raise ValueError("optimizer state was saved for a different parameter layout")
+        self.step_count = int(sd["step_count"])
+        self.m.copy_(sd["exp_avg"]); self.v.copy_(sd["exp_avg_sq"])
+        self.eng.set_rng_state(sd["dropout_rng"])
 
     def grad_norm(self) -> torch.Tensor:
         """Global L2 norm of the (world-averaged) gradient of the last step, as a device scalar."""
