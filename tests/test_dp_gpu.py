@@ -74,4 +74,4 @@ def test_two_ranks_equal_one_large_batch():
     print(f"DP (2 ranks) vs single process after 2 steps: worst update cosine {ret['worst']:.4f} ({ret['worst_k']}), max |dw| diff {ret['maxdiff']:.2e}")
     # Adam turns every gradient element into a step of ~lr whatever its size, so elements whose gradient is bf16/atomics-order noise
     # may step in different directions: compare update DIRECTIONS per tensor (as test_dropin_optimizer_path_matches_trainer does)
-    assert ret["worst"] > 0.9 and ret["maxdiff"] <= 2 * 2.1 * 1e-3
+    assert ret["worst"] > 0.93 and ret["maxdiff"] <= 2 * 2.1 * 1e-3      # measured r02: 0.9466 (block-0 bias table), 3.97e-3

@@ -2,8 +2,9 @@
   (a) golden vectors captured from the REAL reference (tests/golden/*.npz, made by oracle/make_golden.py), and
   (b) the CPU oracle (oracle/vid2seq_ref.py, itself pinned against the reference) on other seeded inputs.
 
-Stated tolerances: loss rel <= 2e-2; greedy tokens equal up to a first divergence; gradients: cosine
->= 0.975 per tensor on the reduced ("small") shapes and gradient-norm ratio within [0.9, 1.1].  Why 0.975 and not 0.99:
+Stated tolerances (SURVEY.md 8c), set just under what the engine measures (round-2 numbers next to each assert): loss rel <= 2e-2;
+greedy tokens equal up to a first divergence; gradients: cosine >= 0.978 per tensor on the reduced ("small") shapes and gradient-norm
+ratio within [0.95, 1.06].  Why 0.978 and not 0.99:
 on these tiny shapes (3 sequences x 24 tokens) the attention q/k/bias gradients are cancellation-dominated, and the
 reference math itself run under torch's bf16 autocast scores 0.977-0.990 against its own fp32 gradients on exactly
 these inputs (tests/tools/bf16_noise.py); the HIP path measures 0.980-0.995.  At full size (t5-base, cfg-1) the per-tensor
@@ -79,7 +80,7 @@ def test_forward_backward_vs_reference_golden(golden_dir, tag, cfg, seed):
         worst = min(worst, cs) if cs == cs else float("nan")
         if not (cs > 0.995):
             print(f"  {name}: cos {cs:.4f} norm ratio {rn:.3f} finite={bool(torch.isfinite(got).all())}")
-        if not (cs > 0.975 and 0.9 < rn < 1.1):
+        if not (cs > 0.978 and 0.95 < rn < 1.06):            # measured r02: worst cosine 0.9803 / 0.9889, norm ratios 0.973 .. 1.039
             bad.append((name, cs, rn))
     print(f"  worst gradient cosine over all tensors: {worst:.5f}; failing tensors: {len(bad)}")
     assert not bad, bad[:10]
@@ -173,7 +174,7 @@ def test_train_recipe_vs_reference_golden(golden_dir):
         print(f"  {name}: update cosine {cs:.4f}, max|w - w_ref| {mx:.2e}")
         # Adam's first steps move every weight by ~lr*sign(g): elements whose tiny gradient changes sign under bf16
         # rounding differ by up to 2*lr per step, so compare the update direction and bound the distance by 2 steps * 2 lr
-        assert cs > 0.9 and mx <= 4.2 * 3e-4 + 1e-6, (name, cs, mx)
+        assert cs > 0.93 and mx <= 4.2 * 3e-4 + 1e-6, (name, cs, mx)      # measured r02: update cosine 0.943 .. 0.9998
     # the bf16 shadow tracks the fp32 master after the fused step
     eng = model.engine()
     assert torch.equal(eng.arena.shadow, eng.arena.master.to(torch.bfloat16))
@@ -217,7 +218,7 @@ def test_greedy_vs_reference_golden(golden_dir):
     first_div = [int((~r).nonzero()[0]) if (~r).any() else n for r in same]
     print("greedy first divergence per row:", first_div, "of", n)
     assert toks[:, 0].eq(0).all()
-    assert min(first_div) >= n // 2, (toks, want)          # bf16 argmax flips only on <1e-2 logit margins
+    assert min(first_div) >= 16, (toks, want)              # measured r02: [17, 25, 25] of 25 (bf16 argmax flips only on <1e-2 logit margins)
     text = model.generate(torch.from_numpy(g["video"]).to(DEV), tok(torch.from_numpy(g["input_ids"])), num_beams=1,
                           max_length=int(g["max_new"]))
     assert isinstance(text, list) and len(text) == want.shape[0] and all(isinstance(t, str) for t in text)
@@ -266,7 +267,7 @@ def test_beam_search_vs_golden(golden_dir):
     print("min_length=7:", "identical" if torch.equal(got_ml, want_ml) else (got_ml.tolist(), want_ml.tolist()))
     assert got_ml.shape == want_ml.shape and (got_ml == want_ml).float().mean() > 0.9
     print(f"beam search rows identical to the fp32 fixture: {same}/{rows}")
-    assert same * 4 >= rows * 3
+    assert same >= rows - 1                                # measured r02: 24/24
     text = model.generate(video, tok(ids), num_beams=nb, max_length=max_new)
     assert isinstance(text, list) and len(text) == out.shape[0]
     text2 = model.generate(video, tok(ids), num_beams=nb, max_length=max_new, num_captions=2)     # num_return_sequences = 2
@@ -333,14 +334,14 @@ def test_full_size_cfg1_vs_reference_golden(golden_dir):
     print(f"  non-finite gradient tensors: {len(nonfinite)} {nonfinite[:12]}")
     tot = float(torch.sqrt(sum((v.float() ** 2).sum() for v in grads.values())))
     print(f"  total grad norm hip={tot:.4f} reference={float(g['grad_norm']):.4f}")
-    assert abs(tot - float(g["grad_norm"])) <= 5e-2 * float(g["grad_norm"])
+    assert abs(tot - float(g["grad_norm"])) <= 2e-2 * float(g["grad_norm"])      # measured r02: 0.7 %
     bad = []
     for k, v in zip(keys, vals):
         r = float(grads[k].float().norm()) / (float(v) + 1e-12)
         if not 0.9 < r < 1.1:
             bad.append((k, r))
     print(f"  per-tensor grad-norm ratio outside [0.9,1.1]: {bad[:8]}")
-    assert len(bad) <= 2
+    assert not bad                                          # measured r02: every tensor inside [0.9, 1.1]
 
 
 def test_full_size_cfg2_size_independent_properties():
@@ -430,7 +431,7 @@ def test_repetition_penalty_vs_golden(golden_dir):
                 rows += 1
                 same += (out[r].tolist() == want[r, :out.shape[1]].tolist() and int(want[r, out.shape[1]:].abs().sum()) == 0)
     print(f"repetition penalty: rows identical to the fp32 fixture: {same}/{rows}")
-    assert same * 4 >= rows * 3
+    assert same >= rows - 1                                # measured r02: 16/16
 
 
 def test_generate_with_nucleus_sampling_runs():
