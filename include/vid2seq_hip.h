@@ -293,6 +293,10 @@ int v2s_repetition_penalty(float* scores, int64_t ld, int32_t rows, int32_t V, c
                            const int32_t* pos_dev, int32_t n_static, float penalty, float* row_lse, void* stream);
 int v2s_kv_gather(const void* src, void* dst, const int32_t* idx, int64_t bs, int64_t rs, int32_t B, int32_t len,
                   int32_t width, void* stream);
+/* HF 4.28 MinLengthLogitsProcessor for greedy_search (generate(min_length=...), vid2seq.py:155): scores[r][token] = -inf for every row
+ * while *pos_dev + 1 < min_length (decoder sequence = start token + *pos_dev decoded tokens) */
+int v2s_ban_token(float* scores, int64_t ld, int32_t rows, int32_t V, int32_t token, const int32_t* pos_dev, int32_t min_length,
+                  void* stream);
 /* T5 span corruption of a 0-padded id batch on the device (util/t5.py:3-32 as used by dataset/dvc_dataset.py:127-145).
  * ids [B][ld_ids] int64, lens [B] valid lengths (<= max_len), noise [B][ld_noise] uint8 (1 = noise token; the reference draws it
  * with numpy's RNG on the host).  den_in / den_out rows receive the corrupted input / target sequence incl. the trailing EOS and

@@ -365,11 +365,12 @@ def repetition_penalty_(scores: torch.Tensor, seq: torch.Tensor, penalty: float)
 
 
 def greedy_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, max_new_tokens: int = 256,
-                    repetition_penalty: float = 1.0):
+                    repetition_penalty: float = 1.0, min_length: int = 1):
     """vid2seq.py:100-167 with num_beams=1, do_sample=False: HF 4.28 GenerationMixin.greedy_search
     rules: start token 0, argmax of the last-position logits, rows that already
     emitted EOS emit pad, stop when every row is finished or after max_new_tokens new tokens
-    (MinLength(1) is a no-op).  Returns int64 [B, <=1+max_new_tokens] including the start token."""
+    (MinLength(1) is a no-op; min_length > 1 bans EOS while the decoder sequence is shorter).  Returns int64 [B, <=1+max_new_tokens]
+    including the start token."""
     memory, mem_mask, _ = encode(P, cfg, video, input_ids, input_mask)
     B = memory.shape[0]
     seq = torch.full((B, 1), cfg.dec_start_id, dtype=torch.long)
@@ -382,6 +383,8 @@ def greedy_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, max
         logits = lm_logits(P, cfg, h[:, -1:]).squeeze(1).float()
         if repetition_penalty != 1.0:                                 # greedy_search: processors run on the raw logits
             repetition_penalty_(logits, seq, repetition_penalty)
+        if seq.shape[1] < min_length:                                 # HF 4.28 MinLengthLogitsProcessor (cur_len = decoder ids so far)
+            logits[:, cfg.eos_id] = -float("inf")
         nxt = logits.argmax(-1)
         nxt = nxt * unfinished + cfg.pad_id * (1 - unfinished)
         seq = torch.cat([seq, nxt[:, None]], 1)

@@ -448,3 +448,56 @@ def test_generate_with_nucleus_sampling_runs():
     samp = model.engine().greedy(video, ids, max_new_tokens=12, sample=(1e-6, 1.0, 5)).cpu()      # nucleus = the argmax token only
     n = min(greedy.shape[1], samp.shape[1])
     assert torch.equal(greedy[:, :n], samp[:, :n])
+
+
+def test_greedy_min_length_and_sampled_num_captions_vs_oracle():
+    """generate(num_beams=1, min_length=k) (EOS banned by v2s_ban_token from the device step counter, inside the replayed graph) against
+    the oracle's greedy loop (itself checked against the installed transformers), and num_captions > 1 with nucleus sampling (HF expands
+    every input row num_return_sequences times)."""
+    cfg = R.RefConfig.small()
+    model = build(cfg, 40).eval()
+    P = synth.init_params(R.param_shapes(cfg), 40, cfg.d_model, cfg.inner, cfg.d_ff)
+    b = synth.make_batch(4, cfg.num_features, 24, 12, cfg.vocab, 40, cfg.vit_dim)
+    Ew = P["t5_model.shared.weight"] * 6.0
+    P["t5_model.shared.weight"] = Ew
+    g0 = R.greedy_generate(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, 6)
+    fav = int(torch.mode(g0[:, 1:].flatten()).values)
+    Ew[1] = Ew[fav] * 1.3
+    with torch.no_grad():
+        model.t5_model.shared.weight.copy_(Ew.to(DEV))
+    video, ids = b["video"].to(DEV), tok(b["input_ids"])
+    for ml in (1, 5, 9):
+        want = R.greedy_generate(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, 12, min_length=ml)
+        got = model.engine().greedy(video, ids, max_new_tokens=12, min_length=ml).cpu()
+        n = min(got.shape[1], want.shape[1])
+        print(f"min_length={ml}: hip {got[0].tolist()} oracle {want[0].tolist()}")
+        assert (got[:, :n] == want[:, :n]).float().mean() > 0.9
+        if ml > 1:
+            assert not (got[:, 1:ml - 1] == 1).any()
+    text = model.generate(video, ids, num_beams=1, max_length=12, min_length=5)
+    assert len(text) == 4
+    caps = model.generate(video, ids, use_nucleus_sampling=True, num_beams=0, max_length=8, top_p=0.9, num_captions=3)
+    assert len(caps) == 12 and all(isinstance(t, str) for t in caps)
+
+
+def test_fused_lm_head_equals_unfused():
+    """Trainer path: LM head + label-smoothed CE + their backward run chunk by chunk inside the forward (Engine.fused_head; no
+    [B*Lo, vocab] logits / d(logits) tensor).  Same kernels on row chunks: loss and every gradient must match the unfused head up to
+    the accumulation order of the chunked embedding weight gradient."""
+    cfg = R.RefConfig.small()
+    b = {k: v.to(DEV) for k, v in synth.make_batch(3, 10, 40, 23, cfg.vocab, 29, cfg.vit_dim, denoising=True).items()}
+    res = {}
+    for fused in (True, False):
+        model = build(cfg, 13).train()
+        eng = model.engine()
+        eng.fused_head, eng.head_rows = fused, 16           # 69 decoder rows -> 5 chunks, the last one ragged
+        tr = Trainer(model, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=0.5)
+        losses = tr.step(b)
+        res[fused] = (losses["loss"].item(), losses["denoising_loss"].item(), tr.grad_norm().item(),
+                      {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()})
+    (l1, d1, n1, g1), (l0, d0, n0, g0) = res[True], res[False]
+    print(f"fused head: loss {l1:.6f}/{l0:.6f} den {d1:.6f}/{d0:.6f} gnorm {n1:.5f}/{n0:.5f}")
+    assert abs(l1 - l0) <= 1e-5 * abs(l0) and abs(d1 - d0) <= 1e-5 * abs(d0) and abs(n1 - n0) <= 1e-3 * n0
+    worst = min(cos(g1[k], g0[k]) for k in g0 if g0[k].abs().max() > 0)
+    print(f"  worst gradient cosine fused vs unfused: {worst:.6f}")
+    assert worst > 0.9995

@@ -601,3 +601,36 @@ def test_constructor_requires_t5_weights_like_the_reference(tmp_path):
     vit = m.visual_encoder.state_dict()
     assert float(vit["blocks.0.norm1.weight"].min()) == 1.0 and float(vit["blocks.0.attn.qkv.bias"].abs().max()) == 0.0
     assert m.t5_model.lm_head.weight is m.t5_model.shared.weight
+
+
+def test_oracle_greedy_min_length_vs_installed_transformers():
+    """generate(min_length=k) with greedy decoding (HF MinLengthLogitsProcessor; un-vendored 4.28 -> cross-checked against the installed
+    release): weights that make EOS the greedy favourite, so the ban is what keeps the sequences alive."""
+    transformers = pytest.importorskip("transformers")
+    from transformers.modeling_outputs import BaseModelOutput
+    cfg = R.RefConfig.small()
+    P = synth.init_params(R.param_shapes(cfg), 40, cfg.d_model, cfg.inner, cfg.d_ff)
+    E = P["t5_model.shared.weight"] * 6.0
+    b = synth.make_batch(4, cfg.num_features, 24, 12, cfg.vocab, 40, cfg.vit_dim)
+    P["t5_model.shared.weight"] = E
+    g = R.greedy_generate(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, 6)
+    fav = int(torch.mode(g[:, 1:].flatten()).values)
+    E[1] = E[fav] * 1.3                                    # EOS beats the favourite token
+    hf = transformers.T5ForConditionalGeneration(transformers.T5Config(
+        vocab_size=cfg.vocab, d_model=cfg.d_model, d_kv=cfg.d_kv, d_ff=cfg.d_ff, num_layers=cfg.n_enc, num_decoder_layers=cfg.n_dec,
+        num_heads=cfg.heads, feed_forward_proj="relu", dropout_rate=0.0, tie_word_embeddings=True, pad_token_id=0, eos_token_id=1,
+        decoder_start_token_id=0))
+    sd = {k[len("t5_model."):]: v for k, v in P.items() if k.startswith("t5_model.")}
+    for a in ("encoder.embed_tokens.weight", "decoder.embed_tokens.weight", "lm_head.weight"):
+        sd[a] = sd["shared.weight"]
+    hf.load_state_dict(sd, strict=False); hf.eval()
+    mem, mm, _ = R.encode(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0)
+    for ml in (1, 5, 9):
+        mine = R.greedy_generate(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, 12, min_length=ml)
+        with torch.no_grad():
+            ref = hf.generate(encoder_outputs=BaseModelOutput(last_hidden_state=mem), attention_mask=mm, num_beams=1, do_sample=False,
+                              max_new_tokens=12, min_length=ml)
+        n = min(mine.shape[1], ref.shape[1])
+        assert torch.equal(mine[:, :n], ref[:, :n]), (ml, mine, ref)
+        if ml > 1:
+            assert not (mine[:, 1:ml - 1] == 1).any()

@@ -24,8 +24,12 @@ batch = {k: v.to(dev) for k, v in synth.make_batch(32, a.frames, a.asr, 256, len
 batch["video"] = batch["video"].to(torch.bfloat16)
 defaults = {}
 def apply(setting):
+    """"gemm_p8=0,eng:fused_head=1": library options, and engine attributes with the eng: prefix"""
     for kv in filter(None, setting.split(",")):
         k, v = kv.split("=")
+        if k.startswith("eng:"):
+            setattr(model.engine(), k[4:], int(v))
+            continue
         defaults.setdefault(k, L.get_option(k))
         L.set_option(k, int(v))
 for s in a.settings:

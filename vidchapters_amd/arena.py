@@ -17,7 +17,10 @@ ALIGN = 64  # elements; keeps every view 256-byte aligned in fp32 and 128-byte a
 
 
 class ParamArena:
-    def __init__(self, named: List[Tuple[str, nn.Parameter]], device: torch.device):
+    def __init__(self, named: List[Tuple[str, nn.Parameter]], device: torch.device, tail_pad: int = 0):
+        """``tail_pad``: zero elements appended after the LAST parameter in all three buffers (the tied embedding is last: the LM-head
+        GEMMs then read it as a [vocab rounded up to 64][d_model] matrix whose extra rows are zero and stay zero -- their gradient
+        is never written and Adam maps (0 weight, 0 gradient) to 0)."""
         self.device = device
         self.names: List[str] = []
         self.offsets: Dict[str, int] = {}
@@ -34,10 +37,10 @@ class ParamArena:
             self.shapes[name] = tuple(p.shape)
             self.params[name] = p
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
-        self.numel = off
-        self.master = torch.zeros(off, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
-        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        self.numel = off + (tail_pad + ALIGN - 1) // ALIGN * ALIGN
+        self.master = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.shadow = torch.zeros(self.numel, dtype=torch.bfloat16, device=device)
         with torch.no_grad():
             for name in self.names:
                 p = self.params[name]

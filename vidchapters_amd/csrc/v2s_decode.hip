@@ -479,6 +479,20 @@ extern "C" int v2s_repetition_penalty(float* scores, int64_t ld, int32_t rows, i
   return V2S_OK;
 }
 
+// HF 4.28 MinLengthLogitsProcessor for greedy_search: scores[:, token] = -inf while the decoder sequence (start token + decoded) is
+// shorter than min_length; the step counter lives on the device so that one captured graph serves every step
+__global__ void ban_token_kernel(float* __restrict__ scores, long ld, int rows, int token, const int* __restrict__ pos_dev, int min_length) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows && *pos_dev + 1 < min_length) scores[(long)r * ld + token] = -INFINITY;
+}
+extern "C" int v2s_ban_token(float* scores, int64_t ld, int32_t rows, int32_t V, int32_t token, const int32_t* pos_dev, int32_t min_length,
+                             void* stream) {
+  V2S_CHECK(scores && pos_dev && rows > 0 && token >= 0 && token < V, V2S_ERR_ARG, "v2s_ban_token: bad args");
+  hipLaunchKernelGGL(ban_token_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, scores, (long)ld, rows, token, pos_dev, min_length);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
 extern "C" int v2s_topp_sample_step(const float* logits, int64_t ld, int32_t rows, int32_t V, float top_p, float temperature, uint32_t seed,
                                     int64_t* next_tok, int32_t* unfinished, int32_t eos_id, int32_t pad_id, int64_t* seq_out, int64_t seq_ld,
                                     const int32_t* pos_dev, float* probs_out, int32_t min_length, void* stream) {

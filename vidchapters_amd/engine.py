@@ -53,10 +53,12 @@ class Engine:
         self.cfg = model.cfg
         c = self.cfg
         self.d, self.inner, self.H, self.ff, self.V = c.d_model, c.inner, c.heads, c.d_ff, c.vocab
-        self.ldv = (self.V + 7) // 8 * 8
+        self.ldv = (self.V + 63) // 64 * 64       # row pitch of logits / d(logits); also the padded row count of the tied embedding (arena tail)
         self.vd, self.vH, self.vmlp = model.vit_dim, model.vit_heads, model.vit_mlp
         L.lib()                                                   # fail loudly if the HIP library is missing
-        self.arena = ParamArena(self._arena_order(), device)
+        order = self._arena_order()
+        assert order[-1][0] == "t5_model.shared.weight"
+        self.arena = ParamArena(order, device, tail_pad=(self.ldv - self.V) * self.d)
         assert self.arena.adjacent(*[self._sa("encoder", 0) + w for w in ("q.weight", "k.weight", "v.weight")])
         self._luts: Dict[Tuple[int, int, bool], torch.Tensor] = {}
         self._far: Dict[Tuple[int, int, bool], Tuple[int, int]] = {}
@@ -76,6 +78,8 @@ class Engine:
         # CUs those leave idle (tails, epilogues, small decoder/ViT launches).  `vstream` lets the temporal ViT (small
         # launches, independent of the T5 encoder) run beside the encoder in both directions (train.Trainer).
         self.overlap = True
+        self.fused_head = True    # Trainer path: LM head + CE + their backward chunk by chunk inside the forward (no [B*Lo, vocab] tensor)
+        self.head_rows = 2048     # decoder rows per chunk: 264 MB of fp32 logits + 132 MB of bf16 d(logits) scratch at vocab 32200
         self.pack = True          # run the text encoder on the valid (non-pad) tokens only: exact, see _pack_plan
         self.wstream = torch.cuda.Stream(device=device)
         self.vstream = torch.cuda.Stream(device=device)
@@ -155,6 +159,12 @@ class Engine:
         Parameters themselves (optimizer.step, load_state_dict, in-place ops) are detected automatically."""
         self.arena._seen_version = -1
 
+    def _head_ws(self) -> torch.Tensor:
+        t = self._ws.get("head_splitk")
+        if t is None:     # split-K slices of the [head_rows, d_model] fp32 d(hidden) chunk (main stream; the wgrad stream has its own)
+            t = self._ws["head_splitk"] = self._f32(16 * self.head_rows * self.d)
+        return t
+
     def _next_seed(self) -> int:
         self._site += 1
         return (self._seed * 0x9E3779B1 + self._site * 0x85EBCA6B) & 0xFFFFFFFF
@@ -184,7 +194,7 @@ class Engine:
 
     # linear helpers ------------------------------------------------------------------------------------------
     def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, wname: str, n_out: int, n_in: int, rows: int, ld_dy=None, ld_x=None,
-               alpha: float = 1.0, shape=None) -> None:
+               alpha: float = 1.0, shape=None, side_ok: bool = False) -> None:
         """dW[n_out, n_in] += alpha * dy[rows, n_out]^T @ x[rows, n_in]  (fp32 accumulate into the gradient arena).
         Runs on the weight-gradient stream unless the target is the tied embedding (whose gradient is also written by
         the embedding scatter-add on the main stream)."""
@@ -192,7 +202,7 @@ class Engine:
             L.gemm(dy, x, self.arena.g(wname, shape), n_out, n_in, rows, transA=True, transB=True,
                    lda=ld_dy if ld_dy is not None else n_out, ldb=ld_x if ld_x is not None else n_in, ldc=n_in,
                    accumulate=True, alpha=alpha, workspace=self._splitk_ws())
-        if not self.overlap or wname == "t5_model.shared.weight":
+        if not self.overlap or (wname == "t5_model.shared.weight" and not side_ok):
             if self.overlap:      # the shared split-K workspace is owned by wstream: wait for its users first
                 torch.cuda.current_stream().wait_stream(self.wstream)
             launch()
@@ -577,9 +587,17 @@ class Engine:
             gpos.index_add_(0, tape["idx"], tmp)
 
     # ========================================================================================== loss head
-    def t5_loss_forward(self, vis, input_ids, input_mask, output_ids, output_mask, tape, vis_ready=None, input_lens=None):
+    def t5_loss_forward(self, vis, input_ids, input_mask, output_ids, output_mask, tape, vis_ready=None, input_lens=None,
+                        head_grad_scale: Optional[float] = None):
         """Encoder on the ASR tokens, [video ; text] memory, decoder on the shifted targets, tied LM head and
-        label-smoothed CE (vid2seq.py:63-98 -> modeling_t5.py:1587-1738).  ``vis``: bf16 [B, T, d] or None."""
+        label-smoothed CE (vid2seq.py:63-98 -> modeling_t5.py:1587-1738).  ``vis``: bf16 [B, T, d] or None.
+
+        ``head_grad_scale`` (Trainer: the loss coefficient d(total)/d(this loss), known before the forward): run the LM head FUSED with
+        its backward, ``head_rows`` decoder rows at a time -- logits chunk -> CE statistics -> d(logits) chunk -> embedding weight
+        gradient (accumulated into the arena) and d(hidden) -- so that no [B*Lo, vocab] tensor ever exists: the 1.05 GB fp32 logits
+        and the 0.53 GB bf16 d(logits) of the unfused path become two scratch chunks that live in the Infinity Cache between their
+        producer and consumer kernels.  Needs a tape (training) and a zeroed / accumulating gradient arena, which Trainer.step provides;
+        the autograd route (loss.backward() of drop-in callers learns the upstream gradient only later) keeps the unfused head."""
         m, c = self.model, self.cfg
         train = m.training
         pe, pd = (m.enc_drop if train else 0.0), (m.dec_drop if train else 0.0)
@@ -631,17 +649,41 @@ class Engine:
         Lo = dec_in.shape[1]
         hs = self.decoder_forward(dec_in, output_mask.to(torch.uint8).contiguous(), mem, S, mem_mask, pd, dec_tape)
         Md = B * Lo
-        logits = self._f32(Md, self.ldv)
         alpha = self.d ** -0.5                                   # tie_word_embeddings rescale (modeling_t5.py:1709-1712)
-        L.gemm(hs, self.arena.w("t5_model.shared.weight"), logits, Md, self.V, self.d, ldc=self.ldv, alpha=alpha)
+        E = self.arena.w("t5_model.shared.weight")
         labels = targets.reshape(-1).contiguous()
         row = self._f32(Md, 2)
         acc = torch.zeros(2, dtype=torch.float32, device=self.device)      # (loss_sum, count)
-        L.ce_fwd(logits, self.ldv, labels, Md, self.V, m.label_smoothing, row, acc[0:1], acc[1:2])
+        logits = dhs = None
+        if head_grad_scale is not None and tape is not None and self.fused_head:
+            # d(loss)/d(logits) needs 1 / (number of non-ignored targets) of the WHOLE batch before the first chunk: count it here
+            gscale = (float(head_grad_scale) / (labels != -100).sum().clamp(min=1).float()).reshape(1).contiguous()
+            dhs = self._bf(Md, self.d)
+            R_ = min(self.head_rows, Md)
+            lg = self._f32(R_, self.ldv)                          # logits scratch, reused by every chunk (stream-ordered)
+            dh32 = self._f32(R_, self.d)
+            Epad = self.arena.shadow[self.arena.offsets["t5_model.shared.weight"]:][:self.ldv * self.d].view(self.ldv, self.d)
+            for r0 in range(0, Md, R_):
+                n = min(R_, Md - r0)
+                L.gemm(hs[r0:r0 + n], E, lg, n, self.V, self.d, ldc=self.ldv, alpha=alpha)
+                L.ce_fwd(lg, self.ldv, labels[r0:r0 + n], n, self.V, m.label_smoothing, row[r0:r0 + n], acc[0:1], acc[1:2])
+                dlog = self._bf(n, self.ldv)                      # fresh per chunk: the weight-gradient stream may still read the previous one
+                L.ce_bwd(lg, self.ldv, labels[r0:r0 + n], row[r0:r0 + n], n, self.V, m.label_smoothing, gscale, dlog, self.ldv)
+                # embedding weight gradient on the weight-gradient stream (the scatter-adds into the same tensor run at the very end of
+                # backward, after join_wgrads); d(hidden): contraction over the padded vocabulary (zero pad columns x zero pad rows), few
+                # output tiles -> fp32 split-K, then one rounding to bf16
+                self._wgrad(dlog, hs[r0:r0 + n], "t5_model.shared.weight", self.V, self.d, n, ld_dy=self.ldv, alpha=alpha, side_ok=True)
+                L.gemm(dlog, Epad, dh32[:n], n, self.d, self.ldv, transB=True, lda=self.ldv, ldb=self.d, alpha=alpha, workspace=self._head_ws())
+                L.cast_bf16(dh32[:n].view(-1), dhs[r0:r0 + n].view(-1), n * self.d)
+        else:
+            logits = self._f32(Md, self.ldv)
+            L.gemm(hs, E, logits, Md, self.V, self.d, ldc=self.ldv, alpha=alpha)
+            L.ce_fwd(logits, self.ldv, labels, Md, self.V, m.label_smoothing, row, acc[0:1], acc[1:2])
         loss = acc[0] / acc[1]
         if tape is not None:
             tape.update(enc=enc_tape, dec=dec_tape, B=B, T=T, Lx=Lx, Lo=Lo, S=S, hs=hs, logits=logits, labels=labels, row=row,
-                        acc=acc, alpha=alpha, mem_rows=mem_rows, enc_rows=plan[1] if plan is not None else 0)
+                        acc=acc, alpha=alpha, mem_rows=mem_rows, enc_rows=plan[1] if plan is not None else 0, dhs=dhs,
+                        head_grad_scale=head_grad_scale)
         return loss
 
     def t5_loss_backward(self, tape, gloss: torch.Tensor, after_decoder=None, after_encoder=None,
@@ -651,15 +693,22 @@ class Engine:
         m = self.model
         B, T, Lx, Lo, S, d = tape["B"], tape["T"], tape["Lx"], tape["Lo"], tape["S"], self.d
         Md = B * Lo
-        gscale = (gloss.reshape(1).float() / tape["acc"][1:2]).contiguous()
-        dlog = self._bf(Md, self.ldv)
-        L.ce_bwd(tape["logits"], self.ldv, tape["labels"], tape["row"], Md, self.V, m.label_smoothing, gscale, dlog, self.ldv)
-        tape["logits"] = None
-        E = self.arena.w("t5_model.shared.weight")
-        self._wgrad(dlog, tape["hs"], "t5_model.shared.weight", self.V, d, Md, ld_dy=self.ldv, alpha=tape["alpha"])
-        dhs = self._bf(Md, d)
-        L.gemm(dlog, E, dhs, Md, d, self.V, transB=True, lda=self.ldv, ldb=d, alpha=tape["alpha"])
-        del dlog
+        if tape.get("dhs") is not None:                      # fused head: its backward ran inside the forward (t5_loss_forward)
+            dhs = tape["dhs"]
+            tape["dhs"] = None
+        else:
+            gscale = (gloss.reshape(1).float() / tape["acc"][1:2]).contiguous()
+            dlog = self._bf(Md, self.ldv)
+            L.ce_bwd(tape["logits"], self.ldv, tape["labels"], tape["row"], Md, self.V, m.label_smoothing, gscale, dlog, self.ldv)
+            tape["logits"] = None
+            E = self.arena.w("t5_model.shared.weight")
+            self._wgrad(dlog, tape["hs"], "t5_model.shared.weight", self.V, d, Md, ld_dy=self.ldv, alpha=tape["alpha"])
+            dhs = self._bf(Md, d)
+            # contraction over the vocabulary padded to a multiple of 64 (zero pad columns of d(logits) x zero pad rows of the arena
+            # tail): K = 32256 instead of 32200 keeps this GEMM on the LDS-DMA kernels
+            Epad = self.arena.shadow[self.arena.offsets["t5_model.shared.weight"]:][:self.ldv * d].view(self.ldv, d)
+            L.gemm(dlog, Epad, dhs, Md, d, self.ldv, transB=True, lda=self.ldv, ldb=d, alpha=tape["alpha"])
+            del dlog
         dmem = self._bf(B * S, d)
         self._stack_backward(tape["dec"], dhs, "decoder", Lo, dmem=dmem)
         dmem3 = dmem.view(B, S, d)
@@ -776,7 +825,7 @@ class Engine:
         device-resident step counter, so the same graph serves all steps.  The all-rows-finished test of HF is evaluated
         every 8 replays; the returned tensor is trimmed to exactly the length HF would have produced.
         ``sample=(top_p, temperature, seed)`` switches the token choice from argmax to nucleus sampling (same loop and stopping
-        rule as HF's sample()); ``min_length`` bans EOS while the sequence is shorter (sampling only; a no-op at HF's default 1)."""
+        rule as HF's sample()); ``min_length`` bans EOS while the decoder sequence is shorter (HF MinLengthLogitsProcessor)."""
         a, c = self.arena, self.cfg
         mem, mem_mask = self.encode(video, input_tokenized)
         B, S, d = mem.shape
@@ -837,6 +886,8 @@ class Engine:
                 L.gemm(n, E, logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
             if repetition_penalty != 1.0:           # HF RepetitionPenaltyLogitsProcessor on the raw logits (greedy_search)
                 L.repetition_penalty(logits, self.ldv, B, self.V, seq, repetition_penalty, pos_dev=pos)
+            if sample is None and min_length > 1 and eos >= 0:      # MinLengthLogitsProcessor of greedy_search (sampling: inside the sampling kernel)
+                L.ban_token(logits, self.ldv, B, self.V, c.eos_id, pos, min_length)
             if sample is not None:                  # nucleus sampling (HF sample(): processors, then temperature / top-p warpers, multinomial)
                 L.topp_sample_step(logits, self.ldv, B, self.V, sample[0], sample[1], sample[2], nxt, unfinished, eos, c.pad_id,
                                    seq_out=seq, seq_ld=maxlen + 1, pos_dev=pos, min_length=min_length)

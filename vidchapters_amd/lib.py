@@ -100,6 +100,7 @@ SYMBOLS = {
     "v2s_topp_sample_step": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _f32, _u32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
     "v2s_repetition_penalty": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),
     "v2s_kv_gather": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "v2s_ban_token": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
 }
 
 _LIB = None
@@ -441,6 +442,10 @@ def repetition_penalty(scores, ld, rows, V, hist, penalty, pos_dev=None, n_stati
     _need(hist, torch.int64, "repetition_penalty hist")
     _check(lib().v2s_repetition_penalty(scores.data_ptr(), ld, rows, V, hist.data_ptr(), hist.stride(0), ptr(pos_dev), n_static, penalty,
                                         ptr(row_lse), stream_ptr()), "v2s_repetition_penalty")
+
+
+def ban_token(scores, ld, rows, V, token, pos_dev, min_length):
+    _check(lib().v2s_ban_token(scores.data_ptr(), ld, rows, V, token, pos_dev.data_ptr(), min_length, stream_ptr()), "v2s_ban_token")
 
 
 def kv_gather(src, dst, idx, bs, rs, B, length, width):

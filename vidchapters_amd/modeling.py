@@ -323,10 +323,11 @@ class Vid2Seq(nn.Module):
         if use_nucleus_sampling:
             # HF sample(): multinomial draws from the top-p filtered softmax.  The draws use a counter-based generator keyed on
             # self.sampling_seed (torch's global RNG stream cannot be reproduced): same distribution, different samples.
-            if num_captions != 1:
-                raise NotImplementedError("num_captions > 1 with nucleus sampling is not implemented")
             if num_beams > 1:       # HF 4.28 would run beam-sample (multinomial beam search) for do_sample with num_beams > 1
                 raise NotImplementedError("nucleus sampling with num_beams > 1 (HF beam-sample) is not implemented; use num_beams <= 1")
+            if num_captions > 1:    # HF: num_return_sequences expands every input row num_captions times and samples them independently
+                video = video.repeat_interleave(num_captions, 0)
+                input_tokenized = {k: v.repeat_interleave(num_captions, 0) for k, v in input_tokenized.items()}
             self.sampling_seed = (getattr(self, "sampling_seed", 0) + 1) & 0xFFFFFFFF
             toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length, repetition_penalty=repetition_penalty,
                               sample=(float(top_p), float(temperature), self.sampling_seed), min_length=min_length)
@@ -338,9 +339,7 @@ class Vid2Seq(nn.Module):
                                    length_penalty=length_penalty, min_length=min_length, repetition_penalty=repetition_penalty,
                                    num_return=num_captions)
         else:
-            if min_length > 1:     # every caller passes 1 (a no-op); the argmax step kernel has no EOS ban
-                raise NotImplementedError("min_length > 1 with greedy decoding is not implemented (beam search and sampling honour it)")
-            toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length, repetition_penalty=repetition_penalty)
+            toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length, repetition_penalty=repetition_penalty, min_length=min_length)
         return batch_decode_spaced(self.t5_tokenizer, toks, skip_special_tokens=True)
 
 

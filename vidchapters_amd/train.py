@@ -181,14 +181,14 @@ class Trainer:
             t1: Dict = {}
             ids = batch["input_ids"]
             losses["loss"] = eng.t5_loss_forward(vis, ids, ids != 0, batch["output_ids"], batch["output_ids"] != 0, t1,
-                                                 vis_ready=vis_ready, input_lens=batch.get("input_lens"))
+                                                 vis_ready=vis_ready, input_lens=batch.get("input_lens"), head_grad_scale=float(self.gen))
             tapes.append((t1, self.gen))
         if self.den:
             t2: Dict = {}
             ids = batch["den_input_ids"]
             losses["denoising_loss"] = eng.t5_loss_forward(vis, ids, ids != 0, batch["den_output_ids"],
                                                            batch["den_output_ids"] != 0, t2, vis_ready=vis_ready,
-                                                           input_lens=batch.get("den_input_lens"))
+                                                           input_lens=batch.get("den_input_lens"), head_grad_scale=float(self.den))
             tapes.append((t2, self.den))
 
         # backward: later passes first; parameter gradients accumulate in the arena.  The ViT backward starts as soon as
