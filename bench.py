@@ -181,6 +181,22 @@ def main():
                                        "ms_per_step": round(dtp * 1e3, 3), "samples_per_s": round(B / dtp, 2),
                                        "note": "engine default (Engine.pack): the text encoder runs on the non-pad tokens only; exact because the "
                                                "reference masks those rows as keys everywhere.  `value` above does NOT use it"}
+    if rank == 0 and world == 1 and not a.no_generate:
+        # the same step replayed from ONE hipGraph (Trainer.step_graph: batch / dropout salt / Adam scalars read from device memory):
+        # host time per step and device time per step; `value` above is the eager path, which is faster on the device on this stack
+        gb = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+        for _ in range(3):
+            trainer.step_graph(gb)
+        torch.cuda.synchronize()
+        enq, wall = [], []
+        for _ in range(5):
+            t0 = time.perf_counter(); trainer.step_graph(gb); t1 = time.perf_counter()
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            enq.append((t1 - t0) * 1e3); wall.append((t2 - t0) * 1e3)
+        t0 = time.perf_counter(); trainer.step(batch); t1 = time.perf_counter(); torch.cuda.synchronize()
+        out["captured_step"] = {"host_enqueue_ms_per_step": round(sorted(enq)[2], 3), "ms_per_step": round(sorted(wall)[2], 3),
+                                "eager_host_enqueue_ms_per_step": round((t1 - t0) * 1e3, 3),
+                                "note": "Trainer.step_graph: one hipGraph launch per step (~2500 kernel nodes on three streams)"}
     if rank == 0 and world == 1 and not a.no_roofline:      # N=1 only: the extra step would issue collectives other ranks do not join
         eng = model.engine()
         was = eng.overlap

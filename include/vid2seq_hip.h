@@ -56,6 +56,12 @@ int v2s_get_option(const char* name);
  * definition that is one field short would make the library read past the caller's buffer. */
 int64_t v2s_sizeof(const char* struct_name);
 
+/* Device-resident dropout salt: while set, every launch that draws a dropout mask (GEMM epilogues, attention, embedding, v2s_dropout)
+ * uses seed ^ *dev_word instead of its by-value seed.  The pointer is read when a launch is ENQUEUED and travels as a kernel argument,
+ * so a training step captured into a hipGraph draws new masks on every replay once the caller changes the word between replays
+ * (vidchapters_amd.train.Trainer.step_graph).  NULL restores the by-value seeds. */
+int v2s_set_seed_salt(const uint32_t* dev_word);
+
 /* ------------------------------------------------------------------------------------------------
  * GEMM:  C[M,N] (+)= epilogue( alpha * sum_k A(m,k) * B(n,k) )
  * replaces every nn.Linear on the path: vit.py:41,53,17,20; modeling_t5.py:304-311,528-536,581,1714
@@ -237,6 +243,8 @@ typedef struct v2s_adam_args {
   const float* gnorm_sq;   /* device scalar: sum of squared grads (for clipping) or NULL */
   float max_norm;          /* <=0: no clipping */
   float grad_scale;        /* extra multiplier applied to g before everything (e.g. 1/world) */
+  const float* hyper_dev;  /* NULL, or device {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)} read by the kernel INSTEAD of lr / step: a captured
+                            * hipGraph replays the launch with the values of the current step */
 } v2s_adam_args;
 int v2s_adam_step(const v2s_adam_args* a, void* stream);
 int v2s_cast_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -501,3 +501,44 @@ def test_fused_lm_head_equals_unfused():
     worst = min(cos(g1[k], g0[k]) for k in g0 if g0[k].abs().max() > 0)
     print(f"  worst gradient cosine fused vs unfused: {worst:.6f}")
     assert worst > 0.9995
+
+
+def test_captured_step_equals_eager_steps():
+    """Trainer.step_graph: the whole step (three streams, ~2500 launches at full size) replayed from one hipGraph; batch, dropout salt and
+    Adam's lr / bias corrections are read from device memory.  Without dropout three graph-path steps (eager warm-up, capture, replay)
+    on three different batches must land where three eager steps land (up to the fp32-atomics order, like the other optimizer tests);
+    with dropout and lr = 0 two replays of the SAME batch must give different losses (new masks per replay)."""
+    cfg = R.RefConfig.small()
+    batches = [{k: v.to(DEV) for k, v in synth.make_batch(3, 10, 40, 17, cfg.vocab, 50 + i, cfg.vit_dim, denoising=True).items()} for i in range(4)]
+    m_e, m_g = build(cfg, 19).train(), build(cfg, 19).train()
+    m_e.engine().pack = False
+    tr_e = Trainer(m_e, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=1.0, schedule="linear_with_warmup", num_training_steps=10)
+    tr_g = Trainer(m_g, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=1.0, schedule="linear_with_warmup", num_training_steps=10)
+    le, lg = [], []
+    for b in batches:
+        le.append(tr_e.step(b)["loss"].item())
+        lg.append(tr_g.step_graph(b)["loss"].item())
+    print("losses eager", [round(x, 5) for x in le], "graph", [round(x, 5) for x in lg])
+    assert tr_g._g["graph"] is not None and tr_g.step_count == tr_e.step_count == 4
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-3 * abs(a)
+    init = build(cfg, 19)
+    worst, maxdiff = 1.0, 0.0
+    for (k, p), (_, q), (_, p0) in zip(m_e.named_parameters(), m_g.named_parameters(), init.named_parameters()):
+        u1, u2 = (p.detach() - p0.detach().to(DEV)).double().flatten(), (q.detach() - p0.detach().to(DEV)).double().flatten()
+        if k.endswith("attn.qkv.bias"):
+            n3 = u1.numel() // 3
+            u1, u2 = torch.cat([u1[:n3], u1[2 * n3:]]), torch.cat([u2[:n3], u2[2 * n3:]])
+        if float(u1.norm()) == 0.0:
+            continue
+        worst = min(worst, float(u1 @ u2 / (u1.norm() * u2.norm() + 1e-30)))
+        maxdiff = max(maxdiff, float((u1 - u2).abs().max()))
+    print(f"  captured vs eager after 4 steps: worst update cosine {worst:.4f}, max |dw| diff {maxdiff:.2e}")
+    assert worst > 0.9 and maxdiff <= 4 * 2.1e-3
+    # dropout: new masks on every replay
+    m_d = build(cfg, 19, vis_drop=0.1, enc_drop=0.1, dec_drop=0.1).train()
+    tr_d = Trainer(m_d, lr=0.0, clip_max_norm=1.0, generative=1.0, denoising=0.0)
+    b = {k: v for k, v in batches[0].items() if not k.startswith("den_")}
+    vals = [tr_d.step_graph(b)["loss"].item() for _ in range(4)]
+    print("  dropout 0.1, lr 0, same batch:", [round(v, 5) for v in vals])
+    assert len({round(v, 6) for v in vals[1:]}) == 3

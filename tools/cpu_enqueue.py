@@ -25,3 +25,16 @@ for pack in (False, True):
         t2 = time.perf_counter()
         enq.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
     print(f"pack={pack}: host enqueue {min(enq):.1f}-{max(enq):.1f} ms per step, step wall {min(tot):.1f}-{max(tot):.1f} ms")
+# the same step replayed from a hipGraph (Trainer.step_graph)
+b2 = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+for _ in range(3): tr.step_graph(b2)
+torch.cuda.synchronize()
+enq, tot = [], []
+for _ in range(8):
+    t0 = time.perf_counter()
+    tr.step_graph(b2)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    enq.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
+print(f"graph replay: host enqueue {min(enq):.2f}-{max(enq):.2f} ms per step, step wall {min(tot):.1f}-{max(tot):.1f} ms")

@@ -42,6 +42,10 @@ int v2s_opt_gemm_p8() { return opt(O_GEMM_P8); }
 int v2s_opt_ce_fused() { return opt(O_CE_FUSED); }
 int v2s_opt_gemm_dbg() { return opt(O_GEMM_DBG); }
 
+static std::atomic<const uint32_t*> g_seed_salt{nullptr};
+const uint32_t* v2s_seed_salt() { return g_seed_salt.load(std::memory_order_relaxed); }
+extern "C" int v2s_set_seed_salt(const uint32_t* dev_word) { g_seed_salt.store(dev_word); return V2S_OK; }
+
 extern "C" int v2s_version(void) { return V2S_ABI_VERSION; }
 extern "C" const char* v2s_last_error(void) { return g_err; }
 

@@ -42,6 +42,7 @@ struct AttnP {
   const uint8_t* key_mask;
   int causal, causal_off;
   uint32_t p16; float inv_keep; uint32_t seed;
+  const uint32_t* salt;   // device word XOR-ed into seed (v2s_set_seed_salt) or NULL
   const bf16_t* d_o; long do_bs, do_rs;
   const float* delta;
   bf16_t *dq, *dk, *dv;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
   uint32_t rowseed[2] = {0u, 0u};
   if (DROP) {
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) rowseed[qb] = drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + Q0 + wq0 + qb * 16 + li)) ^ ((uint32_t)(4 * g) * DROP_C1);
+    for (int qb = 0; qb < 2; ++qb) rowseed[qb] = drop_rowseed(v2s_salted(p.seed, p.salt), (uint32_t)((b * p.H + h) * p.Nq + Q0 + wq0 + qb * 16 + li)) ^ ((uint32_t)(4 * g) * DROP_C1);
   }
   f32x4 ot[2][4];
 #pragma unroll
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
       dl[qb] = p.delta[r];
     }
     rows_real = rows_real && real;
-    if (DROP) rowseed[qb] = drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q)) ^ ((uint32_t)(4 * g) * DROP_C1);
+    if (DROP) rowseed[qb] = drop_rowseed(v2s_salted(p.seed, p.salt), (uint32_t)((b * p.H + h) * p.Nq + q)) ^ ((uint32_t)(4 * g) * DROP_C1);
   }
   const bool seen = __all(rows_real);
   const float isc2 = 1.0f / (p.scale * LOG2E);
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     }
     if (tid < 64) {
       const int q = q0 + tid;
-      if (DROP) rseed = drop_rowseed(p.seed, (uint32_t)((b * p.H + h) * p.Nq + q));
+      if (DROP) rseed = drop_rowseed(v2s_salted(p.seed, p.salt), (uint32_t)((b * p.H + h) * p.Nq + q));
       // rm = m + log2 l (1/l folded into the exponent), rl = value of a MASKED element's exponent: -log2 l for a row whose keys
       // are all masked (uniform distribution, like the reference), -huge otherwise; rows >= Nq: P = 0.  See the dQ kernel.
       rm = 1.0e30f; rl = -3.0e38f; rd = 0.f; rreal = 1;
@@ -911,6 +912,7 @@ int fill(AttnP& p, const v2s_attn_args* a, const char* who, bool bwd) {
   p.p16 = (uint32_t)(a->dropout_p * 65536.0f + 0.5f);
   p.inv_keep = p.p16 ? 1.0f / (1.0f - (float)p.p16 / 65536.0f) : 1.0f;
   p.seed = a->dropout_seed;
+  p.salt = v2s_seed_salt();
   p.d_o = (const bf16_t*)a->d_o; p.do_bs = a->do_bs; p.do_rs = a->do_rs; p.delta = a->delta;
   p.dq = (bf16_t*)a->dq; p.dk = (bf16_t*)a->dk; p.dv = (bf16_t*)a->dv;
   p.dq_bs = a->dq_bs; p.dq_rs = a->dq_rs; p.dk_bs = a->dk_bs; p.dk_rs = a->dk_rs; p.dv_bs = a->dv_bs; p.dv_rs = a->dv_rs;

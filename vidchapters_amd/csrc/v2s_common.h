@@ -33,6 +33,7 @@ void v2s_set_error(const char* fmt, ...);
     }                                                                         \
   } while (0)
 
+const uint32_t* v2s_seed_salt();  // device word XOR-ed into every dropout seed by the kernels (v2s_set_seed_salt), or NULL
 int v2s_opt_tr_read();   // 1 = use ds_read_b64_tr_b16 for transposed operand fragments
 int v2s_opt_gemm_dma();  // 2 = LDS-DMA (global_load_lds) 128x128 main loop for every variant where K % 64 == 0 (default), 1 = transposed only, 0 = never
 int v2s_opt_attn_bwd_part(); // profiling aid for v2s_attn_bwd: 0 = both kernels (default), 1 = dQ only, 2 = dK/dV only
@@ -89,6 +90,8 @@ __device__ __forceinline__ uint32_t v2s_mix32(uint32_t x) {
   x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
   return x;
 }
+// seed of a launch: the by-value seed, XOR the device-resident salt if one is set (captured graphs: new masks per replay)
+__device__ __forceinline__ uint32_t v2s_salted(uint32_t seed, const uint32_t* salt) { return salt ? seed ^ *salt : seed; }
 // bit j of the result = keep element e0 + j
 __device__ __forceinline__ uint32_t v2s_keep8(unsigned long long e0, uint32_t seed, uint32_t p16) {
   const uint32_t base = seed * 0x9E3779B1u + (uint32_t)(e0 >> 1) + (uint32_t)(e0 >> 33) * 0x85EBCA6Bu;

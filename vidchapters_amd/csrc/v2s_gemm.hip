@@ -34,6 +34,7 @@ struct GemmP {
   const bf16_t* z; long ldz;
   const bf16_t* residual; long ldr;
   uint32_t p16; float inv_keep; uint32_t seed;
+  const uint32_t* salt;  // device word XOR-ed into seed (v2s_set_seed_salt) or NULL
   int tilesM, tilesN;
   int splitk, kper;      // split-K (wgrad): slice z covers K range [z*kper, min(K,(z+1)*kper)) and writes ws[z][M][N]
   float* ws;
@@ -178,7 +179,7 @@ __device__ __forceinline__ void epilogue_chunk(const GemmP& p, float (&v)[8], in
     }
   }
   if (p.p16) {
-    v2s_drop8(v, (unsigned long long)(gm + p.row0) * (unsigned long long)p.N + gn, p.seed, p.p16, p.inv_keep);
+    v2s_drop8(v, (unsigned long long)(gm + p.row0) * (unsigned long long)p.N + gn, v2s_salted(p.seed, p.salt), p.p16, p.inv_keep);
   }
   if (p.residual) {
     float rf[8];
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8d_kernel(const GemmP p) {
       u32x4 x = *reinterpret_cast<const u32x4*>(buf + r * 512 + ((cc ^ (r & 15)) << 4));
       const int gm = pm0 + U * 32 + r, gn = pn0 + cc * 8;
       if (p.p16) {
-        const uint32_t m = v2s_keep8((unsigned long long)(gm + p.row0) * (unsigned long long)p.N + gn, p.seed, p.p16);
+        const uint32_t m = v2s_keep8((unsigned long long)(gm + p.row0) * (unsigned long long)p.N + gn, v2s_salted(p.seed, p.salt), p.p16);
         x[0] &= ((m & 1u) ? 0xffffu : 0u) | ((m & 2u) ? 0xffff0000u : 0u);
         x[1] &= ((m & 4u) ? 0xffffu : 0u) | ((m & 8u) ? 0xffff0000u : 0u);
         x[2] &= ((m & 16u) ? 0xffffu : 0u) | ((m & 32u) ? 0xffff0000u : 0u);
@@ -1405,6 +1406,7 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
   p.p16 = (uint32_t)(a->dropout_p * 65536.0f + 0.5f);
   p.inv_keep = p.p16 ? 1.0f / (1.0f - (float)p.p16 / 65536.0f) : 1.0f;
   p.seed = a->dropout_seed;
+  p.salt = v2s_seed_salt();
   p.rms_eps = a->rms_eps;
   p.order = v2s_opt_gemm_order();
   p.dbg = v2s_opt_gemm_dbg();

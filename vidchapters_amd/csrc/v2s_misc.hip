@@ -16,7 +16,8 @@ inline int grid_for(long work_items, int block = 256, int cap = 256 * 8) {
 
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__ ids, const bf16_t* __restrict__ table,
                                                         bf16_t* __restrict__ out, long n, int d, int vocab, uint32_t p16,
-                                                        float inv_keep, uint32_t seed) {
+                                                        float inv_keep, uint32_t seed0, const uint32_t* __restrict__ salt) {
+  const uint32_t seed = v2s_salted(seed0, salt);
   const int cpr = d >> 3;
   const long total = n * cpr;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
@@ -40,7 +41,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__
 // quarter of the atomic rate (tools/ubench/atomic_rate.hip: 1.3 TB/s of operand bytes).
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const long* __restrict__ ids, const bf16_t* __restrict__ dy,
                                                         float* __restrict__ dtable, long n, int d, int vocab, uint32_t p16,
-                                                        float inv_keep, uint32_t seed) {
+                                                        float inv_keep, uint32_t seed0, const uint32_t* __restrict__ salt) {
+  const uint32_t seed = v2s_salted(seed0, salt);
   const long total = n * d;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     const long row = t / d;
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long* __restrict__
 // mode 0: y = x + add[i mod add_n]; mode 1: y = dropout(x); mode 2: y = x + add (same length)
 __global__ __launch_bounds__(256) void ew_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ add,
                                                  bf16_t* __restrict__ y, long n8, long add_n8, int mode, uint32_t p16,
-                                                 float inv_keep, uint32_t seed) {
+                                                 float inv_keep, uint32_t seed0, const uint32_t* __restrict__ salt) {
+  const uint32_t seed = (mode == 1) ? v2s_salted(seed0, salt) : 0u;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n8; t += (long)gridDim.x * 256) {
     float f[8];
     unpack8(*reinterpret_cast<const uint4*>(x + t * 8), f);
@@ -209,7 +212,7 @@ extern "C" int v2s_embed_fwd(const int64_t* ids, const void* table, void* out, i
   const uint32_t p16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
   const float inv = p16 ? 1.0f / (1.0f - p16 / 65536.0f) : 1.f;
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for(n * (d / 8))), dim3(256), 0, (hipStream_t)stream, (const long*)ids,
-                     (const bf16_t*)table, (bf16_t*)out, (long)n, d, vocab, p16, inv, dropout_seed);
+                     (const bf16_t*)table, (bf16_t*)out, (long)n, d, vocab, p16, inv, dropout_seed, v2s_seed_salt());
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
@@ -220,7 +223,7 @@ extern "C" int v2s_embed_bwd(const int64_t* ids, const void* dy, float* dtable, 
   const uint32_t p16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
   const float inv = p16 ? 1.0f / (1.0f - p16 / 65536.0f) : 1.f;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(n * d)), dim3(256), 0, (hipStream_t)stream, (const long*)ids,
-                     (const bf16_t*)dy, dtable, (long)n, d, vocab, p16, inv, dropout_seed);
+                     (const bf16_t*)dy, dtable, (long)n, d, vocab, p16, inv, dropout_seed, v2s_seed_salt());
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
@@ -228,7 +231,7 @@ extern "C" int v2s_embed_bwd(const int64_t* ids, const void* dy, float* dtable, 
 extern "C" int v2s_add_bcast(const void* x, const void* add, void* y, int64_t n, int64_t add_n, void* stream) {
   V2S_CHECK(n > 0 && add_n > 0 && (n % 8) == 0 && (add_n % 8) == 0 && (n % add_n) == 0, V2S_ERR_SHAPE, "v2s_add_bcast: bad sizes %ld %ld", (long)n, (long)add_n);
   hipLaunchKernelGGL(ew_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)add,
-                     (bf16_t*)y, (long)(n / 8), (long)(add_n / 8), 0, 0u, 1.f, 0u);
+                     (bf16_t*)y, (long)(n / 8), (long)(add_n / 8), 0, 0u, 1.f, 0u, (const uint32_t*)nullptr);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
@@ -236,7 +239,7 @@ extern "C" int v2s_add_bcast(const void* x, const void* add, void* y, int64_t n,
 extern "C" int v2s_add(const void* a, const void* b, void* y, int64_t n, void* stream) {
   V2S_CHECK(n > 0 && (n % 8) == 0, V2S_ERR_SHAPE, "v2s_add: n must be a positive multiple of 8");
   hipLaunchKernelGGL(ew_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b,
-                     (bf16_t*)y, (long)(n / 8), (long)(n / 8), 2, 0u, 1.f, 0u);
+                     (bf16_t*)y, (long)(n / 8), (long)(n / 8), 2, 0u, 1.f, 0u, (const uint32_t*)nullptr);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
@@ -246,7 +249,7 @@ extern "C" int v2s_dropout(const void* x, void* y, int64_t n, float p, uint32_t 
   const uint32_t p16 = (uint32_t)(p * 65536.0f + 0.5f);
   const float inv = p16 ? 1.0f / (1.0f - p16 / 65536.0f) : 1.f;
   hipLaunchKernelGGL(ew_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)nullptr,
-                     (bf16_t*)y, (long)(n / 8), 1L, 1, p16, inv, seed);
+                     (bf16_t*)y, (long)(n / 8), 1L, 1, p16, inv, seed, v2s_seed_salt());
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

@@ -42,6 +42,7 @@ struct AdamP {
   long n;
   float lr_bc1, beta1, beta2, eps, wd, inv_sqrt_bc2;
   const float* gnorm_sq; float max_norm, grad_scale;
+  const float* hyper;    // device {lr / bias-correction-1, 1 / sqrt(bias-correction-2)} overriding the by-value pair (graph replay) or NULL
 };
 
 __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, const AdamP& a, float coef) {
@@ -53,7 +54,8 @@ __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, con
   p -= a.lr_bc1 * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(const AdamP a) {
+__global__ __launch_bounds__(256) void adam_kernel(AdamP a) {
+  if (a.hyper) { a.lr_bc1 = a.hyper[0]; a.inv_sqrt_bc2 = a.hyper[1]; }
   float coef = a.grad_scale;
   if (a.gnorm_sq && a.max_norm > 0.f) {
     const float gn = sqrtf(a.gnorm_sq[0]) * a.grad_scale;          // norm of the scaled gradient
@@ -148,6 +150,7 @@ extern "C" int v2s_adam_step(const v2s_adam_args* a, void* stream) {
   p.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   p.beta1 = a->beta1; p.beta2 = a->beta2; p.eps = a->eps; p.wd = a->weight_decay;
   p.gnorm_sq = a->gnorm_sq; p.max_norm = a->max_norm; p.grad_scale = a->grad_scale == 0.f ? 1.f : a->grad_scale;
+  p.hyper = a->hyper_dev;
   hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, p);
   V2S_LAUNCH_CHECK();
   return V2S_OK;

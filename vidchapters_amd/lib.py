@@ -48,7 +48,7 @@ class AttnArgs(C.Structure):
 class AdamArgs(C.Structure):
     _fields_ = [("p", _vp), ("m", _vp), ("v", _vp), ("g", _vp), ("p_bf16", _vp), ("n", _i64),
                 ("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32),
-                ("step", _i32), ("gnorm_sq", _vp), ("max_norm", _f32), ("grad_scale", _f32)]
+                ("step", _i32), ("gnorm_sq", _vp), ("max_norm", _f32), ("grad_scale", _f32), ("hyper_dev", _vp)]
 
 
 class DecodeAttnArgs(C.Structure):
@@ -65,6 +65,7 @@ SYMBOLS = {
     "v2s_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "v2s_get_option": (C.c_int, [C.c_char_p]),
     "v2s_sizeof": (_i64, [C.c_char_p]),
+    "v2s_set_seed_salt": (C.c_int, [_vp]),
     "v2s_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "v2s_colsum": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "v2s_rmsnorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
@@ -386,11 +387,17 @@ def sqnorm(g, n, ws, out):
     _check(lib().v2s_sqnorm(g.data_ptr(), n, ws.data_ptr(), out.data_ptr(), stream_ptr()), "v2s_sqnorm")
 
 
-def adam_step(p, m, v, g, p_bf16, n, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+def set_seed_salt(word: Optional[torch.Tensor]) -> None:
+    """Device int32/uint32 word XOR-ed into every dropout seed of the launches enqueued from now on (None: off)."""
+    _check(lib().v2s_set_seed_salt(None if word is None else word.data_ptr()), "v2s_set_seed_salt")
+
+
+def adam_step(p, m, v, g, p_bf16, n, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0, hyper_dev=None):
     a = AdamArgs()
     a.p, a.m, a.v, a.g, a.p_bf16, a.n = p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), ptr(p_bf16), n
     a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.step = lr, beta1, beta2, eps, wd, step
     a.gnorm_sq, a.max_norm, a.grad_scale = ptr(gnorm_sq), max_norm, grad_scale
+    a.hyper_dev = ptr(hyper_dev)
     _check(lib().v2s_adam_step(C.byref(a), stream_ptr()), "v2s_adam_step")
 
 

@@ -155,6 +155,9 @@ class Trainer:
         """One optimizer step on ``batch`` = {video, input_ids, output_ids[, den_input_ids, den_output_ids]}; optional
         ``input_lens`` / ``den_input_lens`` (host lists of valid lengths, e.g. from the data loader) let the padding-free
         encoder plan its rows without reading the mask back.  Returns device scalars."""
+        return self._step_impl(batch)
+
+    def _step_impl(self, batch: Dict[str, torch.Tensor], hyper_dev: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         m, eng = self.model, self.eng
         assert m.training, "call model.train() first"
         main = torch.cuda.current_stream()
@@ -257,26 +260,88 @@ class Trainer:
         if m.use_video and not state.get("vis_sent"):
             self.sync.ready(*self._r_vis)
         self.sync.finish()
-        self._optimizer_step()
+        self._optimizer_step(hyper_dev)
         return losses
 
-    def _optimizer_step(self) -> None:
+    def _lr_of_step(self, k: int) -> float:
+        """dvc.py:128-133 adjusts the LR *after* optimizer.step(): step 0 runs at args.lr, step k at schedule(k-1)"""
+        return self.lr if k == 0 else lr_at(k - 1, self.total, self.lr, self.schedule, self.warm)
+
+    def _optimizer_step(self, hyper_dev: Optional[torch.Tensor] = None) -> None:
+        """``hyper_dev`` (graph capture): the kernel reads lr / bias corrections from that device pair instead of the by-value arguments,
+        and the step counter is advanced by the caller."""
         eng, a = self.eng, self.eng.arena
-        self.step_count += 1
-        k = self.step_count - 1
-        # dvc.py:128-133 adjusts the LR *after* optimizer.step(): step 0 runs at args.lr, step k at schedule(k-1)
-        lr = self.lr if k == 0 else lr_at(k - 1, self.total, self.lr, self.schedule, self.warm)
+        if hyper_dev is None:
+            self.step_count += 1
+        lr = self._lr_of_step(self.step_count - 1) if hyper_dev is None else self.lr
         self._gnorm_sq.zero_()
         if self.clip > 0:
             L.sqnorm(a.grad, a.numel, self._sq_ws, self._gnorm_sq)
         L.adam_step(a.master, self.m, self.v, a.grad, a.shadow, a.numel, lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                    self.step_count, gnorm_sq=self._gnorm_sq if self.clip > 0 else None, max_norm=self.clip,
-                    grad_scale=1.0 / self.world)
+                    max(1, self.step_count), gnorm_sq=self._gnorm_sq if self.clip > 0 else None, max_norm=self.clip,
+                    grad_scale=1.0 / self.world, hyper_dev=hyper_dev)
         if self.model.num_bins:
             emb = a.f("t5_model.shared.weight")
             embb = a.w("t5_model.shared.weight")
             for _ in range(2):      # dvc.py:120-126 renormalises `shared` and then `lm_head` -- the same tied tensor
                 L.timetoken_renorm(emb, embb, eng.V, eng.d, self.model.num_bins, self._renorm_ws)
+
+    # ------------------------------------------------------------------------------------------------ captured step
+    def step_graph(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """:meth:`step` replayed from a hipGraph: the ~2500 launches of a step (all three streams) are captured once and the host then
+        enqueues a step with ONE graph launch plus the input copies (host time per step: ~20 ms of Python / ctypes -> well under 1 ms).
+        Everything that changes from step to step lives in device memory the captured kernels read:
+          * the batch: static buffers, refilled by copy before each replay (shapes must not change; a new shape re-captures);
+          * dropout: the by-value seeds of the captured launches are XOR-ed with a device salt word that is rewritten every step
+            (v2s_set_seed_salt), so every replay draws new masks;
+          * Adam: lr and the two bias corrections come from a device pair (v2s_adam_args.hyper_dev), computed on the host per step
+            (LR schedule, dvc.py:128-133).
+        The first call runs an ordinary eager step (it creates every lazily allocated workspace), the second call captures.  The
+        padding-free encoder changes shapes with the batch and is switched off; data-parallel runs keep the eager path (collectives
+        are not captured).  Returns the same device scalars on every call (their values are those of the last replay)."""
+        eng = self.eng
+        if self.sync.active:
+            return self.step(batch)
+        tensors = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+        key = tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in tensors.items()))
+        st = getattr(self, "_g", None)
+        if st is None:                                 # first call: an ordinary eager step (creates LUTs, workspaces, kernel attributes)
+            self._g = {"key": key, "graph": None}
+            eng.pack = False
+            return self.step(tensors)
+        if st["key"] != key:                           # new shapes: capture again
+            self._g = st = {"key": key, "graph": None}
+        if st["graph"] is None:
+            eng.pack = False
+            dev = eng.device
+            st["batch"] = {k: torch.empty_like(v) for k, v in tensors.items()}
+            for k, v in tensors.items():
+                st["batch"][k].copy_(v)
+            st["salt"] = torch.zeros(1, dtype=torch.int32, device=dev)
+            st["hyper"] = torch.zeros(2, dtype=torch.float32, device=dev)
+            st["hyper_host"] = torch.zeros(2, dtype=torch.float32).pin_memory()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            L.set_seed_salt(st["salt"])
+            try:
+                with torch.cuda.graph(g):
+                    st["losses"] = self._step_impl(st["batch"], hyper_dev=st["hyper"])
+            finally:
+                L.set_seed_salt(None)
+            st["graph"] = g
+        for k, v in tensors.items():
+            st["batch"][k].copy_(v, non_blocking=True)
+        self.step_count += 1
+        k = self.step_count
+        lr = self._lr_of_step(k - 1)
+        st["hyper_host"][0] = lr / (1.0 - self.betas[0] ** k)
+        st["hyper_host"][1] = 1.0 / math.sqrt(1.0 - self.betas[1] ** k)
+        st["hyper"].copy_(st["hyper_host"], non_blocking=True)
+        seed0, _ = eng.rng_state()
+        salt = ((seed0 ^ (k * 0x9E3779B1)) * 0x85EBCA6B) & 0x7FFFFFFF
+        st["salt"].fill_(salt)
+        st["graph"].replay()
+        return st["losses"]
 
     def state_dict(self) -> Dict:
         """Optimizer state for checkpoint / resume (dvc.py:310-330 saves optimizer.state_dict() next to the model): Adam moments (flat,
