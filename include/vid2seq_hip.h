@@ -274,6 +274,10 @@ typedef struct v2s_decode_attn_args {
   const int32_t* pos_dev;
   int32_t bias_maxlen;
   int32_t kv_group;                        /* >1: KV batch index = b / kv_group (beams sharing the cross K/V); 0/1 = b */
+  /* optional fused cache append (self-attention, needs pos_dev): the step's fresh K / V rows, bf16 [B][H*64] with batch stride new_bs.
+   * Key *pos_dev is read from here instead of the cache, and the (b, h) block writes its pieces into cache row *pos_dev
+   * (replaces a separate v2s_kv_append launch per layer and step; modeling_t5.py:555-556 grows the cache with torch.cat) */
+  const void* new_k; const void* new_v; int64_t new_bs;
 } v2s_decode_attn_args;
 int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream);
 int v2s_argmax_step(const float* logits, int64_t ld, int32_t rows, int32_t V, int64_t* next_tok,

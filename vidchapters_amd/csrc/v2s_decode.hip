@@ -16,6 +16,7 @@ struct DecP {
   const uint8_t* key_mask; long mask_ld;
   float scale;
   const int* pos_dev; int bias_maxlen; int kv_group;
+  const bf16_t *new_k, *new_v; long new_bs;     // the step's fresh K/V rows (fused cache append) or NULL
 };
 
 // one block (4 waves) per (b, h).  lane = (key slot ks = lane>>3, d-chunk c = lane&7): 8 keys per
@@ -26,16 +27,23 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ks = lane >> 3, c = lane & 7;
   int Nk = p.Nk;
   const float* bias_row = p.bias_row;
+  int newpos = -1;                      // key index whose K/V come from new_k / new_v (and are appended to the cache by this block)
   if (p.pos_dev) {                      // device-resident step counter (graph replay)
     const int pos = *p.pos_dev;
     Nk = pos + 1;
     if (bias_row) bias_row += p.bias_maxlen - 1 - pos;
+    if (p.new_k) newpos = pos;
   }
   const int bkv = p.kv_group > 1 ? b / p.kv_group : b;
   float qv[8];
   unpack8(*reinterpret_cast<const uint4*>(p.q + (long)b * p.q_bs + h * 64 + c * 8), qv);
   const bf16_t* kp = p.k + (long)bkv * p.kv_bs + h * 64 + c * 8;
   const bf16_t* vp = p.v + (long)bkv * p.kv_bs + h * 64 + c * 8;
+  if (newpos >= 0 && tid < 16) {        // fused KV-cache append: this (b, h) block owns the 64-wide K and V pieces of the new row
+    const bf16_t* src = (tid < 8 ? p.new_k : p.new_v) + (long)b * p.new_bs + h * 64 + (tid & 7) * 8;
+    bf16_t* dst = const_cast<bf16_t*>(tid < 8 ? p.k : p.v) + (long)b * p.kv_bs + (long)newpos * p.kv_rs + h * 64 + (tid & 7) * 8;
+    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+  }
   float m = -INFINITY, l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // each wave walks the keys in chunks of 32 (4 keys per 8-lane group): the 8 loads of a chunk are issued together so that
   // ~8 KiB per wave are in flight (this kernel is a pure HBM stream: K and V are read exactly once per step)
@@ -46,8 +54,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
       const int k = k0 + ks + 8 * j;
       kr[j] = make_uint4(0, 0, 0, 0); vr[j] = make_uint4(0, 0, 0, 0);
       if (k < Nk) {
-        kr[j] = *reinterpret_cast<const uint4*>(kp + (long)k * p.kv_rs);
-        vr[j] = *reinterpret_cast<const uint4*>(vp + (long)k * p.kv_rs);
+        if (k == newpos) {              // not yet (visibly) in the cache: straight from the projection output
+          kr[j] = *reinterpret_cast<const uint4*>(p.new_k + (long)b * p.new_bs + h * 64 + c * 8);
+          vr[j] = *reinterpret_cast<const uint4*>(p.new_v + (long)b * p.new_bs + h * 64 + c * 8);
+        } else {
+          kr[j] = *reinterpret_cast<const uint4*>(kp + (long)k * p.kv_rs);
+          vr[j] = *reinterpret_cast<const uint4*>(vp + (long)k * p.kv_rs);
+        }
       }
     }
     float sc[4];
@@ -402,6 +415,9 @@ extern "C" int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream) {
   p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.kv_bs = a->kv_bs; p.kv_rs = a->kv_rs;
   p.o = (bf16_t*)a->o; p.o_bs = a->o_bs; p.bias_row = a->bias_row; p.bias_ld = a->bias_ld ? a->bias_ld : a->Nk; p.key_mask = a->key_mask; p.mask_ld = a->mask_ld;
   p.scale = a->scale; p.pos_dev = a->pos_dev; p.bias_maxlen = a->bias_maxlen; p.kv_group = a->kv_group;
+  p.new_k = (const bf16_t*)a->new_k; p.new_v = (const bf16_t*)a->new_v; p.new_bs = a->new_bs;
+  V2S_CHECK(!a->new_k || (a->new_v && a->pos_dev && a->kv_group <= 1 && (a->new_bs % 8) == 0), V2S_ERR_ARG,
+            "v2s_decode_attn: the fused cache append needs new_v, pos_dev and one KV row per batch entry");
   hipLaunchKernelGGL(decode_attn_kernel, dim3(p.B * p.H), dim3(256), 0, (hipStream_t)stream, p);
   V2S_LAUNCH_CHECK();
   return V2S_OK;

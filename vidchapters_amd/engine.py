@@ -868,9 +868,9 @@ class Engine:
             for i in range(nl):
                 sa, ca, fp = self._sa("decoder", i), self._ca(i), self._ffp("decoder", i)
                 proj(h, B, "qkv", i, sa + "q.weight", (3 * inner, d), 0, qkv)
-                L.kv_append(qkv[:, inner:], 3 * inner, cache[i], maxlen * 2 * inner, 2 * inner, B, 2 * inner, 0, pos_dev=pos)
                 L.decode_attn(B, H, maxlen, qkv, 3 * inner, cache[i], cache[i][:, :, inner:], maxlen * 2 * inner, 2 * inner,
-                              ctx, inner, bias_row=diag, bias_ld=2 * maxlen - 1, pos_dev=pos, bias_maxlen=maxlen)
+                              ctx, inner, bias_row=diag, bias_ld=2 * maxlen - 1, pos_dev=pos, bias_maxlen=maxlen,
+                              new_k=qkv[:, inner:], new_v=qkv[:, 2 * inner:], new_bs=3 * inner)       # cache append fused
                 L.gemm(ctx, a.w(sa + "o.weight"), h2, B, d, inner, residual=h)
                 proj(h2, B, "cq", i, ca + "q.weight", (inner, d), 1, q)
                 L.decode_attn(B, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
@@ -979,9 +979,9 @@ class Engine:
             for i in range(nl):
                 sa, ca, fp = self._sa("decoder", i), self._ca(i), self._ffp("decoder", i)
                 proj(h, "qkv", i, sa + "q.weight", (3 * inner, d), 0, qkv)
-                L.kv_append(qkv[:, inner:], 3 * inner, cache[i], cbs, 2 * inner, R, 2 * inner, 0, pos_dev=pos)
                 L.decode_attn(R, H, maxlen, qkv, 3 * inner, cache[i], cache[i][:, :, inner:], cbs, 2 * inner,
-                              ctx, inner, bias_row=diag, bias_ld=2 * maxlen - 1, pos_dev=pos, bias_maxlen=maxlen)
+                              ctx, inner, bias_row=diag, bias_ld=2 * maxlen - 1, pos_dev=pos, bias_maxlen=maxlen,
+                              new_k=qkv[:, inner:], new_v=qkv[:, 2 * inner:], new_bs=3 * inner)       # cache append fused
                 L.gemm(ctx, a.w(sa + "o.weight"), h2, R, d, inner, residual=h)
                 proj(h2, "cq", i, ca + "q.weight", (inner, d), 1, q)
                 L.decode_attn(R, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
