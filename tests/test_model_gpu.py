@@ -542,3 +542,32 @@ def test_captured_step_equals_eager_steps():
     vals = [tr_d.step_graph(b)["loss"].item() for _ in range(4)]
     print("  dropout 0.1, lr 0, same batch:", [round(v, 5) for v in vals])
     assert len({round(v, 6) for v in vals[1:]}) == 3
+
+
+def test_dropout_stream_follows_torch_seed_and_resumes():
+    """the dropout stream is derived from torch.manual_seed() (and the data-parallel rank), not a constant, and its
+    position is part of the training state: same seed -> same masks, other seed -> other masks, rng_state()/set_rng_state() resumes."""
+    cfg = R.RefConfig.small()
+    b = {k: v.to(DEV) for k, v in synth.make_batch(2, 10, 40, 17, cfg.vocab, 9, cfg.vit_dim).items()}
+
+    def run(seed, steps=2, resume_from=None):
+        torch.manual_seed(seed)
+        model = build(cfg, 8, vis_drop=0.1, enc_drop=0.1, dec_drop=0.1).train()
+        tr = Trainer(model, lr=0.0, clip_max_norm=1.0, generative=1.0, denoising=0.0)
+        model.num_bins = 0                      # no time-token renorm: with lr = 0 the weights then stay exactly where they are
+        if resume_from is not None:
+            tr.load_state_dict(resume_from)
+        out = [tr.step(b)["loss"].item() for _ in range(steps)]
+        return out, tr.state_dict()
+
+    a1, _ = run(1)
+    a2, _ = run(1)
+    c1, _ = run(2)
+    assert a1 == a2 and a1 != c1 and a1[0] != a1[1]
+    first, st = run(1, steps=1)
+    second, _ = run(5, steps=1, resume_from=st)          # a different torch seed, but the saved stream position wins
+    assert first + second == a1
+    eng = build(cfg, 8).engine()
+    v = eng.arena._seen_version
+    eng.mark_dirty()
+    assert eng.arena._seen_version != v or v == -1
