@@ -236,16 +236,32 @@ def test_gemm_splitk_policies_agree(split):
     assert relerr(dW, dY.float().T @ X.float()) < 2e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 768, 768), (64, 2304, 768), (37, 768, 3072), (1, 32200, 768), (64, 616, 128)])
+@pytest.mark.parametrize("M,N,K", [(64, 768, 768), (64, 2304, 768), (37, 768, 3072), (1, 32200, 768), (64, 616, 128), (17, 768, 768),
+                                   (64, 32128, 768), (5, 9000, 1024), (33, 8192, 512), (64, 32128, 640)])
 def test_gemm_skinny_decode_kernel(M, N, K):
-    """M <= 64 weight-streaming kernel used by the cached decoder (incl. a ragged N and the epilogues the decode step uses)."""
+    """M <= 64 weight-streaming kernels used by the cached decoder (incl. ragged M / N and the epilogues the decode step uses): the
+    K-split kernel for the layer projections, the LDS-resident-activation kernel for the LM head (N >= 8192, K in {512, 768, 1024})."""
     A, B = rnd(M, K, seed=41, scale=0.5), rnd(N, K, seed=42, scale=0.1)
     ref = A.float() @ B.float().T
     ld = (N + 7) // 8 * 8
     C = torch.zeros(M, ld, dtype=torch.float32, device=DEV)
     L.gemm(A, B, C, M, N, K, ldc=ld, alpha=0.25)
-    assert L.lib().v2s_last_gemm_kernel() == b"gemm_skinny_kernel"
+    wide = N >= 8192 and K in (512, 768, 1024)
+    assert L.lib().v2s_last_gemm_kernel() == (b"gemm_skinny_wide_kernel" if wide else b"gemm_skinny_kernel")
     assert relerr(C[:, :N], 0.25 * ref) < 2e-5
+    if wide:      # the LM head runs with the final RMSNorm fused (rms_eps): rows scaled by rsqrt(mean(x^2) + eps)
+        C2 = torch.zeros(M, ld, dtype=torch.float32, device=DEV)
+        L.gemm(A, B, C2, M, N, K, ldc=ld, alpha=0.25, rms_eps=1e-6)
+        af = A.float()
+        assert relerr(C2[:, :N], 0.25 * ref * torch.rsqrt((af * af).mean(-1, keepdim=True) + 1e-6)) < 2e-5
+        L.set_option("gemm_skinny", 2)      # the K-split kernel on the same problem
+        try:
+            C3 = torch.zeros(M, ld, dtype=torch.float32, device=DEV)
+            L.gemm(A, B, C3, M, N, K, ldc=ld, alpha=0.25, rms_eps=1e-6)
+            assert L.lib().v2s_last_gemm_kernel() == b"gemm_skinny_kernel"
+        finally:
+            L.set_option("gemm_skinny", 1)
+        assert relerr(C2[:, :N], C3[:, :N]) < 2e-5
     if N % 8 == 0:
         res = rnd(M, N, seed=43)
         out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
@@ -783,6 +799,34 @@ def test_decode_kernels():
     s = s + (~mask)[:, None, :].float() * torch.finfo(torch.float32).min
     ref = torch.einsum("bhk,bkhd->bhd", torch.softmax(s, -1), vc[:, :Nk].float().view(B, Nk, H, 64)).reshape(B, W)
     assert relerr(o, ref) < 1e-2
+    # masked keys are never fetched: holes between valid keys, a padded tail, and a row without any valid key (which keeps the
+    # reference's uniform average over its masked keys).  NaN planted in the K/V rows of masked keys must not reach the output.
+    B2, Nk2 = 4, 1100
+    g = torch.Generator().manual_seed(7)
+    mask2 = torch.rand(B2, Nk2, generator=g) < 0.7
+    mask2[0] = True; mask2[1, 640:] = False; mask2[3] = False
+    mask2 = mask2.to(DEV)
+    q2 = rnd(B2, W, seed=11, scale=0.5); k2 = rnd(B2, Nk2, W, seed=12, scale=0.5); v2 = rnd(B2, Nk2, W, seed=13)
+    s2 = torch.einsum("bhd,bkhd->bhk", q2.float().view(B2, H, 64), k2.float().view(B2, Nk2, H, 64))
+    s2 = s2 + (~mask2)[:, None, :].float() * torch.finfo(torch.float32).min
+    ref2 = torch.einsum("bhk,bkhd->bhd", torch.softmax(s2, -1), v2.float().view(B2, Nk2, H, 64)).reshape(B2, W)
+    poison = (~mask2) & mask2.any(1, keepdim=True)
+    k2p, v2p = k2.clone(), v2.clone()
+    k2p[poison] = float("nan"); v2p[poison] = float("nan")
+    o2 = torch.empty(B2, W, dtype=torch.bfloat16, device=DEV)
+    L.decode_attn(B2, H, Nk2, q2, W, k2p, v2p, Nk2 * W, W, o2, W, key_mask=mask2.to(torch.uint8).contiguous(), mask_ld=Nk2)
+    assert torch.isfinite(o2.float()).all()
+    assert relerr(o2, ref2) < 1e-2
+    o3 = torch.empty_like(o2)                        # same result as with the real K/V in place (nothing depends on the skipped rows)
+    L.decode_attn(B2, H, Nk2, q2, W, k2, v2, Nk2 * W, W, o3, W, key_mask=mask2.to(torch.uint8).contiguous(), mask_ld=Nk2)
+    assert torch.equal(o2, o3)
+    # argmax: 16-byte and scalar paths, ties resolve to the lowest index
+    for V2 in (32128, 32201, 7):
+        lg = rnd(B, V2, seed=21, dtype=torch.float32)
+        lg[0, V2 - 1] = 50.0; lg[0, V2 // 2] = 50.0; lg[1, 3] = 60.0; lg[2, V2 - 1] = 70.0
+        nx = torch.empty(B, dtype=torch.int64, device=DEV); un = torch.ones(B, dtype=torch.int32, device=DEV)
+        L.argmax_step(lg, V2, B, V2, nx, un, -1, 0)
+        assert nx.tolist() == [V2 // 2, 3, V2 - 1]
     logits = rnd(B, 32200, seed=5, dtype=torch.float32)
     nxt = torch.empty(B, dtype=torch.int64, device=DEV); unf = torch.tensor([1, 0, 1], dtype=torch.int32, device=DEV)
     logits[2, 1] = 100.0                                          # row 2 emits EOS

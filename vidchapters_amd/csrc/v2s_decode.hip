@@ -44,20 +44,48 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
     bf16_t* dst = const_cast<bf16_t*>(tid < 8 ? p.k : p.v) + (long)b * p.kv_bs + (long)newpos * p.kv_rs + h * 64 + (tid & 7) * 8;
     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
   }
+  // padded encoder positions: their K/V rows are never fetched.  A masked key scores -3e38, so next to any valid key its weight is
+  // exp(-3e38 - m) == 0 exactly and the result does not depend on what was loaded for it; the mask row is staged in LDS once, keys
+  // past the last valid one are not visited and masked keys in between are not loaded (a synthetic ASR batch is ~14% padding: that
+  // share of the cross-attention K/V stream, the largest HBM stream of a decode step).  A row without a single valid key keeps the
+  // reference's uniform average over the masked keys, so nothing is skipped for it.
+  __shared__ uint8_t s_valid[4096];
+  __shared__ int s_last;
+  const bool lds_mask = p.key_mask != nullptr && Nk <= 4096;
+  if (lds_mask) {
+    if (tid == 0) s_last = -1;
+    __syncthreads();
+    int last = -1;
+    for (int k = tid; k < Nk; k += 256) {
+      const uint8_t mv = p.key_mask[(long)bkv * p.mask_ld + k];
+      s_valid[k] = mv;
+      if (mv) last = k;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+    if (lane == 0 && last >= 0) atomicMax(&s_last, last);
+    __syncthreads();
+  }
+  const bool skip = lds_mask && s_last >= 0;
+  const int Nvis = skip ? s_last + 1 : Nk;
   float m = -INFINITY, l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // each wave walks the keys in chunks of 32 (4 keys per 8-lane group): the 8 loads of a chunk are issued together so that
-  // ~8 KiB per wave are in flight (this kernel is a pure HBM stream: K and V are read exactly once per step)
-  for (int k0 = wave * 32; k0 < Nk; k0 += 128) {
+  // ~8 KiB per wave are in flight (this kernel is a pure HBM stream: K and V are read at most once per step)
+  for (int k0 = wave * 32; k0 < Nvis; k0 += 128) {
     uint4 kr[4], vr[4];
+    bool masked[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + ks + 8 * j;
       kr[j] = make_uint4(0, 0, 0, 0); vr[j] = make_uint4(0, 0, 0, 0);
-      if (k < Nk) {
+      masked[j] = false;
+      if (k < Nvis) {
+        if (lds_mask) masked[j] = s_valid[k] == 0;
+        else if (p.key_mask) masked[j] = p.key_mask[(long)bkv * p.mask_ld + k] == 0;
         if (k == newpos) {              // not yet (visibly) in the cache: straight from the projection output
           kr[j] = *reinterpret_cast<const uint4*>(p.new_k + (long)b * p.new_bs + h * 64 + c * 8);
           vr[j] = *reinterpret_cast<const uint4*>(p.new_v + (long)b * p.new_bs + h * 64 + c * 8);
-        } else {
+        } else if (!(skip && masked[j])) {
           kr[j] = *reinterpret_cast<const uint4*>(kp + (long)k * p.kv_rs);
           vr[j] = *reinterpret_cast<const uint4*>(vp + (long)k * p.kv_rs);
         }
@@ -74,10 +102,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
       d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
       const int k = k0 + ks + 8 * j;
       float s = -INFINITY;
-      if (k < Nk) {
+      if (k < Nvis) {
         s = d * p.scale;
         if (bias_row) s += bias_row[(long)h * p.bias_ld + k];
-        if (p.key_mask && p.key_mask[(long)bkv * p.mask_ld + k] == 0) s = -3.0e38f;
+        if (masked[j]) s = -3.0e38f;
       }
       sc[j] = s;
     }
@@ -131,30 +159,35 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
   }
 }
 
-__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, long ld, int V, long* __restrict__ next_tok,
-                                                     int* __restrict__ unfinished, int eos_id, int pad_id, long* __restrict__ seq_out,
-                                                     long seq_ld, const int* __restrict__ pos_dev) {
-  __shared__ float bv[4];
-  __shared__ int bi[4];
+// one 1024-thread block per row: 16-byte loads, the whole row (V ~ 32k fp32 = 128 KiB) in flight in two rounds -- the earlier
+// 256-thread scalar loop took 39.5 us per step for 64 rows (latency-bound; profiles/r02_decode_step.txt)
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, long ld, int V, long* __restrict__ next_tok,
+                                                      int* __restrict__ unfinished, int eos_id, int pad_id, long* __restrict__ seq_out,
+                                                      long seq_ld, const int* __restrict__ pos_dev) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
   const int row = blockIdx.x, tid = threadIdx.x;
   const float* z = logits + (long)row * ld;
   float best = -INFINITY;
   int idx = 0x7fffffff;
-  for (int i = tid; i < V; i += 256) {
-    const float v = z[i];
-    if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+  auto take = [&](float v, int i) { if (v > best || (v == best && i < idx)) { best = v; idx = i; } };
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
+  const int V4 = vec ? (V & ~3) : 0;
+  for (int i = tid * 4; i < V4; i += 4096) {
+    const float4 q = *reinterpret_cast<const float4*>(z + i);
+    take(q.x, i); take(q.y, i + 1); take(q.z, i + 2); take(q.w, i + 3);
   }
+  for (int i = V4 + tid; i < V; i += 1024) take(z[i], i);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float v2 = __shfl_xor(best, o, 64);
     const int i2 = __shfl_xor(idx, o, 64);
-    if (v2 > best || (v2 == best && i2 < idx)) { best = v2; idx = i2; }
+    take(v2, i2);
   }
   if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < 4; ++w)
-      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    for (int w = 1; w < 16; ++w) take(bv[w], bi[w]);
     const int un = unfinished[row];
     const long tok = un ? (long)idx : (long)pad_id;       // finished rows emit pad
     next_tok[row] = tok;
@@ -426,7 +459,7 @@ extern "C" int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream) {
 extern "C" int v2s_argmax_step(const float* logits, int64_t ld, int32_t rows, int32_t V, int64_t* next_tok,
                                int32_t* unfinished, int32_t eos_id, int32_t pad_id, void* stream) {
   V2S_CHECK(logits && next_tok && unfinished && rows > 0 && V > 0, V2S_ERR_ARG, "v2s_argmax_step: bad args");
-  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, V, (long*)next_tok, unfinished,
+  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, (long)ld, V, (long*)next_tok, unfinished,
                      eos_id, pad_id, (long*)nullptr, 0L, (const int*)nullptr);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
@@ -436,7 +469,7 @@ extern "C" int v2s_argmax_step_seq(const float* logits, int64_t ld, int32_t rows
                                    int32_t* unfinished, int32_t eos_id, int32_t pad_id, int64_t* seq_out, int64_t seq_ld,
                                    const int32_t* pos_dev, void* stream) {
   V2S_CHECK(logits && next_tok && unfinished && seq_out && pos_dev && rows > 0 && V > 0, V2S_ERR_ARG, "v2s_argmax_step_seq: bad args");
-  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, V, (long*)next_tok, unfinished,
+  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, (long)ld, V, (long*)next_tok, unfinished,
                      eos_id, pad_id, (long*)seq_out, (long)seq_ld, pos_dev);
   V2S_LAUNCH_CHECK();
   return V2S_OK;

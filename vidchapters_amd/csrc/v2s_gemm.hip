@@ -1170,46 +1170,51 @@ __global__ __launch_bounds__(512, 2) void gemm_p8d_kernel(const GemmP p) {
 // owns 16 output columns: its 4 waves split K four ways, each streaming its [16][K/4] weight slab straight from HBM into MFMA
 // B-fragments (16 B per lane, no LDS) against the L2-resident activations, then the four partial 64x16 tiles are summed through
 // LDS and the usual epilogue runs on 8-wide chunks.  Grid = N/16 blocks (48..200 for the decoder projections, 2013 for the LM head).
-template <int WAVES, int STEPS>
+// MT = 16-row fragments per block: 4 (a block covers all 64 rows; blockIdx.y = 0) or 1 (blockIdx.y walks the row fragments: four
+// times the blocks, a quarter of the activation loads per wave -- the long-K projections, where 48 blocks x one latency-bound load
+// chain each left the chip idle: decoder wo 64x768x3072 18.7 us -> see profiles/r02_decode_step.txt).
+template <int WAVES, int STEPS, int MT>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) {
-  __shared__ float part[WAVES][64][17];
+  __shared__ float part[WAVES][MT * 16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (MT * 16);
   const int kq = p.K / WAVES;                    // multiple of 32 * STEPS (checked by the dispatcher)
   const int kbeg = wave * kq;
   const int r = lane & 15, kc = (lane >> 4) * 8;
   int brow = n0 + r; brow = brow < p.N ? brow : p.N - 1;
   const bf16_t* bp = p.B + (long)brow * p.ldb + kbeg + kc;
-  const bf16_t* ap[4];
+  const bf16_t* ap[MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = i * 16 + r; m = m < p.M ? m : p.M - 1;
+  for (int i = 0; i < MT; ++i) {
+    int m = m0 + i * 16 + r; m = m < p.M ? m : p.M - 1;
     ap[i] = p.A + (long)m * p.lda + kbeg + kc;
   }
-  f32x4 acc[4];
+  f32x4 acc[MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool rms = p.rms_eps > 0.f;
-  float sq[4] = {0.f, 0.f, 0.f, 0.f};       // fused RMSNorm: sum of squares of this lane's A elements, per 16-row fragment
-  // STEPS K-steps (of 32) are loaded back to back before their MFMAs: 5 x STEPS 16-byte loads in flight per lane
+  float sq[MT];                               // fused RMSNorm: sum of squares of this lane's A elements, per 16-row fragment
+#pragma unroll
+  for (int i = 0; i < MT; ++i) sq[i] = 0.f;
+  // STEPS K-steps (of 32) are loaded back to back before their MFMAs: (1 + MT) x STEPS 16-byte loads in flight per lane
   for (int k = 0; k < kq; k += 32 * STEPS) {
-    uint4 bq[STEPS], aq[STEPS][4];
+    uint4 bq[STEPS], aq[STEPS][MT];
 #pragma unroll
     for (int t = 0; t < STEPS; ++t) {
       bq[t] = *reinterpret_cast<const uint4*>(bp + k + t * 32);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) aq[t][i] = *reinterpret_cast<const uint4*>(ap[i] + k + t * 32);
+      for (int i = 0; i < MT; ++i) aq[t][i] = *reinterpret_cast<const uint4*>(ap[i] + k + t * 32);
     }
 #pragma unroll
     for (int t = 0; t < STEPS; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i)
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[t][i]), __builtin_bit_cast(bf16x8, bq[t]), acc[i], 0, 0, 0);
     if (rms) {
 #pragma unroll
       for (int t = 0; t < STEPS; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
           float f[8];
           unpack8(aq[t][i], f);
 #pragma unroll
@@ -1217,10 +1222,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
         }
     }
   }
-  __shared__ float rowsq[WAVES][64];
+  __shared__ float rowsq[WAVES][MT * 16];
   if (rms) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
       float v = sq[i];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
@@ -1228,12 +1233,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) part[wave][i * 16 + (lane >> 4) * 4 + q][lane & 15] = acc[i][q];
   __syncthreads();
-  if (tid < 128) {
-    const int m = tid >> 1, c = (tid & 1) * 8;
+  if (tid < MT * 32) {
+    const int ml = tid >> 1, m = m0 + ml, c = (tid & 1) * 8;
     const int gn = n0 + c;
     if (m < p.M && gn < p.N) {
       float v[8];
@@ -1241,18 +1246,104 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
       for (int j = 0; j < 8; ++j) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) t += part[w][m][c + j];
+        for (int w = 0; w < WAVES; ++w) t += part[w][ml][c + j];
         v[j] = t;
       }
       if (rms) {
         float ss = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) ss += rowsq[w][m];
+        for (int w = 0; w < WAVES; ++w) ss += rowsq[w][ml];
         const float rstd = rsqrtf(ss / (float)p.K + p.rms_eps);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= rstd;
       }
       epilogue_chunk(p, v, m, gn, 0);
+    }
+  }
+}
+
+// LM head of a cached decode step: M <= 64 rows against N ~ 32k columns -- 49 MB of weights, the largest single read of the step.
+// The K-split kernel above re-reads the activations per 16-column block (2013 blocks x 98 KB through L2) and runs 8 dependent rounds
+// of blocks: 39.5 us = 1.25 TB/s (profiles/r02_decode_step.txt).  Here one block per CU stages the 64 x K activations in LDS once;
+// each wave then owns whole 16-column tiles over the full contraction (no cross-wave reduction, no block barrier after the fill):
+// the tile's K/32 weight fragments (24 x 16 B per lane for K = 768) are requested together BEFORE the activation fill, so the HBM
+// stream starts at launch, and the next tile's are requested as soon as the MFMAs have consumed the registers.
+template <int KS>   // K = 32 * KS
+__global__ __launch_bounds__(512) void gemm_skinny_wide_kernel(const GemmP p) {
+  extern __shared__ __align__(16) unsigned char wide_smem[];
+  constexpr int K = KS * 32, PITCH = K + 8;          // row pitch = 2K + 16 bytes: the 16 rows of a fragment read hit distinct banks
+  bf16_t* As = reinterpret_cast<bf16_t*>(wide_smem);
+  float* rowsq = reinterpret_cast<float*>(wide_smem + 64 * PITCH * 2);
+  float* stage = rowsq + 64;                         // 8 waves x [16][17]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kc = (lane >> 4) * 8;
+  const int tiles = (p.N + 15) / 16, stride = gridDim.x * 8;
+  int tile = blockIdx.x * 8 + wave;
+  uint4 bq[KS];
+  auto load_b = [&](int t) {
+    int brow = t * 16 + r; brow = brow < p.N ? brow : p.N - 1;
+    const bf16_t* bp = p.B + (long)brow * p.ldb + kc;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bq[s] = *reinterpret_cast<const uint4*>(bp + s * 32);
+  };
+  if (tile < tiles) load_b(tile);
+  const bool rms = p.rms_eps > 0.f;
+  {
+    const int row = tid >> 3, j = tid & 7;
+    const int m = row < p.M ? row : p.M - 1;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < K / 64; ++i) {
+      const int c = (j + 8 * i) * 8;
+      const uint4 v = *reinterpret_cast<const uint4*>(p.A + (long)m * p.lda + c);
+      *reinterpret_cast<uint4*>(As + row * PITCH + c) = v;
+      if (rms) {
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sq = fmaf(f[e], f[e], sq);
+      }
+    }
+    sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+    if (j == 0) rowsq[row] = sq;
+  }
+  __syncthreads();
+  float* st = stage + wave * (16 * 17);
+  for (; tile < tiles; tile += stride) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(As + (i * 16 + r) * PITCH + s * 32 + kc);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bq[s]), acc[i], 0, 0, 0);
+      }
+    const int n0 = tile * 16;
+    if (tile + stride < tiles) load_b(tile + stride);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // wave-private transpose of one 16 x 16 fragment: DS operations of a wave complete in order, the waitcnt is also the
+      // compiler barrier between the writes and the reads of the other lanes
+#pragma unroll
+      for (int q = 0; q < 4; ++q) st[((lane >> 4) * 4 + q) * 17 + (lane & 15)] = acc[i][q];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane < 32) {
+        const int ml = lane >> 1, m = i * 16 + ml, c = (lane & 1) * 8, gn = n0 + c;
+        if (m < p.M && gn < p.N) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = st[ml * 17 + c + e];
+          if (rms) {
+            const float rstd = rsqrtf(rowsq[m] / (float)p.K + p.rms_eps);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= rstd;
+          }
+          epilogue_chunk(p, v, m, gn, 0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
 }
@@ -1416,16 +1507,55 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
   const bool plain_split = a->workspace && a->c_dtype == V2S_F32 && !a->bias && !a->act && !a->dact && !a->residual && !a->pre &&
                            a->dropout_p == 0.f && a->K >= 1024 && (a->N % 8) == 0;
   if (a->M <= 64 && !a->transA && !a->transB && (a->K % 128) == 0 && v2s_opt_gemm_skinny() != 0) {
+    if (a->N >= 8192 && (a->K == 512 || a->K == 768 || a->K == 1024) && v2s_opt_gemm_skinny() != 2) {
+      p.tilesM = 1; p.tilesN = (a->N + 15) / 16; p.splitk = 1; p.kper = a->K; p.ws = nullptr;
+      g_last_gemm = "gemm_skinny_wide_kernel";
+      const int ncu = num_cus();
+      const int want = (p.tilesN + 7) / 8;
+      const dim3 grid((unsigned)(want < ncu ? want : ncu));
+      const size_t lds = (size_t)64 * (a->K + 8) * 2 + 64 * 4 + 8 * 16 * 17 * 4;
+#define V2S_WIDE(KS_) do { static bool attr = false; \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_skinny_wide_kernel<KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((gemm_skinny_wide_kernel<KS_>), grid, dim3(512), lds, s, p); } while (0)
+      if (a->K == 512) V2S_WIDE(16); else if (a->K == 768) V2S_WIDE(24); else V2S_WIDE(32);
+#undef V2S_WIDE
+      V2S_LAUNCH_CHECK();
+      return V2S_OK;
+    }
     p.tilesM = 1; p.tilesN = (a->N + 15) / 16; p.splitk = 1; p.kper = a->K; p.ws = nullptr;
     g_last_gemm = "gemm_skinny_kernel";
-    const int waves = (a->K % 256) == 0 ? 8 : 4;
+    // row fragments per block: one (grid.y walks them: four times the blocks, a quarter of the activation loads per wave) measured
+    // faster on every decoder projection (greedy B = 64: 1.39 ms/step with four fragments per block, 1.17 with one;
+    // profiles/r02_decode_ab_skinny_mt.txt).  gemm_skinny = 2 keeps the four-fragment blocks, 4 = one fragment and four waves.
+    const int mode = v2s_opt_gemm_skinny();
+    const bool wideN = a->N >= 2048;
+    const int waves = ((a->K % 256) == 0 && mode != 4 && !(mode == 6 && wideN)) ? 8 : 4;
     const int nsteps = a->K / waves / 32;
-    const dim3 grid((unsigned)p.tilesN);
-#define V2S_SKINNY(W_, S_) hipLaunchKernelGGL((gemm_skinny_kernel<W_, S_>), grid, dim3(W_ * 64), 0, s, p)
-    if (waves == 8) {
-      if (nsteps % 4 == 0) V2S_SKINNY(8, 4); else if (nsteps % 3 == 0) V2S_SKINNY(8, 3); else if (nsteps % 2 == 0) V2S_SKINNY(8, 2); else V2S_SKINNY(8, 1);
+    const int mt = mode == 2 ? 4 : (a->N >= 8192 ? 4 : ((mode == 5 && wideN) ? 2 : 1));
+    const dim3 grid((unsigned)p.tilesN, (unsigned)((a->M + mt * 16 - 1) / (mt * 16)));
+#define V2S_SKINNY(W_, S_, MT_) hipLaunchKernelGGL((gemm_skinny_kernel<W_, S_, MT_>), grid, dim3(W_ * 64), 0, s, p)
+    if (mt == 1) {
+      if (waves == 8) {
+        if (nsteps % 12 == 0) V2S_SKINNY(8, 12, 1); else if (nsteps % 8 == 0) V2S_SKINNY(8, 8, 1); else if (nsteps % 6 == 0) V2S_SKINNY(8, 6, 1);
+        else if (nsteps % 4 == 0) V2S_SKINNY(8, 4, 1); else if (nsteps % 3 == 0) V2S_SKINNY(8, 3, 1); else if (nsteps % 2 == 0) V2S_SKINNY(8, 2, 1);
+        else V2S_SKINNY(8, 1, 1);
+      } else {
+        if (nsteps % 12 == 0) V2S_SKINNY(4, 12, 1); else if (nsteps % 8 == 0) V2S_SKINNY(4, 8, 1); else if (nsteps % 6 == 0) V2S_SKINNY(4, 6, 1);
+        else if (nsteps % 4 == 0) V2S_SKINNY(4, 4, 1); else if (nsteps % 3 == 0) V2S_SKINNY(4, 3, 1); else if (nsteps % 2 == 0) V2S_SKINNY(4, 2, 1);
+        else V2S_SKINNY(4, 1, 1);
+      }
+    } else if (mt == 2) {
+      if (waves == 8) {
+        if (nsteps % 6 == 0) V2S_SKINNY(8, 6, 2); else if (nsteps % 4 == 0) V2S_SKINNY(8, 4, 2); else if (nsteps % 3 == 0) V2S_SKINNY(8, 3, 2);
+        else if (nsteps % 2 == 0) V2S_SKINNY(8, 2, 2); else V2S_SKINNY(8, 1, 2);
+      } else {
+        if (nsteps % 6 == 0) V2S_SKINNY(4, 6, 2); else if (nsteps % 4 == 0) V2S_SKINNY(4, 4, 2); else if (nsteps % 3 == 0) V2S_SKINNY(4, 3, 2);
+        else if (nsteps % 2 == 0) V2S_SKINNY(4, 2, 2); else V2S_SKINNY(4, 1, 2);
+      }
+    } else if (waves == 8) {
+      if (nsteps % 4 == 0) V2S_SKINNY(8, 4, 4); else if (nsteps % 3 == 0) V2S_SKINNY(8, 3, 4); else if (nsteps % 2 == 0) V2S_SKINNY(8, 2, 4); else V2S_SKINNY(8, 1, 4);
     } else {
-      if (nsteps % 4 == 0) V2S_SKINNY(4, 4); else if (nsteps % 3 == 0) V2S_SKINNY(4, 3); else if (nsteps % 2 == 0) V2S_SKINNY(4, 2); else V2S_SKINNY(4, 1);
+      if (nsteps % 4 == 0) V2S_SKINNY(4, 4, 4); else if (nsteps % 3 == 0) V2S_SKINNY(4, 3, 4); else if (nsteps % 2 == 0) V2S_SKINNY(4, 2, 4); else V2S_SKINNY(4, 1, 4);
     }
 #undef V2S_SKINNY
     V2S_LAUNCH_CHECK();
