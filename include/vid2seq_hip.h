@@ -41,7 +41,8 @@ const char* v2s_last_error(void);
  *   "gemm_dma"      2: LDS-DMA 128x128 main loop for every variant with K % 64 == 0 (default), 1: transposed-operand variants only,
  *                   0: register-staged loop everywhere
  *   "gemm_big"      1: tile-size heuristics (default), 0: 128x128 only, 2: 256x128 8-wave only, 3: force the 4-wave 256x128x32 kernel
- *   "gemm_skinny"   1: dedicated weight-streaming kernel for M <= 64 (cached decoding; default), 0: general tiles
+ *   "gemm_skinny"   1: dedicated weight-streaming kernels for cached decoding (M <= 64; M <= 512 when N < 8192; default),
+ *                   0: general tiles (2 / 4 / 5 / 6: A/B variants of the block shape, tools/decode_ab.py)
  *   "gemm_order"    GM > 0: grouped tile walk, GM tile rows deep, K slices tile-major (default 4: the blocks an XCD runs together share
  *                   operand slabs in its L2; +20..40 % on the split-K weight gradients), 0: row-major with adjacent K slices
  *   "gemm_split"    1: split-K slice count from the rounds x length cost model (default), 0: fixed block-count target
@@ -103,7 +104,7 @@ typedef struct v2s_gemm_args {
   uint32_t dropout_seed;
   void* workspace;      /* optional fp32 scratch: enables split-K for few-tile/long-K (weight-gradient) shapes */
   int64_t workspace_bytes;
-  float rms_eps;        /* > 0: fused T5 RMSNorm prologue for cached decoding (M <= 64 only): row m of the result is multiplied by
+  float rms_eps;        /* > 0: fused T5 RMSNorm prologue for cached decoding (M <= 64, or M <= 512 with N < 8192): row m of the result is multiplied by
                            rsqrt(mean_k(A[m][k]^2) + rms_eps) before alpha/bias/...; the norm's weight vector must have been folded
                            into B's columns (v2s_scale_cols).  Replaces T5LayerNorm + Linear, modeling_t5.py:263-277 + :528-536 */
 } v2s_gemm_args;

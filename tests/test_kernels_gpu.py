@@ -237,7 +237,8 @@ def test_gemm_splitk_policies_agree(split):
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 768, 768), (64, 2304, 768), (37, 768, 3072), (1, 32200, 768), (64, 616, 128), (17, 768, 768),
-                                   (64, 32128, 768), (5, 9000, 1024), (33, 8192, 512), (64, 32128, 640)])
+                                   (64, 32128, 768), (5, 9000, 1024), (33, 8192, 512), (64, 32128, 640),
+                                   (256, 768, 768), (200, 3072, 768), (512, 768, 3072)])
 def test_gemm_skinny_decode_kernel(M, N, K):
     """M <= 64 weight-streaming kernels used by the cached decoder (incl. ragged M / N and the epilogues the decode step uses): the
     K-split kernel for the layer projections, the LDS-resident-activation kernel for the LM head (N >= 8192, K in {512, 768, 1024})."""
@@ -291,8 +292,8 @@ def test_gemm_fused_rmsnorm_prologue():
     ref = torch.relu((xf * torch.rsqrt((xf * xf).mean(-1, keepdim=True) + 1e-6) * w) @ W.float().T)
     assert relerr(out, ref) < 1.5e-2
     with pytest.raises(RuntimeError, match="rms_eps"):
-        big = rnd(128, K, seed=54)
-        L.gemm(big, Wf, torch.empty(128, N, dtype=torch.bfloat16, device=DEV), 128, N, K, rms_eps=1e-6)
+        big = rnd(640, K, seed=54)
+        L.gemm(big, Wf, torch.empty(640, N, dtype=torch.bfloat16, device=DEV), 640, N, K, rms_eps=1e-6)
 
 
 def test_gemm_splitk_workspace():
@@ -820,6 +821,18 @@ def test_decode_kernels():
     o3 = torch.empty_like(o2)                        # same result as with the real K/V in place (nothing depends on the skipped rows)
     L.decode_attn(B2, H, Nk2, q2, W, k2, v2, Nk2 * W, W, o3, W, key_mask=mask2.to(torch.uint8).contiguous(), mask_ld=Nk2)
     assert torch.equal(o2, o3)
+    # beams of a batch entry share the encoder K/V (kv_group): one block per (entry, head) scores all of them (2 / 4 / 8), any other
+    # group size keeps one block per row; both against a per-row reference
+    for grp in (2, 3, 4, 8):
+        Bq = B2 * grp
+        q4 = rnd(Bq, W, seed=31 + grp, scale=0.5)
+        s4 = torch.einsum("bghd,bkhd->bghk", q4.float().view(B2, grp, H, 64), k2.float().view(B2, Nk2, H, 64))
+        s4 = s4 + (~mask2)[:, None, None, :].float() * torch.finfo(torch.float32).min
+        ref4 = torch.einsum("bghk,bkhd->bghd", torch.softmax(s4, -1), v2.float().view(B2, Nk2, H, 64)).reshape(Bq, W)
+        o4 = torch.empty(Bq, W, dtype=torch.bfloat16, device=DEV)
+        L.decode_attn(Bq, H, Nk2, q4, W, k2p, v2p, Nk2 * W, W, o4, W, key_mask=mask2.to(torch.uint8).contiguous(), mask_ld=Nk2, kv_group=grp)
+        assert torch.isfinite(o4.float()).all()
+        assert relerr(o4, ref4) < 1e-2, grp
     # argmax: 16-byte and scalar paths, ties resolve to the lowest index
     for V2 in (32128, 32201, 7):
         lg = rnd(B, V2, seed=21, dtype=torch.float32)

@@ -19,11 +19,19 @@ struct DecP {
   const bf16_t *new_k, *new_v; long new_bs;     // the step's fresh K/V rows (fused cache append) or NULL
 };
 
-// one block (4 waves) per (b, h).  lane = (key slot ks = lane>>3, d-chunk c = lane&7): 8 keys per
-// wave-instruction, each key's 64-wide dot product = 8 lanes x 8 elements (16-byte loads).
+// one block (4 waves) per (KV row, h).  lane = (key slot ks = lane>>3, d-chunk c = lane&7): 8 keys per wave-instruction, each key's
+// 64-wide dot product = 8 lanes x 8 elements (16-byte loads).  G = queries sharing the block's K/V rows: 1, or the beams of a batch
+// entry against the encoder memory (kv_group): the K/V chunk is fetched and unpacked once and scored against all G queries -- with
+// one block per (beam, head) the 4 beams of an entry each streamed the same rows (cross-attention of a 4-beam step: 90 us vs 40 us
+// for the same K/V bytes at one query per entry; profiles/r02_decode_step.txt).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int G>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
-  __shared__ float s_m[4][8], s_l[4][8], s_o[4][8][64];
-  const int bh = blockIdx.x, h = bh % p.H, b = bh / p.H;
+  __shared__ float s_m[G][4][8], s_l[G][4][8], s_o[G][4][8][8];
+  const int bh = blockIdx.x, h = bh % p.H;
+  const int b0 = bh / p.H * G;                               // first query row of this block
+  const int bkv = p.kv_group > 1 ? b0 / p.kv_group : b0 / G; // its K/V (and mask) row; G > 1 is launched with kv_group = 1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ks = lane >> 3, c = lane & 7;
   int Nk = p.Nk;
   const float* bias_row = p.bias_row;
@@ -32,16 +40,21 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
     const int pos = *p.pos_dev;
     Nk = pos + 1;
     if (bias_row) bias_row += p.bias_maxlen - 1 - pos;
-    if (p.new_k) newpos = pos;
+    if (G == 1 && p.new_k) newpos = pos;
   }
-  const int bkv = p.kv_group > 1 ? b / p.kv_group : b;
-  float qv[8];
-  unpack8(*reinterpret_cast<const uint4*>(p.q + (long)b * p.q_bs + h * 64 + c * 8), qv);
+  f32x2 qv[G][4];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(p.q + (long)(b0 + g) * p.q_bs + h * 64 + c * 8), f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qv[g][e] = f32x2{f[2 * e], f[2 * e + 1]};
+  }
   const bf16_t* kp = p.k + (long)bkv * p.kv_bs + h * 64 + c * 8;
   const bf16_t* vp = p.v + (long)bkv * p.kv_bs + h * 64 + c * 8;
   if (newpos >= 0 && tid < 16) {        // fused KV-cache append: this (b, h) block owns the 64-wide K and V pieces of the new row
-    const bf16_t* src = (tid < 8 ? p.new_k : p.new_v) + (long)b * p.new_bs + h * 64 + (tid & 7) * 8;
-    bf16_t* dst = const_cast<bf16_t*>(tid < 8 ? p.k : p.v) + (long)b * p.kv_bs + (long)newpos * p.kv_rs + h * 64 + (tid & 7) * 8;
+    const bf16_t* src = (tid < 8 ? p.new_k : p.new_v) + (long)b0 * p.new_bs + h * 64 + (tid & 7) * 8;
+    bf16_t* dst = const_cast<bf16_t*>(tid < 8 ? p.k : p.v) + (long)b0 * p.kv_bs + (long)newpos * p.kv_rs + h * 64 + (tid & 7) * 8;
     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
   }
   // padded encoder positions: their K/V rows are never fetched.  A masked key scores -3e38, so next to any valid key its weight is
@@ -68,7 +81,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
   }
   const bool skip = lds_mask && s_last >= 0;
   const int Nvis = skip ? s_last + 1 : Nk;
-  float m = -INFINITY, l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float m[G], l[G];
+  f32x2 acc[G][4];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    m[g] = -INFINITY; l[g] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[g][e] = f32x2{0.f, 0.f};
+  }
   // each wave walks the keys in chunks of 32 (4 keys per 8-lane group): the 8 loads of a chunk are issued together so that
   // ~8 KiB per wave are in flight (this kernel is a pure HBM stream: K and V are read at most once per step)
   for (int k0 = wave * 32; k0 < Nvis; k0 += 128) {
@@ -83,79 +103,99 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
         if (lds_mask) masked[j] = s_valid[k] == 0;
         else if (p.key_mask) masked[j] = p.key_mask[(long)bkv * p.mask_ld + k] == 0;
         if (k == newpos) {              // not yet (visibly) in the cache: straight from the projection output
-          kr[j] = *reinterpret_cast<const uint4*>(p.new_k + (long)b * p.new_bs + h * 64 + c * 8);
-          vr[j] = *reinterpret_cast<const uint4*>(p.new_v + (long)b * p.new_bs + h * 64 + c * 8);
+          kr[j] = *reinterpret_cast<const uint4*>(p.new_k + (long)b0 * p.new_bs + h * 64 + c * 8);
+          vr[j] = *reinterpret_cast<const uint4*>(p.new_v + (long)b0 * p.new_bs + h * 64 + c * 8);
         } else if (!(skip && masked[j])) {
           kr[j] = *reinterpret_cast<const uint4*>(kp + (long)k * p.kv_rs);
           vr[j] = *reinterpret_cast<const uint4*>(vp + (long)k * p.kv_rs);
         }
       }
     }
-    float sc[4];
+    float sc[G][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float kv[8];
-      unpack8(kr[j], kv);
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) d += qv[e] * kv[e];
-      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+      float kf[8];
+      unpack8(kr[j], kf);
       const int k = k0 + ks + 8 * j;
-      float s = -INFINITY;
-      if (k < Nvis) {
-        s = d * p.scale;
-        if (bias_row) s += bias_row[(long)h * p.bias_ld + k];
-        if (masked[j]) s = -3.0e38f;
+      const float bias = (bias_row && k < Nvis) ? bias_row[(long)h * p.bias_ld + k] : 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        f32x2 d2 = qv[g][0] * f32x2{kf[0], kf[1]};
+#pragma unroll
+        for (int e = 1; e < 4; ++e) d2 = __builtin_elementwise_fma(qv[g][e], f32x2{kf[2 * e], kf[2 * e + 1]}, d2);
+        float d = d2.x + d2.y;
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+        float sv = -INFINITY;
+        if (k < Nvis) {
+          sv = d * p.scale + bias;
+          if (masked[j]) sv = -3.0e38f;
+        }
+        sc[g][j] = sv;
       }
-      sc[j] = s;
     }
-    const float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-    if (mx > -INFINITY) {
-      const float mn = fmaxf(m, mx);
-      const float alpha = __expf(m - mn);
-      l *= alpha;
+    f32x2 vf[4][4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+    for (int j = 0; j < 4; ++j) {
+      float f[8];
+      unpack8(vr[j], f);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float pr = __expf(sc[j] - mn);        // exp(-inf) = 0 for out-of-range slots
-        float vv[8];
-        unpack8(vr[j], vv);
-        l += pr;
+      for (int e = 0; e < 4; ++e) vf[j][e] = f32x2{f[2 * e], f[2 * e + 1]};
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += pr * vv[e];
+    for (int g = 0; g < G; ++g) {
+      const float mx = fmaxf(fmaxf(sc[g][0], sc[g][1]), fmaxf(sc[g][2], sc[g][3]));
+      if (mx > -INFINITY) {
+        const float mn = fmaxf(m[g], mx);
+        const float alpha = __expf(m[g] - mn);
+        l[g] *= alpha;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[g][e] *= alpha;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float pr = __expf(sc[g][j] - mn);        // exp(-inf) = 0 for out-of-range slots
+          l[g] += pr;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[g][e] = __builtin_elementwise_fma(f32x2{pr, pr}, vf[j][e], acc[g][e]);
+        }
+        m[g] = mn;
       }
-      m = mn;
     }
   }
   // merge the 8 key slots of this wave (lanes differing in bits 3..5), then the 4 waves through LDS
 #pragma unroll
-  for (int o = 8; o < 64; o <<= 1) {
-    const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
-    const float mn = fmaxf(m, m2);
-    const float a1 = (m == -INFINITY) ? 0.f : __expf(m - mn), a2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
-    l = l * a1 + l2 * a2;
+  for (int g = 0; g < G; ++g) {
+    float mg = m[g], lg = l[g];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = acc[j] * a1 + __shfl_xor(acc[j], o, 64) * a2;
-    m = mn;
-  }
-  if (ks == 0) {
-    s_m[wave][c] = m; s_l[wave][c] = l;
+    for (int o = 8; o < 64; o <<= 1) {
+      const float m2 = __shfl_xor(mg, o, 64), l2 = __shfl_xor(lg, o, 64);
+      const float mn = fmaxf(mg, m2);
+      const float a1 = (mg == -INFINITY) ? 0.f : __expf(mg - mn), a2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
+      lg = lg * a1 + l2 * a2;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s_o[wave][c][j] = acc[j];
+      for (int e = 0; e < 4; ++e) {
+        acc[g][e].x = acc[g][e].x * a1 + __shfl_xor(acc[g][e].x, o, 64) * a2;
+        acc[g][e].y = acc[g][e].y * a1 + __shfl_xor(acc[g][e].y, o, 64) * a2;
+      }
+      mg = mn;
+    }
+    if (ks == 0) {
+      s_m[g][wave][c] = mg; s_l[g][wave][c] = lg;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s_o[g][wave][c][2 * e] = acc[g][e].x; s_o[g][wave][c][2 * e + 1] = acc[g][e].y; }
+    }
   }
   __syncthreads();
-  if (tid < 64) {
-    const int cc = tid >> 3, j = tid & 7;
+  for (int t = tid; t < G * 64; t += 256) {
+    const int g = t >> 6, cc = (t >> 3) & 7, j = t & 7;
     float mm = -INFINITY;
-    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, s_m[w][cc]);
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, s_m[g][w][cc]);
     float ll = 0.f, oo = 0.f;
     for (int w = 0; w < 4; ++w) {
-      const float a = (s_m[w][cc] == -INFINITY) ? 0.f : __expf(s_m[w][cc] - mm);
-      ll += s_l[w][cc] * a;
-      oo += s_o[w][cc][j] * a;
+      const float a = (s_m[g][w][cc] == -INFINITY) ? 0.f : __expf(s_m[g][w][cc] - mm);
+      ll += s_l[g][w][cc] * a;
+      oo += s_o[g][w][cc][j] * a;
     }
-    p.o[(long)b * p.o_bs + h * 64 + cc * 8 + j] = f2bf(oo / ll);
+    p.o[(long)(b0 + g) * p.o_bs + h * 64 + cc * 8 + j] = f2bf(oo / ll);
   }
 }
 
@@ -451,7 +491,14 @@ extern "C" int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream) {
   p.new_k = (const bf16_t*)a->new_k; p.new_v = (const bf16_t*)a->new_v; p.new_bs = a->new_bs;
   V2S_CHECK(!a->new_k || (a->new_v && a->pos_dev && a->kv_group <= 1 && (a->new_bs % 8) == 0), V2S_ERR_ARG,
             "v2s_decode_attn: the fused cache append needs new_v, pos_dev and one KV row per batch entry");
-  hipLaunchKernelGGL(decode_attn_kernel, dim3(p.B * p.H), dim3(256), 0, (hipStream_t)stream, p);
+  // the beams of a batch entry share a block (K/V fetched once) when they divide evenly; any other group size keeps one block per row
+  const int G = (a->kv_group == 2 || a->kv_group == 4 || a->kv_group == 8) && (a->B % a->kv_group) == 0 && !a->new_k ? a->kv_group : 1;
+  const dim3 grid((unsigned)(p.B / G * p.H));
+  hipStream_t s = (hipStream_t)stream;
+  if (G == 8) { p.kv_group = 1; hipLaunchKernelGGL(decode_attn_kernel<8>, grid, dim3(256), 0, s, p); }
+  else if (G == 4) { p.kv_group = 1; hipLaunchKernelGGL(decode_attn_kernel<4>, grid, dim3(256), 0, s, p); }
+  else if (G == 2) { p.kv_group = 1; hipLaunchKernelGGL(decode_attn_kernel<2>, grid, dim3(256), 0, s, p); }
+  else hipLaunchKernelGGL(decode_attn_kernel<1>, grid, dim3(256), 0, s, p);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

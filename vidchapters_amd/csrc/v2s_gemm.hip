@@ -1506,7 +1506,10 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
   const bool tr = v2s_opt_tr_read() != 0;
   const bool plain_split = a->workspace && a->c_dtype == V2S_F32 && !a->bias && !a->act && !a->dact && !a->residual && !a->pre &&
                            a->dropout_p == 0.f && a->K >= 1024 && (a->N % 8) == 0;
-  if (a->M <= 64 && !a->transA && !a->transB && (a->K % 128) == 0 && v2s_opt_gemm_skinny() != 0) {
+  // decode-step projections: M = batch x beams rows (<= 512).  Past 64 rows the 49 MB LM head goes back to the general tiles
+  // (enough of them there), the layer projections stay here: 256 x 768 is 12 tiles of 128 x 128 on 256 CUs.
+  const bool skinny_rows = a->M <= 64 || (a->M <= 512 && a->N < 8192);
+  if (skinny_rows && !a->transA && !a->transB && (a->K % 128) == 0 && v2s_opt_gemm_skinny() != 0) {
     if (a->N >= 8192 && (a->K == 512 || a->K == 768 || a->K == 1024) && v2s_opt_gemm_skinny() != 2) {
       p.tilesM = 1; p.tilesN = (a->N + 15) / 16; p.splitk = 1; p.kper = a->K; p.ws = nullptr;
       g_last_gemm = "gemm_skinny_wide_kernel";
@@ -1528,10 +1531,13 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     // faster on every decoder projection (greedy B = 64: 1.39 ms/step with four fragments per block, 1.17 with one;
     // profiles/r02_decode_ab_skinny_mt.txt).  gemm_skinny = 2 keeps the four-fragment blocks, 4 = one fragment and four waves.
     const int mode = v2s_opt_gemm_skinny();
-    const bool wideN = a->N >= 2048;
-    const int waves = ((a->K % 256) == 0 && mode != 4 && !(mode == 6 && wideN)) ? 8 : 4;
+    const int waves = ((a->K % 256) == 0 && mode != 4) ? 8 : 4;
     const int nsteps = a->K / waves / 32;
-    const int mt = mode == 2 ? 4 : (a->N >= 8192 ? 4 : ((mode == 5 && wideN) ? 2 : 1));
+    // row fragments per block: the fewest (most blocks, least activation traffic per wave) that keep the grid within ~4 blocks per CU
+    const int cap = mode == 5 ? 512 : (mode == 6 ? 2048 : 1024);
+    int mt = 1;
+    while (mt < 4 && (long)p.tilesN * ((a->M + 16 * mt - 1) / (16 * mt)) > cap) mt *= 2;
+    if (a->M <= 64 && (mode == 2 || a->N >= 8192)) mt = 4;
     const dim3 grid((unsigned)p.tilesN, (unsigned)((a->M + mt * 16 - 1) / (mt * 16)));
 #define V2S_SKINNY(W_, S_, MT_) hipLaunchKernelGGL((gemm_skinny_kernel<W_, S_, MT_>), grid, dim3(W_ * 64), 0, s, p)
     if (mt == 1) {
@@ -1561,7 +1567,7 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     V2S_LAUNCH_CHECK();
     return V2S_OK;
   }
-  V2S_CHECK(a->rms_eps <= 0.f, V2S_ERR_ARG, "v2s_gemm: rms_eps (fused RMSNorm) is only available on the M <= 64, K %% 128 == 0 decode path");
+  V2S_CHECK(a->rms_eps <= 0.f, V2S_ERR_ARG, "v2s_gemm: rms_eps (fused RMSNorm) is only available on the decode path (M <= 64, or M <= 512 with N < 8192; K %% 128 == 0)");
   // tile choice: the 256-row kernel (one 8-wave block per CU) when K % 64 == 0 and it yields enough tiles, else 128x128
   int bm = BM, bn = BN;
   const int big_mode = v2s_opt_gemm_big();

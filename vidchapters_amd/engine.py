@@ -963,7 +963,8 @@ class Engine:
         hist = torch.zeros(R, maxlen + 1, dtype=torch.long, device=self.device) if rp else None     # decoder ids so far, per beam
         row_lse = self._f32(R) if rp else None
 
-        fw = self._decode_weights() if (d % 128 == 0 and R <= 64) else None
+        fw = self._decode_weights() if (d % 128 == 0 and R <= 512) else None     # fused norm + projection (v2s_gemm rms_eps)
+        fused_head = fw is not None and R <= 64
         eps = c.eps
 
         def proj(x, key, i, wname, shape, ln_idx, out, **kw):
@@ -990,7 +991,7 @@ class Engine:
                 proj(h, "wi", i, fp + "wi.weight", (self.ff, d), 2, u, act=L.ACT_RELU)
                 L.gemm(u, a.w(fp + "wo.weight"), h2, R, d, self.ff, residual=h)
                 h, h2 = h2, h
-            if fw is not None:
+            if fused_head:
                 L.gemm(h, fw["head"], logits, R, self.V, d, ldc=self.ldv, alpha=d ** -0.5, rms_eps=eps)
             else:
                 L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, R, d, eps)
