@@ -133,13 +133,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
         sc[g][j] = sv;
       }
     }
-    f32x2 vf[4][4];
+    f32x2 vf[4][4];                       // one query: unpacked per key below (registers: the short self-attention blocks want 8 waves/SIMD)
+    if constexpr (G > 1) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float f[8];
-      unpack8(vr[j], f);
+      for (int j = 0; j < 4; ++j) {
+        float f[8];
+        unpack8(vr[j], f);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) vf[j][e] = f32x2{f[2 * e], f[2 * e + 1]};
+        for (int e = 0; e < 4; ++e) vf[j][e] = f32x2{f[2 * e], f[2 * e + 1]};
+      }
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -154,6 +156,12 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
         for (int j = 0; j < 4; ++j) {
           const float pr = __expf(sc[g][j] - mn);        // exp(-inf) = 0 for out-of-range slots
           l[g] += pr;
+          if constexpr (G == 1) {
+            float f[8];
+            unpack8(vr[j], f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vf[j][e] = f32x2{f[2 * e], f[2 * e + 1]};
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[g][e] = __builtin_elementwise_fma(f32x2{pr, pr}, vf[j][e], acc[g][e]);
         }

@@ -1173,50 +1173,62 @@ __global__ __launch_bounds__(512, 2) void gemm_p8d_kernel(const GemmP p) {
 // MT = 16-row fragments per block: 4 (a block covers all 64 rows; blockIdx.y = 0) or 1 (blockIdx.y walks the row fragments: four
 // times the blocks, a quarter of the activation loads per wave -- the long-K projections, where 48 blocks x one latency-bound load
 // chain each left the chip idle: decoder wo 64x768x3072 18.7 us -> see profiles/r02_decode_step.txt).
-template <int WAVES, int STEPS, int MT>
+// NT = 16-column fragments per block (beam search: M = batch x beams = 256 rows made the activation re-reads -- every 16-column
+// block streams all M x K of A through L2 -- the larger stream; a 32 x 32 block halves both).
+template <int WAVES, int STEPS, int MT, int NT = 1>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) {
-  __shared__ float part[WAVES][MT * 16][17];
+  constexpr int PITCH = NT == 1 ? 17 : NT * 16 + 4;
+  __shared__ float part[WAVES][MT * 16][PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (MT * 16);
+  const int n0 = blockIdx.x * (NT * 16), m0 = blockIdx.y * (MT * 16);
   const int kq = p.K / WAVES;                    // multiple of 32 * STEPS (checked by the dispatcher)
   const int kbeg = wave * kq;
   const int r = lane & 15, kc = (lane >> 4) * 8;
-  int brow = n0 + r; brow = brow < p.N ? brow : p.N - 1;
-  const bf16_t* bp = p.B + (long)brow * p.ldb + kbeg + kc;
+  const bf16_t* bp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    int brow = n0 + t * 16 + r; brow = brow < p.N ? brow : p.N - 1;
+    bp[t] = p.B + (long)brow * p.ldb + kbeg + kc;
+  }
   const bf16_t* ap[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     int m = m0 + i * 16 + r; m = m < p.M ? m : p.M - 1;
     ap[i] = p.A + (long)m * p.lda + kbeg + kc;
   }
-  f32x4 acc[MT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool rms = p.rms_eps > 0.f;
   float sq[MT];                               // fused RMSNorm: sum of squares of this lane's A elements, per 16-row fragment
 #pragma unroll
   for (int i = 0; i < MT; ++i) sq[i] = 0.f;
-  // STEPS K-steps (of 32) are loaded back to back before their MFMAs: (1 + MT) x STEPS 16-byte loads in flight per lane
+  // STEPS K-steps (of 32) are loaded back to back before their MFMAs: (NT + MT) x STEPS 16-byte loads in flight per lane
   for (int k = 0; k < kq; k += 32 * STEPS) {
-    uint4 bq[STEPS], aq[STEPS][MT];
+    uint4 bq[STEPS][NT], aq[STEPS][MT];
 #pragma unroll
-    for (int t = 0; t < STEPS; ++t) {
-      bq[t] = *reinterpret_cast<const uint4*>(bp + k + t * 32);
+    for (int s = 0; s < STEPS; ++s) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) aq[t][i] = *reinterpret_cast<const uint4*>(ap[i] + k + t * 32);
+      for (int t = 0; t < NT; ++t) bq[s][t] = *reinterpret_cast<const uint4*>(bp[t] + k + s * 32);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) aq[s][i] = *reinterpret_cast<const uint4*>(ap[i] + k + s * 32);
     }
 #pragma unroll
-    for (int t = 0; t < STEPS; ++t)
+    for (int s = 0; s < STEPS; ++s)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[t][i]), __builtin_bit_cast(bf16x8, bq[t]), acc[i], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[s][i]), __builtin_bit_cast(bf16x8, bq[s][t]), acc[i][t], 0, 0, 0);
     if (rms) {
 #pragma unroll
-      for (int t = 0; t < STEPS; ++t)
+      for (int s = 0; s < STEPS; ++s)
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           float f[8];
-          unpack8(aq[t][i], f);
+          unpack8(aq[s][i], f);
 #pragma unroll
           for (int j = 0; j < 8; ++j) sq[i] = fmaf(f[j], f[j], sq[i]);
         }
@@ -1235,10 +1247,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) part[wave][i * 16 + (lane >> 4) * 4 + q][lane & 15] = acc[i][q];
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part[wave][i * 16 + (lane >> 4) * 4 + q][t * 16 + (lane & 15)] = acc[i][t][q];
   __syncthreads();
-  if (tid < MT * 32) {
-    const int ml = tid >> 1, m = m0 + ml, c = (tid & 1) * 8;
+  for (int e = tid; e < MT * 16 * NT * 2; e += WAVES * 64) {
+    const int ml = e / (NT * 2), m = m0 + ml, c = (e % (NT * 2)) * 8;
     const int gn = n0 + c;
     if (m < p.M && gn < p.N) {
       float v[8];
@@ -1531,38 +1545,47 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     // faster on every decoder projection (greedy B = 64: 1.39 ms/step with four fragments per block, 1.17 with one;
     // profiles/r02_decode_ab_skinny_mt.txt).  gemm_skinny = 2 keeps the four-fragment blocks, 4 = one fragment and four waves.
     const int mode = v2s_opt_gemm_skinny();
-    const int waves = ((a->K % 256) == 0 && mode != 4) ? 8 : 4;
-    const int nsteps = a->K / waves / 32;
+    int waves = ((a->K % 256) == 0 && mode != 4) ? 8 : 4;
     // row fragments per block: the fewest (most blocks, least activation traffic per wave) that keep the grid within ~4 blocks per CU
-    const int cap = mode == 5 ? 512 : (mode == 6 ? 2048 : 1024);
-    int mt = 1;
-    while (mt < 4 && (long)p.tilesN * ((a->M + 16 * mt - 1) / (16 * mt)) > cap) mt *= 2;
+    int mt = 1, nt = 1;
+    while (mt < 4 && (long)p.tilesN * ((a->M + 16 * mt - 1) / (16 * mt)) > 1024) mt *= 2;
     if (a->M <= 64 && (mode == 2 || a->N >= 8192)) mt = 4;
+    if (a->M > 64) { mt = 2; nt = 2; }       // beam rows: 32 x 32 blocks (4-beam step 2.26 -> 2.03 ms; profiles/r02_decode_ab_skinny_mt.txt)
+    // A/B (tools/decode_ab.py): gemm_skinny = <waves><mt><nt> for M > 64, 1<waves><mt><nt> for M <= 64
+    if (a->M > 64 && mode >= 100 && mode < 1000) { waves = mode / 100; mt = (mode / 10) % 10; nt = mode % 10; }
+    if (a->M <= 64 && a->N < 8192 && mode >= 1000) { waves = (mode / 100) % 10; mt = (mode / 10) % 10; nt = mode % 10; }
+    if ((a->K % (waves * 32)) != 0) waves = 4;
+    const int nsteps = a->K / waves / 32;
+    p.tilesN = (a->N + 16 * nt - 1) / (16 * nt);
     const dim3 grid((unsigned)p.tilesN, (unsigned)((a->M + mt * 16 - 1) / (mt * 16)));
-#define V2S_SKINNY(W_, S_, MT_) hipLaunchKernelGGL((gemm_skinny_kernel<W_, S_, MT_>), grid, dim3(W_ * 64), 0, s, p)
-    if (mt == 1) {
+    bool launched = true;
+#define V2S_SKINNY(W_, S_, MT_, NT_) hipLaunchKernelGGL((gemm_skinny_kernel<W_, S_, MT_, NT_>), grid, dim3(W_ * 64), 0, s, p)
+#define V2S_SKINNY_S4(W_, MT_, NT_) do { if (nsteps % 4 == 0) V2S_SKINNY(W_, 4, MT_, NT_); else if (nsteps % 3 == 0) V2S_SKINNY(W_, 3, MT_, NT_); \
+      else if (nsteps % 2 == 0) V2S_SKINNY(W_, 2, MT_, NT_); else V2S_SKINNY(W_, 1, MT_, NT_); } while (0)
+    if (nt == 1 && mt == 1) {
       if (waves == 8) {
-        if (nsteps % 12 == 0) V2S_SKINNY(8, 12, 1); else if (nsteps % 8 == 0) V2S_SKINNY(8, 8, 1); else if (nsteps % 6 == 0) V2S_SKINNY(8, 6, 1);
-        else if (nsteps % 4 == 0) V2S_SKINNY(8, 4, 1); else if (nsteps % 3 == 0) V2S_SKINNY(8, 3, 1); else if (nsteps % 2 == 0) V2S_SKINNY(8, 2, 1);
-        else V2S_SKINNY(8, 1, 1);
+        if (nsteps % 12 == 0) V2S_SKINNY(8, 12, 1, 1); else if (nsteps % 8 == 0) V2S_SKINNY(8, 8, 1, 1); else if (nsteps % 6 == 0) V2S_SKINNY(8, 6, 1, 1);
+        else V2S_SKINNY_S4(8, 1, 1);
       } else {
-        if (nsteps % 12 == 0) V2S_SKINNY(4, 12, 1); else if (nsteps % 8 == 0) V2S_SKINNY(4, 8, 1); else if (nsteps % 6 == 0) V2S_SKINNY(4, 6, 1);
-        else if (nsteps % 4 == 0) V2S_SKINNY(4, 4, 1); else if (nsteps % 3 == 0) V2S_SKINNY(4, 3, 1); else if (nsteps % 2 == 0) V2S_SKINNY(4, 2, 1);
-        else V2S_SKINNY(4, 1, 1);
+        if (nsteps % 12 == 0) V2S_SKINNY(4, 12, 1, 1); else if (nsteps % 8 == 0) V2S_SKINNY(4, 8, 1, 1); else if (nsteps % 6 == 0) V2S_SKINNY(4, 6, 1, 1);
+        else V2S_SKINNY_S4(4, 1, 1);
       }
-    } else if (mt == 2) {
-      if (waves == 8) {
-        if (nsteps % 6 == 0) V2S_SKINNY(8, 6, 2); else if (nsteps % 4 == 0) V2S_SKINNY(8, 4, 2); else if (nsteps % 3 == 0) V2S_SKINNY(8, 3, 2);
-        else if (nsteps % 2 == 0) V2S_SKINNY(8, 2, 2); else V2S_SKINNY(8, 1, 2);
-      } else {
-        if (nsteps % 6 == 0) V2S_SKINNY(4, 6, 2); else if (nsteps % 4 == 0) V2S_SKINNY(4, 4, 2); else if (nsteps % 3 == 0) V2S_SKINNY(4, 3, 2);
-        else if (nsteps % 2 == 0) V2S_SKINNY(4, 2, 2); else V2S_SKINNY(4, 1, 2);
-      }
-    } else if (waves == 8) {
-      if (nsteps % 4 == 0) V2S_SKINNY(8, 4, 4); else if (nsteps % 3 == 0) V2S_SKINNY(8, 3, 4); else if (nsteps % 2 == 0) V2S_SKINNY(8, 2, 4); else V2S_SKINNY(8, 1, 4);
-    } else {
-      if (nsteps % 4 == 0) V2S_SKINNY(4, 4, 4); else if (nsteps % 3 == 0) V2S_SKINNY(4, 3, 4); else if (nsteps % 2 == 0) V2S_SKINNY(4, 2, 4); else V2S_SKINNY(4, 1, 4);
-    }
+    } else if (nt == 1 && mt == 2) {
+      if (waves == 8) { if (nsteps % 6 == 0) V2S_SKINNY(8, 6, 2, 1); else V2S_SKINNY_S4(8, 2, 1); }
+      else { if (nsteps % 6 == 0) V2S_SKINNY(4, 6, 2, 1); else V2S_SKINNY_S4(4, 2, 1); }
+    } else if (nt == 1 && mt == 4) {
+      if (waves == 8) V2S_SKINNY_S4(8, 4, 1); else V2S_SKINNY_S4(4, 4, 1);
+    } else if (nt == 2 && mt == 2) {
+      if (waves == 8) V2S_SKINNY_S4(8, 2, 2); else { if (nsteps % 6 == 0) V2S_SKINNY(4, 6, 2, 2); else V2S_SKINNY_S4(4, 2, 2); }
+    } else if (nt == 2 && mt == 4 && waves == 4) {
+      V2S_SKINNY_S4(4, 4, 2);
+    } else if (nt == 4 && mt == 2 && waves == 4) {
+      V2S_SKINNY_S4(4, 2, 4);
+    } else if (nt == 2 && mt == 1) {
+      if (waves == 8) { if (nsteps % 6 == 0) V2S_SKINNY(8, 6, 1, 2); else V2S_SKINNY_S4(8, 1, 2); } else V2S_SKINNY_S4(4, 1, 2);
+    } else launched = false;
+    V2S_CHECK(launched, V2S_ERR_ARG, "v2s_gemm: gemm_skinny = %d names a block shape that is not built", mode);
+#undef V2S_SKINNY_S4
 #undef V2S_SKINNY
     V2S_LAUNCH_CHECK();
     return V2S_OK;
