@@ -26,8 +26,11 @@ struct DecP {
 // for the same K/V bytes at one query per entry; profiles/r02_decode_step.txt).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// (768 blocks of a B = 64 beam step = 3 per CU: at G = 4 the kernel must fit 3 waves per SIMD -- 168 VGPRs -- or the third block of
+// every CU runs in a second round)
 template <int G>
-__global__ __launch_bounds__(256) void decode_attn_kernel(const DecP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 8 ? 1 : (G == 4 ? 3 : 4))))
+void decode_attn_kernel(const DecP p) {
   __shared__ float s_m[G][4][8], s_l[G][4][8], s_o[G][4][8][8];
   const int bh = blockIdx.x, h = bh % p.H;
   const int b0 = bh / p.H * G;                               // first query row of this block
