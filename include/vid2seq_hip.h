@@ -279,6 +279,11 @@ typedef struct v2s_decode_attn_args {
    * Key *pos_dev is read from here instead of the cache, and the (b, h) block writes its pieces into cache row *pos_dev
    * (replaces a separate v2s_kv_append launch per layer and step; modeling_t5.py:555-556 grows the cache with torch.cat) */
   const void* new_k; const void* new_v; int64_t new_bs;
+  /* optional beam bookkeeping WITHOUT moving the cache (needs new_k): row_map[b*row_map_ld + k] = the cache row that physically holds
+   * key k of query row b.  The (b, h) blocks append the step's K/V into cache row b and set row_map[b][*pos_dev] = b; a beam reorder
+   * is then row_map[b][:] = row_map[src[b]][:] on a [rows][maxlen] int32 table instead of a copy of every cached K/V row
+   * (v2s_kv_gather: 12 layers x rows x len x 3 KB per step; HF reorders the cache itself, modeling_t5.py:1771-1793).  B <= 65535. */
+  int32_t* row_map; int64_t row_map_ld;
 } v2s_decode_attn_args;
 int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream);
 int v2s_argmax_step(const float* logits, int64_t ld, int32_t rows, int32_t V, int64_t* next_tok,

@@ -833,6 +833,25 @@ def test_decode_kernels():
         L.decode_attn(Bq, H, Nk2, q4, W, k2p, v2p, Nk2 * W, W, o4, W, key_mask=mask2.to(torch.uint8).contiguous(), mask_ld=Nk2, kv_group=grp)
         assert torch.isfinite(o4.float()).all()
         assert relerr(o4, ref4) < 1e-2, grp
+    # beam search without moving the cache: key k of row b is read from cache row row_map[b][k]; the step's own key comes from the
+    # projection output, is appended to cache row b, and row_map[b][pos] becomes b
+    Bm, maxlen, pv = 6, 40, 17
+    cache = rnd(Bm, maxlen, 2 * W, seed=61, scale=0.5)
+    rmap = torch.randint(0, Bm, (Bm, maxlen), generator=torch.Generator().manual_seed(5), dtype=torch.int32).to(DEV)
+    qkv = rnd(Bm, 3 * W, seed=62, scale=0.5)
+    posd = torch.tensor([pv], dtype=torch.int32, device=DEV)
+    before = cache.clone()
+    om = torch.empty(Bm, W, dtype=torch.bfloat16, device=DEV)
+    L.decode_attn(Bm, H, maxlen, qkv, 3 * W, cache, cache[:, :, W:], maxlen * 2 * W, 2 * W, om, W, pos_dev=posd, bias_maxlen=maxlen,
+                  new_k=qkv[:, W:], new_v=qkv[:, 2 * W:], new_bs=3 * W, row_map=rmap, row_map_ld=maxlen)
+    ar = torch.arange(pv, device=DEV)
+    hist = before[rmap[:, :pv].long(), ar[None, :]]                                  # [Bm, pv, 2W]
+    Kf = torch.cat([hist[:, :, :W], qkv[:, None, W:2 * W]], 1).float().view(Bm, pv + 1, H, 64)
+    Vf = torch.cat([hist[:, :, W:], qkv[:, None, 2 * W:]], 1).float().view(Bm, pv + 1, H, 64)
+    sm = torch.softmax(torch.einsum("bhd,bkhd->bhk", qkv[:, :W].float().view(Bm, H, 64), Kf), -1)
+    assert relerr(om, torch.einsum("bhk,bkhd->bhd", sm, Vf).reshape(Bm, W)) < 1e-2
+    assert torch.equal(cache[:, pv], qkv[:, W:]) and torch.equal(cache[:, :pv], before[:, :pv])
+    assert rmap[:, pv].tolist() == list(range(Bm))
     # argmax: 16-byte and scalar paths, ties resolve to the lowest index
     for V2 in (32128, 32201, 7):
         lg = rnd(B, V2, seed=21, dtype=torch.float32)

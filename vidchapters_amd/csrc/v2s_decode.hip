@@ -17,6 +17,7 @@ struct DecP {
   float scale;
   const int* pos_dev; int bias_maxlen; int kv_group;
   const bf16_t *new_k, *new_v; long new_bs;     // the step's fresh K/V rows (fused cache append) or NULL
+  int* row_map; long row_map_ld;                // beam search: physical cache row of (query row, key), or NULL
 };
 
 // one block (4 waves) per (KV row, h).  lane = (key slot ks = lane>>3, d-chunk c = lane&7): 8 keys per wave-instruction, each key's
@@ -59,6 +60,16 @@ void decode_attn_kernel(const DecP p) {
     const bf16_t* src = (tid < 8 ? p.new_k : p.new_v) + (long)b0 * p.new_bs + h * 64 + (tid & 7) * 8;
     bf16_t* dst = const_cast<bf16_t*>(tid < 8 ? p.k : p.v) + (long)b0 * p.kv_bs + (long)newpos * p.kv_rs + h * 64 + (tid & 7) * 8;
     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+  }
+  // beam search: the keys of query row b live in the cache rows its ancestors wrote them to (row_map), staged once per block
+  __shared__ unsigned short s_row[G == 1 ? 4096 : 1];
+  const bool mapped = G == 1 && p.row_map != nullptr && Nk <= 4096;
+  if constexpr (G == 1) {
+    if (mapped) {
+      for (int k = tid; k < Nk; k += 256) s_row[k] = (unsigned short)p.row_map[(long)b0 * p.row_map_ld + k];
+      if (h == 0 && tid == 0 && newpos >= 0) p.row_map[(long)b0 * p.row_map_ld + newpos] = b0;
+      __syncthreads();
+    }
   }
   // padded encoder positions: their K/V rows are never fetched.  A masked key scores -3e38, so next to any valid key its weight is
   // exp(-3e38 - m) == 0 exactly and the result does not depend on what was loaded for it; the mask row is staged in LDS once, keys
@@ -109,8 +120,10 @@ void decode_attn_kernel(const DecP p) {
           kr[j] = *reinterpret_cast<const uint4*>(p.new_k + (long)b0 * p.new_bs + h * 64 + c * 8);
           vr[j] = *reinterpret_cast<const uint4*>(p.new_v + (long)b0 * p.new_bs + h * 64 + c * 8);
         } else if (!(skip && masked[j])) {
-          kr[j] = *reinterpret_cast<const uint4*>(kp + (long)k * p.kv_rs);
-          vr[j] = *reinterpret_cast<const uint4*>(vp + (long)k * p.kv_rs);
+          long off = (long)k * p.kv_rs;
+          if constexpr (G == 1) { if (mapped) off += ((long)s_row[k] - bkv) * p.kv_bs; }
+          kr[j] = *reinterpret_cast<const uint4*>(kp + off);
+          vr[j] = *reinterpret_cast<const uint4*>(vp + off);
         }
       }
     }
@@ -500,6 +513,9 @@ extern "C" int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream) {
   p.o = (bf16_t*)a->o; p.o_bs = a->o_bs; p.bias_row = a->bias_row; p.bias_ld = a->bias_ld ? a->bias_ld : a->Nk; p.key_mask = a->key_mask; p.mask_ld = a->mask_ld;
   p.scale = a->scale; p.pos_dev = a->pos_dev; p.bias_maxlen = a->bias_maxlen; p.kv_group = a->kv_group;
   p.new_k = (const bf16_t*)a->new_k; p.new_v = (const bf16_t*)a->new_v; p.new_bs = a->new_bs;
+  p.row_map = a->row_map; p.row_map_ld = a->row_map_ld;
+  V2S_CHECK(!a->row_map || (a->new_k && a->B <= 65535 && a->Nk <= 4096 && a->row_map_ld >= a->Nk), V2S_ERR_ARG,
+            "v2s_decode_attn: row_map needs the fused append (new_k), at most 65535 rows and 4096 keys, row_map_ld >= Nk");
   V2S_CHECK(!a->new_k || (a->new_v && a->pos_dev && a->kv_group <= 1 && (a->new_bs % 8) == 0), V2S_ERR_ARG,
             "v2s_decode_attn: the fused cache append needs new_v, pos_dev and one KV row per batch entry");
   // the beams of a batch entry share a block (K/V fetched once) when they divide evenly; any other group size keeps one block per row

@@ -926,8 +926,9 @@ class Engine:
         The encoder memory is NOT replicated per beam: cross K/V are projected once per batch entry and the nb beams of an
         entry read the same rows (``kv_group``).  A step = decoder forward for B*nb rows -> ``v2s_topk_logprob`` (log-softmax +
         running beam score + per-beam top 2*nb), captured as a hipGraph; the host merges the candidates (beam.BeamScorer) and
-        sends back next tokens, scores and source rows; the self-attention cache is reordered by ``v2s_kv_gather`` into the
-        other half of a ping-pong pair only when the source rows are not the identity (one graph per half)."""
+        sends back next tokens, scores and source rows.  The self-attention cache is never moved: a [rows][maxlen] ``row_map`` says
+        which cache row holds each (beam, position) key, and a beam reorder permutes the rows of that table (v2s_decode_attn
+        row_map) -- HF copies every cached K/V row (modeling_t5.py:1771-1793), 12 layers x rows x len x 3 KB per step."""
         from .beam import BeamScorer
         a, c = self.arena, self.cfg
         mem, mem_mask = self.encode(video, input_tokenized)
@@ -946,7 +947,10 @@ class Engine:
             L.gemm(mem2, a.w(self._ca(i) + "k.weight", (2 * inner, d)), kv, B * S, 2 * inner, d)
             cross.append(kv)
         maxlen = max_new_tokens
-        caches = [[self._bf(R, maxlen, 2 * inner) for _ in range(nl)] for _ in range(2)]
+        if R > 65535 or maxlen > 4096:
+            raise ValueError(f"beam search: at most 65535 beam rows and 4096 new tokens (got {R}, {maxlen})")
+        cache = [self._bf(R, maxlen, 2 * inner) for _ in range(nl)]
+        row_map = torch.zeros(R, maxlen, dtype=torch.int32, device=self.device)
         diag, _ = self._bias_diag("decoder", maxlen, maxlen)
         nxt = torch.full((R,), c.dec_start_id, dtype=torch.long, device=self.device)
         pos = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -974,7 +978,7 @@ class Engine:
                 L.rmsnorm_fwd(x, a.f(self._ln("decoder", i, ln_idx)), n, rstd, R, d, eps)
                 L.gemm(n, a.w(wname, shape), out, R, shape[0], d, **kw)
 
-        def step(cache):
+        def step():
             h, h2 = ha, hb
             L.embed_fwd(nxt, E, h, R, d, self.V)
             for i in range(nl):
@@ -982,7 +986,8 @@ class Engine:
                 proj(h, "qkv", i, sa + "q.weight", (3 * inner, d), 0, qkv)
                 L.decode_attn(R, H, maxlen, qkv, 3 * inner, cache[i], cache[i][:, :, inner:], cbs, 2 * inner,
                               ctx, inner, bias_row=diag, bias_ld=2 * maxlen - 1, pos_dev=pos, bias_maxlen=maxlen,
-                              new_k=qkv[:, inner:], new_v=qkv[:, 2 * inner:], new_bs=3 * inner)       # cache append fused
+                              new_k=qkv[:, inner:], new_v=qkv[:, 2 * inner:], new_bs=3 * inner,         # cache append fused
+                              row_map=row_map, row_map_ld=maxlen)
                 L.gemm(ctx, a.w(sa + "o.weight"), h2, R, d, inner, residual=h)
                 proj(h2, "cq", i, ca + "q.weight", (inner, d), 1, q)
                 L.decode_attn(R, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
@@ -1007,21 +1012,19 @@ class Engine:
             hist.copy_(torch.from_numpy(scorer.seqs))
         bscore.copy_(torch.from_numpy(scorer.scores.reshape(-1)))
         identity = np.arange(R, dtype=np.int32)
-        graphs = [None, None]
-        cur = 0
+        graph = None
         for t in range(maxlen):
             if t == 0 or not use_graph:
-                step(caches[cur])
+                step()
             else:
-                if graphs[cur] is None:
+                if graph is None:
                     torch.cuda.synchronize()
-                    g = torch.cuda.CUDAGraph()
+                    graph = torch.cuda.CUDAGraph()
                     pos_keep = pos.clone()
-                    with torch.cuda.graph(g):
-                        step(caches[cur])
+                    with torch.cuda.graph(graph):
+                        step()
                     pos.copy_(pos_keep)            # capture does not execute, but keep the counter explicit
-                    graphs[cur] = g
-                graphs[cur].replay()
+                graph.replay()
             tok, src, finished = scorer.advance(cand_val.cpu().numpy(), cand_tok.cpu().numpy())
             if finished:
                 break
@@ -1031,9 +1034,7 @@ class Engine:
                 hist.copy_(torch.from_numpy(scorer.seqs))
             if not np.array_equal(src, identity):
                 src_dev.copy_(torch.from_numpy(src))
-                for i in range(nl):
-                    L.kv_gather(caches[cur][i], caches[cur ^ 1][i], src_dev, cbs, 2 * inner, R, t + 1, 2 * inner)
-                cur ^= 1
+                row_map.copy_(row_map.index_select(0, src_dev))
         if not 1 <= num_return <= nb:
             raise ValueError(f"num_captions must be in [1, num_beams] (got {num_return})")
         return torch.from_numpy(scorer.finalize(num_return)).to(self.device)

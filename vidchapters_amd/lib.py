@@ -55,7 +55,7 @@ class DecodeAttnArgs(C.Structure):
     _fields_ = [("B", _i32), ("H", _i32), ("Nk", _i32), ("q", _vp), ("q_bs", _i64), ("k", _vp), ("v", _vp),
                 ("kv_bs", _i64), ("kv_rs", _i64), ("o", _vp), ("o_bs", _i64), ("bias_row", _vp), ("bias_ld", _i64),
                 ("key_mask", _vp), ("mask_ld", _i64), ("scale", _f32), ("pos_dev", _vp), ("bias_maxlen", _i32),
-                ("kv_group", _i32), ("new_k", _vp), ("new_v", _vp), ("new_bs", _i64)]
+                ("kv_group", _i32), ("new_k", _vp), ("new_v", _vp), ("new_bs", _i64), ("row_map", _vp), ("row_map_ld", _i64)]
 
 
 #: every symbol include/vid2seq_hip.h declares (checked by tests/test_abi.py)
@@ -412,13 +412,14 @@ def timetoken_renorm(emb, emb_bf16, V, d, num_bins, ws):
 
 
 def decode_attn(B, H, Nk, q, q_bs, k, v, kv_bs, kv_rs, o, o_bs, bias_row=None, bias_ld=0, key_mask=None, mask_ld=0, scale=1.0,
-                pos_dev=None, bias_maxlen=0, kv_group=0, new_k=None, new_v=None, new_bs=0):
+                pos_dev=None, bias_maxlen=0, kv_group=0, new_k=None, new_v=None, new_bs=0, row_map=None, row_map_ld=0):
     a = DecodeAttnArgs()
     a.B, a.H, a.Nk = B, H, Nk
     a.q, a.q_bs, a.k, a.v, a.kv_bs, a.kv_rs = q.data_ptr(), q_bs, k.data_ptr(), v.data_ptr(), kv_bs, kv_rs
     a.o, a.o_bs, a.bias_row, a.bias_ld, a.key_mask, a.mask_ld, a.scale = o.data_ptr(), o_bs, ptr(bias_row), bias_ld, ptr(key_mask), mask_ld, scale
     a.pos_dev, a.bias_maxlen, a.kv_group = ptr(pos_dev), bias_maxlen, kv_group
     a.new_k, a.new_v, a.new_bs = ptr(new_k), ptr(new_v), new_bs
+    a.row_map, a.row_map_ld = ptr(row_map), row_map_ld
     _check(lib().v2s_decode_attn(C.byref(a), stream_ptr()), "v2s_decode_attn")
 
 
