@@ -57,16 +57,22 @@ class BeamScorer:
         val = cand_val.reshape(B, nb * K)
         tok = cand_tok.reshape(B, nb * K)
         order = np.argsort(-val, axis=1, kind="stable")[:, :2 * nb]
+        tok_sel = np.take_along_axis(tok, order, 1)
+        val_sel = np.take_along_axis(val, order, 1)
+        src_sel = (np.arange(B, dtype=np.int64)[:, None] * nb + order // K).astype(np.int32)
         new_tok = np.full((B, nb), self.pad, dtype=np.int64)
         new_src = np.zeros((B, nb), dtype=np.int32)
         new_sc = np.zeros((B, nb), dtype=np.float32)
-        for b in range(B):
-            if self.done[b]:
-                continue
+        # entries with no EOS among their 2*nb best and fewer than nb finished hypotheses (nothing to push, cannot be done) take
+        # the nb best as they are -- vectorised; the others walk the ranks like BeamSearchScorer.process
+        heap_len = np.fromiter((len(h.items) for h in self.heaps), dtype=np.int64, count=B)
+        slow = ~self.done & ((tok_sel == self.eos).any(1) | (heap_len >= nb))
+        fast = ~self.done & ~slow
+        new_tok[fast], new_src[fast], new_sc[fast] = tok_sel[fast, :nb], src_sel[fast, :nb], val_sel[fast, :nb]
+        for b in np.nonzero(slow)[0]:
             k = 0
             for rank in range(2 * nb):
-                j = int(order[b, rank])
-                t, sc, src = int(tok[b, j]), float(val[b, j]), b * nb + j // K
+                t, sc, src = int(tok_sel[b, rank]), float(val_sel[b, rank]), int(src_sel[b, rank])
                 if t == self.eos:
                     if rank < nb:
                         self.heaps[b].push(self.seqs[src, :self.cur_len].copy(), sc)
@@ -75,7 +81,7 @@ class BeamScorer:
                 k += 1
                 if k == nb:
                     break
-            if self.heaps[b].full_and_unbeatable(float(val[b, order[b, 0]]), self.cur_len):
+            if self.heaps[b].full_and_unbeatable(float(val_sel[b, 0]), self.cur_len):
                 self.done[b] = True
         self.scores = new_sc
         src = new_src.reshape(-1)

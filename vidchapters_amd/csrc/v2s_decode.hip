@@ -278,14 +278,17 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict
 // per row: log-softmax over V fp32 logits, add the row's running beam score, keep the K best (value, token) pairs, sorted
 // descending (HF 4.28 beam_search: log_softmax + beam_scores[:, None] then topk over the beams of a batch entry; the top-2*nb
 // of a batch entry are always among the per-beam top-2*nb, which the host merges).
-template <int K>
-__global__ __launch_bounds__(256) void topk_logprob_kernel(const float* __restrict__ logits, long ld, int V,
-                                                           const float* __restrict__ beam_scores, float* __restrict__ out_val,
-                                                           int* __restrict__ out_idx, int ban_tok, const int* __restrict__ pos_dev, int min_length, const float* __restrict__ row_lse) {
-  __shared__ float sv[256 * K];
-  __shared__ int si[256 * K];
-  __shared__ float red_m[4], red_s[4], best_v[4];
-  __shared__ int best_t[4], best_o[4];
+// NT threads per row (1024, or 512 for K = 16: the candidate lists take NT * K * 8 bytes of LDS), 16-byte loads: the 256-thread scalar
+// loop took 66 us per beam step for 256 rows (profiles/r02_decode_step.txt)
+template <int K, int NT>
+__global__ __launch_bounds__(NT) void topk_logprob_kernel(const float* __restrict__ logits, long ld, int V,
+                                                          const float* __restrict__ beam_scores, float* __restrict__ out_val,
+                                                          int* __restrict__ out_idx, int ban_tok, const int* __restrict__ pos_dev, int min_length, const float* __restrict__ row_lse) {
+  constexpr int NW = NT / 64;
+  __shared__ float sv[NT * K];
+  __shared__ int si[NT * K];
+  __shared__ float red_m[NW], red_s[NW], best_v[NW];
+  __shared__ int best_t[NW], best_o[NW];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* z = logits + (long)row * ld;
   // HF MinLengthLogitsProcessor: EOS is not a candidate while the decoder sequence (start token + decoded) is shorter than min_length
@@ -294,11 +297,7 @@ __global__ __launch_bounds__(256) void topk_logprob_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < K; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
   float m = -INFINITY, ssum = 0.f;
-  for (int i = tid; i < V; i += 256) {
-    const float v = z[i];
-    const float mn = fmaxf(m, v);
-    ssum = ssum * __expf(m - mn) + __expf(v - mn);
-    m = mn;
+  auto consider = [&](float v, int i) {
     if (v > tv[K - 1] && i != ban) {           // insert (a banned token -- EOS below min_length -- counts in the softmax only) into the sorted (descending) list; equal values keep the lower index first
       tv[K - 1] = v; ti[K - 1] = i;
 #pragma unroll
@@ -306,6 +305,22 @@ __global__ __launch_bounds__(256) void topk_logprob_kernel(const float* __restri
         if (tv[j] > tv[j - 1]) { const float a = tv[j]; tv[j] = tv[j - 1]; tv[j - 1] = a; const int b = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = b; }
       }
     }
+  };
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
+  const int V4 = vec ? (V & ~3) : 0;
+  for (int i = tid * 4; i < V4; i += NT * 4) {
+    const float4 q = *reinterpret_cast<const float4*>(z + i);
+    const float mn = fmaxf(fmaxf(m, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
+    ssum = ssum * __expf(m - mn) + ((__expf(q.x - mn) + __expf(q.y - mn)) + (__expf(q.z - mn) + __expf(q.w - mn)));
+    m = mn;
+    consider(q.x, i); consider(q.y, i + 1); consider(q.z, i + 2); consider(q.w, i + 3);
+  }
+  for (int i = V4 + tid; i < V; i += NT) {
+    const float v = z[i];
+    const float mn = fmaxf(m, v);
+    ssum = ssum * __expf(m - mn) + __expf(v - mn);
+    m = mn;
+    consider(v, i);
   }
   // block log-sum-exp
 #pragma unroll
@@ -319,12 +334,13 @@ __global__ __launch_bounds__(256) void topk_logprob_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < K; ++j) { sv[tid * K + j] = tv[j]; si[tid * K + j] = ti[j]; }
   __syncthreads();
-  float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+  float M = red_m[0];
+  for (int w = 1; w < NW; ++w) M = fmaxf(M, red_m[w]);
   float S = 0.f;
-  for (int w = 0; w < 4; ++w) S += red_s[w] * __expf(red_m[w] - M);
+  for (int w = 0; w < NW; ++w) S += red_m[w] == -INFINITY ? 0.f : red_s[w] * __expf(red_m[w] - M);
   const float lse = row_lse ? row_lse[row] : M + logf(S);      // a processor may have rewritten logits against a stored lse
   const float base = beam_scores ? beam_scores[row] : 0.f;
-  // K rounds of block-wide argmax over the heads of the 256 sorted lists
+  // K rounds of block-wide argmax over the heads of the NT sorted lists
   int head = 0;
   for (int r = 0; r < K; ++r) {
     float v = head < K ? sv[tid * K + head] : -INFINITY;
@@ -339,7 +355,7 @@ __global__ __launch_bounds__(256) void topk_logprob_kernel(const float* __restri
     if (lane == 0) { best_v[wave] = v; best_t[wave] = t; best_o[wave] = owner; }
     __syncthreads();
     float bv = best_v[0]; int bt = best_t[0], bo = best_o[0];
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < NW; ++w)
       if (best_v[w] > bv || (best_v[w] == bv && best_t[w] < bt)) { bv = best_v[w]; bt = best_t[w]; bo = best_o[w]; }
     if (tid == bo) ++head;
     if (tid == 0) { out_val[(long)row * K + r] = bv - lse + base; out_idx[(long)row * K + r] = bt; }
@@ -573,10 +589,10 @@ extern "C" int v2s_topk_logprob(const float* logits, int64_t ld, int32_t rows, i
   V2S_CHECK(logits && out_val && out_idx && rows > 0 && V > 0, V2S_ERR_ARG, "v2s_topk_logprob: bad args");
   V2S_CHECK(K == 2 || K == 4 || K == 8 || K == 16, V2S_ERR_ARG, "v2s_topk_logprob: K must be 2, 4, 8 or 16 (got %d)", K);
   hipStream_t s = (hipStream_t)stream;
-  if (K == 2) hipLaunchKernelGGL((topk_logprob_kernel<2>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
-  else if (K == 4) hipLaunchKernelGGL((topk_logprob_kernel<4>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
-  else if (K == 8) hipLaunchKernelGGL((topk_logprob_kernel<8>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
-  else hipLaunchKernelGGL((topk_logprob_kernel<16>), dim3(rows), dim3(256), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
+  if (K == 2) hipLaunchKernelGGL((topk_logprob_kernel<2, 1024>), dim3(rows), dim3(1024), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
+  else if (K == 4) hipLaunchKernelGGL((topk_logprob_kernel<4, 1024>), dim3(rows), dim3(1024), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
+  else if (K == 8) hipLaunchKernelGGL((topk_logprob_kernel<8, 1024>), dim3(rows), dim3(1024), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
+  else hipLaunchKernelGGL((topk_logprob_kernel<16, 512>), dim3(rows), dim3(512), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

@@ -1576,7 +1576,8 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     } else if (nt == 1 && mt == 4) {
       if (waves == 8) V2S_SKINNY_S4(8, 4, 1); else V2S_SKINNY_S4(4, 4, 1);
     } else if (nt == 2 && mt == 2) {
-      if (waves == 8) V2S_SKINNY_S4(8, 2, 2); else { if (nsteps % 6 == 0) V2S_SKINNY(4, 6, 2, 2); else V2S_SKINNY_S4(4, 2, 2); }
+      if (waves == 8) { if (nsteps % 6 == 0) V2S_SKINNY(8, 6, 2, 2); else V2S_SKINNY_S4(8, 2, 2); }
+      else { if (nsteps % 6 == 0) V2S_SKINNY(4, 6, 2, 2); else V2S_SKINNY_S4(4, 2, 2); }
     } else if (nt == 2 && mt == 4 && waves == 4) {
       V2S_SKINNY_S4(4, 4, 2);
     } else if (nt == 4 && mt == 2 && waves == 4) {

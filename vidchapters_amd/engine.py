@@ -952,11 +952,20 @@ class Engine:
         cache = [self._bf(R, maxlen, 2 * inner) for _ in range(nl)]
         row_map = torch.zeros(R, maxlen, dtype=torch.int32, device=self.device)
         diag, _ = self._bias_diag("decoder", maxlen, maxlen)
-        nxt = torch.full((R,), c.dec_start_id, dtype=torch.long, device=self.device)
+        # host <-> device traffic of a step is one copy each way through pinned buffers: [tokens int64 | scores f32 | source rows i32]
+        # down, [candidate values f32 | candidate tokens i32] up
+        h2d = torch.zeros(4 * R, dtype=torch.int32, device=self.device)
+        h2d_host = torch.zeros(4 * R, dtype=torch.int32).pin_memory()
+        nxt = h2d[:2 * R].view(torch.long)
+        nxt.fill_(c.dec_start_id)
         pos = torch.zeros(1, dtype=torch.int32, device=self.device)
-        bscore = torch.zeros(R, dtype=torch.float32, device=self.device)
-        src_dev = torch.zeros(R, dtype=torch.int32, device=self.device)
-        cand_val = self._f32(R, K); cand_tok = torch.zeros(R, K, dtype=torch.int32, device=self.device)
+        bscore = h2d[2 * R:3 * R].view(torch.float32)
+        src_dev = h2d[3 * R:]
+        cand = torch.zeros(2, R, K, dtype=torch.int32, device=self.device)
+        cand_host = torch.zeros(2, R, K, dtype=torch.int32).pin_memory()
+        cand_val, cand_tok = cand[0].view(torch.float32), cand[1]
+        h_tok, h_score, h_src = (h2d_host[:2 * R].view(torch.long).numpy(), h2d_host[2 * R:3 * R].view(torch.float32).numpy(),
+                                 h2d_host[3 * R:].numpy())
         logits = self._f32(R, self.ldv)
         E = a.w("t5_model.shared.weight")
         n = self._bf(R, d); rstd = self._f32(R)
@@ -1025,15 +1034,16 @@ class Engine:
                         step()
                     pos.copy_(pos_keep)            # capture does not execute, but keep the counter explicit
                 graph.replay()
-            tok, src, finished = scorer.advance(cand_val.cpu().numpy(), cand_tok.cpu().numpy())
+            cand_host.copy_(cand, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            tok, src, finished = scorer.advance(cand_host[0].view(torch.float32).numpy(), cand_host[1].numpy())
             if finished:
                 break
-            nxt.copy_(torch.from_numpy(tok))
-            bscore.copy_(torch.from_numpy(scorer.scores.reshape(-1)))
+            h_tok[:] = tok; h_score[:] = scorer.scores.reshape(-1); h_src[:] = src
+            h2d.copy_(h2d_host, non_blocking=True)
             if rp:
                 hist.copy_(torch.from_numpy(scorer.seqs))
             if not np.array_equal(src, identity):
-                src_dev.copy_(torch.from_numpy(src))
                 row_map.copy_(row_map.index_select(0, src_dev))
         if not 1 <= num_return <= nb:
             raise ValueError(f"num_captions must be in [1, num_beams] (got {num_return})")
