@@ -285,18 +285,19 @@ def generate_leg(model, tok, dev, Lx, B=64, new_tokens=256):
     model.train()
     ms_step = dt / max(steps, 1) * 1e3
     return {"batch": B, "decode_steps": int(steps), "seconds": round(dt, 4), "sequences_per_s": round(B / dt, 2),
-            "ms_per_decode_step": round(ms_step, 3), "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, ms_step, rows=B),
+            "ms_per_decode_step": round(ms_step, 3), "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, ms_step, rows=B, valid_keys=100 * B + int((ids != 0).sum())),
             "note": "encode + 256 greedy decode steps (EOS stop disabled so that every run decodes the full length), static KV cache"}
 
 
-def decode_roofline(model, B, S, maxlen, ms_step, rows):
+def decode_roofline(model, B, S, maxlen, ms_step, rows, valid_keys=None):
     """HBM roofline of one cached decode step (the step is bandwidth-bound: every byte below is read once per step and nothing is reused
-    across steps): cross-attention K/V of every layer for every batch entry (shared by the beams of an entry), the self-attention cache
+    across steps): cross-attention K/V of every layer for every VALID encoder position of every batch entry (`valid_keys` = their
+    count over the batch; padded positions are never fetched; shared by the beams of an entry), the self-attention cache
     (average fill maxlen/2), the bf16 decoder weights incl. the tied LM head, and the fp32 logits written and read back.  `achieved`
     includes the encoder pass amortised over the steps (ms_per_decode_step is end-to-end / steps)."""
     c = model.cfg
     d, inner, ff, nl, V = c.d_model, c.inner, c.d_ff, c.n_dec, c.vocab
-    cross = nl * B * S * 2 * inner * 2
+    cross = nl * (valid_keys if valid_keys is not None else B * S) * 2 * inner * 2
     selfc = nl * rows * (maxlen / 2) * 2 * inner * 2
     weights = nl * (3 * inner * d + inner * d + inner * d + inner * d + 2 * d * ff) * 2 + V * d * 2
     logits = rows * V * 4 * 2
@@ -325,7 +326,8 @@ def beam_leg(model, tok, dev, Lx, B=16, new_tokens=64, num_beams=4):
     model.train()
     return {"batch": B, "num_beams": num_beams, "max_new_tokens": new_tokens, "returned_length": int(toks.shape[1]), "seconds": round(dt, 4),
             "sequences_per_s": round(B / dt, 2), "ms_per_decode_step": round(dt / new_tokens * 1e3, 3),
-            "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, dt / new_tokens * 1e3, rows=B * num_beams),
+            "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, dt / new_tokens * 1e3, rows=B * num_beams,
+                                        valid_keys=100 * B + int((ids != 0).sum())),
             "note": "encode + beam search, min_length = max length so that every run decodes all steps"}
 
 
