@@ -1428,6 +1428,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 
 }  // namespace
 
+static int num_cus() {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, n = 0;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return ncu;
+}
+
 // Tile width of the 8-phase kernel for this shape, 0 = keep the older kernels.  (Rules from tools/gemm_p8_ab.py, profiles/r02_gemm_p8_ab.txt.)
 static int p8_auto(const v2s_gemm_args* a, bool deferred_ok) {
   // measured, variants interleaved in one process (tools/gemm_p8_ablate.py, gemm_p8_ab.py; profiles/r02_gemm_p8*.txt), us old / 8-phase
@@ -1436,7 +1445,15 @@ static int p8_auto(const v2s_gemm_args* a, bool deferred_ok) {
   // few-tile shapes (N = 768: 375 tiles on 256 CUs; the 8192- and 3200-row decoder / ViT shapes) stay on the 128 x 128 kernels.
   if (a->M < 256 || a->N < 256) return 0;
   const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
-  if (t256 < 512) return (a->transA && t256 >= 256 && a->K >= 4096) ? 256 : 0;
+  if (t256 < 512) {
+    // under two rounds of 256 x 256 tiles the 128 x 128 kernels win on tail quantisation -- unless the tiles happen to fill whole
+    // rounds (t5-large: 16000 x 1024 -> 252 tiles, 32000 x 1024 -> 500): 16000x1024x4096 141 -> 122 us, 16000x1024x3072 (dgrad) 104 -> 90
+    const int ncu = num_cus();
+    const long rounds = (t256 + ncu - 1) / ncu;
+    const bool full_rounds = v2s_opt_gemm_p8() != 5 && t256 * 100 >= rounds * ncu * 92 && a->K >= 1024 && !a->transA;
+    if (full_rounds) return 256;
+    return (a->transA && t256 >= 256 && a->K >= 4096) ? 256 : 0;
+  }
   if (deferred_ok && a->K <= 1536) return 256;          // p8_decide turns deferred_ok into the deferred form
   if (a->K >= 1024 || a->transA) return 256;
   return 0;
@@ -1461,14 +1478,6 @@ static void p8_decide(const v2s_gemm_args* a, bool tr, int& p8, bool& p8d) {
   else { p8 = p8_auto(a, p8d_ok); p8d = p8 == 256 && p8d_ok && a->K <= 1536; }
 }
 
-static int num_cus() {
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0, n = 0;
-    ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-  }
-  return ncu;
-}
 
 static thread_local const char* g_last_gemm = "";
 extern "C" const char* v2s_last_gemm_kernel(void) { return g_last_gemm; }
