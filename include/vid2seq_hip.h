@@ -107,6 +107,10 @@ typedef struct v2s_gemm_args {
   float rms_eps;        /* > 0: fused T5 RMSNorm prologue for cached decoding (M <= 64, or M <= 512 with N < 8192): row m of the result is multiplied by
                            rsqrt(mean_k(A[m][k]^2) + rms_eps) before alpha/bias/...; the norm's weight vector must have been folded
                            into B's columns (v2s_scale_cols).  Replaces T5LayerNorm + Linear, modeling_t5.py:263-277 + :528-536 */
+  int32_t decode;       /* 1: the call is part of a cached decode step (a chain of small dependent launches): the weight-streaming
+                           kernels then also take 64 < M <= 512 rows (beam search).  They split K across the waves of a block, so
+                           their fp32 summation order differs from the tiled kernels; training keeps 0 and with it results that do
+                           not depend on how many rows a call has (M <= 64 always takes them) */
 } v2s_gemm_args;
 
 int v2s_gemm(const v2s_gemm_args* args, void* stream);

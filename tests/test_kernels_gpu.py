@@ -246,19 +246,24 @@ def test_gemm_skinny_decode_kernel(M, N, K):
     ref = A.float() @ B.float().T
     ld = (N + 7) // 8 * 8
     C = torch.zeros(M, ld, dtype=torch.float32, device=DEV)
-    L.gemm(A, B, C, M, N, K, ldc=ld, alpha=0.25)
+    L.gemm(A, B, C, M, N, K, ldc=ld, alpha=0.25, decode=True)
+    if M > 64:        # without the decode flag a call with more than 64 rows stays on the K-sequential tiled kernels
+        Ct = torch.zeros(M, ld, dtype=torch.float32, device=DEV)
+        L.gemm(A, B, Ct, M, N, K, ldc=ld, alpha=0.25)
+        assert b"skinny" not in L.lib().v2s_last_gemm_kernel()
+        L.gemm(A, B, C, M, N, K, ldc=ld, alpha=0.25, decode=True)
     wide = N >= 8192 and K in (512, 768, 1024)
     assert L.lib().v2s_last_gemm_kernel() == (b"gemm_skinny_wide_kernel" if wide else b"gemm_skinny_kernel")
     assert relerr(C[:, :N], 0.25 * ref) < 2e-5
     if wide:      # the LM head runs with the final RMSNorm fused (rms_eps): rows scaled by rsqrt(mean(x^2) + eps)
         C2 = torch.zeros(M, ld, dtype=torch.float32, device=DEV)
-        L.gemm(A, B, C2, M, N, K, ldc=ld, alpha=0.25, rms_eps=1e-6)
+        L.gemm(A, B, C2, M, N, K, ldc=ld, alpha=0.25, rms_eps=1e-6, decode=True)
         af = A.float()
         assert relerr(C2[:, :N], 0.25 * ref * torch.rsqrt((af * af).mean(-1, keepdim=True) + 1e-6)) < 2e-5
         L.set_option("gemm_skinny", 2)      # the K-split kernel on the same problem
         try:
             C3 = torch.zeros(M, ld, dtype=torch.float32, device=DEV)
-            L.gemm(A, B, C3, M, N, K, ldc=ld, alpha=0.25, rms_eps=1e-6)
+            L.gemm(A, B, C3, M, N, K, ldc=ld, alpha=0.25, rms_eps=1e-6, decode=True)
             assert L.lib().v2s_last_gemm_kernel() == b"gemm_skinny_kernel"
         finally:
             L.set_option("gemm_skinny", 1)
@@ -266,12 +271,12 @@ def test_gemm_skinny_decode_kernel(M, N, K):
     if N % 8 == 0:
         res = rnd(M, N, seed=43)
         out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-        L.gemm(A, B, out, M, N, K, act=L.ACT_RELU, residual=res)
+        L.gemm(A, B, out, M, N, K, act=L.ACT_RELU, residual=res, decode=True)
         assert relerr(out, torch.relu(ref) + res.float()) < 1e-2
         L.set_option("gemm_skinny", 0)
         try:
             out2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-            L.gemm(A, B, out2, M, N, K, act=L.ACT_RELU, residual=res)
+            L.gemm(A, B, out2, M, N, K, act=L.ACT_RELU, residual=res, decode=True)
         finally:
             L.set_option("gemm_skinny", 1)
         assert relerr(out, out2) < 1e-2

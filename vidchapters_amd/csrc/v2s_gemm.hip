@@ -1531,7 +1531,7 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
                            a->dropout_p == 0.f && a->K >= 1024 && (a->N % 8) == 0;
   // decode-step projections: M = batch x beams rows (<= 512).  Past 64 rows the 49 MB LM head goes back to the general tiles
   // (enough of them there), the layer projections stay here: 256 x 768 is 12 tiles of 128 x 128 on 256 CUs.
-  const bool skinny_rows = a->M <= 64 || (a->M <= 512 && a->N < 8192);
+  const bool skinny_rows = a->M <= 64 || (a->decode != 0 && a->M <= 512 && a->N < 8192);
   if (skinny_rows && !a->transA && !a->transB && (a->K % 128) == 0 && v2s_opt_gemm_skinny() != 0) {
     if (a->N >= 8192 && (a->K == 512 || a->K == 768 || a->K == 1024) && v2s_opt_gemm_skinny() != 2) {
       p.tilesM = 1; p.tilesN = (a->N + 15) / 16; p.splitk = 1; p.kper = a->K; p.ws = nullptr;
@@ -1600,7 +1600,7 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     V2S_LAUNCH_CHECK();
     return V2S_OK;
   }
-  V2S_CHECK(a->rms_eps <= 0.f, V2S_ERR_ARG, "v2s_gemm: rms_eps (fused RMSNorm) is only available on the decode path (M <= 64, or M <= 512 with N < 8192; K %% 128 == 0)");
+  V2S_CHECK(a->rms_eps <= 0.f, V2S_ERR_ARG, "v2s_gemm: rms_eps (fused RMSNorm) is only available on the decode path (M <= 64, or decode = 1 and M <= 512 with N < 8192; K %% 128 == 0)");
   // tile choice: the 256-row kernel (one 8-wave block per CU) when K % 64 == 0 and it yields enough tiles, else 128x128
   int bm = BM, bn = BN;
   const int big_mode = v2s_opt_gemm_big();

@@ -857,10 +857,10 @@ class Engine:
         def proj(x, rows, key, i, wname, shape, ln_idx, out, **kw):
             """RMSNorm + Linear of a decode step: one fused skinny GEMM (folded weights) or norm kernel + GEMM."""
             if fw is not None:
-                L.gemm(x, fw[key][i], out, rows, shape[0], d, rms_eps=eps, **kw)
+                L.gemm(x, fw[key][i], out, rows, shape[0], d, rms_eps=eps, **kw, decode=True)
             else:
                 L.rmsnorm_fwd(x, a.f(self._ln("decoder", i, ln_idx)), n, rstd, rows, d, eps)
-                L.gemm(n, a.w(wname, shape), out, rows, shape[0], d, **kw)
+                L.gemm(n, a.w(wname, shape), out, rows, shape[0], d, **kw, decode=True)
 
         def step():
             h, h2 = ha, hb
@@ -871,19 +871,19 @@ class Engine:
                 L.decode_attn(B, H, maxlen, qkv, 3 * inner, cache[i], cache[i][:, :, inner:], maxlen * 2 * inner, 2 * inner,
                               ctx, inner, bias_row=diag, bias_ld=2 * maxlen - 1, pos_dev=pos, bias_maxlen=maxlen,
                               new_k=qkv[:, inner:], new_v=qkv[:, 2 * inner:], new_bs=3 * inner)       # cache append fused
-                L.gemm(ctx, a.w(sa + "o.weight"), h2, B, d, inner, residual=h)
+                L.gemm(ctx, a.w(sa + "o.weight"), h2, B, d, inner, residual=h, decode=True)
                 proj(h2, B, "cq", i, ca + "q.weight", (inner, d), 1, q)
                 L.decode_attn(B, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
                               key_mask=mem_mask, mask_ld=S)
-                L.gemm(ctx, a.w(ca + "o.weight"), h, B, d, inner, residual=h2)
+                L.gemm(ctx, a.w(ca + "o.weight"), h, B, d, inner, residual=h2, decode=True)
                 proj(h, B, "wi", i, fp + "wi.weight", (self.ff, d), 2, u, act=L.ACT_RELU)
-                L.gemm(u, a.w(fp + "wo.weight"), h2, B, d, self.ff, residual=h)
+                L.gemm(u, a.w(fp + "wo.weight"), h2, B, d, self.ff, residual=h, decode=True)
                 h, h2 = h2, h
             if fw is not None:
-                L.gemm(h, fw["head"], logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5, rms_eps=eps)
+                L.gemm(h, fw["head"], logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5, rms_eps=eps, decode=True)
             else:
                 L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, B, d, eps)
-                L.gemm(n, E, logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
+                L.gemm(n, E, logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5, decode=True)
             if repetition_penalty != 1.0:           # HF RepetitionPenaltyLogitsProcessor on the raw logits (greedy_search)
                 L.repetition_penalty(logits, self.ldv, B, self.V, seq, repetition_penalty, pos_dev=pos)
             if sample is None and min_length > 1 and eos >= 0:      # MinLengthLogitsProcessor of greedy_search (sampling: inside the sampling kernel)
@@ -982,10 +982,10 @@ class Engine:
 
         def proj(x, key, i, wname, shape, ln_idx, out, **kw):
             if fw is not None:
-                L.gemm(x, fw[key][i], out, R, shape[0], d, rms_eps=eps, **kw)
+                L.gemm(x, fw[key][i], out, R, shape[0], d, rms_eps=eps, **kw, decode=True)
             else:
                 L.rmsnorm_fwd(x, a.f(self._ln("decoder", i, ln_idx)), n, rstd, R, d, eps)
-                L.gemm(n, a.w(wname, shape), out, R, shape[0], d, **kw)
+                L.gemm(n, a.w(wname, shape), out, R, shape[0], d, **kw, decode=True)
 
         def step():
             h, h2 = ha, hb
@@ -997,19 +997,19 @@ class Engine:
                               ctx, inner, bias_row=diag, bias_ld=2 * maxlen - 1, pos_dev=pos, bias_maxlen=maxlen,
                               new_k=qkv[:, inner:], new_v=qkv[:, 2 * inner:], new_bs=3 * inner,         # cache append fused
                               row_map=row_map, row_map_ld=maxlen)
-                L.gemm(ctx, a.w(sa + "o.weight"), h2, R, d, inner, residual=h)
+                L.gemm(ctx, a.w(sa + "o.weight"), h2, R, d, inner, residual=h, decode=True)
                 proj(h2, "cq", i, ca + "q.weight", (inner, d), 1, q)
                 L.decode_attn(R, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
                               key_mask=mem_mask, mask_ld=S, kv_group=nb)
-                L.gemm(ctx, a.w(ca + "o.weight"), h, R, d, inner, residual=h2)
+                L.gemm(ctx, a.w(ca + "o.weight"), h, R, d, inner, residual=h2, decode=True)
                 proj(h, "wi", i, fp + "wi.weight", (self.ff, d), 2, u, act=L.ACT_RELU)
-                L.gemm(u, a.w(fp + "wo.weight"), h2, R, d, self.ff, residual=h)
+                L.gemm(u, a.w(fp + "wo.weight"), h2, R, d, self.ff, residual=h, decode=True)
                 h, h2 = h2, h
             if fused_head:
-                L.gemm(h, fw["head"], logits, R, self.V, d, ldc=self.ldv, alpha=d ** -0.5, rms_eps=eps)
+                L.gemm(h, fw["head"], logits, R, self.V, d, ldc=self.ldv, alpha=d ** -0.5, rms_eps=eps, decode=True)
             else:
                 L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, R, d, eps)
-                L.gemm(n, E, logits, R, self.V, d, ldc=self.ldv, alpha=d ** -0.5)
+                L.gemm(n, E, logits, R, self.V, d, ldc=self.ldv, alpha=d ** -0.5, decode=True)
             if rp:          # processor on the log-probabilities (beam_search): rewrites the logits against the stored row lse
                 L.repetition_penalty(logits, self.ldv, R, self.V, hist, repetition_penalty, pos_dev=pos, row_lse=row_lse)
             L.topk_logprob(logits, self.ldv, R, self.V, K, bscore, cand_val, cand_tok, ban_token=c.eos_id, pos_dev=pos,

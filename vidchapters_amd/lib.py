@@ -29,7 +29,7 @@ class GemmArgs(C.Structure):
                 ("c_dtype", _i32), ("accumulate", _i32), ("alpha", _f32), ("bias", _vp), ("act", _i32),
                 ("pre", _vp), ("dact", _i32), ("z", _vp), ("ldz", _i64), ("residual", _vp), ("ldr", _i64),
                 ("dropout_p", _f32), ("dropout_seed", _u32), ("workspace", _vp), ("workspace_bytes", _i64),
-                ("rms_eps", _f32)]
+                ("rms_eps", _f32), ("decode", _i32)]
 
 
 class AttnArgs(C.Structure):
@@ -204,7 +204,7 @@ class KernelTimer:
 # --------------------------------------------------------------------------------------------- GEMM
 def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, K: int, *, transA=False, transB=False,
          lda=None, ldb=None, ldc=None, accumulate=False, alpha=1.0, bias=None, act=ACT_NONE, pre=None, dact=ACT_NONE,
-         z=None, ldz=None, residual=None, ldr=None, dropout_p=0.0, dropout_seed=0, workspace=None, rms_eps=0.0) -> None:
+         z=None, ldz=None, residual=None, ldr=None, dropout_p=0.0, dropout_seed=0, workspace=None, rms_eps=0.0, decode=False) -> None:
     """C[M,N] (+)= epilogue(alpha * A(m,k) B(n,k)); see include/vid2seq_hip.h for layouts."""
     _need(A, torch.bfloat16, "gemm A"); _need(B, torch.bfloat16, "gemm B")
     a = GemmArgs()
@@ -229,6 +229,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, 
     a.dropout_p = dropout_p
     a.dropout_seed = dropout_seed & 0xFFFFFFFF
     a.rms_eps = rms_eps
+    a.decode = 1 if decode else 0
     if workspace is not None:
         a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     kt = KernelTimer.active
