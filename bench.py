@@ -193,9 +193,13 @@ def main():
             t0 = time.perf_counter(); trainer.step_graph(gb); t1 = time.perf_counter()
             torch.cuda.synchronize(); t2 = time.perf_counter()
             enq.append((t1 - t0) * 1e3); wall.append((t2 - t0) * 1e3)
-        t0 = time.perf_counter(); trainer.step(batch); t1 = time.perf_counter(); torch.cuda.synchronize()
+        eag = []
+        for _ in range(4):               # the first eager step after the replays re-creates the eager workspaces: not counted
+            t0 = time.perf_counter(); trainer.step(batch); t1 = time.perf_counter(); torch.cuda.synchronize()
+            eag.append((t1 - t0) * 1e3)
+        eag = sorted(eag[1:])
         out["captured_step"] = {"host_enqueue_ms_per_step": round(sorted(enq)[2], 3), "ms_per_step": round(sorted(wall)[2], 3),
-                                "eager_host_enqueue_ms_per_step": round((t1 - t0) * 1e3, 3),
+                                "eager_host_enqueue_ms_per_step": round(eag[1], 3),
                                 "note": "Trainer.step_graph: one hipGraph launch per step (~2500 kernel nodes on three streams)"}
     if rank == 0 and world == 1 and not a.no_roofline:      # N=1 only: the extra step would issue collectives other ranks do not join
         eng = model.engine()
