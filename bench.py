@@ -199,8 +199,8 @@ def main():
             eag.append((t1 - t0) * 1e3)
         eag = sorted(eag[1:])
         out["captured_step"] = {"host_enqueue_ms_per_step": round(sorted(enq)[2], 3), "ms_per_step": round(sorted(wall)[2], 3),
-                                "eager_host_enqueue_ms_per_step": round(eag[1], 3),
-                                "note": "Trainer.step_graph: one hipGraph launch per step (~2500 kernel nodes on three streams)"}
+                                "eager_host_call_ms_per_step": round(eag[1], 3),
+                                "note": "Trainer.step_graph: one hipGraph launch per step (~2500 kernel nodes on three streams).  eager_host_call = time inside the eager Trainer.step() on the host, which includes waiting for room in the launch queue once the host is ~1000 launches ahead of the GPU (tools/cpu_enqueue.py measures 15-23 ms of pure enqueue work)"}
     if rank == 0 and world == 1 and not a.no_roofline:      # N=1 only: the extra step would issue collectives other ranks do not join
         eng = model.engine()
         was = eng.overlap

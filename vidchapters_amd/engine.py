@@ -955,14 +955,16 @@ class Engine:
         # host <-> device traffic of a step is one copy each way through pinned buffers: [tokens int64 | scores f32 | source rows i32]
         # down, [candidate values f32 | candidate tokens i32] up
         h2d = torch.zeros(4 * R, dtype=torch.int32, device=self.device)
-        h2d_host = torch.zeros(4 * R, dtype=torch.int32).pin_memory()
+        pins = self._ws.setdefault("beam_pinned", {})          # pinned staging is allocated once per (rows, K): hipHostMalloc costs ms
+        if (R, K) not in pins:
+            pins[(R, K)] = (torch.zeros(4 * R, dtype=torch.int32).pin_memory(), torch.zeros(2, R, K, dtype=torch.int32).pin_memory())
+        h2d_host, cand_host = pins[(R, K)]
         nxt = h2d[:2 * R].view(torch.long)
         nxt.fill_(c.dec_start_id)
         pos = torch.zeros(1, dtype=torch.int32, device=self.device)
         bscore = h2d[2 * R:3 * R].view(torch.float32)
         src_dev = h2d[3 * R:]
         cand = torch.zeros(2, R, K, dtype=torch.int32, device=self.device)
-        cand_host = torch.zeros(2, R, K, dtype=torch.int32).pin_memory()
         cand_val, cand_tok = cand[0].view(torch.float32), cand[1]
         h_tok, h_score, h_src = (h2d_host[:2 * R].view(torch.long).numpy(), h2d_host[2 * R:3 * R].view(torch.float32).numpy(),
                                  h2d_host[3 * R:].numpy())
