@@ -37,7 +37,7 @@ const uint32_t* v2s_seed_salt();  // device word XOR-ed into every dropout seed 
 int v2s_opt_tr_read();   // 1 = use ds_read_b64_tr_b16 for transposed operand fragments
 int v2s_opt_gemm_dma();  // 2 = LDS-DMA (global_load_lds) 128x128 main loop for every variant where K % 64 == 0 (default), 1 = transposed only, 0 = never
 int v2s_opt_attn_bwd_part(); // profiling aid for v2s_attn_bwd: 0 = both kernels (default), 1 = dQ only, 2 = dK/dV only
-int v2s_opt_gemm_skinny(); // 1 = dedicated M <= 64 kernel for cached decoding (default; 2 / 4 = its A/B variants), 0 = general tiles
+int v2s_opt_gemm_skinny(); // 1 = weight-streaming kernels for cached decoding (default; other values: A/B block shapes, see the header), 0 = general tiles
 int v2s_opt_gemm_order(); // tile walk of the tiled GEMM kernels: GM > 0 = grouped GM tile rows deep with tile-major split-K (default 4), 0 = row-major
 int v2s_opt_gemm_split(); // 1 = split-K slice count from the rounds x length cost model (default), 0 = fixed block-count target
 int v2s_opt_gemm_p8();   // 8-phase ping-pong 256-row kernel: 0 = never, 1 = where it measured faster (default), 2 = 256x256 wherever legal, 3 = 256x128 wherever legal
