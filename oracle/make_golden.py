@@ -829,10 +829,57 @@ def case_shape(v2s, tag, cfg, B, T, L, Lo, seed, check_oracle=True):
     npz(f"{tag}_scalars.npz", **arrs)
 
 
+def ref_greedy_margins(m, batch, max_new, penalty=1.0):
+    """ref_greedy without the EOS stop, returning the tokens and the top-1 / top-2 logit margin of every step (a bf16 engine can
+    only be held to the steps whose margin exceeds its logit noise).  penalty != 1: HF-4.28 RepetitionPenaltyLogitsProcessor on the
+    decoder ids so far (restated; the processor itself is un-vendored)."""
+    from transformers.modeling_outputs import BaseModelOutput
+    with torch.no_grad():
+        _, _, mem, atts = ref_logits(m, batch)
+        B = mem.shape[0]
+        seq = torch.zeros(B, 1, dtype=torch.long)
+        past, margins = None, []
+        for _ in range(max_new):
+            step = seq if past is None else seq[:, -1:]
+            o = m.t5_model(encoder_outputs=BaseModelOutput(last_hidden_state=mem), attention_mask=atts,
+                           decoder_input_ids=step, past_key_values=past, use_cache=True, return_dict=True)
+            past = o.past_key_values
+            lg = o.logits[:, -1].clone()
+            if penalty != 1.0:
+                sc = lg.gather(1, seq)
+                lg.scatter_(1, seq, torch.where(sc < 0, sc * penalty, sc / penalty))
+            top = lg.topk(2, -1)
+            margins.append(top.values[:, 0] - top.values[:, 1])
+            seq = torch.cat([seq, top.indices[:, :1]], 1)
+        return seq, torch.stack(margins, 1)
+
+
+def case_greedy_full(v2s, B=2, T=100, L=1000, max_new=24, seed=2026):
+    """cfg-4 at the reference's own sizes (t5-base, 100 frames, 1000 ASR tokens): greedy tokens of the REFERENCE cached forward, plain
+    and with repetition_penalty 1.3 (a random-init model repeats one token without it), plus the per-step logit margins."""
+    cfg = R.RefConfig()
+    print(f"[full_cfg4 greedy] B={B} T={T} L={L} {max_new} new tokens (reference fp32 CPU, cached decoding)")
+    P = oracle_params(cfg, seed, grad=False)
+    m = build_ref_model(v2s, cfg, P).eval()
+    batch = synth.make_batch(B, T, L, 8, cfg.vocab, seed, cfg.vit_dim)
+    arrs = {"seed": seed, "B": B, "T": T, "L": L, "max_new": max_new}
+    for tag, pen in (("", 1.0), ("_rp", 1.3)):
+        seq, mar = ref_greedy_margins(m, batch, max_new, pen)
+        assert not (seq == 1).any(), "an EOS in the fixture: the oracle's loop would stop there"
+        want = R.greedy_generate(P, cfg, batch["video"], batch["input_ids"], batch["input_ids"] != 0, max_new, repetition_penalty=pen)
+        firm = (mar > 1e-3).all(1)
+        assert want.shape == seq.shape and torch.equal(want[firm], seq[firm]), (want, seq)
+        print(f"  penalty {pen}: row 0 tokens {seq[0, :10].tolist()} ... min margin {float(mar.min()):.4f}, median {float(mar.median()):.4f}")
+        arrs["tokens" + tag], arrs["margins" + tag] = seq, mar
+    arrs["penalty"] = 1.3
+    npz("full_cfg4_greedy.npz", **arrs)
+
+
 def case_shapes(v2s):
     case_shape(v2s, "full_cfg2", R.RefConfig(), B=2, T=100, L=1000, Lo=256, seed=2024)
     large = R.RefConfig(d_model=1024, d_kv=64, heads=16, d_ff=4096, n_enc=24, n_dec=24, num_features=200)
     case_shape(v2s, "large_cfg5", large, B=1, T=200, L=2000, Lo=256, seed=2025)
+    case_greedy_full(v2s)
 
 
 def main():

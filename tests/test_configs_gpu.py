@@ -185,6 +185,34 @@ def test_cfg4_greedy_batch64_rows_equal_single_sequence_runs():
     assert isinstance(text, list) and len(text) == 4
 
 
+def test_cfg4_greedy_vs_reference_cached_decoding(golden_dir):
+    """cfg-4 shapes against the REFERENCE: tests/golden/full_cfg4_greedy.npz holds the tokens of a hand-rolled greedy loop over the
+    reference's own cached forward (t5-base, 100 frames, 1000 ASR tokens, fp32 CPU; plain and with repetition_penalty 1.3, since a
+    random-init model repeats one token otherwise) and the top-1 / top-2 logit margin of every step.  The bf16 path may leave the
+    reference's sequence only at a step whose reference margin is below 0.02 (logit std 0.2; measured bf16 logit noise ~0.003)."""
+    g = np.load(os.path.join(golden_dir, "full_cfg4_greedy.npz"))
+    B, T, L, max_new, seed = int(g["B"]), int(g["T"]), int(g["L"]), int(g["max_new"]), int(g["seed"])
+    model = Vid2Seq("t5-base", tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
+                    init_seed=seed, device=DEV).eval()
+    b = synth.make_batch(B, T, L, 8, 32200, seed, 768)
+    video, ids = b["video"].to(DEV), b["input_ids"].to(DEV)
+    inp = {"input_ids": ids, "attention_mask": ids != 0}
+    checked = 0
+    for tag, pen in (("", 1.0), ("_rp", float(g["penalty"]))):
+        want, mar = torch.from_numpy(g["tokens" + tag]), torch.from_numpy(g["margins" + tag])
+        got = model.engine().greedy(video, inp, max_new_tokens=max_new, stop_at_eos=False, repetition_penalty=pen).cpu()
+        assert got.shape == want.shape
+        for r in range(B):
+            diff = (got[r] != want[r]).nonzero()
+            n = int(diff[0]) if len(diff) else max_new + 1           # leading tokens identical to the reference's
+            # a divergence is only legitimate at a step the reference itself decided by less than the margin (token n comes from step n-1)
+            assert n == max_new + 1 or float(mar[r, n - 1]) < 0.02, (tag, r, n, float(mar[r, n - 1]), got[r].tolist(), want[r].tolist())
+            checked += n
+            print(f"cfg-4 vs reference{tag} row {r}: first {n} of {max_new + 1} tokens identical"
+                  + ("" if n == max_new + 1 else f" (reference margin at the diverging step: {float(mar[r, n - 1]):.4f})"))
+    assert checked >= 60            # measured: 25 + 25 + 20 + 25 of 4 x 25
+
+
 def _nccl_world1(rank, port, ret):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
