@@ -189,6 +189,9 @@ typedef struct v2s_attn_args {
    * Rows of pad tokens simply do not exist -- the reference computes them and masks them as keys (modeling_t5.py:996), so the
    * rows that remain are identical */
   const int32_t* seq_off;
+  /* 1: seq_off packs the QUERY side only (q, o, d_o, dq; ml / delta keep their [B][H][Nq] indexing): K, V, dK, dV stay dense
+   * [B][Nk] with their batch strides and key_mask is allowed -- cross-attention of a padding-free decoder over the padded memory */
+  int32_t seq_q_only;
 } v2s_attn_args;
 
 int v2s_attn_fwd(const v2s_attn_args* a, void* stream);

@@ -508,6 +508,42 @@ def test_attention_packed_equals_padded(N, H, drop):
     assert relerr(dd, dd_pad) < 1e-5
 
 
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_cross_attention_query_packed_equals_padded(drop):
+    """seq_q_only: the query side packed (a padding-free decoder), K / V dense with the memory's key mask == the padded call on every
+    query row that exists (output, dQ) and on every key (dK, dV: pad query rows carry a zero upstream gradient in the model), bit for bit."""
+    B, H, Nq, Nk = 3, 4, 200, 330
+    W = H * 64
+    lens = [Nq, 133, 1]
+    off = [0]
+    for n in lens:
+        off.append(off[-1] + n)
+    T = off[-1]
+    q_pad = rnd(B, Nq, W, seed=1, scale=0.5); kv = rnd(B, Nk, 2 * W, seed=2, scale=0.5)
+    do_pad = rnd(B, Nq, W, seed=3)
+    for b_, n_ in enumerate(lens):
+        do_pad[b_, n_:] = 0
+    kmask = (torch.arange(Nk, device=DEV)[None, :] < torch.tensor([Nk, 250, 101], device=DEV)[:, None]).to(torch.uint8).contiguous()
+    sq, skv = (Nq * W, W), (Nk * 2 * W, 2 * W)
+    o_pad = torch.zeros(B, Nq, W, dtype=torch.bfloat16, device=DEV); ml = torch.zeros(B, H, Nq, 2, device=DEV)
+    a = L.attn_args(B, H, Nq, Nk, q_pad, kv, kv[..., W:], o_pad, sq, skv, skv, sq, ml=ml, key_mask=kmask, dropout_p=drop, dropout_seed=4)
+    L.attn_fwd(a)
+    dq_pad = torch.zeros_like(q_pad); dkv_pad = torch.zeros_like(kv); delta = torch.zeros(B, H, Nq, device=DEV)
+    L.attn_bwd(a, do_pad, sq, delta, dq_pad, dkv_pad, dkv_pad[..., W:], sq, skv, skv)
+    rows = torch.cat([torch.arange(n, device=DEV) + b * Nq for b, n in enumerate(lens)])
+    q = q_pad.view(B * Nq, W)[rows].contiguous(); d_o = do_pad.view(B * Nq, W)[rows].contiguous()
+    o = torch.zeros(T, W, dtype=torch.bfloat16, device=DEV); ml2 = torch.zeros(B, H, Nq, 2, device=DEV)
+    so = torch.tensor(off, dtype=torch.int32, device=DEV)
+    a2 = L.attn_args(B, H, Nq, Nk, q, kv, kv[..., W:], o, (0, W), skv, skv, (0, W), ml=ml2, key_mask=kmask, dropout_p=drop, dropout_seed=4,
+                     seq_off=so, seq_q_only=True)
+    L.attn_fwd(a2)
+    dq = torch.zeros_like(q); dkv = torch.zeros_like(kv); delta2 = torch.zeros(B, H, Nq, device=DEV)
+    L.attn_bwd(a2, d_o, (0, W), delta2, dq, dkv, dkv[..., W:], (0, W), skv, skv)
+    assert torch.equal(o, o_pad.view(B * Nq, W)[rows])
+    assert torch.equal(dq, dq_pad.view(B * Nq, W)[rows])
+    assert torch.equal(dkv, dkv_pad)
+
+
 def test_attention_fully_masked_row_is_uniform():
     B, H, N = 1, 1, 70
     W = 64
