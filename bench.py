@@ -93,8 +93,10 @@ def main():
     batch = {k: v.to(dev) for k, v in synth.make_batch(B, T, Lx, Lo, len(tok), 1234 + rank, 768, denoising=a.denoising > 0).items()}
     batch["video"] = batch["video"].to(torch.bfloat16)       # features resident in HBM as bf16 (documented in DESIGN.md)
     batch["input_lens"] = (batch["input_ids"] != 0).sum(1).tolist()      # host-side lengths, as a data loader knows them
+    batch["output_lens"] = (batch["output_ids"] != 0).sum(1).tolist()
     if "den_input_ids" in batch:
         batch["den_input_lens"] = (batch["den_input_ids"] != 0).sum(1).tolist()
+        batch["den_output_lens"] = (batch["den_output_ids"] != 0).sum(1).tolist()
     model.engine().pack = a.packing
 
     def barrier():
@@ -177,10 +179,12 @@ def main():
         torch.cuda.synchronize()
         dtp = (time.perf_counter() - t0) / 3
         eng.pack = False
-        out["padding_free_encoder"] = {"valid_encoder_tokens": int(sum(batch["input_lens"])), "padded_encoder_tokens": int(B * Lx),
-                                       "ms_per_step": round(dtp * 1e3, 3), "samples_per_s": round(B / dtp, 2),
-                                       "note": "engine default (Engine.pack): the text encoder runs on the non-pad tokens only; exact because the "
-                                               "reference masks those rows as keys everywhere.  `value` above does NOT use it"}
+        out["padding_free"] = {"valid_encoder_tokens": int(sum(batch["input_lens"])), "padded_encoder_tokens": int(B * Lx),
+                               "valid_decoder_rows": int(sum(batch["output_lens"])), "padded_decoder_rows": int(B * Lo),
+                               "ms_per_step": round(dtp * 1e3, 3), "samples_per_s": round(B / dtp, 2),
+                               "note": "engine default (Engine.pack, Engine.pack_dec): the text encoder runs on the non-pad tokens only and the "
+                                       "decoder on the rows of real targets only; exact because the reference masks those rows as keys everywhere "
+                                       "and ignores their labels.  `value` above does NOT use it"}
     if rank == 0 and world == 1 and not a.no_generate:
         # the same step replayed from ONE hipGraph (Trainer.step_graph: batch / dropout salt / Adam scalars read from device memory):
         # host time per step and device time per step; `value` above is the eager path, which is faster on the device on this stack

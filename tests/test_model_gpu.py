@@ -412,25 +412,34 @@ def test_full_size_cfg2_size_independent_properties():
 
 
 def test_padding_free_encoder_is_exact():
-    """Engine.pack: the text encoder runs on the non-pad tokens only.  Loss and every parameter gradient must equal the dense
-    (reference-like) path up to the order of floating-point accumulation in the weight-gradient GEMMs."""
+    """Engine.pack / Engine.pack_dec: the text encoder runs on the non-pad tokens only, the decoder on the rows of real targets only
+    (q-packed cross-attention over the dense memory).  Loss and every parameter gradient must equal the dense (reference-like) path up
+    to the order of floating-point accumulation in the weight-gradient GEMMs."""
     cfg = R.RefConfig.small()
     b = synth.make_batch(4, 10, 150, 40, cfg.vocab, 19, cfg.vit_dim)
     b["input_ids"][2, 5:] = 0                      # a short row; row 0..3 have different lengths
+    b["output_ids"][1, 9:] = 0; b["output_ids"][1, 8] = 1            # short target rows: the decoder plan must find room for its filler rows
+    b["output_ids"][3, 15:] = 0; b["output_ids"][3, 14] = 1
     args = (b["video"].to(DEV), tok(b["input_ids"]), tok(b["output_ids"]))
     res = {}
-    for pack in (True, False):
+    for mode in ("enc+dec", "enc", "dense"):
         model = build(cfg, 31).eval()
-        model.engine().pack = pack
+        eng = model.engine()
+        eng.pack, eng.pack_dec = mode != "dense", mode == "enc+dec"
+        if mode == "enc+dec":
+            plan = eng._pack_plan_dec(b["output_ids"].to(DEV) != 0)
+            assert plan is not None and plan[1] % 64 == 0 and plan[1] < 4 * 40, plan
         out, _ = model(*args)
         out["loss"].backward()
-        res[pack] = (out["loss"].item(), named_grads(model))
-    (lp, gp), (ld, gd) = res[True], res[False]
-    print(f"loss packed {lp:.7f} dense {ld:.7f}")
-    assert abs(lp - ld) <= 1e-5 * abs(ld)
-    worst = min(cos(gp[k], gd[k]) for k in gp if gd[k].abs().max() > 0)
-    print(f"  worst gradient cosine packed vs dense: {worst:.6f}")
-    assert worst > 0.9995
+        res[mode] = (out["loss"].item(), named_grads(model))
+    ld, gd = res["dense"]
+    for mode in ("enc+dec", "enc"):
+        lp, gp = res[mode]
+        print(f"loss packed ({mode}) {lp:.7f} dense {ld:.7f}")
+        assert abs(lp - ld) <= 1e-5 * abs(ld)
+        worst = min(cos(gp[k], gd[k]) for k in gp if gd[k].abs().max() > 0)
+        print(f"  worst gradient cosine packed ({mode}) vs dense: {worst:.6f}")
+        assert worst > 0.9995
     # generate() goes through the same encoder
     model.engine().pack = True
     t1 = model.engine().greedy(args[0], args[1], max_new_tokens=8).cpu()

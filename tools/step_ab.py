@@ -22,6 +22,8 @@ model.engine().pack = False
 tr = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=0.0)
 batch = {k: v.to(dev) for k, v in synth.make_batch(32, a.frames, a.asr, 256, len(tok), 1234, 768).items()}
 batch["video"] = batch["video"].to(torch.bfloat16)
+batch["input_lens"] = (batch["input_ids"] != 0).sum(1).tolist()         # host-side lengths, as a data loader knows them
+batch["output_lens"] = (batch["output_ids"] != 0).sum(1).tolist()
 defaults = {}
 def apply(setting):
     """"gemm_p8=0,eng:fused_head=1": library options, and engine attributes with the eng: prefix"""

@@ -81,6 +81,7 @@ class Engine:
         self.fused_head = True    # Trainer path: LM head + CE + their backward chunk by chunk inside the forward (no [B*Lo, vocab] tensor)
         self.head_rows = 2048     # decoder rows per chunk: 264 MB of fp32 logits + 132 MB of bf16 d(logits) scratch at vocab 32200
         self.pack = True          # run the text encoder on the valid (non-pad) tokens only: exact, see _pack_plan
+        self.pack_dec = True      # likewise the decoder rows of pad targets (labels -100, masked as keys): see _pack_plan_dec
         self.wstream = torch.cuda.Stream(device=device)
         self.vstream = torch.cuda.Stream(device=device)
         self.arena.refresh_shadow(force=True)
@@ -253,9 +254,10 @@ class Engine:
                              B=B, N=N, M=M, p=p, seed_o=seed_o))
         return out
 
-    def _cross_attn(self, i: int, h, B: int, Nq: int, mem, S: int, mem_mask, p: float, tape, kv=None):
+    def _cross_attn(self, i: int, h, B: int, Nq: int, mem, S: int, mem_mask, p: float, tape, kv=None, pack=None):
+        """``pack`` = (seq_off, rows): the query rows are packed (padding-free decoder), the memory stays dense [B, S]."""
         a = self.arena
-        Mq, Mk, d, inner = B * Nq, B * S, self.d, self.inner
+        Mq, Mk, d, inner = (pack[1] if pack is not None else B * Nq), B * S, self.d, self.inner
         n = self._bf(Mq, d); rstd = self._f32(Mq)
         L.rmsnorm_fwd(h, a.f(self._ln("decoder", i, 1)), n, rstd, Mq, d, self.cfg.eps)
         q = self._bf(Mq, inner)
@@ -268,14 +270,15 @@ class Engine:
         seed_a = self._next_seed()
         kst = (S * 2 * inner, 2 * inner)
         args = L.attn_args(B, self.H, Nq, S, q, kv, kv[:, inner:], ctx, (Nq * inner, inner), kst, kst, (Nq * inner, inner),
-                           ml=ml, scale=1.0, key_mask=mem_mask, dropout_p=p, dropout_seed=seed_a)
+                           ml=ml, scale=1.0, key_mask=mem_mask, dropout_p=p, dropout_seed=seed_a,
+                           seq_off=pack[0] if pack is not None else None, seq_q_only=pack is not None)
         L.attn_fwd(args)
         out = self._bf(Mq, d)
         seed_o = self._next_seed()
         L.gemm(ctx, a.w(self._ca(i) + "o.weight"), out, Mq, d, inner, residual=h, dropout_p=p, dropout_seed=seed_o)
         if tape is not None:
             tape.append(_Rec(kind="cross", i=i, h=h, n=n, rstd=rstd, q=q, kv=kv, ctx=ctx, ml=ml, args=args, mem=mem,
-                             B=B, Nq=Nq, S=S, p=p, seed_o=seed_o))
+                             B=B, Nq=Nq, S=S, p=p, seed_o=seed_o, Mq=Mq))
         return out
 
     def _ffn(self, stack: str, i: int, h, M: int, p: float, tape):
@@ -336,7 +339,7 @@ class Engine:
     def _cross_attn_bwd(self, r, dh, dmem, first: bool):
         a = self.arena
         B, Nq, S, d, inner = r.B, r.Nq, r.S, self.d, self.inner
-        Mq, Mk = B * Nq, B * S
+        Mq, Mk = r.Mq, B * S
         ca = self._ca(r.i)
         df = self._drop(dh, r.p, r.seed_o)
         self._wgrad(df, r.ctx, ca + "o.weight", d, inner, Mq)
@@ -442,7 +445,54 @@ class Engine:
             plan = plans[key] = (torch.from_numpy(off).to(self.device), padded, torch.from_numpy(rows).to(self.device), len(seqs), total)
         return (plan[0], plan[1], plan[2], plan[3], Lx, plan[4])
 
-    def decoder_forward(self, dec_ids, dec_mask_u8, mem, S: int, mem_mask_u8, p: float, tape):
+    def _pack_plan_dec(self, output_mask: torch.Tensor, lens=None):
+        """Row bookkeeping for running the decoder on the rows of real targets only.  Decoder position j of a sample consumes target
+        j-1 and predicts target j; positions at and beyond the sample's target length are pad inputs with label -100 that the reference
+        masks as keys (vid2seq.py:92, modeling_t5.py:996): nothing that reaches the loss reads them.  Unlike the encoder the stack is
+        causal, so the row count is brought to a multiple of 64 (the weight-gradient GEMMs contract over it) by simply KEEPING a few of
+        the pad positions at the end of sequences that have them -- they come after every valid row of their sequence, so no valid
+        query ever sees them -- instead of adding dummy sequences.  Returns (seq_off, rows, tok_rows, B, Lo) or None (dense path)."""
+        B, Lo = output_mask.shape
+        if lens is None:
+            m = output_mask.to(torch.bool)
+            if Lo > 1 and not bool((m[:, 1:] <= m[:, :-1]).all().item()):
+                return None
+            lens = m.sum(1).tolist()
+        lens = [max(1, int(x)) for x in lens]           # an empty target row still feeds the start token (row 0)
+        total = sum(lens)
+        fill = (-total) % 64
+        if total + fill >= B * Lo:
+            return None
+        key = ("dec", B, Lo, tuple(lens))
+        plans = self._ws.setdefault("pack_plans", {})
+        plan = plans.get(key)
+        if plan is None:
+            if len(plans) >= 8:
+                plans.clear()
+            ext = list(lens)
+            for b in range(B - 1, -1, -1):              # pad positions kept as rows, from the last sequence backwards
+                take = min(fill, Lo - ext[b])
+                ext[b] += take; fill -= take
+                if fill == 0:
+                    break
+            off = np.zeros(B + 1, dtype=np.int32)
+            off[1:] = np.cumsum(ext)
+            rows = np.concatenate([np.arange(n, dtype=np.int64) + b * Lo for b, n in enumerate(ext)])
+            plan = plans[key] = (torch.from_numpy(off).to(self.device), int(off[-1]), torch.from_numpy(rows).to(self.device))
+        return (plan[0], plan[1], plan[2], B, Lo)
+
+    def decoder_forward(self, dec_ids, dec_mask_u8, mem, S: int, mem_mask_u8, p: float, tape, pack=None):
+        """``pack`` = (seq_off, rows, tok_rows, B, Lo) from _pack_plan_dec: ``dec_ids`` is then the 1-D packed id vector and the result
+        has ``rows`` rows."""
+        if pack is not None:
+            B, Lo, M = pack[3], pack[4], pack[1]
+            h = self._embed(dec_ids, p, tape)
+            diag, _ = self._bias_diag("decoder", Lo, Lo)
+            for i in range(self.cfg.n_dec):
+                h = self._self_attn("decoder", i, h, B, Lo, diag, None, True, p, tape, pack=pack[:2])
+                h = self._cross_attn(i, h, B, Lo, mem, S, mem_mask_u8, p, tape, pack=pack[:2])
+                h = self._ffn("decoder", i, h, M, p, tape)
+            return self._final_norm("decoder", h, M, p, tape)
         B, Lo = dec_ids.shape
         h = self._embed(dec_ids, p, tape)
         diag, _ = self._bias_diag("decoder", Lo, Lo)
@@ -588,7 +638,7 @@ class Engine:
 
     # ========================================================================================== loss head
     def t5_loss_forward(self, vis, input_ids, input_mask, output_ids, output_mask, tape, vis_ready=None, input_lens=None,
-                        head_grad_scale: Optional[float] = None):
+                        head_grad_scale: Optional[float] = None, output_lens=None):
         """Encoder on the ASR tokens, [video ; text] memory, decoder on the shifted targets, tied LM head and
         label-smoothed CE (vid2seq.py:63-98 -> modeling_t5.py:1587-1738).  ``vis``: bf16 [B, T, d] or None.
 
@@ -647,11 +697,17 @@ class Engine:
         dec_in[:, 0] = c.dec_start_id
         dec_in = dec_in.masked_fill(dec_in == -100, c.pad_id)
         Lo = dec_in.shape[1]
-        hs = self.decoder_forward(dec_in, output_mask.to(torch.uint8).contiguous(), mem, S, mem_mask, pd, dec_tape)
-        Md = B * Lo
+        dplan = self._pack_plan_dec(output_mask, output_lens) if (self.pack and self.pack_dec) else None
+        if dplan is not None:               # decoder rows of real targets only (plus a few kept pad rows: row count % 64 == 0)
+            hs = self.decoder_forward(dec_in.reshape(-1).index_select(0, dplan[2]), None, mem, S, mem_mask, pd, dec_tape, pack=dplan)
+            Md = dplan[1]
+            labels = targets.reshape(-1).index_select(0, dplan[2]).contiguous()
+        else:
+            hs = self.decoder_forward(dec_in, output_mask.to(torch.uint8).contiguous(), mem, S, mem_mask, pd, dec_tape)
+            Md = B * Lo
+            labels = targets.reshape(-1).contiguous()
         alpha = self.d ** -0.5                                   # tie_word_embeddings rescale (modeling_t5.py:1709-1712)
         E = self.arena.w("t5_model.shared.weight")
-        labels = targets.reshape(-1).contiguous()
         row = self._f32(Md, 2)
         acc = torch.zeros(2, dtype=torch.float32, device=self.device)      # (loss_sum, count)
         logits = dhs = None
@@ -681,7 +737,7 @@ class Engine:
             L.ce_fwd(logits, self.ldv, labels, Md, self.V, m.label_smoothing, row, acc[0:1], acc[1:2])
         loss = acc[0] / acc[1]
         if tape is not None:
-            tape.update(enc=enc_tape, dec=dec_tape, B=B, T=T, Lx=Lx, Lo=Lo, S=S, hs=hs, logits=logits, labels=labels, row=row,
+            tape.update(enc=enc_tape, dec=dec_tape, B=B, T=T, Lx=Lx, Lo=Lo, S=S, Md=Md, hs=hs, logits=logits, labels=labels, row=row,
                         acc=acc, alpha=alpha, mem_rows=mem_rows, enc_rows=plan[1] if plan is not None else 0, dhs=dhs,
                         head_grad_scale=head_grad_scale)
         return loss
@@ -692,7 +748,7 @@ class Engine:
         gradients of that stack are complete (data-parallel all-reduce hooks)."""
         m = self.model
         B, T, Lx, Lo, S, d = tape["B"], tape["T"], tape["Lx"], tape["Lo"], tape["S"], self.d
-        Md = B * Lo
+        Md = tape["Md"]
         if tape.get("dhs") is not None:                      # fused head: its backward ran inside the forward (t5_loss_forward)
             dhs = tape["dhs"]
             tape["dhs"] = None

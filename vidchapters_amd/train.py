@@ -153,7 +153,7 @@ class Trainer:
     # ------------------------------------------------------------------------------------------------
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """One optimizer step on ``batch`` = {video, input_ids, output_ids[, den_input_ids, den_output_ids]}; optional
-        ``input_lens`` / ``den_input_lens`` (host lists of valid lengths, e.g. from the data loader) let the padding-free
+        ``input_lens`` / ``den_input_lens`` / ``output_lens`` / ``den_output_lens`` (host lists of valid lengths, e.g. from the data loader) let the padding-free
         encoder plan its rows without reading the mask back.  Returns device scalars."""
         return self._step_impl(batch)
 
@@ -184,14 +184,16 @@ class Trainer:
             t1: Dict = {}
             ids = batch["input_ids"]
             losses["loss"] = eng.t5_loss_forward(vis, ids, ids != 0, batch["output_ids"], batch["output_ids"] != 0, t1,
-                                                 vis_ready=vis_ready, input_lens=batch.get("input_lens"), head_grad_scale=float(self.gen))
+                                                 vis_ready=vis_ready, input_lens=batch.get("input_lens"), head_grad_scale=float(self.gen),
+                                                 output_lens=batch.get("output_lens"))
             tapes.append((t1, self.gen))
         if self.den:
             t2: Dict = {}
             ids = batch["den_input_ids"]
             losses["denoising_loss"] = eng.t5_loss_forward(vis, ids, ids != 0, batch["den_output_ids"],
                                                            batch["den_output_ids"] != 0, t2, vis_ready=vis_ready,
-                                                           input_lens=batch.get("den_input_lens"), head_grad_scale=float(self.den))
+                                                           input_lens=batch.get("den_input_lens"), head_grad_scale=float(self.den),
+                                                           output_lens=batch.get("den_output_lens"))
             tapes.append((t2, self.den))
 
         # backward: later passes first; parameter gradients accumulate in the arena.  The ViT backward starts as soon as
