@@ -192,6 +192,10 @@ typedef struct v2s_attn_args {
   /* 1: seq_off packs the QUERY side only (q, o, d_o, dq; ml / delta keep their [B][H][Nq] indexing): K, V, dK, dV stay dense
    * [B][Nk] with their batch strides and key_mask is allowed -- cross-attention of a padding-free decoder over the padded memory */
   int32_t seq_q_only;
+  /* optional row offsets of the KEY side (B+1 int32 on the device): K, V, dK, dV of sequence b occupy rows [kv_seq_off[b],
+   * kv_seq_off[b+1]) (batch strides ignored, Nk = the nominal maximum, key_mask must be NULL) -- cross-attention over a padding-free
+   * [video ; text] memory; the query side is dense or packed by seq_off independently */
+  const int32_t* kv_seq_off;
 } v2s_attn_args;
 
 int v2s_attn_fwd(const v2s_attn_args* a, void* stream);

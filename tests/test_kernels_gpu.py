@@ -542,6 +542,30 @@ def test_cross_attention_query_packed_equals_padded(drop):
     assert torch.equal(o, o_pad.view(B * Nq, W)[rows])
     assert torch.equal(dq, dq_pad.view(B * Nq, W)[rows])
     assert torch.equal(dkv, dkv_pad)
+    # key side packed as well (kv_seq_off: the valid memory rows only, no key mask), query side packed or dense
+    klens = [Nk, 250, 101]
+    koff = [0]
+    for n in klens:
+        koff.append(koff[-1] + n)
+    krows = torch.cat([torch.arange(n, device=DEV) + b * Nk for b, n in enumerate(klens)])
+    kvp = kv.view(B * Nk, 2 * W)[krows].contiguous()
+    ko = torch.tensor(koff, dtype=torch.int32, device=DEV)
+    for q_packed in (True, False):
+        o3 = torch.zeros_like(o if q_packed else o_pad); ml3 = torch.zeros(B, H, Nq, 2, device=DEV)
+        qq, dd_o = (q, d_o) if q_packed else (q_pad, do_pad)
+        qst = (0, W) if q_packed else sq
+        a3 = L.attn_args(B, H, Nq, Nk, qq, kvp, kvp[:, W:], o3, qst, (0, 2 * W), (0, 2 * W), qst, ml=ml3, dropout_p=drop, dropout_seed=4,
+                         seq_off=so if q_packed else None, seq_q_only=q_packed, kv_seq_off=ko)
+        L.attn_fwd(a3)
+        dq3 = torch.zeros_like(qq); dkv3 = torch.zeros_like(kvp); delta3 = torch.zeros(B, H, Nq, device=DEV)
+        L.attn_bwd(a3, dd_o, qst, delta3, dq3, dkv3, dkv3[:, W:], qst, (0, 2 * W), (0, 2 * W))
+        if q_packed:
+            assert torch.equal(o3, o) and torch.equal(dq3, dq)
+        else:
+            for b_, n_ in enumerate(lens):          # rows that exist; the padded call's pad query rows carry garbage-free but unused values
+                assert torch.equal(o3[b_, :n_], o_pad[b_, :n_]) and torch.equal(dq3[b_, :n_], dq_pad[b_, :n_])
+        assert torch.equal(dkv3, dkv_pad.view(B * Nk, 2 * W)[krows])
+        assert dkv_pad.view(B * Nk, 2 * W)[krows].abs().sum() > 0
 
 
 def test_attention_fully_masked_row_is_uniform():

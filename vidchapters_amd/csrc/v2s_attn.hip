@@ -51,6 +51,7 @@ struct AttnP {
   int far_lo, far_hi;   // all relative positions <= far_lo (>= far_hi) share one bias bucket
   const int* seq_off;   // packed self-attention: sequence b = rows [seq_off[b], seq_off[b+1]) of every operand (batch strides unused)
   int seq_q_only;       // seq_off applies to the query side only (q, o, d_o, dq); K / V / dK / dV stay dense [B][Nk] (cross-attention)
+  const int* kv_seq_off; // K / V / dK / dV packed with their OWN row offsets (cross-attention over a padding-free memory); else see above
 };
 
 // byte offset of element (row, d) inside a [rows][64] bf16 LDS tile
@@ -189,12 +190,14 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
   const int qblk = id % nqb, bh = id / nqb, h = bh % p.H, b = bh / p.H;
   const int Q0 = qblk * 128, wq0 = wave * 32;
   const int row0_ = p.seq_off ? p.seq_off[b] : 0;                          // packed (varlen) self-attention: first row of sequence b
-  const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq, nk_ = (p.seq_off && !p.seq_q_only) ? nq_ : p.Nk;
+  const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq;
+  const int* kso_ = p.kv_seq_off ? p.kv_seq_off : ((p.seq_off && !p.seq_q_only) ? p.seq_off : nullptr);     // row offsets of the key side
+  const int krow0_ = kso_ ? kso_[b] : 0, nk_ = kso_ ? kso_[b + 1] - krow0_ : p.Nk;
   if (Q0 >= nq_) return;                                                   // block beyond the end of a short sequence
 
   const bf16_t* qp = p.q + (p.seq_off ? (long)row0_ * p.q_rs : (long)b * p.q_bs) + h * HD;
-  const bf16_t* kp = p.k + ((p.seq_off && !p.seq_q_only) ? (long)row0_ * p.k_rs : (long)b * p.k_bs) + h * HD;
-  const bf16_t* vp = p.v + ((p.seq_off && !p.seq_q_only) ? (long)row0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
+  const bf16_t* kp = p.k + (kso_ ? (long)krow0_ * p.k_rs : (long)b * p.k_bs) + h * HD;
+  const bf16_t* vp = p.v + (kso_ ? (long)krow0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
 
   bf16x8 qf[2][2];
 #pragma unroll
@@ -423,7 +426,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   const int qblk = id % nqb, bh = id / nqb, h = bh % p.H, b = bh / p.H;
   const int Q0 = qblk * 128, wq0 = wave * 32;
   const int row0_ = p.seq_off ? p.seq_off[b] : 0;                          // packed (varlen) self-attention: first row of sequence b
-  const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq, nk_ = (p.seq_off && !p.seq_q_only) ? nq_ : p.Nk;
+  const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq;
+  const int* kso_ = p.kv_seq_off ? p.kv_seq_off : ((p.seq_off && !p.seq_q_only) ? p.seq_off : nullptr);     // row offsets of the key side
+  const int krow0_ = kso_ ? kso_[b] : 0, nk_ = kso_ ? kso_[b + 1] - krow0_ : p.Nk;
   if (Q0 >= nq_) return;                                                   // block beyond the end of a short sequence
   const bool want_dbias = BIAS && p.dbias_diag != nullptr;
   // per-diagonal bias-gradient window of this block, index (k - q) + (Q0 + 127) in [0, Nk+127), accumulated in 64-bit
@@ -438,8 +443,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 
   const bf16_t* qp = p.q + (p.seq_off ? (long)row0_ * p.q_rs : (long)b * p.q_bs) + h * HD;
   const bf16_t* dop = p.d_o + (p.seq_off ? (long)row0_ * p.do_rs : (long)b * p.do_bs) + h * HD;
-  const bf16_t* kp = p.k + ((p.seq_off && !p.seq_q_only) ? (long)row0_ * p.k_rs : (long)b * p.k_bs) + h * HD;
-  const bf16_t* vp = p.v + ((p.seq_off && !p.seq_q_only) ? (long)row0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
+  const bf16_t* kp = p.k + (kso_ ? (long)krow0_ * p.k_rs : (long)b * p.k_bs) + h * HD;
+  const bf16_t* vp = p.v + (kso_ ? (long)krow0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
 
   bf16x8 qf[2][2], dof[2][2];
   float m2[2], xmask[2], dl[2];
@@ -664,13 +669,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   const int kblk = id % nkb, bh = id / nkb, h = bh % p.H, b = bh / p.H;
   const int K0 = kblk * 128, wk0 = wave * 32;
   const int row0_ = p.seq_off ? p.seq_off[b] : 0;
-  const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq, nk_ = (p.seq_off && !p.seq_q_only) ? nq_ : p.Nk;
+  const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq;
+  const int* kso_ = p.kv_seq_off ? p.kv_seq_off : ((p.seq_off && !p.seq_q_only) ? p.seq_off : nullptr);     // row offsets of the key side
+  const int krow0_ = kso_ ? kso_[b] : 0, nk_ = kso_ ? kso_[b + 1] - krow0_ : p.Nk;
   if (K0 >= nk_) return;
 
   const bf16_t* qp = p.q + (p.seq_off ? (long)row0_ * p.q_rs : (long)b * p.q_bs) + h * HD;
   const bf16_t* dop = p.d_o + (p.seq_off ? (long)row0_ * p.do_rs : (long)b * p.do_bs) + h * HD;
-  const bf16_t* kp = p.k + ((p.seq_off && !p.seq_q_only) ? (long)row0_ * p.k_rs : (long)b * p.k_bs) + h * HD;
-  const bf16_t* vp = p.v + ((p.seq_off && !p.seq_q_only) ? (long)row0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
+  const bf16_t* kp = p.k + (kso_ ? (long)krow0_ * p.k_rs : (long)b * p.k_bs) + h * HD;
+  const bf16_t* vp = p.v + (kso_ ? (long)krow0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
 
   bf16x8 kf[2][2], vf[2][2];
   uint32_t kflag[2];
@@ -856,8 +863,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   for (int kb = 0; kb < 2; ++kb) {
     const int k = K0 + wk0 + kb * 16 + li;
     if (k < nk_) {
-      bf16_t* dkp = p.dk + ((p.seq_off && !p.seq_q_only) ? (long)row0_ * p.dk_rs : (long)b * p.dk_bs) + (long)k * p.dk_rs + h * HD;
-      bf16_t* dvp = p.dv + ((p.seq_off && !p.seq_q_only) ? (long)row0_ * p.dv_rs : (long)b * p.dv_bs) + (long)k * p.dv_rs + h * HD;
+      bf16_t* dkp = p.dk + (kso_ ? (long)krow0_ * p.dk_rs : (long)b * p.dk_bs) + (long)k * p.dk_rs + h * HD;
+      bf16_t* dvp = p.dv + (kso_ ? (long)krow0_ * p.dv_rs : (long)b * p.dv_bs) + (long)k * p.dv_rs + h * HD;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         uint2 w;
@@ -918,8 +925,9 @@ int fill(AttnP& p, const v2s_attn_args* a, const char* who, bool bwd) {
   p.dq = (bf16_t*)a->dq; p.dk = (bf16_t*)a->dk; p.dv = (bf16_t*)a->dv;
   p.dq_bs = a->dq_bs; p.dq_rs = a->dq_rs; p.dk_bs = a->dk_bs; p.dk_rs = a->dk_rs; p.dv_bs = a->dv_bs; p.dv_rs = a->dv_rs;
   p.dbias_diag = a->dbias_diag;
-  p.seq_off = a->seq_off; p.seq_q_only = (a->seq_off && a->seq_q_only) ? 1 : 0;
-  V2S_CHECK(!a->seq_off || a->seq_q_only || (a->Nq == a->Nk && !a->key_mask), V2S_ERR_ARG, "%s: seq_off (packed self-attention) needs Nq == Nk and no key_mask", who);
+  p.seq_off = a->seq_off; p.seq_q_only = (a->seq_off && a->seq_q_only) ? 1 : 0; p.kv_seq_off = a->kv_seq_off;
+  V2S_CHECK(!a->seq_off || a->seq_q_only || a->kv_seq_off || (a->Nq == a->Nk && !a->key_mask), V2S_ERR_ARG, "%s: seq_off (packed self-attention) needs Nq == Nk and no key_mask", who);
+  V2S_CHECK(!a->kv_seq_off || !a->key_mask, V2S_ERR_ARG, "%s: kv_seq_off (packed keys) excludes key_mask: pad keys simply do not exist", who);
   // far buckets: disabled (every diagonal resolved) unless the caller states lo < hi
   if (a->bias_far_lo < a->bias_far_hi) { p.far_lo = a->bias_far_lo; p.far_hi = a->bias_far_hi; }
   else { p.far_lo = -(1 << 30); p.far_hi = (1 << 30); }

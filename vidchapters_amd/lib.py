@@ -42,7 +42,7 @@ class AttnArgs(C.Structure):
                 ("d_o", _vp), ("do_bs", _i64), ("do_rs", _i64), ("delta", _vp),
                 ("dq", _vp), ("dk", _vp), ("dv", _vp),
                 ("dq_bs", _i64), ("dq_rs", _i64), ("dk_bs", _i64), ("dk_rs", _i64), ("dv_bs", _i64), ("dv_rs", _i64),
-                ("dbias_diag", _vp), ("bias_far_lo", _i32), ("bias_far_hi", _i32), ("seq_off", _vp), ("seq_q_only", _i32)]
+                ("dbias_diag", _vp), ("bias_far_lo", _i32), ("bias_far_hi", _i32), ("seq_off", _vp), ("seq_q_only", _i32), ("kv_seq_off", _vp)]
 
 
 class AdamArgs(C.Structure):
@@ -278,7 +278,7 @@ def layernorm_bwd(x, w, mean, rstd, dy, dx, dx_add, dw, db, rows, cols):
 
 # --------------------------------------------------------------------------------------------- attention
 def attn_args(B, H, Nq, Nk, q, k, v, o, q_st, k_st, v_st, o_st, *, ml=None, scale=1.0, bias_diag=None, key_mask=None,
-              causal=False, causal_off=0, dropout_p=0.0, dropout_seed=0, seq_off=None, seq_q_only=False) -> AttnArgs:
+              causal=False, causal_off=0, dropout_p=0.0, dropout_seed=0, seq_off=None, seq_q_only=False, kv_seq_off=None) -> AttnArgs:
     """q_st etc. are (batch_stride, row_stride) in elements; q/k/v/o are tensors whose data_ptr() already
     points at column 0 of head 0."""
     a = AttnArgs()
@@ -292,6 +292,9 @@ def attn_args(B, H, Nq, Nk, q, k, v, o, q_st, k_st, v_st, o_st, *, ml=None, scal
         _need(seq_off, torch.int32, "attn seq_off")
     a.seq_off = ptr(seq_off)
     a.seq_q_only = 1 if (seq_q_only and seq_off is not None) else 0
+    if kv_seq_off is not None:
+        _need(kv_seq_off, torch.int32, "attn kv_seq_off")
+    a.kv_seq_off = ptr(kv_seq_off)
     # the struct only carries raw pointers: keep every tensor alive for as long as the struct (backward reuses it)
     a._refs = (q, k, v, o, ml, bias_diag, key_mask, seq_off)
     return a
