@@ -413,7 +413,7 @@ def test_full_size_cfg2_size_independent_properties():
 
 def test_padding_free_encoder_is_exact():
     """Engine.pack / Engine.pack_dec: the text encoder runs on the non-pad tokens only, the decoder on the rows of real targets only
-    (q-packed cross-attention over the dense memory).  Loss and every parameter gradient must equal the dense (reference-like) path up
+    (q-packed cross-attention), the [video ; text] memory without its pad rows (key-packed cross-attention).  Loss and every parameter gradient must equal the dense (reference-like) path up
     to the order of floating-point accumulation in the weight-gradient GEMMs."""
     cfg = R.RefConfig.small()
     b = synth.make_batch(4, 10, 150, 40, cfg.vocab, 19, cfg.vit_dim)
@@ -422,10 +422,10 @@ def test_padding_free_encoder_is_exact():
     b["output_ids"][3, 15:] = 0; b["output_ids"][3, 14] = 1
     args = (b["video"].to(DEV), tok(b["input_ids"]), tok(b["output_ids"]))
     res = {}
-    for mode in ("enc+dec", "enc", "dense"):
+    for mode in ("enc+dec+mem", "enc+dec", "enc", "dense"):
         model = build(cfg, 31).eval()
         eng = model.engine()
-        eng.pack, eng.pack_dec = mode != "dense", mode == "enc+dec"
+        eng.pack, eng.pack_dec, eng.pack_mem = mode != "dense", mode.startswith("enc+dec"), mode == "enc+dec+mem"
         if mode == "enc+dec":
             plan = eng._pack_plan_dec(b["output_ids"].to(DEV) != 0)
             assert plan is not None and plan[1] % 64 == 0 and plan[1] < 4 * 40, plan
@@ -433,7 +433,7 @@ def test_padding_free_encoder_is_exact():
         out["loss"].backward()
         res[mode] = (out["loss"].item(), named_grads(model))
     ld, gd = res["dense"]
-    for mode in ("enc+dec", "enc"):
+    for mode in ("enc+dec+mem", "enc+dec", "enc"):
         lp, gp = res[mode]
         print(f"loss packed ({mode}) {lp:.7f} dense {ld:.7f}")
         assert abs(lp - ld) <= 1e-5 * abs(ld)

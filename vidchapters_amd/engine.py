@@ -82,6 +82,7 @@ class Engine:
         self.head_rows = 2048     # decoder rows per chunk: 264 MB of fp32 logits + 132 MB of bf16 d(logits) scratch at vocab 32200
         self.pack = True          # run the text encoder on the valid (non-pad) tokens only: exact, see _pack_plan
         self.pack_dec = True      # likewise the decoder rows of pad targets (labels -100, masked as keys): see _pack_plan_dec
+        self.pack_mem = True      # and the [video ; text] memory the decoder attends to: see _mem_plan
         self.wstream = torch.cuda.Stream(device=device)
         self.vstream = torch.cuda.Stream(device=device)
         self.arena.refresh_shadow(force=True)
@@ -254,10 +255,11 @@ class Engine:
                              B=B, N=N, M=M, p=p, seed_o=seed_o))
         return out
 
-    def _cross_attn(self, i: int, h, B: int, Nq: int, mem, S: int, mem_mask, p: float, tape, kv=None, pack=None):
-        """``pack`` = (seq_off, rows): the query rows are packed (padding-free decoder), the memory stays dense [B, S]."""
+    def _cross_attn(self, i: int, h, B: int, Nq: int, mem, S: int, mem_mask, p: float, tape, kv=None, pack=None, kpack=None):
+        """``pack`` = (seq_off, rows): the query rows are packed (padding-free decoder).  ``kpack`` = (kv_off, rows, real rows): the
+        memory is packed too (_mem_plan), else it is dense [B, S] with ``mem_mask``."""
         a = self.arena
-        Mq, Mk, d, inner = (pack[1] if pack is not None else B * Nq), B * S, self.d, self.inner
+        Mq, Mk, d, inner = (pack[1] if pack is not None else B * Nq), (kpack[1] if kpack is not None else B * S), self.d, self.inner
         n = self._bf(Mq, d); rstd = self._f32(Mq)
         L.rmsnorm_fwd(h, a.f(self._ln("decoder", i, 1)), n, rstd, Mq, d, self.cfg.eps)
         q = self._bf(Mq, inner)
@@ -270,15 +272,16 @@ class Engine:
         seed_a = self._next_seed()
         kst = (S * 2 * inner, 2 * inner)
         args = L.attn_args(B, self.H, Nq, S, q, kv, kv[:, inner:], ctx, (Nq * inner, inner), kst, kst, (Nq * inner, inner),
-                           ml=ml, scale=1.0, key_mask=mem_mask, dropout_p=p, dropout_seed=seed_a,
-                           seq_off=pack[0] if pack is not None else None, seq_q_only=pack is not None)
+                           ml=ml, scale=1.0, key_mask=None if kpack is not None else mem_mask, dropout_p=p, dropout_seed=seed_a,
+                           seq_off=pack[0] if pack is not None else None, seq_q_only=pack is not None,
+                           kv_seq_off=kpack[0] if kpack is not None else None)
         L.attn_fwd(args)
         out = self._bf(Mq, d)
         seed_o = self._next_seed()
         L.gemm(ctx, a.w(self._ca(i) + "o.weight"), out, Mq, d, inner, residual=h, dropout_p=p, dropout_seed=seed_o)
         if tape is not None:
             tape.append(_Rec(kind="cross", i=i, h=h, n=n, rstd=rstd, q=q, kv=kv, ctx=ctx, ml=ml, args=args, mem=mem,
-                             B=B, Nq=Nq, S=S, p=p, seed_o=seed_o, Mq=Mq))
+                             B=B, Nq=Nq, S=S, p=p, seed_o=seed_o, Mq=Mq, Mk=Mk, k_real=kpack[2] if kpack is not None else Mk))
         return out
 
     def _ffn(self, stack: str, i: int, h, M: int, p: float, tape):
@@ -339,12 +342,14 @@ class Engine:
     def _cross_attn_bwd(self, r, dh, dmem, first: bool):
         a = self.arena
         B, Nq, S, d, inner = r.B, r.Nq, r.S, self.d, self.inner
-        Mq, Mk = r.Mq, B * S
+        Mq, Mk = r.Mq, r.Mk
         ca = self._ca(r.i)
         df = self._drop(dh, r.p, r.seed_o)
         self._wgrad(df, r.ctx, ca + "o.weight", d, inner, Mq)
         dctx = self._dgrad(df, a.w(ca + "o.weight"), Mq, inner, d)
         dq = self._bf(Mq, inner); dkv = self._bf(Mk, 2 * inner)
+        if r.k_real < Mk:
+            dkv[r.k_real:].zero_()        # filler rows of a packed memory belong to no sequence: the kernels never write them
         delta = self._f32(B, self.H, Nq)
         kst = (S * 2 * inner, 2 * inner)
         L.attn_bwd(r.args, dctx, (Nq * inner, inner), delta, dq, dkv, dkv[:, inner:], (Nq * inner, inner), kst, kst)
@@ -428,7 +433,7 @@ class Engine:
         plans = self._ws.setdefault("pack_plans", {})
         plan = plans.get(key)
         if plan is None:
-            if len(plans) >= 8:
+            if len(plans) >= 24:                          # (tapes keep the plans they use alive: t5_loss_forward keep_alive)
                 plans.clear()
             total = int(sum(lens))
             padded = (total + 63) // 64 * 64          # row count a multiple of 64: the weight-gradient GEMMs contract over it (K % 64)
@@ -443,7 +448,26 @@ class Engine:
             rows = np.concatenate([np.arange(n, dtype=np.int64) + b * Lx for b, n in enumerate(lens)] +
                                   [np.zeros(padded - total, dtype=np.int64)])
             plan = plans[key] = (torch.from_numpy(off).to(self.device), padded, torch.from_numpy(rows).to(self.device), len(seqs), total)
-        return (plan[0], plan[1], plan[2], plan[3], Lx, plan[4])
+        return (plan[0], plan[1], plan[2], plan[3], Lx, plan[4], tuple(lens))
+
+    def _mem_plan(self, lens, T: int):
+        """Padding-free [video ; text] memory: sample b occupies rows [off[b], off[b+1]) = its T visual rows followed by its valid text
+        rows; the row count is rounded up to a multiple of 64 with zero rows that belong to no sample (the cross-attention key ranges
+        never reach them).  Returns (kv_off int32 [B+1], rows, vis_pos [B*T], txt_pos [sum(lens)], real_rows), device tensors cached."""
+        key = ("mem", T, tuple(lens))
+        plans = self._ws.setdefault("pack_plans", {})
+        plan = plans.get(key)
+        if plan is None:
+            B = len(lens)
+            off = np.zeros(B + 1, dtype=np.int32)
+            off[1:] = np.cumsum([T + n for n in lens])
+            total = int(off[-1])
+            vis_pos = (off[:B, None].astype(np.int64) + np.arange(T, dtype=np.int64)[None, :]).reshape(-1)
+            txt_pos = np.concatenate([off[b] + T + np.arange(n, dtype=np.int64) for b, n in enumerate(lens)])
+            dev = self.device
+            plan = plans[key] = (torch.from_numpy(off).to(dev), (total + 63) // 64 * 64, torch.from_numpy(vis_pos).to(dev),
+                                 torch.from_numpy(txt_pos).to(dev), total)
+        return plan
 
     def _pack_plan_dec(self, output_mask: torch.Tensor, lens=None):
         """Row bookkeeping for running the decoder on the rows of real targets only.  Decoder position j of a sample consumes target
@@ -466,9 +490,7 @@ class Engine:
         key = ("dec", B, Lo, tuple(lens))
         plans = self._ws.setdefault("pack_plans", {})
         plan = plans.get(key)
-        if plan is None:
-            if len(plans) >= 8:
-                plans.clear()
+        if plan is None:                                # (the cache is only ever emptied by _pack_plan, at the start of a forward)
             ext = list(lens)
             for b in range(B - 1, -1, -1):              # pad positions kept as rows, from the last sequence backwards
                 take = min(fill, Lo - ext[b])
@@ -481,7 +503,7 @@ class Engine:
             plan = plans[key] = (torch.from_numpy(off).to(self.device), int(off[-1]), torch.from_numpy(rows).to(self.device))
         return (plan[0], plan[1], plan[2], B, Lo)
 
-    def decoder_forward(self, dec_ids, dec_mask_u8, mem, S: int, mem_mask_u8, p: float, tape, pack=None):
+    def decoder_forward(self, dec_ids, dec_mask_u8, mem, S: int, mem_mask_u8, p: float, tape, pack=None, kpack=None):
         """``pack`` = (seq_off, rows, tok_rows, B, Lo) from _pack_plan_dec: ``dec_ids`` is then the 1-D packed id vector and the result
         has ``rows`` rows."""
         if pack is not None:
@@ -490,7 +512,7 @@ class Engine:
             diag, _ = self._bias_diag("decoder", Lo, Lo)
             for i in range(self.cfg.n_dec):
                 h = self._self_attn("decoder", i, h, B, Lo, diag, None, True, p, tape, pack=pack[:2])
-                h = self._cross_attn(i, h, B, Lo, mem, S, mem_mask_u8, p, tape, pack=pack[:2])
+                h = self._cross_attn(i, h, B, Lo, mem, S, mem_mask_u8, p, tape, pack=pack[:2], kpack=kpack)
                 h = self._ffn("decoder", i, h, M, p, tape)
             return self._final_norm("decoder", h, M, p, tape)
         B, Lo = dec_ids.shape
@@ -498,7 +520,7 @@ class Engine:
         diag, _ = self._bias_diag("decoder", Lo, Lo)
         for i in range(self.cfg.n_dec):
             h = self._self_attn("decoder", i, h, B, Lo, diag, dec_mask_u8, True, p, tape)
-            h = self._cross_attn(i, h, B, Lo, mem, S, mem_mask_u8, p, tape)
+            h = self._cross_attn(i, h, B, Lo, mem, S, mem_mask_u8, p, tape, kpack=kpack)
             h = self._ffn("decoder", i, h, B * Lo, p, tape)
         return self._final_norm("decoder", h, B * Lo, p, tape)
 
@@ -675,8 +697,16 @@ class Engine:
         if vis_ready is not None:           # the ViT ran on its own stream beside the encoder
             torch.cuda.current_stream().wait_event(vis_ready)
             vis.record_stream(torch.cuda.current_stream())
-        mem_rows = None
-        if plan is not None:                # [video ; text] memory with the packed encoder rows scattered back; pad rows = 0
+        mem_rows = vis_rows = kpack = None
+        if plan is not None and self.pack_mem:      # padding-free memory: [video ; valid text] rows per sample, no pad rows at all
+            kv_off, Mk_p, vis_pos, txt_pos, real = self._mem_plan(plan[6], T)
+            mem = torch.zeros(Mk_p, self.d, dtype=torch.bfloat16, device=self.device) if Mk_p > real else self._bf(Mk_p, self.d)
+            if T:
+                mem.index_copy_(0, vis_pos, parts[0].reshape(B * T, self.d))
+                vis_rows = vis_pos
+            mem.index_copy_(0, txt_pos, enc[:plan[5]])
+            mem_rows, mem_mask, kpack = txt_pos, None, (kv_off, Mk_p, real)
+        elif plan is not None:              # [video ; text] memory with the packed encoder rows scattered back; pad rows = 0
             mem3 = torch.zeros(B, S, self.d, dtype=torch.bfloat16, device=self.device)
             if T:
                 mem3[:, :T] = parts[0]
@@ -699,11 +729,11 @@ class Engine:
         Lo = dec_in.shape[1]
         dplan = self._pack_plan_dec(output_mask, output_lens) if (self.pack and self.pack_dec) else None
         if dplan is not None:               # decoder rows of real targets only (plus a few kept pad rows: row count % 64 == 0)
-            hs = self.decoder_forward(dec_in.reshape(-1).index_select(0, dplan[2]), None, mem, S, mem_mask, pd, dec_tape, pack=dplan)
+            hs = self.decoder_forward(dec_in.reshape(-1).index_select(0, dplan[2]), None, mem, S, mem_mask, pd, dec_tape, pack=dplan, kpack=kpack)
             Md = dplan[1]
             labels = targets.reshape(-1).index_select(0, dplan[2]).contiguous()
         else:
-            hs = self.decoder_forward(dec_in, output_mask.to(torch.uint8).contiguous(), mem, S, mem_mask, pd, dec_tape)
+            hs = self.decoder_forward(dec_in, output_mask.to(torch.uint8).contiguous(), mem, S, mem_mask, pd, dec_tape, kpack=kpack)
             Md = B * Lo
             labels = targets.reshape(-1).contiguous()
         alpha = self.d ** -0.5                                   # tie_word_embeddings rescale (modeling_t5.py:1709-1712)
@@ -738,7 +768,9 @@ class Engine:
         loss = acc[0] / acc[1]
         if tape is not None:
             tape.update(enc=enc_tape, dec=dec_tape, B=B, T=T, Lx=Lx, Lo=Lo, S=S, Md=Md, hs=hs, logits=logits, labels=labels, row=row,
-                        acc=acc, alpha=alpha, mem_rows=mem_rows, enc_rows=plan[1] if plan is not None else 0, dhs=dhs,
+                        acc=acc, alpha=alpha, mem_rows=mem_rows, vis_rows=vis_rows, Mk=kpack[1] if kpack is not None else B * S,
+                        mem_packed=kpack is not None, keep_alive=(plan, dplan, kpack),   # the saved attention args point into these
+                        enc_rows=plan[1] if plan is not None else 0, dhs=dhs,
                         head_grad_scale=head_grad_scale)
         return loss
 
@@ -765,12 +797,16 @@ class Engine:
             Epad = self.arena.shadow[self.arena.offsets["t5_model.shared.weight"]:][:self.ldv * d].view(self.ldv, d)
             L.gemm(dlog, Epad, dhs, Md, d, self.ldv, transB=True, lda=self.ldv, ldb=d, alpha=tape["alpha"])
             del dlog
-        dmem = self._bf(B * S, d)
+        dmem = self._bf(tape["Mk"], d)
         self._stack_backward(tape["dec"], dhs, "decoder", Lo, dmem=dmem)
-        dmem3 = dmem.view(B, S, d)
+        packed_mem = bool(tape.get("mem_packed"))
+        dmem3 = None if packed_mem else dmem.view(B, S, d)
         dvis = None
         if m.use_video:
-            dvis = dmem3[:, :T].contiguous() if Lx else dmem3
+            if packed_mem:
+                dvis = dmem.index_select(0, tape["vis_rows"]).view(B, T, d)
+            else:
+                dvis = dmem3[:, :T].contiguous() if Lx else dmem3
         if after_decoder is not None:
             after_decoder(dvis)               # DP hook / ViT backward may start now, beside the encoder backward
         if m.use_speech:
