@@ -65,3 +65,36 @@ def test_gradsync_ranges_cover_arena_once():
     assert all(n.startswith("t5_model.encoder.") for n in order[first_enc:first_vis])
     assert order[-1] == "t5_model.shared.weight" and order[-2] == "visual_encoder.pos_embed"
     assert len(order) == len(set(order)) == len(dict(m.named_parameters()))
+
+
+def test_padding_free_plans_host_logic():
+    """Row bookkeeping of the padding-free decoder and memory (host logic only, device tensors on the CPU): offsets, kept pad rows,
+    row counts a multiple of 64, disjoint cover of the packed memory."""
+    import numpy as np
+    from vidchapters_amd.engine import Engine
+    stub = type("E", (), {"_ws": {}, "device": torch.device("cpu")})()
+    B, Lo = 5, 40
+    lens = [40, 9, 15, 31, 1]
+    mask = (torch.arange(Lo)[None, :] < torch.tensor(lens)[:, None])
+    off, rows, tok_rows, b_, lo_ = Engine._pack_plan_dec(stub, mask)
+    off = off.numpy()
+    assert (b_, lo_) == (B, Lo) and rows % 64 == 0 and rows == off[-1] == tok_rows.numel() and rows < B * Lo
+    ext = np.diff(off)
+    assert all(lens[i] <= ext[i] <= Lo for i in range(B)) and ext.sum() - sum(lens) == (-sum(lens)) % 64
+    want = np.concatenate([np.arange(ext[i]) + i * Lo for i in range(B)])
+    assert np.array_equal(tok_rows.numpy(), want)                       # every sequence is a prefix of its padded row range
+    assert Engine._pack_plan_dec(stub, mask, lens=lens)[1] == rows      # host lengths: same plan, no read-back
+    holes = mask.clone(); holes[1, 3] = False
+    assert Engine._pack_plan_dec(stub, holes) is None                   # not a prefix mask -> dense path
+    full = torch.ones(B, Lo, dtype=torch.bool)
+    assert Engine._pack_plan_dec(stub, full) is None                    # nothing to drop
+    tight = (torch.arange(Lo)[None, :] < torch.tensor([40, 40, 40, 40, 33])[:, None])
+    assert Engine._pack_plan_dec(stub, tight) is None                   # 193 rows + 63 filler rows is more than the 200 dense rows
+    T, tl = 10, (7, 30, 1)
+    kv_off, mrows, vis_pos, txt_pos, real = Engine._mem_plan(stub, tl, T)
+    kv_off = kv_off.numpy()
+    assert real == sum(T + n for n in tl) == kv_off[-1] and mrows % 64 == 0 and 0 <= mrows - real < 64
+    cover = np.concatenate([vis_pos.numpy(), txt_pos.numpy()])
+    assert np.array_equal(np.sort(cover), np.arange(real))              # each real row is written exactly once
+    for b in range(len(tl)):
+        assert np.array_equal(vis_pos.numpy()[b * T:(b + 1) * T], kv_off[b] + np.arange(T))      # [video ; text] per sample
