@@ -85,6 +85,8 @@ class Engine:
         self.pack_mem = True      # and the [video ; text] memory the decoder attends to: see _mem_plan
         self.wstream = torch.cuda.Stream(device=device)
         self.vstream = torch.cuda.Stream(device=device)
+        self.kstream = torch.cuda.Stream(device=device)   # cross-attention K|V projections of all decoder layers (forward) / the d(memory) chain (backward)
+        self.overlap_kv = True    # see decoder_forward / _cross_attn_bwd
         self.arena.refresh_shadow(force=True)
 
     # ------------------------------------------------------------------------------------------ names / arena order
@@ -267,6 +269,9 @@ class Engine:
         if kv is None:
             kv = self._bf(Mk, 2 * inner)
             L.gemm(mem, a.w(self._ca(i) + "k.weight", (2 * inner, d)), kv, Mk, 2 * inner, d)
+        elif isinstance(kv, tuple):            # projected ahead on the K|V stream (_cross_kv_ahead)
+            kv, ready = kv
+            torch.cuda.current_stream().wait_event(ready)
         ctx = self._bf(Mq, inner)
         ml = self._f32(B, self.H, Nq, 2) if tape is not None else None
         seed_a = self._next_seed()
@@ -356,9 +361,20 @@ class Engine:
         self._wgrad(dq, r.n, ca + "q.weight", inner, d, Mq)
         dn = self._dgrad(dq, a.w(ca + "q.weight"), Mq, d, inner)
         self._wgrad(dkv, r.mem, ca + "k.weight", 2 * inner, d, Mk, shape=(2 * inner, d))
-        # dmem accumulates over the decoder layers (residual add in the GEMM epilogue, in place)
-        self._dgrad(dkv, a.w(ca + "k.weight", (2 * inner, d)), Mk, d, 2 * inner, out=dmem,
-                    **({} if first else dict(residual=dmem)))
+        # dmem accumulates over the decoder layers (residual add in the GEMM epilogue, in place).  Nothing in the decoder's backward
+        # reads it, so the chain runs on the K|V stream beside the decoder's small launches; t5_loss_backward joins before using it.
+        if self.overlap and self.overlap_kv:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.kstream.wait_event(ev)
+            with torch.cuda.stream(self.kstream):
+                self._dgrad(dkv, a.w(ca + "k.weight", (2 * inner, d)), Mk, d, 2 * inner, out=dmem,
+                            **({} if first else dict(residual=dmem)))
+            dkv.record_stream(self.kstream)
+            dmem.record_stream(self.kstream)
+        else:
+            self._dgrad(dkv, a.w(ca + "k.weight", (2 * inner, d)), Mk, d, 2 * inner, out=dmem,
+                        **({} if first else dict(residual=dmem)))
         dx = self._bf(Mq, d)
         ln = self._ln("decoder", r.i, 1)
         L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), Mq, d)
@@ -503,24 +519,48 @@ class Engine:
             plan = plans[key] = (torch.from_numpy(off).to(self.device), int(off[-1]), torch.from_numpy(rows).to(self.device))
         return (plan[0], plan[1], plan[2], B, Lo)
 
+    def _cross_kv_ahead(self, mem, Mk: int):
+        """The K|V projections of the memory for ALL decoder layers depend on nothing but the encoder output: issued on their own
+        stream before the decoder starts, the big [Mk, 2*inner] GEMMs run beside the decoder's small (8192-row: 384..1152 tiles on 512
+        slots) launches instead of in between them.  Returns [(kv_i, ready event_i)] or None (single-stream execution)."""
+        if not (self.overlap and self.overlap_kv):
+            return None
+        a, d, inner = self.arena, self.d, self.inner
+        main = torch.cuda.current_stream()
+        self.kstream.wait_stream(main)
+        out = []
+        with torch.cuda.stream(self.kstream):
+            for i in range(self.cfg.n_dec):
+                kv = self._bf(Mk, 2 * inner)
+                L.gemm(mem, a.w(self._ca(i) + "k.weight", (2 * inner, d)), kv, Mk, 2 * inner, d)
+                ev = torch.cuda.Event()
+                ev.record(self.kstream)
+                kv.record_stream(main)
+                out.append((kv, ev))
+        mem.record_stream(self.kstream)
+        return out
+
     def decoder_forward(self, dec_ids, dec_mask_u8, mem, S: int, mem_mask_u8, p: float, tape, pack=None, kpack=None):
         """``pack`` = (seq_off, rows, tok_rows, B, Lo) from _pack_plan_dec: ``dec_ids`` is then the 1-D packed id vector and the result
         has ``rows`` rows."""
         if pack is not None:
             B, Lo, M = pack[3], pack[4], pack[1]
+            ahead = self._cross_kv_ahead(mem, kpack[1] if kpack is not None else B * S)
             h = self._embed(dec_ids, p, tape)
             diag, _ = self._bias_diag("decoder", Lo, Lo)
             for i in range(self.cfg.n_dec):
                 h = self._self_attn("decoder", i, h, B, Lo, diag, None, True, p, tape, pack=pack[:2])
-                h = self._cross_attn(i, h, B, Lo, mem, S, mem_mask_u8, p, tape, pack=pack[:2], kpack=kpack)
+                h = self._cross_attn(i, h, B, Lo, mem, S, mem_mask_u8, p, tape, pack=pack[:2], kpack=kpack,
+                                     kv=ahead[i] if ahead is not None else None)
                 h = self._ffn("decoder", i, h, M, p, tape)
             return self._final_norm("decoder", h, M, p, tape)
         B, Lo = dec_ids.shape
+        ahead = self._cross_kv_ahead(mem, kpack[1] if kpack is not None else B * S)
         h = self._embed(dec_ids, p, tape)
         diag, _ = self._bias_diag("decoder", Lo, Lo)
         for i in range(self.cfg.n_dec):
             h = self._self_attn("decoder", i, h, B, Lo, diag, dec_mask_u8, True, p, tape)
-            h = self._cross_attn(i, h, B, Lo, mem, S, mem_mask_u8, p, tape, kpack=kpack)
+            h = self._cross_attn(i, h, B, Lo, mem, S, mem_mask_u8, p, tape, kpack=kpack, kv=ahead[i] if ahead is not None else None)
             h = self._ffn("decoder", i, h, B * Lo, p, tape)
         return self._final_norm("decoder", h, B * Lo, p, tape)
 
@@ -799,6 +839,8 @@ class Engine:
             del dlog
         dmem = self._bf(tape["Mk"], d)
         self._stack_backward(tape["dec"], dhs, "decoder", Lo, dmem=dmem)
+        if self.overlap and self.overlap_kv:
+            torch.cuda.current_stream().wait_stream(self.kstream)          # the d(memory) chain of _cross_attn_bwd
         packed_mem = bool(tape.get("mem_packed"))
         dmem3 = None if packed_mem else dmem.view(B, S, d)
         dvis = None
