@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--packing", action="store_true", help="measure `value` with the padding-free text encoder (the engine's default; exact). "
                     "Off here: `value` computes the pad rows like the reference does, the padding-free rate is reported beside it")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each: `value` is the first, the others give the spread")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream execution (A/B for the stream overlap)")
     ap.add_argument("--no-generate", action="store_true", help="skip the greedy generate() leg (cfg-4, reported as an extra field)")
     ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the data-parallel gradient all-reduce")
@@ -125,6 +126,21 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # run-to-run spread: the same bracketed region twice more (`value` is the FIRST region, the one the contract defines; the repeats
+    # only say how far a single region moves on this box -- clocks / thermals move it by a percent or two)
+    region_ms = [dt / a.steps * 1e3]
+    for _ in range(max(0, a.repeats - 1)):
+        barrier()
+        t0r = time.perf_counter()
+        for i in range(a.steps):
+            trainer.step(batch)
+        barrier()
+        dtr = time.perf_counter() - t0r
+        if world > 1:
+            t = torch.tensor([dtr], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtr = float(t.item())
+        region_ms.append(dtr / a.steps * 1e3)
     loss_val = float(losses["loss"].item())
     log(f"timed region done: {dt / a.steps * 1e3:.1f} ms/step")
     ms_per_step = dt / a.steps * 1e3
@@ -153,6 +169,10 @@ def main():
                    "global_batch": world * B, "parallelism": f"dp{world}", "weights": "deterministic synthetic init (no checkpoints offline)"},
         "ms_per_step_hipevent_median": round(med_ms, 3), "samples_per_s_hipevent_median": round(world * B / (med_ms / 1e3), 2),
         "timing_note": "value = steps / wall time between the two barrier+synchronize brackets (max over ranks); the median is over per-step HIP-event intervals on rank 0",
+        "ms_per_step_hipevent_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
+        "repeats": {"regions": len(region_ms), "ms_per_step": [round(x, 3) for x in region_ms],
+                    "samples_per_s_min_median_max": [round(world * B / (x / 1e3), 2) for x in (max(region_ms), sorted(region_ms)[len(region_ms) // 2], min(region_ms))],
+                    "note": "the bracketed region of --steps steps repeated back to back in this process; `value` is region 0"},
         "loss": round(loss_val, 5),
         "model_tflops_per_step_per_gpu": round(step_tflop, 2),
         "executed_tflops_per_step_per_gpu": round(exec_tflop, 2),
@@ -375,8 +395,10 @@ def cpu_baseline(model, tok, Lx, Lo, threads=32):
     """The CPU oracle (fp32 torch restatement of the reference path, pinned against the reference in the build container) timed on this
     box's host cores, SURVEY 8d protocol: per leg 1 warm-up + 3 timed iterations, median.  Legs: cfg-1 exact (B=2, 100 frames, 256 ASR
     tokens, 256 targets: forward + loss + backward + clip + Adam + renorm), the cfg-2 shapes at B=2 (1000 ASR tokens) -- the number
-    `value` is compared with -- and 32 greedy decode steps at B=2.  32 threads: on the 2 x 64-core GPU host more threads are slower for
-    these matrix sizes (measured r01: B=1 step 3.4 s at 32 threads, 13.7 s at 128)."""
+    `value` is compared with -- and 32 greedy decode steps at B=2.  Thread count: SURVEY 8d says os.cpu_count(), but on the 2 x 64-core
+    GPU host torch's CPU kernels get SLOWER beyond a few dozen threads at these matrix sizes (measured r01: B=1 step 3.4 s at 32
+    threads, 13.7 s at 128), so the cfg-2 leg is timed at 32 threads AND at os.cpu_count() threads (bounded: one warm-up, at most two
+    timed steps) and `value` / `cores` report the faster of the two -- the other one is listed beside it."""
     from oracle import vid2seq_ref as R
     from vidchapters_amd import synth
     ncores = os.cpu_count() or 1
@@ -385,28 +407,41 @@ def cpu_baseline(model, tok, Lx, Lo, threads=32):
     cfg = R.RefConfig(vocab=len(tok))
     P = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
 
-    def timed(fn, n=3):
-        fn()
+    def timed(fn, n=3, budget_s=None):
+        t0 = time.perf_counter(); fn(); warm = time.perf_counter() - t0
+        if budget_s is not None and warm > budget_s:          # too slow to repeat within the bench's time budget: the warm-up is the sample
+            return warm, 1
         ts = []
         for _ in range(n):
             t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
-        return sorted(ts)[len(ts) // 2]
+        return sorted(ts)[len(ts) // 2], n
 
     legs = {}
     for name, L_in in (("cfg1_exact_B2_L256", 256), ("cfg2_shapes_B2", Lx)):
         b = synth.make_batch(2, 100, L_in, Lo, len(tok), 99, 768)
         state = {}
-        dt = timed(lambda: R.train_step(P, state, cfg, b, lr=3e-4, clip=1.0, generative=1.0, denoising=0.0))
-        legs[name] = {"samples_per_s": round(2 / dt, 4), "seconds_per_step": round(dt, 3)}
+        dt, _ = timed(lambda: R.train_step(P, state, cfg, b, lr=3e-4, clip=1.0, generative=1.0, denoising=0.0))
+        legs[name] = {"samples_per_s": round(2 / dt, 4), "seconds_per_step": round(dt, 3), "threads": threads}
+    main, used = legs["cfg2_shapes_B2"], threads
+    if ncores > threads:                                      # the same leg on every logical core of the host
+        torch.set_num_threads(ncores)
+        b = synth.make_batch(2, 100, Lx, Lo, len(tok), 99, 768)
+        state = {}
+        dt, n = timed(lambda: R.train_step(P, state, cfg, b, lr=3e-4, clip=1.0, generative=1.0, denoising=0.0), n=2, budget_s=12.0)
+        legs["cfg2_shapes_B2_all_cores"] = {"samples_per_s": round(2 / dt, 4), "seconds_per_step": round(dt, 3), "threads": ncores, "timed_steps": n}
+        if dt < main["seconds_per_step"]:
+            main, used = legs["cfg2_shapes_B2_all_cores"], ncores
+        torch.set_num_threads(threads)
     b = synth.make_batch(2, 100, Lx, 8, len(tok), 98, 768)
     Pd = {k: v.detach() for k, v in P.items()}
-    dtg = timed(lambda: R.greedy_generate(Pd, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, 32), n=3)
-    legs["greedy_32_steps_B2"] = {"sequences_per_s": round(2 / dtg, 4), "seconds": round(dtg, 3)}
-    main = legs["cfg2_shapes_B2"]
-    return {"value": main["samples_per_s"], "unit": "samples/s", "cores": threads, "kind": "port",
-            "host": {"cpu_model": _cpu_model_string(), "logical_cores": ncores, "threads_used": threads},
-            "sample": f"median of 3 timed optimizer steps after 1 warm-up (fwd+bwd+clip+Adam+renorm) at B=2, 100 frames, {Lx} ASR tokens, {Lo} target "
-                      f"tokens, fp32 torch CPU oracle, dropout 0; {main['seconds_per_step']} s per step",
+    dtg, _ = timed(lambda: R.greedy_generate(Pd, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, 32), n=3)
+    legs["greedy_32_steps_B2"] = {"sequences_per_s": round(2 / dtg, 4), "seconds": round(dtg, 3), "threads": threads}
+    return {"value": main["samples_per_s"], "unit": "samples/s", "cores": used, "kind": "port",
+            "host": {"cpu_model": _cpu_model_string(), "logical_cores": ncores, "threads_used": used,
+                     "threads_tried": sorted({threads, ncores})},
+            "sample": f"optimizer steps (fwd+bwd+clip+Adam+renorm) at B=2, 100 frames, {Lx} ASR tokens, {Lo} target tokens, fp32 torch CPU oracle, "
+                      f"dropout 0, after 1 warm-up: median of 3 at {threads} threads, up to 2 at {ncores} threads; the faster setting is reported: "
+                      f"{main['seconds_per_step']} s per step at {used} threads",
             "legs": legs}
 
 

@@ -96,7 +96,9 @@ typedef struct v2s_gemm_args {
   int32_t act;          /* V2S_ACT_* applied in the forward direction */
   void* pre;            /* bf16 [M][ldc] or NULL: pre-activation copy (needed by GELU backward) */
   int32_t dact;         /* V2S_ACT_*: multiply by act'(z) (RELU: z>0 ? 1:0 with z = forward output;
-                           GELU: gelu'(z) with z = saved pre-activation) */
+                           GELU: gelu'(z) with z = saved pre-activation).  RELU together with dropout_p > 0: z must be the forward
+                           GEMM's own output dropout(relu(.)) (same p): z > 0 then already says "active and kept", so only the
+                           1/(1-p) scale is applied and dropout_seed is not consulted */
   const void* z;        /* bf16 [M][ldz] */
   int64_t ldz;
   const void* residual; /* bf16 [M][ldr] or NULL */
@@ -152,7 +154,9 @@ int v2s_layernorm_bwd(const void* x, const float* w, const float* mean, const fl
  *   P = softmax_k(S); dropout(P); O[b,q,h,:] = P V.   head_dim must be 64.
  *   Q/K/V/O are bf16 with element strides (batch stride, row stride); head h sits at column h*64.
  *   `ml` fp32 [B][H][Nq][2] = (row max, row sum) saved for backward.
- *   backward needs `delta` fp32 [B][H][Nq] = sum_d dO*O (v2s_attn_delta) and produces dQ,dK,dV
+ *   backward needs `o` (the forward output) and a caller-owned fp32 workspace `delta` [B][H][Nq][4] that v2s_attn_bwd fills
+ *   itself (per row: -(m + log2 l), exponent of a masked element, -sum_d dO*O, dropout row seed: written by its dQ kernel, read
+ *   by its dK/dV kernel) and produces dQ,dK,dV
  *   (same strides as q/k/v via dq_*, dk_*, dv_*) and, if bias != NULL, dbias_diag fp32
  *   [H][Nq+Nk-1] accumulated (+=) per relative position (bucket-reduced by v2s_bias_bucket_bwd).
  * ---------------------------------------------------------------------------------------------- */
@@ -173,7 +177,7 @@ typedef struct v2s_attn_args {
   /* backward only */
   const void* d_o;
   int64_t do_bs, do_rs;
-  const float* delta;     /* [B][H][Nq] */
+  float* delta;           /* workspace [B][H][Nq][4], 16-byte aligned (see above) */
   void *dq, *dk, *dv;
   int64_t dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
   float* dbias_diag;      /* fp32 [H][Nq+Nk-1], += ; or NULL */
@@ -184,7 +188,7 @@ typedef struct v2s_attn_args {
   int32_t bias_far_lo, bias_far_hi;
   /* optional packed ("varlen") SELF-attention: B+1 int32 row offsets on the device.  Sequence b then occupies rows
    * [seq_off[b], seq_off[b+1]) of q/k/v/o (and d_o/dq/dk/dv): the *_bs batch strides are ignored, Nq = Nk = the nominal
-   * (maximum) length that sizes the grid, the bias diagonal table, ml and delta ([B][H][Nq] as before) -- no sequence may be longer;
+   * (maximum) length that sizes the grid, the bias diagonal table, ml and delta ([B][H][Nq] indexing as before) -- no sequence may be longer;
    * key_mask must be NULL.
    * Rows of pad tokens simply do not exist -- the reference computes them and masks them as keys (modeling_t5.py:996), so the
    * rows that remain are identical */
@@ -199,7 +203,7 @@ typedef struct v2s_attn_args {
 } v2s_attn_args;
 
 int v2s_attn_fwd(const v2s_attn_args* a, void* stream);
-int v2s_attn_delta(const v2s_attn_args* a, float* delta, void* stream); /* delta = rowsum(dO * O) */
+int v2s_attn_delta(const v2s_attn_args* a, float* delta, void* stream); /* stand-alone delta[B][H][Nq] = rowsum(dO * O); v2s_attn_bwd no longer needs it */
 int v2s_attn_bwd(const v2s_attn_args* a, void* stream);
 
 /* relative-position bias (modeling_t5.py:397-460): host passes the bucket LUT lut[i] = bucket(i-(Nq-1)),

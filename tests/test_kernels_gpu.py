@@ -453,7 +453,7 @@ def test_attention_fwd_bwd(B, H, Nq, Nk, scale, use_bias, use_mask, causal, tr_m
     ref.backward(d_o.float().view(B, Nq, H, 64))
     dqkv_q = torch.zeros(B, Nq, 3 * W, dtype=torch.bfloat16, device=DEV)
     dqkv_k = dqkv_q if Nq == Nk else torch.zeros(B, Nk, 3 * W, dtype=torch.bfloat16, device=DEV)
-    delta = torch.empty(B, H, Nq, dtype=torch.float32, device=DEV)
+    delta = torch.empty(B, H, Nq, 4, dtype=torch.float32, device=DEV)
     ddiag = torch.zeros(H, Nq + Nk - 1, dtype=torch.float32, device=DEV) if use_bias else None
     L.attn_bwd(a, d_o, (Nq * W, W), delta, dqkv_q[..., :W], dqkv_k[..., W:2 * W], dqkv_k[..., 2 * W:],
                (Nq * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), dbias_diag=ddiag)
@@ -491,7 +491,7 @@ def test_attention_packed_equals_padded(N, H, drop):
     a = L.attn_args(B, H, N, N, qkv_pad, qkv_pad[..., W:], qkv_pad[..., 2 * W:], o_pad, st3, st3, st3, st1, ml=ml, bias_diag=diag,
                     key_mask=mask, dropout_p=drop, dropout_seed=9)
     L.attn_fwd(a)
-    dqkv_pad = torch.zeros_like(qkv_pad); delta = torch.zeros(B, H, N, device=DEV); dd_pad = torch.zeros_like(diag)
+    dqkv_pad = torch.zeros_like(qkv_pad); delta = torch.zeros(B, H, N, 4, device=DEV); dd_pad = torch.zeros_like(diag)
     L.attn_bwd(a, do_pad, st1, delta, dqkv_pad, dqkv_pad[..., W:], dqkv_pad[..., 2 * W:], st3, st3, st3, dbias_diag=dd_pad, far=(-60, 60))
     # packed call on the rows that exist
     rows = torch.cat([torch.arange(n, device=DEV) + b * N for b, n in enumerate(lens)])
@@ -501,7 +501,7 @@ def test_attention_packed_equals_padded(N, H, drop):
     a2 = L.attn_args(B, H, N, N, qkv, qkv[:, W:], qkv[:, 2 * W:], o, (0, 3 * W), (0, 3 * W), (0, 3 * W), (0, W), ml=ml2, bias_diag=diag,
                      dropout_p=drop, dropout_seed=9, seq_off=so)
     L.attn_fwd(a2)
-    dqkv = torch.zeros_like(qkv); delta2 = torch.zeros(B, H, N, device=DEV); dd = torch.zeros_like(diag)
+    dqkv = torch.zeros_like(qkv); delta2 = torch.zeros(B, H, N, 4, device=DEV); dd = torch.zeros_like(diag)
     L.attn_bwd(a2, d_o, (0, W), delta2, dqkv, dqkv[:, W:], dqkv[:, 2 * W:], (0, 3 * W), (0, 3 * W), (0, 3 * W), dbias_diag=dd, far=(-60, 60))
     assert torch.equal(o, o_pad.view(B * N, W)[rows])
     assert torch.equal(dqkv, dqkv_pad.view(B * N, 3 * W)[rows])
@@ -528,7 +528,7 @@ def test_cross_attention_query_packed_equals_padded(drop):
     o_pad = torch.zeros(B, Nq, W, dtype=torch.bfloat16, device=DEV); ml = torch.zeros(B, H, Nq, 2, device=DEV)
     a = L.attn_args(B, H, Nq, Nk, q_pad, kv, kv[..., W:], o_pad, sq, skv, skv, sq, ml=ml, key_mask=kmask, dropout_p=drop, dropout_seed=4)
     L.attn_fwd(a)
-    dq_pad = torch.zeros_like(q_pad); dkv_pad = torch.zeros_like(kv); delta = torch.zeros(B, H, Nq, device=DEV)
+    dq_pad = torch.zeros_like(q_pad); dkv_pad = torch.zeros_like(kv); delta = torch.zeros(B, H, Nq, 4, device=DEV)
     L.attn_bwd(a, do_pad, sq, delta, dq_pad, dkv_pad, dkv_pad[..., W:], sq, skv, skv)
     rows = torch.cat([torch.arange(n, device=DEV) + b * Nq for b, n in enumerate(lens)])
     q = q_pad.view(B * Nq, W)[rows].contiguous(); d_o = do_pad.view(B * Nq, W)[rows].contiguous()
@@ -537,7 +537,7 @@ def test_cross_attention_query_packed_equals_padded(drop):
     a2 = L.attn_args(B, H, Nq, Nk, q, kv, kv[..., W:], o, (0, W), skv, skv, (0, W), ml=ml2, key_mask=kmask, dropout_p=drop, dropout_seed=4,
                      seq_off=so, seq_q_only=True)
     L.attn_fwd(a2)
-    dq = torch.zeros_like(q); dkv = torch.zeros_like(kv); delta2 = torch.zeros(B, H, Nq, device=DEV)
+    dq = torch.zeros_like(q); dkv = torch.zeros_like(kv); delta2 = torch.zeros(B, H, Nq, 4, device=DEV)
     L.attn_bwd(a2, d_o, (0, W), delta2, dq, dkv, dkv[..., W:], (0, W), skv, skv)
     assert torch.equal(o, o_pad.view(B * Nq, W)[rows])
     assert torch.equal(dq, dq_pad.view(B * Nq, W)[rows])
@@ -557,7 +557,7 @@ def test_cross_attention_query_packed_equals_padded(drop):
         a3 = L.attn_args(B, H, Nq, Nk, qq, kvp, kvp[:, W:], o3, qst, (0, 2 * W), (0, 2 * W), qst, ml=ml3, dropout_p=drop, dropout_seed=4,
                          seq_off=so if q_packed else None, seq_q_only=q_packed, kv_seq_off=ko)
         L.attn_fwd(a3)
-        dq3 = torch.zeros_like(qq); dkv3 = torch.zeros_like(kvp); delta3 = torch.zeros(B, H, Nq, device=DEV)
+        dq3 = torch.zeros_like(qq); dkv3 = torch.zeros_like(kvp); delta3 = torch.zeros(B, H, Nq, 4, device=DEV)
         L.attn_bwd(a3, dd_o, qst, delta3, dq3, dkv3, dkv3[:, W:], qst, (0, 2 * W), (0, 2 * W))
         if q_packed:
             assert torch.equal(o3, o) and torch.equal(dq3, dq)
@@ -585,7 +585,7 @@ def test_attention_fully_masked_row_is_uniform():
     L.attn_fwd(a)
     d_o = rnd(B, N, W, seed=4)
     dq, dk, dv = (torch.zeros(B, N, W, dtype=torch.bfloat16, device=DEV) for _ in range(3))
-    delta = torch.empty(B, H, N, dtype=torch.float32, device=DEV)
+    delta = torch.empty(B, H, N, 4, dtype=torch.float32, device=DEV)
     L.attn_bwd(a, d_o, (N * W, W), delta, dq, dk, dv, (N * W, W), (N * W, W), (N * W, W))
     P = torch.full((B, N, N), 1.0 / N, device=DEV)
     dP = d_o.float() @ v.float().transpose(1, 2)
@@ -608,7 +608,7 @@ def test_attention_dropout_consistency():
     # O is linear in V for a fixed mask: <dO, O(V=D)> == <dV, D>  ties the forward mask to the dK/dV kernel's mask
     d_o = rnd(B, Nq, W, seed=5)
     dq, dk, dv = (torch.zeros(B, n, W, dtype=torch.bfloat16, device=DEV) for n in (Nq, Nk, Nk))
-    delta = torch.empty(B, H, Nq, dtype=torch.float32, device=DEV)
+    delta = torch.empty(B, H, Nq, 4, dtype=torch.float32, device=DEV)
     L.attn_bwd(a, d_o, (Nq * W, W), delta, dq, dk, dv, (Nq * W, W), (Nk * W, W), (Nk * W, W))
     D = rnd(B, Nk, W, seed=6)
     oD = torch.empty_like(o0)
@@ -641,7 +641,7 @@ def test_attention_dropout_backward_with_extracted_mask():
     L.attn_fwd(a)
     d_o = rnd(B, Nq, W, seed=5)
     dq, dk, dv = (torch.zeros(B, n, W, dtype=torch.bfloat16, device=DEV) for n in (Nq, Nk, Nk))
-    delta = torch.empty(B, H, Nq, dtype=torch.float32, device=DEV)
+    delta = torch.empty(B, H, Nq, 4, dtype=torch.float32, device=DEV)
     L.attn_bwd(a, d_o, (Nq * W, W), delta, dq, dk, dv, (Nq * W, W), (Nk * W, W), (Nk * W, W))
     Pd = P * keep / (1 - pdrop)
     dP = (d_o.float() @ v.float().transpose(1, 2)) * keep / (1 - pdrop)

@@ -14,7 +14,7 @@ def make(B, H, Nq, Nk, bias, masked, causal, drop, dbias):
     W = H * 64
     q = (torch.randn(B, Nq, W, device=dev) * 0.5).to(torch.bfloat16); k = (torch.randn(B, Nk, W, device=dev) * 0.5).to(torch.bfloat16)
     v = torch.randn(B, Nk, W, device=dev).to(torch.bfloat16); d_o = torch.randn(B, Nq, W, device=dev).to(torch.bfloat16)
-    o = torch.empty_like(q); ml = torch.empty(B, H, Nq, 2, device=dev); delta = torch.empty(B, H, Nq, device=dev)
+    o = torch.empty_like(q); ml = torch.empty(B, H, Nq, 2, device=dev); delta = torch.empty(B, H, Nq, 4, device=dev)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     diag = torch.randn(H, Nq + Nk - 1, device=dev) if bias else None
     ddiag = torch.zeros(H, Nq + Nk - 1, device=dev) if (bias and dbias) else None
@@ -30,6 +30,10 @@ def make(B, H, Nq, Nk, bias, masked, causal, drop, dbias):
     def bwd():
         a = L.attn_args(B, H, Nq, Nk, q, k, v, o, sq, sk, sk, sq, ml=ml, scale=1.0, bias_diag=diag, key_mask=mask, causal=causal,
                         dropout_p=0.1 if drop else 0.0, dropout_seed=5)
+        if "r2attn" in L.LIB_PATH:      # the round-2 kernels need delta = rowsum(dO * O) from a separate launch first
+            import ctypes as C
+            a.d_o = d_o.data_ptr(); a.do_bs, a.do_rs = sq
+            L._check(L.lib().v2s_attn_delta(C.byref(a), delta.data_ptr(), L.stream_ptr()), "v2s_attn_delta")
         L.attn_bwd(a, d_o, sq, delta, dq, dk, dv, sq, sk, sk, dbias_diag=ddiag, far=(-91, 91) if ddiag is not None else (0, 0))
     return fwd, bwd, 4.0 * B * H * Nq * Nk * 64
 

@@ -11,7 +11,7 @@ d_o = torch.randn(B, N, W, device=dev).to(torch.bfloat16)
 o = torch.empty(B, N, W, dtype=torch.bfloat16, device=dev)
 ml = torch.empty(B, H, N, 2, dtype=torch.float32, device=dev)
 dqkv = torch.empty_like(qkv)
-delta = torch.empty(B, H, N, dtype=torch.float32, device=dev)
+delta = torch.empty(B, H, N, 4, dtype=torch.float32, device=dev)
 diag = torch.randn(H, 2 * N - 1, device=dev)
 ddiag = torch.zeros(H, 2 * N - 1, device=dev)
 lens = torch.randint(700, 1001, (B,), device=dev)

@@ -10,7 +10,7 @@ W = H * 64
 torch.manual_seed(0)
 q = (torch.randn(B, N, W, device=dev) * 0.5).to(torch.bfloat16); k = (torch.randn(B, N, W, device=dev) * 0.5).to(torch.bfloat16)
 v = torch.randn(B, N, W, device=dev).to(torch.bfloat16); d_o = torch.randn(B, N, W, device=dev).to(torch.bfloat16)
-o = torch.empty_like(q); ml = torch.empty(B, H, N, 2, device=dev); delta = torch.empty(B, H, N, device=dev)
+o = torch.empty_like(q); ml = torch.empty(B, H, N, 2, device=dev); delta = torch.empty(B, H, N, 4, device=dev)
 dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
 diag = torch.randn(H, 2 * N - 1, device=dev); ddiag = torch.zeros(H, 2 * N - 1, device=dev)
 lens = torch.randint(int(0.7 * N), N + 1, (B,), device=dev)

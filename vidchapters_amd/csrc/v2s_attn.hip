@@ -12,15 +12,27 @@
 // One LDS image (32-byte column chunks XOR-swizzled by (row>>1)&3) serves both the ds_read_b128 row
 // fragments and the transpose reads without bank conflicts.
 //
-// head_dim 64 makes these kernels VALU-bound (few MFMA flops per score element), so the per-element work is
-// specialised at compile time (bias / causal / dropout) and per tile at run time:
-//   * "clean" tiles (no masked or out-of-range key, no causal edge) take a branch-free path;
-//   * tiles whose keys are all masked (padding tail) or all in the causal future are skipped outright once
-//     every row of the wave has seen a real key -- their probabilities are exactly 0 then, so the result is
-//     bit-identical to processing them (rows that have seen no real key keep the reference's uniform
-//     distribution semantics and are never skipped);
-//   * the relative-position bias window is staged in LDS in four 1-float-shifted copies so that each lane
-//     fetches its 4 consecutive diagonals with one aligned ds_read_b128.
+// head_dim 64 makes these kernels instruction-issue-bound (few MFMA flops per score element: rocprofv3 SQ counters put some wave
+// issuing on 70-80 % of the SIMD cycles with the matrix pipe 16-23 % busy, profiles/r01_pmc_sq_attention.txt), so round 3 rebuilt the
+// loops around the instruction count per score element:
+//   * everything that does not change from tile to tile is staged ONCE per block: the relative-position bias window of the block
+//     (all diagonals k - q it can touch, four 1-float-shifted copies so that a lane fetches its 4 consecutive diagonals with one
+//     aligned ds_read_b128), the key flags (masked / out of range) and the per-tile "any / all flagged" state.  The loop body only
+//     moves K/V (or Q/dO) tiles: four buffer_load_dwordx4 per thread whose out-of-range rows the hardware bounds check zero-fills
+//     (no address compares, no branches) and four ds_write_b128;
+//   * the bias enters through the ACCUMULATOR: the score MFMAs start from bias / scale read straight from the LDS window, so the
+//     softmax needs no bias add; max(), the exponent argument (one packed fma per two elements: s * scale*log2e - m), the row sum,
+//     the rescale of the output accumulator (skipped when no row maximum of the wave moved), the bf16 packing and the backward
+//     products all run on two elements per instruction (v_pk_fma/mul/add_f32, v_max3_f32, v_cvt_pk_bf16_f32);
+//   * attention-probability dropout draws TWO 16-bit numbers from one 32-bit hash (see drop_* below) and applies them without
+//     v_cmp / v_cndmask: in the forward as an AND mask on the packed bf16 pair (5 instructions per 2 elements instead of 8);
+//   * "clean" tiles (no masked or out-of-range key, no causal edge) take a branch-free path; tiles whose keys are all masked
+//     (padding tail) or all in the causal future are skipped outright once every row of the wave has seen a real key -- their
+//     probabilities are exactly 0 then, so the result is bit-identical to processing them (rows that have seen no real key keep
+//     the reference's uniform distribution semantics and are never skipped);
+//   * delta = rowsum(dO * O) is computed by the dQ kernel from the fragments it loads anyway and handed to the dK/dV kernel,
+//     together with m + log2 l and the dropout row seed, as one float4 per row (no separate delta launch, one 16-byte load per
+//     row and tile in the dK/dV kernel instead of three loads, a log2 and a hash).
 #include <math.h>
 #include "v2s_common.h"
 
@@ -43,8 +55,9 @@ struct AttnP {
   int causal, causal_off;
   uint32_t p16; float inv_keep; uint32_t seed;
   const uint32_t* salt;   // device word XOR-ed into seed (v2s_set_seed_salt) or NULL
+  uint32_t tm1pk, tpk; int ts32;   // dropout thresholds: (Ts-1) and Ts replicated in both 16-bit halves, Ts << 16 (Ts = p16 - 32768)
   const bf16_t* d_o; long do_bs, do_rs;
-  const float* delta;
+  float* rowstat;         // [B][H][Nq][4]: -(m + log2 l), exponent of a masked element, -delta, dropout row seed (written by the dQ kernel)
   bf16_t *dq, *dk, *dv;
   long dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
   float* dbias_diag;
@@ -53,6 +66,10 @@ struct AttnP {
   int seq_q_only;       // seq_off applies to the query side only (q, o, d_o, dq); K / V / dK / dV stay dense [B][Nk] (cross-attention)
   const int* kv_seq_off; // K / V / dK / dV packed with their OWN row offsets (cross-attention over a padding-free memory); else see above
 };
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // byte offset of element (row, d) inside a [rows][64] bf16 LDS tile
 __device__ __forceinline__ int tile_off(int row, int d) {
@@ -89,16 +106,20 @@ __device__ __forceinline__ bf16x8 col_frag(const char* tile, int rbase, int dbas
   }
 }
 
-// cooperative 64x64 tile load: thread -> (row = tid>>3 (+32), 16-byte chunk = tid&7)
-__device__ __forceinline__ void tile_load(const bf16_t* base, long rs, int row0, int nrows, int tid, uint4 (&r)[2]) {
-  const int chunk = tid & 7, rr = tid >> 3;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = row0 + rr + i * 32;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < nrows) v = *reinterpret_cast<const uint4*>(base + (long)row * rs + chunk * 8);
-    r[i] = v;
-  }
+// ---- tile movement -------------------------------------------------------------------------------------
+// A [rows][64] bf16 slice of one (sequence, head) as a raw buffer: loads of rows >= `rows` return zeros (hardware bounds check), so
+// the tile loop needs no row compares.  Everything that varies per lane or per tile goes into the VGPR offset (the range check of a
+// raw buffer covers the VGPR + immediate offset only).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const bf16_t* base, long rs, int rows) {
+  const int bytes = rows > 0 ? (int)(((long)(rows - 1) * rs + HD) * 2) : 0;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, bytes, 0x00020000);
+}
+// cooperative 64x64 tile load: thread -> (row = tid>>3 (+32), 16-byte chunk = tid&7); voff = byte offset of (tile row 0 + tid>>3, chunk)
+__device__ __forceinline__ void tile_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t step32, uint4 (&out)[2]) {
+  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+  const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, voff + step32, 0, 0);
+  out[0] = make_uint4(a[0], a[1], a[2], a[3]);
+  out[1] = make_uint4(b[0], b[1], b[2], b[3]);
 }
 __device__ __forceinline__ void tile_store(char* tile, int tid, const uint4 (&r)[2]) {
   const int chunk = tid & 7, rr = tid >> 3;
@@ -106,84 +127,120 @@ __device__ __forceinline__ void tile_store(char* tile, int tid, const uint4 (&r)
   for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(tile + tile_off(rr + i * 32, chunk * 8)) = r[i];
 }
 
+// ---- two-elements-per-instruction fp32 helpers ------------------------------------------------------------
 // two fp32 -> one packed bf16 pair with a single v_cvt_pk_bf16_f32 (element-wise casts compile to one conversion per element
 // plus a v_perm to merge them)
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
   const f32x2 v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
-// a + b on two fp32 lanes per instruction (the compiler splits a <2 x float> add that feeds scalar transcendental ops)
+// (the compiler splits <2 x float> arithmetic that feeds scalar transcendental ops: force the packed forms)
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
   f32x2 d;
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
-__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
-  const uint4 w = make_uint4(cvt_pk(a[0], a[1]), cvt_pk(a[2], a[3]), cvt_pk(b[0], b[1]), cvt_pk(b[2], b[3]));
-  return __builtin_bit_cast(bf16x8, w);
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
 }
-
-// attention-probability dropout: keep(b,h,q,k) <=> mul24(rowseed(b,h,q) ^ keyhash(k), C2) >= (p16 << 16): a per-row seed (one
-// full hash per row) and one xor-multiply per element, decided on the top 16 bits of the low product word.  The multiply is the
-// 24-bit one (v_mul_u32_u24, full rate; v_mul_lo_u32 is quarter rate and was ~1/6 of the VALU time of a tile).  keyhash(k) =
-// ((k & ~63) * C1) ^ ((k & 0xC) * C1) ^ ((k & 0x33) * C1): in the forward / dQ kernels a lane's 16 keys of a tile are
-// k = k0 + 4g + (16 kb + r), so the 4g term is folded into the row seed once per kernel, the k0 term once per tile (scalar
-// multiply), and the last term is an instruction literal -- one v_xor per element, no address arithmetic.  Same definition in
-// all three kernels (forward mask == backward mask).
-constexpr uint32_t DROP_C1 = 0x9E3779B1u, DROP_C2 = 0x00EBCA77u;
-__device__ __forceinline__ uint32_t drop_rowseed(uint32_t seed, uint32_t rowid) { return v2s_hash32(seed ^ (rowid * 0x9E3779B1u)); }
-__device__ __forceinline__ uint32_t drop_keyhash(uint32_t k) { return ((k & ~63u) * DROP_C1) ^ ((k & 0xCu) * DROP_C1) ^ ((k & 0x33u) * DROP_C1); }
-__device__ __forceinline__ bool drop_keep(uint32_t rowseed, uint32_t kc1, uint32_t thr) {   // kc1 = (part of) keyhash(k), thr = p16 << 16
-  return __umul24(rowseed ^ kc1, DROP_C2) >= thr;
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
 }
-
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; x <= ~0 here
 
-// ---- LDS stage layout ---------------------------------------------------------------------------------
+// ---- attention-probability dropout ------------------------------------------------------------------------
+// One 32-bit hash serves the key pair (2j, 2j+1) of a row:
+//     h(row, j) = mul24( (rowseed(b,h,q) ^ pairhash(j)) & 0xFFFFFF, C2 )        (low 32 bits of the 24 x 24 bit product)
+//     draw(q, k) = signed 16-bit half (k & 1) of h(row, k >> 1);   element kept  <=>  draw >= Ts = p16 - 32768,
+// i.e. P(drop) = p16 / 65536 exactly as before (inv_keep is derived from p16).  pairhash(j) = ((j & ~31) * C1) ^ ((j & 6) * C1) ^
+// ((j & 0x19) * C1): in the forward / dQ kernels a lane's 16 keys of a tile are k = k0 + 4g + (16 kb + r), so the (j & 6) = 2g term is
+// folded into the row seed once per kernel, the (j & ~31) = k0 / 2 term once per tile (scalar multiply), and the last term is an
+// instruction literal -- one v_xor and one v_mul_u32_u24 per PAIR, no address arithmetic.  The decision never goes through
+// v_cmp / v_cndmask in those kernels:
+//   forward: e = sat16(Ts - 1 - draw) per half (v_pk_sub_i16 clamp) is negative <=> keep; v_pk_ashrrev_i16 15 turns it into
+//            0xFFFF / 0 per half = an AND mask for the packed bf16 probability pair;
+//   dQ:      d = sat16(draw - Ts) is negative <=> drop; the two sign bits, spread to 32 bits (v_ashrrev_i32 31 / v_bfe_i32 15,1),
+//            clear the fp32 dP elements (v_bfi_b32) before the packed fma that forms dP / keep - delta;
+//   dK/dV:   a lane owns ONE key and four rows, so the pair does not help; it evaluates its half with one 32-bit compare:
+//            mul_lo(a, k odd ? C2 : C2 << 16) moves the half into the top 16 bits, kept <=> (int32) >= Ts << 16.
+// Same definition in all three kernels (forward mask == backward mask; tests extract it from the forward and replay it).
+constexpr uint32_t DROP_C1 = 0x9E3779B1u, DROP_C2 = 0x00EBCA77u, DROP_M24 = 0x00FFFFFFu;
+__device__ __forceinline__ uint32_t drop_rowseed(uint32_t seed, uint32_t rowid) { return v2s_hash32(seed ^ (rowid * 0x9E3779B1u)) & DROP_M24; }
+__device__ __forceinline__ uint32_t drop_pairhash(uint32_t j) { return (((j & ~31u) * DROP_C1) ^ ((j & 6u) * DROP_C1) ^ ((j & 0x19u) * DROP_C1)) & DROP_M24; }
+// AND mask (0xFFFF per kept half) for the packed pair whose hash input is a = rowseed ^ pairhash
+__device__ __forceinline__ uint32_t drop_keepmask_pk(uint32_t a, uint32_t tm1pk) {
+  const uint32_t h = __umul24(a, DROP_C2);
+  uint32_t e, mk;
+  asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(e) : "v"(tm1pk), "v"(h));
+  asm("v_pk_ashrrev_i16 %0, 15, %1" : "=v"(mk) : "v"(e));
+  return mk;
+}
+// 32-bit "dropped" masks (all ones / zero) of the even-key (lo) and odd-key (hi) element of a pair
+__device__ __forceinline__ void drop_dropmask32(uint32_t a, uint32_t tpk, uint32_t& lo, uint32_t& hi) {
+  const uint32_t h = __umul24(a, DROP_C2);
+  uint32_t d;
+  asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(h), "v"(tpk));
+  hi = (uint32_t)((int32_t)d >> 31);
+  lo = (uint32_t)__builtin_amdgcn_sbfe((int32_t)d, 15, 1);
+}
+__device__ __forceinline__ float clear_if(uint32_t mask, float x) {   // mask all ones -> 0, mask zero -> x  (v_bfi_b32)
+  return __uint_as_float(~mask & __float_as_uint(x));
+}
+
+// ---- block-level staging (once per block) ------------------------------------------------------------------
 constexpr int KV_TILE = 8192;                 // one [64][64] bf16 tile
-constexpr int OFF_BIAS = 2 * KV_TILE;         // 4 x 192 floats: copy s holds w[i+s] at index i
-constexpr int BIAS_COPY = 208;                // floats per copy: 192 used; 208 = 3 * 64 + 16 puts copy s 16 banks after copy s-1, so the
-                                              // four copies that lanes with consecutive diagonals read (same 4-float group, different shift)
-                                              // fall on different banks (at 192 they shared one 4-bank window: 4-way conflict on every read)
-constexpr int OFF_FLAG = OFF_BIAS + 4 * BIAS_COPY * 4;   // 64 key flags (0 keep, 1 masked, 2 out of range)
-constexpr int OFF_STATE = OFF_FLAG + 64;      // int[2]: OR of flags, AND of (flag != 0)
-constexpr int OFF_MS = OFF_STATE + 16;        // dkv kernel: (m + log2 l)[64], masked-element exponent[64], delta[64], dropout row seed[64]
-constexpr int STAGE = OFF_MS + 4 * 64 * 4;    // + 64 dropout row seeds (dkv kernel)
-static_assert(STAGE % 16 == 0 && OFF_MS % 16 == 0 && OFF_BIAS % 16 == 0, "LDS carve alignment");
-
-// bias window write: thread i (< 192) holds w[i]; copy s stores it at index i - s
-__device__ __forceinline__ void bias_store(char* stage, int tid, float w) {
-  float* b = reinterpret_cast<float*>(stage + OFF_BIAS);
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-    if (tid - s >= 0) b[s * BIAS_COPY + tid - s] = w;
-}
+constexpr int STAGE2 = 2 * KV_TILE;           // K|V (or Q|dO) of one pipeline stage
+// bias window: WL = len64 + 128 floats (len64 = nominal key / query count rounded up to 64), four copies; copy s holds w[i+s] at index
+// i.  CS = floats per copy = WL rounded up to 64, plus 16: copy s starts 16 banks after copy s-1, so the four copies that lanes with
+// consecutive diagonals read (same 4-float group, different shift) fall on different banks.
+__host__ __device__ __forceinline__ int bias_cs(int len64) { return ((len64 + 128 + 63) & ~63) + 16; }
 // aligned read of w[i0 .. i0+3] for any i0 >= 0
-__device__ __forceinline__ float4 bias_read4(const char* stage, int i0) {
+__device__ __forceinline__ f32x4 bias_read4(const char* win, int CS, int i0) {
   const int s = i0 & 3;
-  return *reinterpret_cast<const float4*>(stage + OFF_BIAS + (s * BIAS_COPY + (i0 - s)) * 4);
+  return *reinterpret_cast<const f32x4*>(win + (s * CS + (i0 - s)) * 4);
 }
-
-// flags of one tile -> (any, all) in LDS state words; executed by the first wave (tid < 64)
-__device__ __forceinline__ void state_store(char* stage, int tid, uint32_t flag) {
-  const unsigned long long any = __ballot(flag != 0);
-  if (tid == 0) {
-    int* st = reinterpret_cast<int*>(stage + OFF_STATE);
-    st[0] = any != 0ull;
-    st[1] = any == ~0ull;
+// window entry i <-> relative position d = i + dbase; value = bias_diag[h][d + Nq - 1] * mul (0 outside the table)
+__device__ __forceinline__ void bias_stage(char* win, int CS, int WL, int dbase, const float* __restrict__ diag_h, int ndiag, int nq, float mul,
+                                           int tid) {
+  float* b = reinterpret_cast<float*>(win);
+  for (int i = tid; i < WL; i += 256) {
+    const int gi = i + dbase + nq - 1;
+    const float w = (gi >= 0 && gi < ndiag) ? diag_h[gi] * mul : 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (i - s >= 0) b[s * CS + i - s] = w;
   }
+}
+// key flags (0 keep, 1 masked, 2 out of range) of all len64 keys, then per 64-key tile: bit 0 = some key flagged, bit 1 = all flagged.
+// Contains two block barriers.
+__device__ __forceinline__ void flags_stage(uint8_t* flag, uint8_t* state, int len64, int nk_, const uint8_t* __restrict__ mask_b, int tid) {
+  for (int k = tid; k < len64; k += 256) flag[k] = (k >= nk_) ? 2 : ((mask_b && mask_b[k] == 0) ? 1 : 0);
+  __syncthreads();
+  const int lane = tid & 63;
+  for (int t = tid >> 6; t < (len64 >> 6); t += 4) {
+    const unsigned long long any = __ballot(flag[t * 64 + lane] != 0);
+    if (lane == 0) state[t] = (uint8_t)((any != 0ull ? 1 : 0) | (any == ~0ull ? 2 : 0));
+  }
+  __syncthreads();
 }
 
 // ====================================================================================== forward
-// block = 4 waves x 32 query rows; loop over 64-key tiles.  Three blocks per CU (<= 168 VGPRs; a dozen cold spills in the bias
-// variants) instead of two: inside a wave the score MFMAs, the softmax VALU work and the PV MFMAs are serial, and only waves in
-// different phases overlap them, so a third wave per SIMD is worth 8-13 % (encoder layer 308 -> 284 us, tools/attn_ab.py).  The
-// causal variants spill into their hot path at that budget (28 -> 32 us) and stay at two.
+// block = 4 waves x 32 query rows; loop over 64-key tiles.  Three blocks per CU (<= 168 VGPRs) instead of two: inside a wave the
+// score MFMAs, the softmax VALU work and the PV MFMAs are serial, and only waves in different phases overlap them, so a third
+// wave per SIMD is worth 8-13 % (tools/attn_ab.py).  The causal variants spill into their hot path at that budget and stay at two.
+// LDS: [2 x (K tile | V tile)] [bias window] [key flags] [tile states]
 template <bool TR, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const AttnP p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int nqb = (p.Nq + 127) >> 7;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -195,9 +252,18 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
   const int krow0_ = kso_ ? kso_[b] : 0, nk_ = kso_ ? kso_[b + 1] - krow0_ : p.Nk;
   if (Q0 >= nq_) return;                                                   // block beyond the end of a short sequence
 
+  const int len64 = (p.Nk + 63) & ~63;
+  const int CS = BIAS ? bias_cs(len64) : 0;
+  char* s_bias = smem + 2 * STAGE2;
+  uint8_t* s_flag = reinterpret_cast<uint8_t*>(s_bias + 4 * CS * 4);
+  uint8_t* s_state = s_flag + len64;
+
   const bf16_t* qp = p.q + (p.seq_off ? (long)row0_ * p.q_rs : (long)b * p.q_bs) + h * HD;
   const bf16_t* kp = p.k + (kso_ ? (long)krow0_ * p.k_rs : (long)b * p.k_bs) + h * HD;
   const bf16_t* vp = p.v + (kso_ ? (long)krow0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
+  const __amdgpu_buffer_rsrc_t krs = tile_rsrc(kp, p.k_rs, nk_), vrs = tile_rsrc(vp, p.v_rs, nk_);
+  uint32_t kvoff = (uint32_t)(((tid >> 3) * p.k_rs + (tid & 7) * 8) * 2), vvoff = (uint32_t)(((tid >> 3) * p.v_rs + (tid & 7) * 8) * 2);
+  const uint32_t kstep32 = (uint32_t)(32 * p.k_rs * 2), vstep32 = (uint32_t)(32 * p.v_rs * 2);
 
   bf16x8 qf[2][2];
 #pragma unroll
@@ -210,11 +276,19 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
       qf[qb][ks] = __builtin_bit_cast(bf16x8, v);
     }
   }
+  uint4 rk[2], rv[2];
+  tile_load(krs, kvoff, kstep32, rk);
+  tile_load(vrs, vvoff, vstep32, rv);
+
+  if (BIAS) bias_stage(s_bias, CS, len64 + 128, -(Q0 + 127), p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
+  flags_stage(s_flag, s_state, len64, nk_, p.key_mask ? p.key_mask + (long)b * p.Nk : nullptr, tid);
+
   float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
   uint32_t rowseed[2] = {0u, 0u};
   if (DROP) {
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) rowseed[qb] = drop_rowseed(v2s_salted(p.seed, p.salt), (uint32_t)((b * p.H + h) * p.Nq + Q0 + wq0 + qb * 16 + li)) ^ ((uint32_t)(4 * g) * DROP_C1);
+    for (int qb = 0; qb < 2; ++qb)
+      rowseed[qb] = drop_rowseed(v2s_salted(p.seed, p.salt), (uint32_t)((b * p.H + h) * p.Nq + Q0 + wq0 + qb * 16 + li)) ^ ((uint32_t)(2 * g) * DROP_C1);
   }
   f32x4 ot[2][4];
 #pragma unroll
@@ -225,57 +299,37 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
   const int ntiles = (nk_ + 63) >> 6;
   const float sc2 = p.scale * LOG2E;
   const int qmin = Q0 + wq0, qmax = qmin + 31;
-  uint4 rk[2], rv[2];
-  float rbias = 0.f;
-  uint32_t rflag = 0;
+  // lane part of the bias-window index of element (qb, kb, r = 0): (k0 + kb*16 + 4g) - (Q0 + qq) + (Q0 + 127)
+  const int bidx0 = 4 * g + 127 - (wq0 + li);
 
-  auto prefetch = [&](int t) {
-    const int k0 = t * 64;
-    tile_load(kp, p.k_rs, k0, nk_, tid, rk);
-    tile_load(vp, p.v_rs, k0, nk_, tid, rv);
-    if (BIAS && tid < 192) {
-      const int idx = k0 - Q0 - 127 + tid + p.Nq - 1;
-      rbias = (idx >= 0 && idx < p.Nq + p.Nk - 1) ? p.bias_diag[(long)h * (p.Nq + p.Nk - 1) + idx] * LOG2E : 0.f;
-    }
-    if (tid < 64) {
-      const int k = k0 + tid;
-      rflag = (k >= nk_) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
-    }
-  };
-  auto commit = [&](int s) {
-    char* st = smem + s * STAGE;
-    tile_store(st, tid, rk);
-    tile_store(st + KV_TILE, tid, rv);
-    if (BIAS && tid < 192) bias_store(st, tid, rbias);
-    if (tid < 64) {
-      reinterpret_cast<uint8_t*>(st + OFF_FLAG)[tid] = (uint8_t)rflag;
-      state_store(st, tid, rflag);
-    }
-  };
-
-  prefetch(0);
-  commit(0);
+  tile_store(smem, tid, rk);
+  tile_store(smem + KV_TILE, tid, rv);
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
-    const char* sK = smem + (t & 1) * STAGE;
+    const char* sK = smem + (t & 1) * STAGE2;
     const char* sV = sK + KV_TILE;
     const int k0 = t * 64;
-    if (t + 1 < ntiles) prefetch(t + 1);
-
-    const int* tstate = reinterpret_cast<const int*>(sK + OFF_STATE);
-    const bool any_flag = tstate[0] != 0, all_flag = tstate[1] != 0;
+    if (t + 1 < ntiles) {
+      kvoff += 2 * kstep32; vvoff += 2 * vstep32;
+      tile_load(krs, kvoff, kstep32, rk);
+      tile_load(vrs, vvoff, vstep32, rv);
+    }
+    const int tstate = s_state[t];
+    const bool any_flag = (tstate & 1) != 0, all_flag = (tstate & 2) != 0;
     const bool future = CAUSAL && (k0 > qmax + p.causal_off);            // every element causally masked
     const bool edge = CAUSAL && (k0 + 63 > qmin + p.causal_off);         // some element causally masked
     const bool seen = __all((m[0] > REAL_MIN) && (m[1] > REAL_MIN));     // every row already saw a real key
     const bool skip = (all_flag || future) && seen;
 
     if (!skip) {
+      // accumulators start from bias / scale: acc * (scale * log2e) is the biased score in the log2 domain
       f32x4 st[2][4];
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) st[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < 4; ++kb)
+          st[qb][kb] = BIAS ? bias_read4(s_bias, CS, k0 + kb * 16 + bidx0 - qb * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -287,33 +341,32 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
 
       bf16x8 pf[2][2];
       const bool clean = !any_flag && !edge;
+      // clean tiles keep the raw accumulators (x = acc * sc2 - m in one packed fma); tiles with masked elements go through the scaled
+      // domain (x = s - m must be EXACTLY 0 for a masked element of a row whose keys are all masked)
+      const float mult = clean ? sc2 : 1.0f;
+      const f32x2 mult2 = {mult, mult};
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
-        const int qq = wq0 + qb * 16 + li, q = Q0 + qq;
-        float mx = -INFINITY;
+        float mx;
         if (clean) {
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb) {
-            float4 bw = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (BIAS) bw = bias_read4(sK, kb * 16 + 4 * g + 127 - qq);
-            st[qb][kb][0] = fmaf(st[qb][kb][0], sc2, bw.x);
-            st[qb][kb][1] = fmaf(st[qb][kb][1], sc2, bw.y);
-            st[qb][kb][2] = fmaf(st[qb][kb][2], sc2, bw.z);
-            st[qb][kb][3] = fmaf(st[qb][kb][3], sc2, bw.w);
-            mx = fmaxf(fmaxf(mx, fmaxf(st[qb][kb][0], st[qb][kb][1])), fmaxf(st[qb][kb][2], st[qb][kb][3]));
-          }
+          mx = max3(st[qb][0][0], st[qb][0][1], st[qb][0][2]);
+          mx = max3(mx, st[qb][0][3], st[qb][1][0]);
+          mx = max3(mx, st[qb][1][1], st[qb][1][2]);
+          mx = max3(mx, st[qb][1][3], st[qb][2][0]);
+          mx = max3(mx, st[qb][2][1], st[qb][2][2]);
+          mx = max3(mx, st[qb][2][3], st[qb][3][0]);
+          mx = max3(mx, st[qb][3][1], st[qb][3][2]);
+          mx = fmaxf(mx, st[qb][3][3]);
         } else {
-          const uint8_t* fl = reinterpret_cast<const uint8_t*>(sK + OFF_FLAG);
+          const int q = Q0 + wq0 + qb * 16 + li;
+          mx = -INFINITY;
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb) {
-            const uint32_t f4 = *reinterpret_cast<const uint32_t*>(fl + kb * 16 + 4 * g);
-            float4 bw = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (BIAS) bw = bias_read4(sK, kb * 16 + 4 * g + 127 - qq);
-            const float bwv[4] = {bw.x, bw.y, bw.z, bw.w};
+            const uint32_t f4 = *reinterpret_cast<const uint32_t*>(s_flag + k0 + kb * 16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int kk = kb * 16 + 4 * g + r;
-              float s = fmaf(st[qb][kb][r], sc2, bwv[r]);
+              float s = st[qb][kb][r] * sc2;
               uint32_t f = (f4 >> (8 * r)) & 0xffu;
               if (CAUSAL && (k0 + kk) > q + p.causal_off) f |= 1u;
               s = (f & 2u) ? -INFINITY : ((f & 1u) ? MASKED2 : s);
@@ -324,28 +377,38 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m[qb], mx);
+        const float mn = fmaxf(m[qb], mx * mult);
         const float alpha = fast_exp2(m[qb] - mn);
         m[qb] = mn;
-        f32x4 rs4 = f32x4{0.f, 0.f, 0.f, 0.f};     // subtraction and row sum as 4-vectors: v_pk_add_f32 handles two elements each
-        const uint32_t rseed = rowseed[qb] ^ ((uint32_t)k0 * DROP_C1);
-        const uint32_t thr = p.p16 << 16;
-        const f32x2 nmn2 = f32x2{-mn, -mn};
+        const f32x2 nmn2 = {-mn, -mn};
+        f32x2 rs2 = {0.f, 0.f};
+        const uint32_t rseed = rowseed[qb] ^ ((uint32_t)(k0 >> 1) * DROP_C1);
+        uint32_t pw[4][2];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-          const f32x2 x01 = pk_add(f32x2{st[qb][kb][0], st[qb][kb][1]}, nmn2), x23 = pk_add(f32x2{st[qb][kb][2], st[qb][kb][3]}, nmn2);
-          const f32x4 pv4 = f32x4{fast_exp2(x01[0]), fast_exp2(x01[1]), fast_exp2(x23[0]), fast_exp2(x23[1])};
-          rs4 += pv4;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            st[qb][kb][r] = (!DROP || drop_keep(rseed, (uint32_t)(kb * 16 + r) * DROP_C1, thr)) ? pv4[r] : 0.f;   // 1/(1-p) is applied once, to the output row
+          const f32x2 x01 = pk_fma(f32x2{st[qb][kb][0], st[qb][kb][1]}, mult2, nmn2);
+          const f32x2 x23 = pk_fma(f32x2{st[qb][kb][2], st[qb][kb][3]}, mult2, nmn2);
+          const f32x2 p01 = {fast_exp2(x01[0]), fast_exp2(x01[1])}, p23 = {fast_exp2(x23[0]), fast_exp2(x23[1])};
+          rs2 = pk_add(rs2, p01);
+          rs2 = pk_add(rs2, p23);
+          pw[kb][0] = cvt_pk(p01[0], p01[1]);
+          pw[kb][1] = cvt_pk(p23[0], p23[1]);
+          if (DROP) {                                       // 1/(1-p) is applied once, to the output row
+            pw[kb][0] &= drop_keepmask_pk(rseed ^ ((uint32_t)(kb * 8 + 0) * DROP_C1), p.tm1pk);
+            pw[kb][1] &= drop_keepmask_pk(rseed ^ ((uint32_t)(kb * 8 + 1) * DROP_C1), p.tm1pk);
+          }
         }
-        const float rs = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
-        lsum[qb] = lsum[qb] * alpha + rs;
+        lsum[qb] = lsum[qb] * alpha + (rs2[0] + rs2[1]);
+        if (__any(alpha != 1.0f)) {                         // some row maximum of this wave moved: rescale the output accumulators
+          const f32x2 a2 = {alpha, alpha};
 #pragma unroll
-        for (int db = 0; db < 4; ++db) ot[qb][db] *= alpha;
-        pf[qb][0] = pack_frag(st[qb][0], st[qb][1]);
-        pf[qb][1] = pack_frag(st[qb][2], st[qb][3]);
+          for (int db = 0; db < 4; ++db) {
+            const f32x2 lo = pk_mul(f32x2{ot[qb][db][0], ot[qb][db][1]}, a2), hi = pk_mul(f32x2{ot[qb][db][2], ot[qb][db][3]}, a2);
+            ot[qb][db] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+          }
+        }
+        pf[qb][0] = __builtin_bit_cast(bf16x8, make_uint4(pw[0][0], pw[0][1], pw[1][0], pw[1][1]));
+        pf[qb][1] = __builtin_bit_cast(bf16x8, make_uint4(pw[2][0], pw[2][1], pw[3][0], pw[3][1]));
       }
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
@@ -356,7 +419,11 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
           for (int qb = 0; qb < 2; ++qb) ot[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][kh], ot[qb][db], 0, 0, 0);
         }
     }
-    if (t + 1 < ntiles) commit((t + 1) & 1);
+    if (t + 1 < ntiles) {
+      char* nx = smem + ((t + 1) & 1) * STAGE2;
+      tile_store(nx, tid, rk);
+      tile_store(nx + KV_TILE, tid, rv);
+    }
     __syncthreads();
   }
 
@@ -385,14 +452,13 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
   }
 }
 
-// ====================================================================================== delta = rowsum(dO * O)
+// ====================================================================================== delta = rowsum(dO * O)  (stand-alone utility)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p, float* __restrict__ delta) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per 8 elements of a (b,q,h) row
   const long total = (long)p.B * p.Nq * p.H * 8;
   float s = 0.f;
   int b = 0, q = 0, h = 0;
   if (t < total) {
-    const int c = (int)(t & 7);
     long r = t >> 3;
     h = (int)(r % p.H); r /= p.H;
     q = (int)(r % p.Nq); b = (int)(r / p.Nq);
@@ -412,13 +478,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p, float* _
   if (t < total && q >= 0 && (t & 7) == 0) delta[((long)(b * p.H + h)) * p.Nq + q] = s;
 }
 
-// ====================================================================================== backward: dQ (+ dbias)
+// ====================================================================================== backward: dQ (+ dbias, + row statistics)
 // same decomposition as the forward: wave = 32 query rows, loop over key tiles.
 // Tiles that are fully masked / fully in the causal future contribute exactly zero to dQ and dbias whenever
 // the row statistics come from a real key (m > REAL_MIN), and are skipped under that condition.
+// The prologue also computes delta = rowsum(dO * O) of the block's rows (it holds the dO fragments anyway) and writes the per-row
+// statistics the dK/dV kernel needs (p.rowstat), so v2s_attn_bwd launches the dK/dV kernel AFTER this one.
+// LDS: [2 x (K tile | V tile)] [bias-gradient window: (Nk + 128) x 8 bytes] [bias window] [key flags] [tile states]
 template <bool TR, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2*STAGE + (Nk+128)*8 (dbias window) bytes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // scalar: the per-block bias-gradient routing below branches on it
   const int nqb = (p.Nq + 127) >> 7;
@@ -434,17 +503,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   // per-diagonal bias-gradient window of this block, index (k - q) + (Q0 + 127) in [0, Nk+127), accumulated in 64-bit
   // fixed point (2^-40 units): LDS float atomics run at ~0.33 lane-ops/clk/CU on gfx950, 64-bit integer ones at ~8
   // (tools/ubench/lds_atomic.hip) -- and the integer sum is exact and order-independent.
-  unsigned long long* dbw = reinterpret_cast<unsigned long long*>(smem + 2 * STAGE);
+  const int len64 = (p.Nk + 63) & ~63;
+  const int CS = BIAS ? bias_cs(len64) : 0;
+  unsigned long long* dbw = reinterpret_cast<unsigned long long*>(smem + 2 * STAGE2);
+  char* s_bias = smem + 2 * STAGE2 + (BIAS ? ((p.Nk + 129) & ~1) * 8 : 0);
+  uint8_t* s_flag = reinterpret_cast<uint8_t*>(s_bias + 4 * CS * 4);
+  uint8_t* s_state = s_flag + len64;
   const int ndb = p.Nk + 127;
   if (want_dbias) {
     for (int i = tid; i < ndb; i += 256) dbw[i] = 0ull;
   }
-  float acc_lo = 0.f, acc_hi = 0.f;    // bias-gradient mass of the two "far" buckets (no per-diagonal resolution needed)
+  f32x2 acc_lo = {0.f, 0.f}, acc_hi = {0.f, 0.f};    // bias-gradient mass of the two "far" buckets (no per-diagonal resolution needed)
 
   const bf16_t* qp = p.q + (p.seq_off ? (long)row0_ * p.q_rs : (long)b * p.q_bs) + h * HD;
   const bf16_t* dop = p.d_o + (p.seq_off ? (long)row0_ * p.do_rs : (long)b * p.do_bs) + h * HD;
+  const bf16_t* op = p.o + (p.seq_off ? (long)row0_ * p.o_rs : (long)b * p.o_bs) + h * HD;
   const bf16_t* kp = p.k + (kso_ ? (long)krow0_ * p.k_rs : (long)b * p.k_bs) + h * HD;
   const bf16_t* vp = p.v + (kso_ ? (long)krow0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
+  const __amdgpu_buffer_rsrc_t krs = tile_rsrc(kp, p.k_rs, nk_), vrs = tile_rsrc(vp, p.v_rs, nk_);
+  uint32_t kvoff = (uint32_t)(((tid >> 3) * p.k_rs + (tid & 7) * 8) * 2), vvoff = (uint32_t)(((tid >> 3) * p.v_rs + (tid & 7) * 8) * 2);
+  const uint32_t kstep32 = (uint32_t)(32 * p.k_rs * 2), vstep32 = (uint32_t)(32 * p.v_rs * 2);
+  uint4 rk[2], rv[2];
+  tile_load(krs, kvoff, kstep32, rk);
+  tile_load(vrs, vvoff, vstep32, rv);
 
   bf16x8 qf[2][2], dof[2][2];
   float m2[2], xmask[2], dl[2];
@@ -453,35 +534,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int q = Q0 + wq0 + qb * 16 + li;
+    float dsum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+      uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0), o = make_uint4(0, 0, 0, 0);
       if (q < nq_) {
         v = *reinterpret_cast<const uint4*>(qp + (long)q * p.q_rs + ks * 32 + g * 8);
         w = *reinterpret_cast<const uint4*>(dop + (long)q * p.do_rs + ks * 32 + g * 8);
+        o = *reinterpret_cast<const uint4*>(op + (long)q * p.o_rs + ks * 32 + g * 8);
       }
       qf[qb][ks] = __builtin_bit_cast(bf16x8, v);
       dof[qb][ks] = __builtin_bit_cast(bf16x8, w);
+      float of[8], df[8];
+      unpack8(o, of); unpack8(w, df);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dsum = fmaf(of[j], df[j], dsum);
     }
+    dsum += __shfl_xor(dsum, 16, 64);            // delta = sum over the 64 columns of dO * O: the four lane groups hold 16 each
+    dsum += __shfl_xor(dsum, 32, 64);
     // 1/l is folded into the exponent: P = exp2(s - (m + log2 l)).  Rows >= Nq: huge offset => P = 0 => dS = 0.  A row whose
     // keys are ALL masked (m <= REAL_MIN) keeps the reference's uniform distribution: its masked elements evaluate to
     // exp2(-log2 l) = 1/l (xmask), every other row's masked elements to 0.
     m2[qb] = 1.0e30f; xmask[qb] = -3.0e38f; dl[qb] = 0.f;
     bool real = true;
+    const uint32_t rs24 = DROP ? drop_rowseed(v2s_salted(p.seed, p.salt), (uint32_t)((b * p.H + h) * p.Nq + q)) : 0u;
     if (q < nq_) {
       const long r = ((long)(b * p.H + h)) * p.Nq + q;
       const float mm = p.ml[r * 2], l2 = __log2f(p.ml[r * 2 + 1]);
       real = mm > REAL_MIN;
       m2[qb] = real ? mm + l2 : 0.f;
       xmask[qb] = real ? -3.0e38f : -l2;
-      dl[qb] = p.delta[r];
+      dl[qb] = dsum;
+      if (g == 0) *reinterpret_cast<float4*>(p.rowstat + r * 4) = make_float4(-m2[qb], xmask[qb], -dsum, __uint_as_float(rs24));
     }
     rows_real = rows_real && real;
-    if (DROP) rowseed[qb] = drop_rowseed(v2s_salted(p.seed, p.salt), (uint32_t)((b * p.H + h) * p.Nq + q)) ^ ((uint32_t)(4 * g) * DROP_C1);
+    rowseed[qb] = rs24 ^ ((uint32_t)(2 * g) * DROP_C1);
   }
   const bool seen = __all(rows_real);
-  const float isc2 = 1.0f / (p.scale * LOG2E);
-  const float ninit[2] = {-m2[0] * isc2, -m2[1] * isc2};
+
+  if (BIAS) bias_stage(s_bias, CS, len64 + 128, -(Q0 + 127), p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
+  flags_stage(s_flag, s_state, len64, nk_, p.key_mask ? p.key_mask + (long)b * p.Nk : nullptr, tid);
+
   f32x4 dqt[2][4];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
@@ -490,56 +583,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 
   const int ntiles = (nk_ + 63) >> 6;
   const float sc2 = p.scale * LOG2E;
+  const f32x2 sc22 = {sc2, sc2};
+  const float ik = DROP ? p.inv_keep : 1.0f;
+  const f32x2 ik2 = {ik, ik};
   const int qmin = Q0 + wq0, qmax = qmin + 31;
-  uint4 rk[2], rv[2];
-  float rbias = 0.f;
-  uint32_t rflag = 0;
-  auto prefetch = [&](int t) {
-    const int k0 = t * 64;
-    tile_load(kp, p.k_rs, k0, nk_, tid, rk);
-    tile_load(vp, p.v_rs, k0, nk_, tid, rv);
-    if (BIAS && tid < 192) {
-      const int idx = k0 - Q0 - 127 + tid + p.Nq - 1;
-      rbias = (idx >= 0 && idx < p.Nq + p.Nk - 1) ? p.bias_diag[(long)h * (p.Nq + p.Nk - 1) + idx] * LOG2E : 0.f;
-    }
-    if (tid < 64) {
-      const int k = k0 + tid;
-      rflag = (k >= nk_) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
-    }
-  };
-  auto commit = [&](int s) {
-    char* st = smem + s * STAGE;
-    tile_store(st, tid, rk);
-    tile_store(st + KV_TILE, tid, rv);
-    if (BIAS && tid < 192) bias_store(st, tid, rbias);
-    if (tid < 64) {
-      reinterpret_cast<uint8_t*>(st + OFF_FLAG)[tid] = (uint8_t)rflag;
-      state_store(st, tid, rflag);
-    }
-  };
-  prefetch(0);
-  commit(0);
+  const int bidx0 = 4 * g + 127 - (wq0 + li);
+
+  tile_store(smem, tid, rk);
+  tile_store(smem + KV_TILE, tid, rv);
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
-    const char* sK = smem + (t & 1) * STAGE;
+    const char* sK = smem + (t & 1) * STAGE2;
     const char* sV = sK + KV_TILE;
     const int k0 = t * 64;
-    if (t + 1 < ntiles) prefetch(t + 1);
-
-    const int* tstate = reinterpret_cast<const int*>(sK + OFF_STATE);
-    const bool any_flag = tstate[0] != 0, all_flag = tstate[1] != 0;
+    if (t + 1 < ntiles) {
+      kvoff += 2 * kstep32; vvoff += 2 * vstep32;
+      tile_load(krs, kvoff, kstep32, rk);
+      tile_load(vrs, vvoff, vstep32, rv);
+    }
+    const int tstate = s_state[t];
+    const bool any_flag = (tstate & 1) != 0, all_flag = (tstate & 2) != 0;
     const bool future = CAUSAL && (k0 > qmax + p.causal_off);
     const bool edge = CAUSAL && (k0 + 63 > qmin + p.causal_off);
     const bool skip = (all_flag || future) && seen;
 
     if (!skip) {
-      // the score accumulators start at -m/sc2 so that fma(acc, sc2, bias) is already (s - m) in the log2 domain
       f32x4 st[2][4], dp[2][4];
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) { st[qb][kb] = f32x4{ninit[qb], ninit[qb], ninit[qb], ninit[qb]}; dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int kb = 0; kb < 4; ++kb) {
+          st[qb][kb] = BIAS ? bias_read4(s_bias, CS, k0 + kb * 16 + bidx0 - qb * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -553,64 +630,71 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
           }
         }
       const bool clean = !any_flag && !edge;
-      // bias-gradient routing per 16x16 block (qb, kb): relative positions d = k - q span a 31-wide range; blocks entirely in
-      // a far bucket just sum their dS (1: far-low, 2: far-high), only the near-diagonal blocks (3) resolve diagonals
+      // bias-gradient routing: relative positions d = k - q of a 16x16 block (qb, kb) span a 31-wide range; blocks entirely in
+      // a far bucket just sum their dS (1: far-low, 2: far-high), only the near-diagonal blocks (3) resolve diagonals.  Most
+      // TILES lie entirely in one far bucket (troute != 3): decided once per tile with scalar compares.
+      const int troute = !want_dbias ? 0 : ((k0 + 63 - qmin) <= p.far_lo ? 1 : ((k0 - qmax) >= p.far_hi ? 2 : 3));
       bf16x8 dsf[2][2];
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const int qq = wq0 + qb * 16 + li, q = Q0 + qq;
-        const uint8_t* fl = reinterpret_cast<const uint8_t*>(sK + OFF_FLAG);
-        const uint32_t rseed = rowseed[qb] ^ ((uint32_t)k0 * DROP_C1);
-        const uint32_t thr = p.p16 << 16;
-        const float dl_q = dl[qb], ndl_q = -dl_q, xm_q = xmask[qb];
+        const uint32_t rseed = rowseed[qb] ^ ((uint32_t)(k0 >> 1) * DROP_C1);
+        const float ndl_q = -dl[qb], xm_q = xmask[qb], nm2_q = -m2[qb];
+        const f32x2 ndl2 = {ndl_q, ndl_q}, nm22 = {nm2_q, nm2_q};
         const int qlo = Q0 + wq0 + qb * 16;            // rows of this block: qlo .. qlo+15
+        uint32_t dw[4][2];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
           const int klo = k0 + kb * 16;
-          const int route = !want_dbias ? 0 : ((klo + 15 - qlo) <= p.far_lo ? 1 : ((klo - (qlo + 15)) >= p.far_hi ? 2 : 3));
-          float4 bw = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (BIAS) bw = bias_read4(sK, kb * 16 + 4 * g + 127 - qq);
-          const float bwv[4] = {bw.x, bw.y, bw.z, bw.w};
-          float x[4];
+          const int route = troute != 3 ? troute : ((klo + 15 - qlo) <= p.far_lo ? 1 : ((klo - (qlo + 15)) >= p.far_hi ? 2 : 3));
+          f32x2 x01, x23;
           if (clean) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = fmaf(st[qb][kb][r], sc2, bwv[r]);
+            x01 = pk_fma(f32x2{st[qb][kb][0], st[qb][kb][1]}, sc22, nm22);
+            x23 = pk_fma(f32x2{st[qb][kb][2], st[qb][kb][3]}, sc22, nm22);
           } else {
-            const uint32_t f4 = *reinterpret_cast<const uint32_t*>(fl + kb * 16 + 4 * g);
+            const uint32_t f4 = *reinterpret_cast<const uint32_t*>(s_flag + k0 + kb * 16 + 4 * g);
+            float x[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               uint32_t f = (f4 >> (8 * r)) & 0xffu;
               if (CAUSAL && (k0 + kb * 16 + 4 * g + r) > q + p.causal_off) f |= 1u;
-              x[r] = (f & 2u) ? -INFINITY : ((f & 1u) ? xm_q : fmaf(st[qb][kb][r], sc2, bwv[r]));
+              x[r] = (f & 2u) ? -INFINITY : ((f & 1u) ? xm_q : fmaf(st[qb][kb][r], sc2, nm2_q));
             }
+            x01 = f32x2{x[0], x[1]}; x23 = f32x2{x[2], x[3]};
           }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pr = fast_exp2(x[r]);                       // already divided by l
-            float u = fmaf(dp[qb][kb][r], DROP ? p.inv_keep : 1.0f, ndl_q);      // dP/(1-p) - delta on kept elements
-            if (DROP) u = drop_keep(rseed, (uint32_t)(kb * 16 + r) * DROP_C1, thr) ? u : ndl_q;
-            st[qb][kb][r] = pr * u;
+          const f32x2 p01 = {fast_exp2(x01[0]), fast_exp2(x01[1])}, p23 = {fast_exp2(x23[0]), fast_exp2(x23[1])};   // already divided by l
+          f32x2 d01 = {dp[qb][kb][0], dp[qb][kb][1]}, d23 = {dp[qb][kb][2], dp[qb][kb][3]};
+          if (DROP) {                                       // dropped elements: dP -> 0, so that u = -delta there
+            uint32_t mlo, mhi;
+            drop_dropmask32(rseed ^ ((uint32_t)(kb * 8 + 0) * DROP_C1), p.tpk, mlo, mhi);
+            d01 = f32x2{clear_if(mlo, d01[0]), clear_if(mhi, d01[1])};
+            drop_dropmask32(rseed ^ ((uint32_t)(kb * 8 + 1) * DROP_C1), p.tpk, mlo, mhi);
+            d23 = f32x2{clear_if(mlo, d23[0]), clear_if(mhi, d23[1])};
           }
+          const f32x2 s01 = pk_mul(p01, pk_fma(d01, ik2, ndl2)), s23 = pk_mul(p23, pk_fma(d23, ik2, ndl2));   // dS = P * (dP/(1-p) - delta)
           if (BIAS && route != 0) {      // route is wave-uniform: one scalar branch per 16x16 block, none per element
             if (route == 3) {            // near-diagonal block: every element goes to its own diagonal of the window
+              const float dsv[4] = {s01[0], s01[1], s23[0], s23[1]};
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 // float -> 2^-40 fixed point without the (emulated, ~11 instruction) float->int64 conversion: adding
                 // 1.5 * 2^12 in double leaves round(ds * 2^40) (two's complement, |ds| < 2048) in the low 51 mantissa bits;
                 // the magic number's bit pattern has a zero low word, so subtracting its high word yields the integer.
-                const double md = (double)st[qb][kb][r] + 6144.0;
+                const double md = (double)dsv[r] + 6144.0;
                 const unsigned long long bits = __builtin_bit_cast(unsigned long long, md) - 0x40B8000000000000ull;
                 atomicAdd(&dbw[(k0 + kb * 16 + 4 * g + r) + 127 - qq], bits);
               }
+            } else if (route == 1) {
+              acc_lo = pk_add(acc_lo, pk_add(s01, s23));
             } else {
-              const float lsum_ds = (st[qb][kb][0] + st[qb][kb][1]) + (st[qb][kb][2] + st[qb][kb][3]);
-              if (route == 1) acc_lo += lsum_ds;
-              else acc_hi += lsum_ds;
+              acc_hi = pk_add(acc_hi, pk_add(s01, s23));
             }
           }
+          dw[kb][0] = cvt_pk(s01[0], s01[1]);
+          dw[kb][1] = cvt_pk(s23[0], s23[1]);
         }
-        dsf[qb][0] = pack_frag(st[qb][0], st[qb][1]);
-        dsf[qb][1] = pack_frag(st[qb][2], st[qb][3]);
+        dsf[qb][0] = __builtin_bit_cast(bf16x8, make_uint4(dw[0][0], dw[0][1], dw[1][0], dw[1][1]));
+        dsf[qb][1] = __builtin_bit_cast(bf16x8, make_uint4(dw[2][0], dw[2][1], dw[3][0], dw[3][1]));
       }
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
@@ -621,7 +705,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
           for (int qb = 0; qb < 2; ++qb) dqt[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qb][kh], dqt[qb][db], 0, 0, 0);
         }
     }
-    if (t + 1 < ntiles) commit((t + 1) & 1);
+    if (t + 1 < ntiles) {
+      char* nx = smem + ((t + 1) & 1) * STAGE2;
+      tile_store(nx, tid, rk);
+      tile_store(nx + KV_TILE, tid, rv);
+    }
     __syncthreads();
   }
 
@@ -629,13 +717,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   for (int qb = 0; qb < 2; ++qb) {
     const int q = Q0 + wq0 + qb * 16 + li;
     if (q < nq_) {
-      bf16_t* op = p.dq + (p.seq_off ? (long)row0_ * p.dq_rs : (long)b * p.dq_bs) + (long)q * p.dq_rs + h * HD;
+      bf16_t* dqp = p.dq + (p.seq_off ? (long)row0_ * p.dq_rs : (long)b * p.dq_bs) + (long)q * p.dq_rs + h * HD;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         uint2 w;
         w.x = pack2bf(dqt[qb][db][0] * p.scale, dqt[qb][db][1] * p.scale);
         w.y = pack2bf(dqt[qb][db][2] * p.scale, dqt[qb][db][3] * p.scale);
-        *reinterpret_cast<uint2*>(op + db * 16 + 4 * g) = w;
+        *reinterpret_cast<uint2*>(dqp + db * 16 + 4 * g) = w;
       }
     }
   }
@@ -643,12 +731,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
     // dbw index i <-> (k - q) = i - (Q0 + 127);  global index = (k - q) + Nq - 1.  The far-bucket masses go to the
     // diagonals far_lo / far_hi themselves (same bucket): dbias_diag is meaningful after bucket reduction.
     float* dst = p.dbias_diag + (long)h * (p.Nq + p.Nk - 1);
-    acc_lo = wave_sum(acc_lo);
-    acc_hi = wave_sum(acc_hi);
+    const float slo = wave_sum(acc_lo[0] + acc_lo[1]);
+    const float shi = wave_sum(acc_hi[0] + acc_hi[1]);
     if (lane == 0) {
       const int glo = p.far_lo + p.Nq - 1, ghi = p.far_hi + p.Nq - 1;
-      if (acc_lo != 0.f && glo >= 0 && glo < p.Nq + p.Nk - 1) atomicAdd(dst + glo, acc_lo);
-      if (acc_hi != 0.f && ghi >= 0 && ghi < p.Nq + p.Nk - 1) atomicAdd(dst + ghi, acc_hi);
+      if (slo != 0.f && glo >= 0 && glo < p.Nq + p.Nk - 1) atomicAdd(dst + glo, slo);
+      if (shi != 0.f && ghi >= 0 && ghi < p.Nq + p.Nk - 1) atomicAdd(dst + ghi, shi);
     }
     for (int i = tid; i < ndb; i += 256) {
       const int gi = i - (Q0 + 127) + p.Nq - 1;
@@ -660,9 +748,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 
 // ====================================================================================== backward: dK, dV
 // wave = 32 keys (2 key blocks), block = 128 keys, loop over 64-query tiles (Q and dO tiles in LDS).
+// LDS: [2 x (Q tile | dO tile | row statistics 4 x 64 floats | state)] [bias window]
+constexpr int DKV_MS = STAGE2;                   // -(m + log2 l)[64], masked-element exponent[64], -delta[64], dropout row seed[64]
+constexpr int DKV_STATE = DKV_MS + 4 * 64 * 4;   // int: every row of the tile has real statistics
+constexpr int DKV_STAGE = DKV_STATE + 16;
 template <bool TR, bool BIAS, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int nkb = (p.Nk + 127) >> 7;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -674,13 +766,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   const int krow0_ = kso_ ? kso_[b] : 0, nk_ = kso_ ? kso_[b + 1] - krow0_ : p.Nk;
   if (K0 >= nk_) return;
 
+  const int len64 = (p.Nq + 63) & ~63;
+  const int CS = BIAS ? bias_cs(len64) : 0;
+  char* s_bias = smem + 2 * DKV_STAGE;
+
   const bf16_t* qp = p.q + (p.seq_off ? (long)row0_ * p.q_rs : (long)b * p.q_bs) + h * HD;
   const bf16_t* dop = p.d_o + (p.seq_off ? (long)row0_ * p.do_rs : (long)b * p.do_bs) + h * HD;
   const bf16_t* kp = p.k + (kso_ ? (long)krow0_ * p.k_rs : (long)b * p.k_bs) + h * HD;
   const bf16_t* vp = p.v + (kso_ ? (long)krow0_ * p.v_rs : (long)b * p.v_bs) + h * HD;
+  const __amdgpu_buffer_rsrc_t qrs = tile_rsrc(qp, p.q_rs, nq_), dors = tile_rsrc(dop, p.do_rs, nq_);
+  uint32_t qvoff = (uint32_t)(((tid >> 3) * p.q_rs + (tid & 7) * 8) * 2), dovoff = (uint32_t)(((tid >> 3) * p.do_rs + (tid & 7) * 8) * 2);
+  const uint32_t qstep32 = (uint32_t)(32 * p.q_rs * 2), dostep32 = (uint32_t)(32 * p.do_rs * 2);
+  uint4 rq[2], rdo[2];
+  tile_load(qrs, qvoff, qstep32, rq);
+  tile_load(dors, dovoff, dostep32, rdo);
+  const float* rsp = p.rowstat + ((long)(b * p.H + h)) * p.Nq * 4;
+  // per-row statistics of a query tile (written by the dQ kernel): rows >= Nq: P = 0
+  float4 rstat = make_float4(-1.0e30f, -3.0e38f, 0.f, 0.f);
+  if (tid < 64 && tid < nq_) rstat = *reinterpret_cast<const float4*>(rsp + (long)tid * 4);
 
   bf16x8 kf[2][2], vf[2][2];
-  uint32_t kflag[2];
+  uint32_t kflag[2], kc[2], cmul[2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     const int k = K0 + wk0 + kb * 16 + li;
@@ -695,6 +801,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       vf[kb][ks] = __builtin_bit_cast(bf16x8, c);
     }
     kflag[kb] = (k >= nk_) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
+    kc[kb] = drop_pairhash((uint32_t)k >> 1);
+    cmul[kb] = (k & 1) ? DROP_C2 : (DROP_C2 << 16);      // moves this key's 16-bit half of the pair hash into the top half
   }
   const bool keys_clean = __all(kflag[0] == 0u && kflag[1] == 0u);
   const int kmin = K0 + wk0, kmax = kmin + 31;
@@ -704,64 +812,49 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 #pragma unroll
     for (int db = 0; db < 4; ++db) { dkt[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+  // bias window of this key block: entry i <-> relative position d = i + (K0 - len64 + 1)  (q < len64, k - K0 in [0, 128))
+  if (BIAS) bias_stage(s_bias, CS, len64 + 128, K0 - len64 + 1, p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
+
   const int ntiles = (nq_ + 63) >> 6;
-  const float sc2 = p.scale * LOG2E, isc2 = 1.0f / sc2;
-  const uint32_t thr = p.p16 << 16;
-  uint4 rq[2], rdo[2];
-  float rbias = 0.f;
-  float rm = 0.f, rl = 0.f, rd = 0.f;
-  int rreal = 1;
-  uint32_t rseed = 0;
-  // bias window for this (128-key block, 64-query tile): index (k - q) - dmin, dmin = K0 - (q0 + 63); 191 entries
-  auto prefetch = [&](int t) {
-    const int q0 = t * 64;
-    tile_load(qp, p.q_rs, q0, nq_, tid, rq);
-    tile_load(dop, p.do_rs, q0, nq_, tid, rdo);
-    if (BIAS && tid < 192) {
-      const int idx = K0 - q0 - 63 + tid + p.Nq - 1;
-      rbias = (idx >= 0 && idx < p.Nq + p.Nk - 1) ? p.bias_diag[(long)h * (p.Nq + p.Nk - 1) + idx] * LOG2E : 0.f;
-    }
-    if (tid < 64) {
-      const int q = q0 + tid;
-      if (DROP) rseed = drop_rowseed(v2s_salted(p.seed, p.salt), (uint32_t)((b * p.H + h) * p.Nq + q));
-      // rm = m + log2 l (1/l folded into the exponent), rl = value of a MASKED element's exponent: -log2 l for a row whose keys
-      // are all masked (uniform distribution, like the reference), -huge otherwise; rows >= Nq: P = 0.  See the dQ kernel.
-      rm = 1.0e30f; rl = -3.0e38f; rd = 0.f; rreal = 1;
-      if (q < nq_) {
-        const long r = ((long)(b * p.H + h)) * p.Nq + q;
-        const float mm = p.ml[r * 2], l2 = __log2f(p.ml[r * 2 + 1]);
-        rreal = mm > REAL_MIN;
-        rm = rreal ? mm + l2 : 0.f; rl = rreal ? -3.0e38f : -l2; rd = p.delta[r];
-      }
-    }
-  };
+  const float sc2 = p.scale * LOG2E;
+  const f32x2 sc22 = {sc2, sc2};
+  const float ik = DROP ? p.inv_keep : 1.0f;
+  const f32x2 ik2 = {ik, ik};
+  // window index of element (q, k): (k - q) - (K0 - len64 + 1); a lane's four rows r = 0..3 of a block sit at DEcreasing indices
+  // i0 - r, read as one aligned float4 at i0 - 3
+  const int bidx0 = wk0 + li + len64 - 1 - 4 * g - 3;
+
   auto commit = [&](int s) {
-    char* st = smem + s * STAGE;
+    char* st = smem + s * DKV_STAGE;
     tile_store(st, tid, rq);
     tile_store(st + KV_TILE, tid, rdo);
-    if (BIAS && tid < 192) bias_store(st, tid, rbias);
     if (tid < 64) {
-      float* ms = reinterpret_cast<float*>(st + OFF_MS);
-      ms[tid] = rm; ms[64 + tid] = rl; ms[128 + tid] = rd;
-      if (DROP) reinterpret_cast<uint32_t*>(ms)[192 + tid] = rseed;
+      float* ms = reinterpret_cast<float*>(st + DKV_MS);
+      ms[tid] = rstat.x; ms[64 + tid] = rstat.y; ms[128 + tid] = rstat.z; ms[192 + tid] = rstat.w;
       // "every query row of this tile has real statistics": lets all-masked / all-future key blocks skip the tile
-      const unsigned long long real = __ballot(rreal != 0);
-      if (tid == 0) reinterpret_cast<int*>(st + OFF_STATE)[0] = (real == ~0ull);
+      const unsigned long long real = __ballot(rstat.y < REAL_MIN);
+      if (tid == 0) reinterpret_cast<int*>(st + DKV_STATE)[0] = (real == ~0ull);
     }
   };
-  prefetch(0);
   commit(0);
   __syncthreads();
 
   const bool keys_all_masked = __all(kflag[0] != 0u && kflag[1] != 0u);
   for (int t = 0; t < ntiles; ++t) {
-    const char* sQ = smem + (t & 1) * STAGE;
+    const char* sQ = smem + (t & 1) * DKV_STAGE;
     const char* sDO = sQ + KV_TILE;
-    const float* ms = reinterpret_cast<const float*>(sQ + OFF_MS);
+    const float* ms = reinterpret_cast<const float*>(sQ + DKV_MS);
     const int q0 = t * 64;
-    if (t + 1 < ntiles) prefetch(t + 1);
+    if (t + 1 < ntiles) {
+      qvoff += 2 * qstep32; dovoff += 2 * dostep32;
+      tile_load(qrs, qvoff, qstep32, rq);
+      tile_load(dors, dovoff, dostep32, rdo);
+      const int qn = q0 + 64 + tid;
+      rstat = make_float4(-1.0e30f, -3.0e38f, 0.f, 0.f);
+      if (tid < 64 && qn < nq_) rstat = *reinterpret_cast<const float4*>(rsp + (long)qn * 4);
+    }
 
-    const bool rows_real = reinterpret_cast<const int*>(sQ + OFF_STATE)[0] != 0;
+    const bool rows_real = reinterpret_cast<const int*>(sQ + DKV_STATE)[0] != 0;
     const bool future = CAUSAL && (kmin > q0 + 63 + p.causal_off);     // every (q, k) pair of this tile is causally masked
     const bool edge = CAUSAL && (kmax > q0 + p.causal_off);
     const bool skip = (keys_all_masked || future) && rows_real;
@@ -771,16 +864,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
       // two halves of 32 query rows each (keeps the live score registers at 2x2 fragments)
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh) {
-        // S[q][key] and dP[q][key]:  D[row = q = qb*16 + 4g + r][col = key = kb*16 + li]
-        // score accumulators start at -m[q]/sc2 (row q = 4g + r), see the dQ kernel
+        // S[q][key] and dP[q][key]:  D[row = q = qb*16 + 4g + r][col = key = kb*16 + li]; score accumulators start from bias / scale
         f32x4 st[2][2], dp[2][2];
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-          const float4 mi4 = *reinterpret_cast<const float4*>(ms + (2 * qh + qi) * 16 + 4 * g);
-          const f32x4 init = f32x4{-mi4.x * isc2, -mi4.y * isc2, -mi4.z * isc2, -mi4.w * isc2};
+        for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb) { st[qi][kb] = init; dp[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        }
+          for (int kb = 0; kb < 2; ++kb) {
+            f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (BIAS) {
+              const f32x4 bw = bias_read4(s_bias, CS, kb * 16 + bidx0 - q0 - (2 * qh + qi) * 16);
+              init = f32x4{bw[3], bw[2], bw[1], bw[0]};
+            }
+            st[qi][kb] = init; dp[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -797,51 +893,54 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
           const int qb = 2 * qh + qi;
-          const float4 lv = *reinterpret_cast<const float4*>(ms + 64 + qb * 16 + 4 * g);
-          const float4 dv4 = *reinterpret_cast<const float4*>(ms + 128 + qb * 16 + 4 * g);
-          const float lr[4] = {lv.x, lv.y, lv.z, lv.w}, dr[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
-          uint4 sd4 = make_uint4(0, 0, 0, 0);
-          if (DROP) sd4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(ms) + 192 + qb * 16 + 4 * g);
-          const uint32_t sdr[4] = {sd4.x, sd4.y, sd4.z, sd4.w};
+          const f32x4 nm4 = *reinterpret_cast<const f32x4*>(ms + qb * 16 + 4 * g);          // -(m + log2 l) of rows r = 0..3
+          const f32x4 lv = *reinterpret_cast<const f32x4*>(ms + 64 + qb * 16 + 4 * g);      // exponent of a masked element
+          const f32x4 nd4 = *reinterpret_cast<const f32x4*>(ms + 128 + qb * 16 + 4 * g);    // -delta
+          u32x4 sd4 = u32x4{0u, 0u, 0u, 0u};
+          if (DROP) sd4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(ms) + 192 + qb * 16 + 4 * g);
+          const f32x2 nm01 = {nm4[0], nm4[1]}, nm23 = {nm4[2], nm4[3]}, nd01 = {nd4[0], nd4[1]}, nd23 = {nd4[2], nd4[3]};
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb) {
-            const int kk = wk0 + kb * 16 + li, k = K0 + kk;
-            const uint32_t kc = drop_keyhash((uint32_t)k);
-            // window entries for r = 0..3 sit at decreasing indices i0 - r with i0 = kk + 63 - (qb*16 + 4g)
-            float bwv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (BIAS) {
-              const float4 bw = bias_read4(sQ, kk + 63 - (qb * 16 + 4 * g) - 3);
-              bwv[0] = bw.w; bwv[1] = bw.z; bwv[2] = bw.y; bwv[3] = bw.x;
-            }
-            float x[4];
+            const int k = K0 + wk0 + kb * 16 + li;
+            f32x2 x01, x23;
             if (clean) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) x[r] = fmaf(st[qi][kb][r], sc2, bwv[r]);
+              x01 = pk_fma(f32x2{st[qi][kb][0], st[qi][kb][1]}, sc22, nm01);
+              x23 = pk_fma(f32x2{st[qi][kb][2], st[qi][kb][3]}, sc22, nm23);
             } else {
+              float x[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int q = q0 + qb * 16 + 4 * g + r;
                 uint32_t f = kflag[kb];
                 if (CAUSAL && k > q + p.causal_off) f |= 1u;
-                x[r] = (f & 2u) ? -INFINITY : ((f & 1u) ? lr[r] : fmaf(st[qi][kb][r], sc2, bwv[r]));
+                x[r] = (f & 2u) ? -INFINITY : ((f & 1u) ? lv[r] : fmaf(st[qi][kb][r], sc2, nm4[r]));
               }
+              x01 = f32x2{x[0], x[1]}; x23 = f32x2{x[2], x[3]};
             }
+            const f32x2 p01 = {fast_exp2(x01[0]), fast_exp2(x01[1])}, p23 = {fast_exp2(x23[0]), fast_exp2(x23[1])};   // already divided by l
+            f32x2 pd01 = pk_mul(p01, ik2), pd23 = pk_mul(p23, ik2);
+            if (DROP) {
+              float pdv[4] = {pd01[0], pd01[1], pd23[0], pd23[1]};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float pr = fast_exp2(x[r]);                    // already divided by l
-              float pd = pr;
-              if (DROP) pd = drop_keep(sdr[r], kc, thr) ? pr * p.inv_keep : 0.f;
-              st[qi][kb][r] = fmaf(pd, dp[qi][kb][r], -(pr * dr[r]));   // dS = P * (dP_dropped - delta)
-              dp[qi][kb][r] = pd;
+              for (int r = 0; r < 4; ++r)
+                pdv[r] = ((int32_t)((sd4[r] ^ kc[kb]) * cmul[kb]) >= p.ts32) ? pdv[r] : 0.f;
+              pd01 = f32x2{pdv[0], pdv[1]}; pd23 = f32x2{pdv[2], pdv[3]};
             }
+            // dS = Pd * dP - P * delta
+            const f32x2 s01 = pk_fma(pd01, f32x2{dp[qi][kb][0], dp[qi][kb][1]}, pk_mul(p01, nd01));
+            const f32x2 s23 = pk_fma(pd23, f32x2{dp[qi][kb][2], dp[qi][kb][3]}, pk_mul(p23, nd23));
+            st[qi][kb] = f32x4{s01[0], s01[1], s23[0], s23[1]};
+            dp[qi][kb] = f32x4{pd01[0], pd01[1], pd23[0], pd23[1]};
           }
         }
         // dV^T[d][key] += dO^T[d][q] * Pd[q][key] ; dK^T[d][key] += Q^T[d][q] * dS[q][key]
         bf16x8 pdf[2], dsf[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-          pdf[kb] = pack_frag(dp[0][kb], dp[1][kb]);
-          dsf[kb] = pack_frag(st[0][kb], st[1][kb]);
+          pdf[kb] = __builtin_bit_cast(bf16x8, make_uint4(cvt_pk(dp[0][kb][0], dp[0][kb][1]), cvt_pk(dp[0][kb][2], dp[0][kb][3]),
+                                                           cvt_pk(dp[1][kb][0], dp[1][kb][1]), cvt_pk(dp[1][kb][2], dp[1][kb][3])));
+          dsf[kb] = __builtin_bit_cast(bf16x8, make_uint4(cvt_pk(st[0][kb][0], st[0][kb][1]), cvt_pk(st[0][kb][2], st[0][kb][3]),
+                                                           cvt_pk(st[1][kb][0], st[1][kb][1]), cvt_pk(st[1][kb][2], st[1][kb][3])));
         }
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
@@ -908,9 +1007,14 @@ __global__ __launch_bounds__(256) void bias_bucket_bwd_kernel(const float* __res
 int fill(AttnP& p, const v2s_attn_args* a, const char* who, bool bwd) {
   V2S_CHECK(a != nullptr, V2S_ERR_ARG, "%s: null args", who);
   V2S_CHECK(a->B > 0 && a->H > 0 && a->Nq > 0 && a->Nk > 0, V2S_ERR_SHAPE, "%s: bad shape B=%d H=%d Nq=%d Nk=%d", who, a->B, a->H, a->Nq, a->Nk);
+  V2S_CHECK(a->Nq <= 4096 && a->Nk <= 4096, V2S_ERR_SHAPE, "%s: at most 4096 queries / keys per sequence (Nq=%d Nk=%d)", who, a->Nq, a->Nk);
   V2S_CHECK(((a->q_rs | a->k_rs | a->v_rs | a->o_rs | a->q_bs | a->k_bs | a->v_bs | a->o_bs) % 8) == 0, V2S_ERR_ALIGN, "%s: strides must be multiples of 8 elements", who);
   V2S_CHECK((((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->o) & 15) == 0, V2S_ERR_ALIGN, "%s: pointers must be 16-byte aligned", who);
   V2S_CHECK(a->dropout_p >= 0.f && a->dropout_p < 1.f, V2S_ERR_ARG, "%s: dropout_p out of range", who);
+  V2S_CHECK(a->scale > 0.f, V2S_ERR_ARG, "%s: scale must be positive", who);
+  // the tile loads address rows through 32-bit byte offsets from the first row of a (sequence, head)
+  V2S_CHECK((long)a->Nk * a->k_rs < (1L << 30) && (long)a->Nk * a->v_rs < (1L << 30) && (long)a->Nq * a->q_rs < (1L << 30), V2S_ERR_SHAPE,
+            "%s: rows x row stride must stay below 2^30 elements per sequence", who);
   p.B = a->B; p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk;
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v;
   p.q_bs = a->q_bs; p.q_rs = a->q_rs; p.k_bs = a->k_bs; p.k_rs = a->k_rs; p.v_bs = a->v_bs; p.v_rs = a->v_rs;
@@ -921,7 +1025,13 @@ int fill(AttnP& p, const v2s_attn_args* a, const char* who, bool bwd) {
   p.inv_keep = p.p16 ? 1.0f / (1.0f - (float)p.p16 / 65536.0f) : 1.0f;
   p.seed = a->dropout_seed;
   p.salt = v2s_seed_salt();
-  p.d_o = (const bf16_t*)a->d_o; p.do_bs = a->do_bs; p.do_rs = a->do_rs; p.delta = a->delta;
+  {                                               // thresholds of the 16-bit dropout draws (see drop_* in the kernels)
+    const int ts = (int)p.p16 - 32768;
+    p.tpk = ((uint32_t)ts & 0xFFFFu) * 0x10001u;
+    p.tm1pk = ((uint32_t)(ts - 1) & 0xFFFFu) * 0x10001u;
+    p.ts32 = (int)((uint32_t)ts << 16);
+  }
+  p.d_o = (const bf16_t*)a->d_o; p.do_bs = a->do_bs; p.do_rs = a->do_rs; p.rowstat = a->delta;
   p.dq = (bf16_t*)a->dq; p.dk = (bf16_t*)a->dk; p.dv = (bf16_t*)a->dv;
   p.dq_bs = a->dq_bs; p.dq_rs = a->dq_rs; p.dk_bs = a->dk_bs; p.dk_rs = a->dk_rs; p.dv_bs = a->dv_bs; p.dv_rs = a->dv_rs;
   p.dbias_diag = a->dbias_diag;
@@ -934,31 +1044,56 @@ int fill(AttnP& p, const v2s_attn_args* a, const char* who, bool bwd) {
   if (bwd) {
     V2S_CHECK(a->d_o && a->ml && a->dq && a->dk && a->dv, V2S_ERR_ARG, "%s: backward needs d_o, ml, dq, dk, dv", who);
     V2S_CHECK(((a->do_rs | a->do_bs | a->dq_rs | a->dk_rs | a->dv_rs | a->dq_bs | a->dk_bs | a->dv_bs) % 8) == 0, V2S_ERR_ALIGN, "%s: grad strides must be multiples of 8", who);
+    V2S_CHECK((long)a->Nq * a->do_rs < (1L << 30), V2S_ERR_SHAPE, "%s: rows x row stride must stay below 2^30 elements per sequence", who);
   }
   return V2S_OK;
 }
 
-// compile-time specialisation dispatch: (tr_read, bias, causal, dropout)
-#define V2S_DISPATCH4(KERNEL, tr, bias, causal, drop, ...)                                                    \
+// dynamic LDS of the three kernels (layouts at the kernels)
+size_t lds_fwd(const AttnP& p, bool bias) {
+  const int len64 = (p.Nk + 63) & ~63;
+  return 2 * (size_t)STAGE2 + (bias ? (size_t)4 * bias_cs(len64) * 4 : 0) + len64 + 64;
+}
+size_t lds_dq(const AttnP& p, bool bias) {
+  const int len64 = (p.Nk + 63) & ~63;
+  return 2 * (size_t)STAGE2 + (bias ? (size_t)((p.Nk + 129) & ~1) * 8 + (size_t)4 * bias_cs(len64) * 4 : 0) + len64 + 64;
+}
+size_t lds_dkv(const AttnP& p, bool bias) {
+  const int len64 = (p.Nq + 63) & ~63;
+  return 2 * (size_t)DKV_STAGE + (bias ? (size_t)4 * bias_cs(len64) * 4 : 0);
+}
+
+// compile-time specialisation dispatch: (tr_read, bias, causal, dropout).  Every instantiation may use the whole 160 KiB of LDS
+// (long sequences with a bias window: hipFuncSetAttribute once per instantiation).
+#define V2S_LAUNCH_ATTN(KERNEL, T_, B_, C_, D_, grid, dyn, stream, p)                                                       \
+  do {                                                                                                                      \
+    static bool attr__ = false;                                                                                             \
+    if (!attr__) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)KERNEL<T_, B_, C_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr__ = true;                                                                                                        \
+    }                                                                                                                       \
+    hipLaunchKernelGGL((KERNEL<T_, B_, C_, D_>), grid, dim3(256), dyn, stream, p);                                           \
+  } while (0)
+#define V2S_DISPATCH4(KERNEL, tr, bias, causal, drop, grid, dyn, stream, p)                                   \
   do {                                                                                                        \
     const int key__ = ((tr) ? 8 : 0) | ((bias) ? 4 : 0) | ((causal) ? 2 : 0) | ((drop) ? 1 : 0);              \
     switch (key__) {                                                                                          \
-      case 0: hipLaunchKernelGGL((KERNEL<false, false, false, false>), __VA_ARGS__); break;                   \
-      case 1: hipLaunchKernelGGL((KERNEL<false, false, false, true>), __VA_ARGS__); break;                    \
-      case 2: hipLaunchKernelGGL((KERNEL<false, false, true, false>), __VA_ARGS__); break;                    \
-      case 3: hipLaunchKernelGGL((KERNEL<false, false, true, true>), __VA_ARGS__); break;                     \
-      case 4: hipLaunchKernelGGL((KERNEL<false, true, false, false>), __VA_ARGS__); break;                    \
-      case 5: hipLaunchKernelGGL((KERNEL<false, true, false, true>), __VA_ARGS__); break;                     \
-      case 6: hipLaunchKernelGGL((KERNEL<false, true, true, false>), __VA_ARGS__); break;                     \
-      case 7: hipLaunchKernelGGL((KERNEL<false, true, true, true>), __VA_ARGS__); break;                      \
-      case 8: hipLaunchKernelGGL((KERNEL<true, false, false, false>), __VA_ARGS__); break;                    \
-      case 9: hipLaunchKernelGGL((KERNEL<true, false, false, true>), __VA_ARGS__); break;                     \
-      case 10: hipLaunchKernelGGL((KERNEL<true, false, true, false>), __VA_ARGS__); break;                    \
-      case 11: hipLaunchKernelGGL((KERNEL<true, false, true, true>), __VA_ARGS__); break;                     \
-      case 12: hipLaunchKernelGGL((KERNEL<true, true, false, false>), __VA_ARGS__); break;                    \
-      case 13: hipLaunchKernelGGL((KERNEL<true, true, false, true>), __VA_ARGS__); break;                     \
-      case 14: hipLaunchKernelGGL((KERNEL<true, true, true, false>), __VA_ARGS__); break;                     \
-      default: hipLaunchKernelGGL((KERNEL<true, true, true, true>), __VA_ARGS__); break;                      \
+      case 0: V2S_LAUNCH_ATTN(KERNEL, false, false, false, false, grid, dyn, stream, p); break;               \
+      case 1: V2S_LAUNCH_ATTN(KERNEL, false, false, false, true, grid, dyn, stream, p); break;                \
+      case 2: V2S_LAUNCH_ATTN(KERNEL, false, false, true, false, grid, dyn, stream, p); break;                \
+      case 3: V2S_LAUNCH_ATTN(KERNEL, false, false, true, true, grid, dyn, stream, p); break;                 \
+      case 4: V2S_LAUNCH_ATTN(KERNEL, false, true, false, false, grid, dyn, stream, p); break;                \
+      case 5: V2S_LAUNCH_ATTN(KERNEL, false, true, false, true, grid, dyn, stream, p); break;                 \
+      case 6: V2S_LAUNCH_ATTN(KERNEL, false, true, true, false, grid, dyn, stream, p); break;                 \
+      case 7: V2S_LAUNCH_ATTN(KERNEL, false, true, true, true, grid, dyn, stream, p); break;                  \
+      case 8: V2S_LAUNCH_ATTN(KERNEL, true, false, false, false, grid, dyn, stream, p); break;                \
+      case 9: V2S_LAUNCH_ATTN(KERNEL, true, false, false, true, grid, dyn, stream, p); break;                 \
+      case 10: V2S_LAUNCH_ATTN(KERNEL, true, false, true, false, grid, dyn, stream, p); break;                \
+      case 11: V2S_LAUNCH_ATTN(KERNEL, true, false, true, true, grid, dyn, stream, p); break;                 \
+      case 12: V2S_LAUNCH_ATTN(KERNEL, true, true, false, false, grid, dyn, stream, p); break;                \
+      case 13: V2S_LAUNCH_ATTN(KERNEL, true, true, false, true, grid, dyn, stream, p); break;                 \
+      case 14: V2S_LAUNCH_ATTN(KERNEL, true, true, true, false, grid, dyn, stream, p); break;                 \
+      default: V2S_LAUNCH_ATTN(KERNEL, true, true, true, true, grid, dyn, stream, p); break;                  \
     }                                                                                                         \
   } while (0)
 
@@ -968,8 +1103,10 @@ extern "C" int v2s_attn_fwd(const v2s_attn_args* a, void* stream) {
   AttnP p;
   if (int e = fill(p, a, "v2s_attn_fwd", false)) return e;
   const int grid = ((p.Nq + 127) / 128) * p.H * p.B;
-  V2S_DISPATCH4(attn_fwd_kernel, v2s_opt_tr_read() != 0, p.bias_diag != nullptr, p.causal != 0, p.p16 != 0, dim3(grid), dim3(256), 0,
-                (hipStream_t)stream, p);
+  const bool bias = p.bias_diag != nullptr;
+  const size_t dyn = lds_fwd(p, bias);
+  V2S_CHECK(dyn <= 160 * 1024, V2S_ERR_SHAPE, "v2s_attn_fwd: Nk=%d too large for the LDS bias window", p.Nk);
+  V2S_DISPATCH4(attn_fwd_kernel, v2s_opt_tr_read() != 0, bias, p.causal != 0, p.p16 != 0, dim3(grid), dyn, (hipStream_t)stream, p);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
@@ -987,20 +1124,22 @@ extern "C" int v2s_attn_delta(const v2s_attn_args* a, float* delta, void* stream
 extern "C" int v2s_attn_bwd(const v2s_attn_args* a, void* stream) {
   AttnP p;
   if (int e = fill(p, a, "v2s_attn_bwd", true)) return e;
-  V2S_CHECK(a->delta != nullptr, V2S_ERR_ARG, "v2s_attn_bwd: delta missing (call v2s_attn_delta first)");
+  V2S_CHECK(a->delta != nullptr, V2S_ERR_ARG, "v2s_attn_bwd: the row-statistics workspace `delta` (fp32 [B][H][Nq][4]) is missing");
+  V2S_CHECK(((uintptr_t)a->delta & 15) == 0, V2S_ERR_ALIGN, "v2s_attn_bwd: `delta` must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const bool tr = v2s_opt_tr_read() != 0, bias = p.bias_diag != nullptr, causal = p.causal != 0, drop = p.p16 != 0;
   const int gq = ((p.Nq + 127) / 128) * p.H * p.B;
-  const size_t dyn = 2 * (size_t)STAGE + (size_t)(p.Nk + 128) * 8;
-  V2S_CHECK(dyn <= 64 * 1024, V2S_ERR_SHAPE, "v2s_attn_bwd: Nk=%d too large for the LDS dbias window", p.Nk);
-  const int part = v2s_opt_attn_bwd_part();      // profiling aid: 1 = dQ kernel only, 2 = dK/dV kernel only (0 = both)
+  const size_t dyn_q = lds_dq(p, bias), dyn_kv = lds_dkv(p, bias);
+  V2S_CHECK(dyn_q <= 160 * 1024 && dyn_kv <= 160 * 1024, V2S_ERR_SHAPE, "v2s_attn_bwd: Nq=%d Nk=%d too large for the LDS bias windows", p.Nq, p.Nk);
+  const int part = v2s_opt_attn_bwd_part();      // profiling aid: 1 = dQ kernel only, 2 = dK/dV kernel only (needs the row statistics of an
+                                                 // earlier dQ launch with the same arguments); 0 = both
   if (part != 2) {
-    V2S_DISPATCH4(attn_bwd_dq_kernel, tr, bias, causal, drop, dim3(gq), dim3(256), dyn, s, p);
+    V2S_DISPATCH4(attn_bwd_dq_kernel, tr, bias, causal, drop, dim3(gq), dyn_q, s, p);
     V2S_LAUNCH_CHECK();
   }
   if (part != 1) {
     const int gk = ((p.Nk + 127) / 128) * p.H * p.B;
-    V2S_DISPATCH4(attn_bwd_dkv_kernel, tr, bias, causal, drop, dim3(gk), dim3(256), 0, s, p);
+    V2S_DISPATCH4(attn_bwd_dkv_kernel, tr, bias, causal, drop, dim3(gk), dyn_kv, s, p);
     V2S_LAUNCH_CHECK();
   }
   return V2S_OK;

@@ -179,7 +179,14 @@ __device__ __forceinline__ void epilogue_chunk(const GemmP& p, float (&v)[8], in
     }
   }
   if (p.p16) {
-    v2s_drop8(v, (unsigned long long)(gm + p.row0) * (unsigned long long)p.N + gn, v2s_salted(p.seed, p.salt), p.p16, p.inv_keep);
+    if (p.dact == V2S_ACT_RELU) {
+      // z is the forward's dropout(relu(.)) output: z > 0 <=> the unit was active AND kept, so the select above already applied the
+      // mask and only the 1/(1-p) scale is left -- no need to regenerate the hash (identical result)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= p.inv_keep;
+    } else {
+      v2s_drop8(v, (unsigned long long)(gm + p.row0) * (unsigned long long)p.N + gn, v2s_salted(p.seed, p.salt), p.p16, p.inv_keep);
+    }
   }
   if (p.residual) {
     float rf[8];

@@ -332,7 +332,7 @@ class Engine:
         self._wgrad(df, r.ctx, sa + "o.weight", d, inner, M)
         dctx = self._dgrad(df, a.w(sa + "o.weight"), M, inner, d)
         dqkv = self._bf(M, 3 * inner)
-        delta = self._f32(B, self.H, N)
+        delta = self._f32(B, self.H, N, 4)       # row statistics handed from the dQ to the dK/dV kernel (v2s_attn_bwd workspace)
         st = (N * 3 * inner, 3 * inner)
         self._lut(N, N, r.stack == "encoder")
         L.attn_bwd(r.args, dctx, (N * inner, inner), delta, dqkv, dqkv[:, inner:], dqkv[:, 2 * inner:], st, st, st,
@@ -355,7 +355,7 @@ class Engine:
         dq = self._bf(Mq, inner); dkv = self._bf(Mk, 2 * inner)
         if r.k_real < Mk:
             dkv[r.k_real:].zero_()        # filler rows of a packed memory belong to no sequence: the kernels never write them
-        delta = self._f32(B, self.H, Nq)
+        delta = self._f32(B, self.H, Nq, 4)
         kst = (S * 2 * inner, 2 * inner)
         L.attn_bwd(r.args, dctx, (Nq * inner, inner), delta, dq, dkv, dkv[:, inner:], (Nq * inner, inner), kst, kst)
         self._wgrad(dq, r.n, ca + "q.weight", inner, d, Mq)
@@ -403,6 +403,11 @@ class Engine:
         return dx
 
     def _embed_bwd(self, r, dh):
+        # the LM head's weight-gradient chunks accumulate into the same tensor on the weight-gradient stream (fused head, side_ok): the
+        # non-atomic read-modify-write epilogue of those GEMMs must be complete before the scatter-add touches the rows
+        ev = getattr(self, "_head_wgrad_ev", None)
+        if ev is not None and self.overlap:
+            torch.cuda.current_stream().wait_event(ev)
         L.embed_bwd(r.ids, dh, self.arena.g("t5_model.shared.weight"), r.n, self.d, self.V, r.p, r.seed)
 
     # ========================================================================================== T5 stacks
@@ -474,6 +479,8 @@ class Engine:
         plans = self._ws.setdefault("pack_plans", {})
         plan = plans.get(key)
         if plan is None:
+            if len(plans) >= 24:                          # bounded like _pack_plan's (tapes keep the plans they use alive)
+                plans.clear()
             B = len(lens)
             off = np.zeros(B + 1, dtype=np.int32)
             off[1:] = np.cumsum([T + n for n in lens])
@@ -506,7 +513,9 @@ class Engine:
         key = ("dec", B, Lo, tuple(lens))
         plans = self._ws.setdefault("pack_plans", {})
         plan = plans.get(key)
-        if plan is None:                                # (the cache is only ever emptied by _pack_plan, at the start of a forward)
+        if plan is None:
+            if len(plans) >= 24:                            # bounded: without a text encoder (use_speech=False) _pack_plan never empties it
+                plans.clear()
             ext = list(lens)
             for b in range(B - 1, -1, -1):              # pad positions kept as rows, from the last sequence backwards
                 take = min(fill, Lo - ext[b])
@@ -679,7 +688,7 @@ class Engine:
             L.colsum(df1, M, C, a.g(pre + "attn.proj.bias"))
             self._wgrad(df1, r.ctx, pre + "attn.proj.weight", C, C, M)
             dctx = self._dgrad(df1, a.w(pre + "attn.proj.weight"), M, C, C)
-            dqkv = self._bf(M, 3 * C); delta = self._f32(B, Hh, T)
+            dqkv = self._bf(M, 3 * C); delta = self._f32(B, Hh, T, 4)
             st = (T * 3 * C, 3 * C)
             L.attn_bwd(r.args, dctx, (T * C, C), delta, dqkv, dqkv[:, C:], dqkv[:, 2 * C:], st, st, st)
             L.colsum(dqkv, M, 3 * C, a.g(pre + "attn.qkv.bias"))
@@ -795,12 +804,15 @@ class Engine:
                 L.ce_fwd(lg, self.ldv, labels[r0:r0 + n], n, self.V, m.label_smoothing, row[r0:r0 + n], acc[0:1], acc[1:2])
                 dlog = self._bf(n, self.ldv)                      # fresh per chunk: the weight-gradient stream may still read the previous one
                 L.ce_bwd(lg, self.ldv, labels[r0:r0 + n], row[r0:r0 + n], n, self.V, m.label_smoothing, gscale, dlog, self.ldv)
-                # embedding weight gradient on the weight-gradient stream (the scatter-adds into the same tensor run at the very end of
-                # backward, after join_wgrads); d(hidden): contraction over the padded vocabulary (zero pad columns x zero pad rows), few
+                # embedding weight gradient on the weight-gradient stream (the scatter-adds into the same tensor wait for the event
+                # recorded after the last chunk, see _embed_bwd); d(hidden): contraction over the padded vocabulary (zero pad columns x zero pad rows), few
                 # output tiles -> fp32 split-K, then one rounding to bf16
                 self._wgrad(dlog, hs[r0:r0 + n], "t5_model.shared.weight", self.V, self.d, n, ld_dy=self.ldv, alpha=alpha, side_ok=True)
                 L.gemm(dlog, Epad, dh32[:n], n, self.d, self.ldv, transB=True, lda=self.ldv, ldb=self.d, alpha=alpha, workspace=self._head_ws())
                 L.cast_bf16(dh32[:n].view(-1), dhs[r0:r0 + n].view(-1), n * self.d)
+            if self.overlap:                                      # _embed_bwd waits for this before its scatter-add into the same tensor
+                self._head_wgrad_ev = torch.cuda.Event()
+                self._head_wgrad_ev.record(self.wstream)
         else:
             logits = self._f32(Md, self.ldv)
             L.gemm(hs, E, logits, Md, self.V, self.d, ldc=self.ldv, alpha=alpha)

@@ -58,7 +58,7 @@ class DecodeAttnArgs(C.Structure):
                 ("kv_group", _i32), ("new_k", _vp), ("new_v", _vp), ("new_bs", _i64), ("row_map", _vp), ("row_map_ld", _i64)]
 
 
-#: every symbol include/vid2seq_hip.h declares (checked by tests/test_abi.py)
+#: every symbol include/vid2seq_hip.h declares (checked by tests/test_oracle_cpu.py::test_c_abi_exports_every_declared_symbol)
 SYMBOLS = {
     "v2s_version": (C.c_int, []),
     "v2s_last_error": (C.c_char_p, []),
@@ -314,12 +314,14 @@ def attn_fwd(a: AttnArgs) -> None:
 
 def attn_bwd(a: AttnArgs, d_o, do_st, delta, dq, dk, dv, dq_st, dk_st, dv_st, dbias_diag=None, far=(0, 0)) -> None:
     a.d_o = d_o.data_ptr(); a.do_bs, a.do_rs = do_st
+    _need(delta, torch.float32, "attn_bwd row-statistics workspace (delta)")
+    if delta.numel() < a.B * a.H * a.Nq * 4:
+        raise ValueError(f"attn_bwd: `delta` is the fp32 [B, H, Nq, 4] row-statistics workspace of v2s_attn_bwd ({a.B * a.H * a.Nq * 4} floats), got {delta.numel()}")
     a.delta = delta.data_ptr()
     a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     a.dq_bs, a.dq_rs = dq_st; a.dk_bs, a.dk_rs = dk_st; a.dv_bs, a.dv_rs = dv_st
     a.dbias_diag = ptr(dbias_diag)
     a.bias_far_lo, a.bias_far_hi = far
-    _check(lib().v2s_attn_delta(C.byref(a), delta.data_ptr(), stream_ptr()), "v2s_attn_delta")
     kt = KernelTimer.active
     if kt is not None and kt.by_symbol:          # time the two kernels of the call separately, tagged with their symbols
         flags = ", ".join("true" if f else "false" for f in (get_option("tr_read") != 0, bool(a.bias_diag), bool(a.causal), a.dropout_p > 0))

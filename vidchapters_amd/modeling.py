@@ -229,7 +229,7 @@ class Vid2Seq(nn.Module):
 
     def reference_init(self) -> None:
         """The initialisation the reference's constructor leaves behind for everything that does not come from the T5 checkpoint:
-        ViT (vit.py:101-115: xavier_uniform linears, zero biases, LayerNorm 1 / 0, trunc_normal(0.02) pos_embed), proj_v2t
+        ViT (vit.py:101-115: xavier_uniform linears, biases N(0, 1e-6), LayerNorm 1 / 0, trunc_normal(0.02) pos_embed), proj_v2t
         (nn.Linear default), and for the T5 holder HF's ``_init_weights`` laws (embedding N(0, 1): the law the ``num_bins`` time-token
         rows keep after ``resize_token_embeddings``, vid2seq.py:39-40; norms 1) until a checkpoint overwrites the text rows."""
         c = self.cfg
@@ -241,7 +241,7 @@ class Vid2Seq(nn.Module):
                     elif ".norm" in name or name.startswith("visual_encoder.norm."):
                         p.fill_(1.0 if name.endswith("weight") else 0.0)
                     elif name.endswith(".bias"):
-                        p.zero_()
+                        nn.init.normal_(p, std=1e-6)      # vit.py:104-108
                     else:
                         nn.init.xavier_uniform_(p)
                 elif name.startswith("proj_v2t."):

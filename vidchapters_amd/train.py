@@ -293,7 +293,8 @@ class Trainer:
         """:meth:`step` replayed from a hipGraph: the ~2500 launches of a step (all three streams) are captured once and the host then
         enqueues a step with ONE graph launch plus the input copies (host time per step: ~20 ms of Python / ctypes -> well under 1 ms).
         Everything that changes from step to step lives in device memory the captured kernels read:
-          * the batch: static buffers, refilled by copy before each replay (shapes must not change; a new shape re-captures);
+          * the batch: static buffers, refilled by copy before each replay (a new shape runs one eager step and re-captures on the
+            call after it; callers that pass PINNED host tensors must not rewrite them before the step has consumed them);
           * dropout: the by-value seeds of the captured launches are XOR-ed with a device salt word that is rewritten every step
             (v2s_set_seed_salt), so every replay draws new masks;
           * Adam: lr and the two bias corrections come from a device pair (v2s_adam_args.hyper_dev), computed on the host per step
@@ -307,38 +308,44 @@ class Trainer:
         tensors = {k: v for k, v in batch.items() if torch.is_tensor(v)}
         key = tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in tensors.items()))
         st = getattr(self, "_g", None)
-        if st is None:                                 # first call: an ordinary eager step (creates LUTs, workspaces, kernel attributes)
+        if st is None or st["key"] != key:
+            # first call, or new shapes: an ordinary eager step first (it creates the LUTs, workspaces and kernel attributes of these
+            # shapes -- host-to-device copies are illegal inside a capture); the next call captures
             self._g = {"key": key, "graph": None}
+            pack = eng.pack
             eng.pack = False
-            return self.step(tensors)
-        if st["key"] != key:                           # new shapes: capture again
-            self._g = st = {"key": key, "graph": None}
+            try:
+                return self.step(tensors)
+            finally:
+                eng.pack = pack                        # eager steps of the caller keep their padding-free setting
         if st["graph"] is None:
-            eng.pack = False
             dev = eng.device
             st["batch"] = {k: torch.empty_like(v) for k, v in tensors.items()}
             for k, v in tensors.items():
                 st["batch"][k].copy_(v)
             st["salt"] = torch.zeros(1, dtype=torch.int32, device=dev)
             st["hyper"] = torch.zeros(2, dtype=torch.float32, device=dev)
-            st["hyper_host"] = torch.zeros(2, dtype=torch.float32).pin_memory()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             L.set_seed_salt(st["salt"])
+            pack = eng.pack
+            eng.pack = False
             try:
                 with torch.cuda.graph(g):
                     st["losses"] = self._step_impl(st["batch"], hyper_dev=st["hyper"])
             finally:
                 L.set_seed_salt(None)
+                eng.pack = pack
             st["graph"] = g
         for k, v in tensors.items():
             st["batch"][k].copy_(v, non_blocking=True)
         self.step_count += 1
         k = self.step_count
         lr = self._lr_of_step(k - 1)
-        st["hyper_host"][0] = lr / (1.0 - self.betas[0] ** k)
-        st["hyper_host"][1] = 1.0 / math.sqrt(1.0 - self.betas[1] ** k)
-        st["hyper"].copy_(st["hyper_host"], non_blocking=True)
+        # by-value fills (the scalars travel as kernel arguments): a pinned staging buffer reused every step could be rewritten by the
+        # host for step k+1 before the queued copy of step k has run -- the host is many steps ahead of the device here
+        st["hyper"][0:1].fill_(lr / (1.0 - self.betas[0] ** k))
+        st["hyper"][1:2].fill_(1.0 / math.sqrt(1.0 - self.betas[1] ** k))
         seed0, _ = eng.rng_state()
         salt = ((seed0 ^ (k * 0x9E3779B1)) * 0x85EBCA6B) & 0x7FFFFFFF
         st["salt"].fill_(salt)
