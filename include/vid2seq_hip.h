@@ -143,6 +143,14 @@ int v2s_layernorm_fwd(const void* x, const float* w, const float* b, void* y, fl
                       int32_t rows, int32_t cols, float eps, void* stream);
 int v2s_layernorm_bwd(const void* x, const float* w, const float* mean, const float* rstd, const void* dy,
                       void* dx, const void* dx_add, float* dw, float* db, int32_t rows, int32_t cols, void* stream);
+/* The same backward with a second output dx_drop = dropout(dx; dropout_p, dropout_seed) (bf16 [rows][cols], mask and values identical to
+ * v2s_dropout on the stored dx): the gradient operand of the sublayer the backward pass visits next, whose forward dropped its
+ * output before the residual add (modeling_t5.py:618,654,353; vit.py:54,21) -- saves re-reading the residual-stream gradient */
+int v2s_rmsnorm_bwd_drop(const void* x, const float* w, const float* rstd, const void* dy, void* dx, const void* dx_add,
+                         float* dw, int32_t rows, int32_t cols, void* dx_drop, float dropout_p, uint32_t dropout_seed, void* stream);
+int v2s_layernorm_bwd_drop(const void* x, const float* w, const float* mean, const float* rstd, const void* dy, void* dx,
+                           const void* dx_add, float* dw, float* db, int32_t rows, int32_t cols, void* dx_drop, float dropout_p,
+                           uint32_t dropout_seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention (flash-style, scores never materialised)

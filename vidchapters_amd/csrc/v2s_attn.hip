@@ -156,6 +156,25 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
   return d;
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; x <= ~0 here
+// hipcc does not pad hardware hazards around inline asm (cdna_hip_programming.md 5.7):
+//   * a v_exp_f32 result needs one wait state before a non-transcendental VALU reads it -> the packed ops whose operands may come
+//     straight from fast_exp2 start with s_nop 0 (the *_t variants);
+//   * an MFMA result must not be read by an asm statement before the matrix pipe has written it back (up to 18 wait states after
+//     the issue of an 8-pass MFMA).  mfma_settle() sits between a group of MFMAs and the first asm reader of their accumulators: the
+//     "+v" operands order it after every MFMA of the group and before every reader, the nops inside cover the write-back.
+__device__ __forceinline__ f32x2 pk_add_t(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("s_nop 0\n\tv_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ f32x2 pk_mul_t(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ void mfma_settle(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4, f32x4& a5, f32x4& a6, f32x4& a7) {
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+}
 
 // ---- attention-probability dropout ------------------------------------------------------------------------
 // One 32-bit hash serves the key pair (2j, 2j+1) of a row:
@@ -339,6 +358,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
           for (int qb = 0; qb < 2; ++qb) st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], st[qb][kb], 0, 0, 0);
         }
 
+      mfma_settle(st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1], st[1][2], st[1][3]);
       bf16x8 pf[2][2];
       const bool clean = !any_flag && !edge;
       // clean tiles keep the raw accumulators (x = acc * sc2 - m in one packed fma); tiles with masked elements go through the scaled
@@ -389,8 +409,8 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
           const f32x2 x01 = pk_fma(f32x2{st[qb][kb][0], st[qb][kb][1]}, mult2, nmn2);
           const f32x2 x23 = pk_fma(f32x2{st[qb][kb][2], st[qb][kb][3]}, mult2, nmn2);
           const f32x2 p01 = {fast_exp2(x01[0]), fast_exp2(x01[1])}, p23 = {fast_exp2(x23[0]), fast_exp2(x23[1])};
-          rs2 = pk_add(rs2, p01);
-          rs2 = pk_add(rs2, p23);
+          rs2 = pk_add_t(rs2, p01);
+          rs2 = pk_add_t(rs2, p23);
           pw[kb][0] = cvt_pk(p01[0], p01[1]);
           pw[kb][1] = cvt_pk(p23[0], p23[1]);
           if (DROP) {                                       // 1/(1-p) is applied once, to the output row
@@ -400,12 +420,8 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
         }
         lsum[qb] = lsum[qb] * alpha + (rs2[0] + rs2[1]);
         if (__any(alpha != 1.0f)) {                         // some row maximum of this wave moved: rescale the output accumulators
-          const f32x2 a2 = {alpha, alpha};
 #pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            const f32x2 lo = pk_mul(f32x2{ot[qb][db][0], ot[qb][db][1]}, a2), hi = pk_mul(f32x2{ot[qb][db][2], ot[qb][db][3]}, a2);
-            ot[qb][db] = f32x4{lo[0], lo[1], hi[0], hi[1]};
-          }
+          for (int db = 0; db < 4; ++db) ot[qb][db] *= alpha;      // plain C (compiles to v_pk_mul_f32): these are MFMA accumulators
         }
         pf[qb][0] = __builtin_bit_cast(bf16x8, make_uint4(pw[0][0], pw[0][1], pw[1][0], pw[1][1]));
         pf[qb][1] = __builtin_bit_cast(bf16x8, make_uint4(pw[2][0], pw[2][1], pw[3][0], pw[3][1]));
@@ -629,6 +645,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
             dp[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qb][ks], dp[qb][kb], 0, 0, 0);
           }
         }
+      mfma_settle(st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1], st[1][2], st[1][3]);
+      mfma_settle(dp[0][0], dp[0][1], dp[0][2], dp[0][3], dp[1][0], dp[1][1], dp[1][2], dp[1][3]);
       const bool clean = !any_flag && !edge;
       // bias-gradient routing: relative positions d = k - q of a 16x16 block (qb, kb) span a 31-wide range; blocks entirely in
       // a far bucket just sum their dS (1: far-low, 2: far-high), only the near-diagonal blocks (3) resolve diagonals.  Most
@@ -671,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
             drop_dropmask32(rseed ^ ((uint32_t)(kb * 8 + 1) * DROP_C1), p.tpk, mlo, mhi);
             d23 = f32x2{clear_if(mlo, d23[0]), clear_if(mhi, d23[1])};
           }
-          const f32x2 s01 = pk_mul(p01, pk_fma(d01, ik2, ndl2)), s23 = pk_mul(p23, pk_fma(d23, ik2, ndl2));   // dS = P * (dP/(1-p) - delta)
+          const f32x2 s01 = pk_mul_t(p01, pk_fma(d01, ik2, ndl2)), s23 = pk_mul_t(p23, pk_fma(d23, ik2, ndl2));   // dS = P * (dP/(1-p) - delta)
           if (BIAS && route != 0) {      // route is wave-uniform: one scalar branch per 16x16 block, none per element
             if (route == 3) {            // near-diagonal block: every element goes to its own diagonal of the window
               const float dsv[4] = {s01[0], s01[1], s23[0], s23[1]};
@@ -889,6 +907,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
               dp[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[kb][ks], dp[qi][kb], 0, 0, 0);
             }
           }
+        mfma_settle(st[0][0], st[0][1], st[1][0], st[1][1], dp[0][0], dp[0][1], dp[1][0], dp[1][1]);
         // P (dropped) -> dp registers become Pd ; st registers become dS
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
@@ -918,7 +937,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
               x01 = f32x2{x[0], x[1]}; x23 = f32x2{x[2], x[3]};
             }
             const f32x2 p01 = {fast_exp2(x01[0]), fast_exp2(x01[1])}, p23 = {fast_exp2(x23[0]), fast_exp2(x23[1])};   // already divided by l
-            f32x2 pd01 = pk_mul(p01, ik2), pd23 = pk_mul(p23, ik2);
+            f32x2 pd01 = pk_mul_t(p01, ik2), pd23 = pk_mul_t(p23, ik2);
             if (DROP) {
               float pdv[4] = {pd01[0], pd01[1], pd23[0], pd23[1]};
 #pragma unroll
@@ -927,8 +946,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
               pd01 = f32x2{pdv[0], pdv[1]}; pd23 = f32x2{pdv[2], pdv[3]};
             }
             // dS = Pd * dP - P * delta
-            const f32x2 s01 = pk_fma(pd01, f32x2{dp[qi][kb][0], dp[qi][kb][1]}, pk_mul(p01, nd01));
-            const f32x2 s23 = pk_fma(pd23, f32x2{dp[qi][kb][2], dp[qi][kb][3]}, pk_mul(p23, nd23));
+            const f32x2 s01 = pk_fma(pd01, f32x2{dp[qi][kb][0], dp[qi][kb][1]}, pk_mul_t(p01, nd01));
+            const f32x2 s23 = pk_fma(pd23, f32x2{dp[qi][kb][2], dp[qi][kb][3]}, pk_mul_t(p23, nd23));
             st[qi][kb] = f32x4{s01[0], s01[1], s23[0], s23[1]};
             dp[qi][kb] = f32x4{pd01[0], pd01[1], pd23[0], pd23[1]};
           }

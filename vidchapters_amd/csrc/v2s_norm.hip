@@ -3,7 +3,10 @@
 //   RMSNorm  : model/modeling_t5.py:263-277 (T5LayerNorm.forward)
 //   LayerNorm: torch nn.LayerNorm as used at model/vit.py:64,69,99 (eps 1e-5, affine)
 // Backward produces dx (+ fused residual-gradient add); dw/db are reduced per wave in registers, per block in LDS and
-// added to the caller's fp32 gradient with one hardware float atomic per column per block.
+// added to the caller's fp32 gradient with one hardware float atomic per column per block.  Optionally it also writes
+// dropout(dx) -- the operand the NEXT sublayer of the backward pass starts from (the reference drops the sublayer output before the
+// residual add, modeling_t5.py:618,654,353; vit.py:54,21) -- so that the residual-stream gradient is not re-read by a separate
+// elementwise launch: same mask and bit-identical values as v2s_dropout applied to the stored dx.
 #include "v2s_common.h"
 
 namespace {
@@ -79,7 +82,8 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
                                                        const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                        const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
                                                        const bf16_t* __restrict__ dx_add, float* __restrict__ dw_out,
-                                                       float* __restrict__ db_out, int rows, int cols) {
+                                                       float* __restrict__ db_out, int rows, int cols, bf16_t* __restrict__ dx_drop,
+                                                       uint32_t p16, float inv_keep, uint32_t seed, const uint32_t* __restrict__ salt) {
   __shared__ float red[4][NCH * 512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = cols >> 3;
@@ -148,7 +152,14 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] += a[j];
         }
-        *reinterpret_cast<uint4*>(dx + (long)row * cols + c * 8) = pack8(o);
+        const uint4 pk = pack8(o);
+        *reinterpret_cast<uint4*>(dx + (long)row * cols + c * 8) = pk;
+        if (dx_drop) {                      // dropout of the ROUNDED value: identical to v2s_dropout(dx)
+          float r[8];
+          unpack8(pk, r);
+          v2s_drop8(r, (unsigned long long)row * (unsigned long long)cols + (unsigned long long)(c * 8), v2s_salted(seed, salt), p16, inv_keep);
+          *reinterpret_cast<uint4*>(dx_drop + (long)row * cols + c * 8) = pack8(r);
+        }
       }
     }
   }
@@ -199,32 +210,49 @@ extern "C" int v2s_layernorm_fwd(const void* x, const float* w, const float* b, 
   return V2S_OK;
 }
 
-extern "C" int v2s_rmsnorm_bwd(const void* x, const float* w, const float* rstd, const void* dy, void* dx,
-                               const void* dx_add, float* dw, int32_t rows, int32_t cols, void* stream) {
-  if (int e = check_shape("v2s_rmsnorm_bwd", rows, cols)) return e;
+// shared launcher of the four backward entry points
+template <bool LN>
+static int norm_bwd_launch(const char* who, const void* x, const float* w, const float* mean, const float* rstd, const void* dy, void* dx,
+                           const void* dx_add, float* dw, float* db, int32_t rows, int32_t cols, void* dx_drop, float dropout_p,
+                           uint32_t dropout_seed, void* stream) {
+  if (int e = check_shape(who, rows, cols)) return e;
+  V2S_CHECK(dropout_p >= 0.f && dropout_p < 1.f, V2S_ERR_ARG, "%s: dropout_p out of range", who);
   const int nb = bwd_blocks(rows);
   hipStream_t s = (hipStream_t)stream;
+  const uint32_t p16 = (uint32_t)(dropout_p * 65536.0f + 0.5f);
+  const float inv_keep = p16 ? 1.0f / (1.0f - (float)p16 / 65536.0f) : 1.0f;
+  bf16_t* dd = (dx_drop && p16) ? (bf16_t*)dx_drop : nullptr;
+  V2S_CHECK(!(dx_drop && !p16), V2S_ERR_ARG, "%s: dx_drop needs dropout_p > 0", who);
   if (cols <= 1024)
-    hipLaunchKernelGGL((norm_bwd_kernel<false, 2>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, (const float*)nullptr, rstd,
-                       (const bf16_t*)dy, (bf16_t*)dx, (const bf16_t*)dx_add, dw, (float*)nullptr, rows, cols);
+    hipLaunchKernelGGL((norm_bwd_kernel<LN, 2>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy, (bf16_t*)dx,
+                       (const bf16_t*)dx_add, dw, db, rows, cols, dd, p16, inv_keep, dropout_seed, v2s_seed_salt());
   else
-    hipLaunchKernelGGL((norm_bwd_kernel<false, 4>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, (const float*)nullptr, rstd,
-                       (const bf16_t*)dy, (bf16_t*)dx, (const bf16_t*)dx_add, dw, (float*)nullptr, rows, cols);
+    hipLaunchKernelGGL((norm_bwd_kernel<LN, 4>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy, (bf16_t*)dx,
+                       (const bf16_t*)dx_add, dw, db, rows, cols, dd, p16, inv_keep, dropout_seed, v2s_seed_salt());
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
 
+extern "C" int v2s_rmsnorm_bwd(const void* x, const float* w, const float* rstd, const void* dy, void* dx,
+                               const void* dx_add, float* dw, int32_t rows, int32_t cols, void* stream) {
+  return norm_bwd_launch<false>("v2s_rmsnorm_bwd", x, w, nullptr, rstd, dy, dx, dx_add, dw, nullptr, rows, cols, nullptr, 0.f, 0u, stream);
+}
+
 extern "C" int v2s_layernorm_bwd(const void* x, const float* w, const float* mean, const float* rstd, const void* dy,
                                  void* dx, const void* dx_add, float* dw, float* db, int32_t rows, int32_t cols, void* stream) {
-  if (int e = check_shape("v2s_layernorm_bwd", rows, cols)) return e;
-  const int nb = bwd_blocks(rows);
-  hipStream_t s = (hipStream_t)stream;
-  if (cols <= 1024)
-    hipLaunchKernelGGL((norm_bwd_kernel<true, 2>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy,
-                       (bf16_t*)dx, (const bf16_t*)dx_add, dw, db, rows, cols);
-  else
-    hipLaunchKernelGGL((norm_bwd_kernel<true, 4>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy,
-                       (bf16_t*)dx, (const bf16_t*)dx_add, dw, db, rows, cols);
-  V2S_LAUNCH_CHECK();
-  return V2S_OK;
+  return norm_bwd_launch<true>("v2s_layernorm_bwd", x, w, mean, rstd, dy, dx, dx_add, dw, db, rows, cols, nullptr, 0.f, 0u, stream);
+}
+
+extern "C" int v2s_rmsnorm_bwd_drop(const void* x, const float* w, const float* rstd, const void* dy, void* dx, const void* dx_add,
+                                    float* dw, int32_t rows, int32_t cols, void* dx_drop, float dropout_p, uint32_t dropout_seed,
+                                    void* stream) {
+  return norm_bwd_launch<false>("v2s_rmsnorm_bwd_drop", x, w, nullptr, rstd, dy, dx, dx_add, dw, nullptr, rows, cols, dx_drop, dropout_p,
+                                dropout_seed, stream);
+}
+
+extern "C" int v2s_layernorm_bwd_drop(const void* x, const float* w, const float* mean, const float* rstd, const void* dy, void* dx,
+                                      const void* dx_add, float* dw, float* db, int32_t rows, int32_t cols, void* dx_drop,
+                                      float dropout_p, uint32_t dropout_seed, void* stream) {
+  return norm_bwd_launch<true>("v2s_layernorm_bwd_drop", x, w, mean, rstd, dy, dx, dx_add, dw, db, rows, cols, dx_drop, dropout_p,
+                               dropout_seed, stream);
 }

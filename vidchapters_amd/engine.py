@@ -324,11 +324,25 @@ class Engine:
         return out
 
     # ========================================================================================== T5 sublayers (backward)
-    def _self_attn_bwd(self, r, dh, dbias_diag):
+    def _norm_bwd_next(self, x, wname, rstd, dn, dh, rows, nxt):
+        """RMSNorm backward of a sublayer + the residual-gradient add.  ``nxt`` = (p, seed) of the sublayer the backward pass visits
+        next: its input gradient dropout(dx) is produced by the same launch (second output) instead of a separate elementwise pass over
+        the residual-stream gradient.  Returns (dx, dropout(dx) or None)."""
+        a = self.arena
+        dx = self._bf(rows, self.d)
+        dxd = self._bf(rows, self.d) if (nxt is not None and nxt[0] > 0.0) else None
+        if dxd is not None:
+            L.rmsnorm_bwd(x, a.f(wname), rstd, dn, dx, dh, a.g(wname), rows, self.d, dx_drop=dxd, dropout_p=nxt[0], dropout_seed=nxt[1])
+        else:
+            L.rmsnorm_bwd(x, a.f(wname), rstd, dn, dx, dh, a.g(wname), rows, self.d)
+        return dx, dxd
+
+    def _self_attn_bwd(self, r, dh, dbias_diag, df=None, nxt=None):
         a = self.arena
         B, N, M, d, inner = r.B, r.N, r.M, self.d, self.inner
         sa = self._sa(r.stack, r.i)
-        df = self._drop(dh, r.p, r.seed_o)
+        if df is None:
+            df = self._drop(dh, r.p, r.seed_o)
         self._wgrad(df, r.ctx, sa + "o.weight", d, inner, M)
         dctx = self._dgrad(df, a.w(sa + "o.weight"), M, inner, d)
         dqkv = self._bf(M, 3 * inner)
@@ -339,17 +353,15 @@ class Engine:
                    dbias_diag=dbias_diag, far=self._far[(N, N, r.stack == "encoder")])
         self._wgrad(dqkv, r.n, sa + "q.weight", 3 * inner, d, M, shape=(3 * inner, d))
         dn = self._dgrad(dqkv, a.w(sa + "q.weight", (3 * inner, d)), M, d, 3 * inner)
-        dx = self._bf(M, d)
-        ln = self._ln(r.stack, r.i, 0)
-        L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), M, d)
-        return dx
+        return self._norm_bwd_next(r.h, self._ln(r.stack, r.i, 0), r.rstd, dn, dh, M, nxt)
 
-    def _cross_attn_bwd(self, r, dh, dmem, first: bool):
+    def _cross_attn_bwd(self, r, dh, dmem, first: bool, df=None, nxt=None):
         a = self.arena
         B, Nq, S, d, inner = r.B, r.Nq, r.S, self.d, self.inner
         Mq, Mk = r.Mq, r.Mk
         ca = self._ca(r.i)
-        df = self._drop(dh, r.p, r.seed_o)
+        if df is None:
+            df = self._drop(dh, r.p, r.seed_o)
         self._wgrad(df, r.ctx, ca + "o.weight", d, inner, Mq)
         dctx = self._dgrad(df, a.w(ca + "o.weight"), Mq, inner, d)
         dq = self._bf(Mq, inner); dkv = self._bf(Mk, 2 * inner)
@@ -375,32 +387,23 @@ class Engine:
         else:
             self._dgrad(dkv, a.w(ca + "k.weight", (2 * inner, d)), Mk, d, 2 * inner, out=dmem,
                         **({} if first else dict(residual=dmem)))
-        dx = self._bf(Mq, d)
-        ln = self._ln("decoder", r.i, 1)
-        L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), Mq, d)
-        return dx
+        return self._norm_bwd_next(r.h, self._ln("decoder", r.i, 1), r.rstd, dn, dh, Mq, nxt)
 
-    def _ffn_bwd(self, r, dh):
+    def _ffn_bwd(self, r, dh, df=None, nxt=None):
         a = self.arena
         M, d, ff = r.M, self.d, self.ff
         fp = self._ffp(r.stack, r.i)
-        df = self._drop(dh, r.p, r.seed_o)
+        if df is None:
+            df = self._drop(dh, r.p, r.seed_o)
         self._wgrad(df, r.u, fp + "wo.weight", d, ff, M)
         du = self._dgrad(df, a.w(fp + "wo.weight"), M, ff, d, dact=L.ACT_RELU, z=r.u, dropout_p=r.p, dropout_seed=r.seed_u)
         self._wgrad(du, r.n, fp + "wi.weight", ff, d, M)
         dn = self._dgrad(du, a.w(fp + "wi.weight"), M, d, ff)
-        dx = self._bf(M, d)
-        ln = self._ln(r.stack, r.i, 2 if r.stack == "decoder" else 1)
-        L.rmsnorm_bwd(r.h, a.f(ln), r.rstd, dn, dx, dh, a.g(ln), M, d)
-        return dx
+        return self._norm_bwd_next(r.h, self._ln(r.stack, r.i, 2 if r.stack == "decoder" else 1), r.rstd, dn, dh, M, nxt)
 
-    def _final_norm_bwd(self, r, dout):
-        a = self.arena
-        name = f"t5_model.{r.stack}.final_layer_norm.weight"
+    def _final_norm_bwd(self, r, dout, nxt=None):
         dn = self._drop(dout, r.p, r.seed)
-        dx = self._bf(r.M, self.d)
-        L.rmsnorm_bwd(r.h, a.f(name), r.rstd, dn, dx, None, a.g(name), r.M, self.d)
-        return dx
+        return self._norm_bwd_next(r.h, f"t5_model.{r.stack}.final_layer_norm.weight", r.rstd, dn, None, r.M, nxt)
 
     def _embed_bwd(self, r, dh):
         # the LM head's weight-gradient chunks accumulate into the same tensor on the weight-gradient stream (fused head, side_ok): the
@@ -579,18 +582,23 @@ class Engine:
         a = self.arena
         lut = self._lut(nq, nq, stack == "encoder")
         ddiag = torch.zeros(self.H, 2 * nq - 1, dtype=torch.float32, device=self.device)
-        dh = dout
+        dh, df = dout, None
         first_cross = True
-        for r in reversed(tape):
+        recs = list(reversed(tape))
+        for idx, r in enumerate(recs):
+            # (p, seed) of the output dropout of the sublayer visited next: its gradient operand dropout(dh) comes out of this
+            # sublayer's norm backward (second output)
+            nr = recs[idx + 1] if idx + 1 < len(recs) else None
+            nxt = (nr.p, nr.seed_o) if (nr is not None and nr.kind in ("ffn", "cross", "self")) else None
             if r.kind == "final":
-                dh = self._final_norm_bwd(r, dh)
+                dh, df = self._final_norm_bwd(r, dh, nxt)
             elif r.kind == "ffn":
-                dh = self._ffn_bwd(r, dh)
+                dh, df = self._ffn_bwd(r, dh, df, nxt)
             elif r.kind == "cross":
-                dh = self._cross_attn_bwd(r, dh, dmem, first_cross)
+                dh, df = self._cross_attn_bwd(r, dh, dmem, first_cross, df, nxt)
                 first_cross = False
             elif r.kind == "self":
-                dh = self._self_attn_bwd(r, dh, ddiag)
+                dh, df = self._self_attn_bwd(r, dh, ddiag, df, nxt)
                 if layer_done is not None:        # all parameter gradients of block r.i are enqueued (except block 0's bias table)
                     layer_done(r.i)
             elif r.kind == "embed":
@@ -668,12 +676,20 @@ class Engine:
             L.colsum(dvis, M, self.d, a.g("proj_v2t.bias"))
             self._wgrad(dvis, tape["normed"], "proj_v2t.weight", self.d, C, M)
             dvis = self._dgrad(dvis, a.w("proj_v2t.weight"), M, C, self.d)
-        dx = self._bf(M, C)
-        L.layernorm_bwd(tape["xf"], a.f("visual_encoder.norm.weight"), tape["meanf"], tape["rstdf"], dvis, dx, None,
-                        a.g("visual_encoder.norm.weight"), a.g("visual_encoder.norm.bias"), M, C)
-        for r in reversed(tape["recs"]):
+        recs = list(reversed(tape["recs"]))
+
+        def ln_bwd(x, pre_norm, mean, rstd, dn, dres, nxt_seed):
+            """LayerNorm backward (+ residual-gradient add) with dropout(dx) for the next consumer as a second output"""
+            dx_ = self._bf(M, C)
+            dxd = self._bf(M, C) if p > 0.0 else None
+            kw = dict(dx_drop=dxd, dropout_p=p, dropout_seed=nxt_seed) if dxd is not None else {}
+            L.layernorm_bwd(x, a.f(pre_norm + "weight"), mean, rstd, dn, dx_, dres, a.g(pre_norm + "weight"), a.g(pre_norm + "bias"), M, C, **kw)
+            return dx_, (dxd if dxd is not None else dx_)
+
+        first_seed = recs[0].seed_2 if recs else tape["seed0"]
+        dx, df2 = ln_bwd(tape["xf"], "visual_encoder.norm.", tape["meanf"], tape["rstdf"], dvis, None, first_seed)
+        for idx, r in enumerate(recs):
             pre = r.pre
-            df2 = self._drop(dx, p, r.seed_2)
             L.colsum(df2, M, C, a.g(pre + "mlp.fc2.bias"))
             self._wgrad(df2, r.u, pre + "mlp.fc2.weight", C, mlp, M)
             du = self._dgrad(df2, a.w(pre + "mlp.fc2.weight"), M, mlp, C, dact=L.ACT_GELU, z=r.upre, dropout_p=p,
@@ -681,10 +697,7 @@ class Engine:
             L.colsum(du, M, mlp, a.g(pre + "mlp.fc1.bias"))
             self._wgrad(du, r.n2, pre + "mlp.fc1.weight", mlp, C, M)
             dn2 = self._dgrad(du, a.w(pre + "mlp.fc1.weight"), M, C, mlp)
-            dx1 = self._bf(M, C)
-            L.layernorm_bwd(r.x1, a.f(pre + "norm2.weight"), r.mean2, r.rstd2, dn2, dx1, dx, a.g(pre + "norm2.weight"),
-                            a.g(pre + "norm2.bias"), M, C)
-            df1 = self._drop(dx1, p, r.seed_p)
+            dx1, df1 = ln_bwd(r.x1, pre + "norm2.", r.mean2, r.rstd2, dn2, dx, r.seed_p)
             L.colsum(df1, M, C, a.g(pre + "attn.proj.bias"))
             self._wgrad(df1, r.ctx, pre + "attn.proj.weight", C, C, M)
             dctx = self._dgrad(df1, a.w(pre + "attn.proj.weight"), M, C, C)
@@ -694,11 +707,9 @@ class Engine:
             L.colsum(dqkv, M, 3 * C, a.g(pre + "attn.qkv.bias"))
             self._wgrad(dqkv, r.n1, pre + "attn.qkv.weight", 3 * C, C, M)
             dn1 = self._dgrad(dqkv, a.w(pre + "attn.qkv.weight"), M, C, 3 * C)
-            dx0 = self._bf(M, C)
-            L.layernorm_bwd(r.x, a.f(pre + "norm1.weight"), r.mean1, r.rstd1, dn1, dx0, dx1, a.g(pre + "norm1.weight"),
-                            a.g(pre + "norm1.bias"), M, C)
-            dx = dx0
-        dx = self._drop(dx, p, tape["seed0"])
+            nseed = recs[idx + 1].seed_2 if idx + 1 < len(recs) else tape["seed0"]      # next block's fc2 dropout, or the input dropout
+            dx, df2 = ln_bwd(r.x, pre + "norm1.", r.mean1, r.rstd1, dn1, dx1, nseed)
+        dx = df2                                                   # = dropout(dx; seed0), vit.py:126
         gpos = a.g("visual_encoder.pos_embed", (m.num_features, C))
         if tape["idx"] is None:
             L.bcast_grad(dx, gpos, M * C, T * C)

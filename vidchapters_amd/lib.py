@@ -72,6 +72,8 @@ SYMBOLS = {
     "v2s_rmsnorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "v2s_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "v2s_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "v2s_rmsnorm_bwd_drop": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _f32, _u32, _vp]),
+    "v2s_layernorm_bwd_drop": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _f32, _u32, _vp]),
     "v2s_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "v2s_attn_delta": (C.c_int, [C.POINTER(AttnArgs), _vp, _vp]),
     "v2s_attn_bwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
@@ -259,7 +261,13 @@ def rmsnorm_fwd(x, w, y, rstd, rows, cols, eps):
            "v2s_rmsnorm_fwd")
 
 
-def rmsnorm_bwd(x, w, rstd, dy, dx, dx_add, dw, rows, cols):
+def rmsnorm_bwd(x, w, rstd, dy, dx, dx_add, dw, rows, cols, dx_drop=None, dropout_p=0.0, dropout_seed=0):
+    """``dx_drop`` (bf16, optional): second output dropout(dx; dropout_p, dropout_seed), same mask / values as ``dropout(dx, ...)``."""
+    if dx_drop is not None:
+        _check(lib().v2s_rmsnorm_bwd_drop(x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(), ptr(dx_add),
+                                          dw.data_ptr(), rows, cols, dx_drop.data_ptr(), dropout_p, dropout_seed & 0xFFFFFFFF, stream_ptr()),
+               "v2s_rmsnorm_bwd_drop")
+        return
     _check(lib().v2s_rmsnorm_bwd(x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(), ptr(dx_add),
                                  dw.data_ptr(), rows, cols, stream_ptr()), "v2s_rmsnorm_bwd")
 
@@ -270,7 +278,12 @@ def layernorm_fwd(x, w, b, y, mean, rstd, rows, cols, eps):
                                    rows, cols, eps, stream_ptr()), "v2s_layernorm_fwd")
 
 
-def layernorm_bwd(x, w, mean, rstd, dy, dx, dx_add, dw, db, rows, cols):
+def layernorm_bwd(x, w, mean, rstd, dy, dx, dx_add, dw, db, rows, cols, dx_drop=None, dropout_p=0.0, dropout_seed=0):
+    if dx_drop is not None:
+        _check(lib().v2s_layernorm_bwd_drop(x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(),
+                                            ptr(dx_add), dw.data_ptr(), db.data_ptr(), rows, cols, dx_drop.data_ptr(), dropout_p,
+                                            dropout_seed & 0xFFFFFFFF, stream_ptr()), "v2s_layernorm_bwd_drop")
+        return
     _check(lib().v2s_layernorm_bwd(x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dx.data_ptr(),
                                    ptr(dx_add), dw.data_ptr(), db.data_ptr(), rows, cols, stream_ptr()),
            "v2s_layernorm_bwd")
