@@ -106,11 +106,14 @@ def main():
         torch.cuda.synchronize()
 
     log("batch ready; warmup")
+    # the warm-up steps run back to back like the timed ones (no synchronisation in between): the host enqueues 2-3 steps ahead of the
+    # device, so the caching allocator needs the activations of several steps at once -- it must reach THAT steady state during the
+    # warm-up, not in the first steps of the timed region (one hipMalloc-bound step of 80+ ms in a 10-step region is 5 % of `value`)
     for i in range(a.warmup):
         losses = trainer.step(batch)
-        torch.cuda.synchronize()
-        log(f"warmup step {i} done, loss {float(losses['loss'].item()):.4f}")
     barrier()
+    if a.warmup:
+        log(f"{a.warmup} warmup steps done, loss {float(losses['loss'].item()):.4f}")
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
     evs[0].record()

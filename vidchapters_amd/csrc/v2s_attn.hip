@@ -200,7 +200,8 @@ __device__ __forceinline__ uint32_t drop_keepmask_pk(uint32_t a, uint32_t tm1pk)
   const uint32_t h = __umul24(a, DROP_C2);
   uint32_t e, mk;
   asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(e) : "v"(tm1pk), "v"(h));
-  asm("v_pk_ashrrev_i16 %0, 15, %1" : "=v"(mk) : "v"(e));
+  asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(mk) : "v"(e));   // op_sel_hi: the HIGH lane also takes the low half of the inline
+                                                                              // constant as its shift amount (its high half is 0)
   return mk;
 }
 // 32-bit "dropped" masks (all ones / zero) of the even-key (lo) and odd-key (hi) element of a pair
