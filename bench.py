@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--no-generate", action="store_true", help="skip the greedy generate() leg (cfg-4, reported as an extra field)")
     ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the data-parallel gradient all-reduce")
     ap.add_argument("--bucket-mib", type=int, default=48, help="wire bytes per gradient all-reduce (MiB)")
+    ap.add_argument("--shard-optimizer", action="store_true", help="data parallel: reduce-scatter the gradient buckets, Adam on the local 1/N "
+                    "stripes, all-gather the bf16 shadow weights (train.GradSync shard=True) instead of all-reduce + full Adam on every rank")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,7 +92,7 @@ def main():
     log(f"model built: {sum(p.numel() for p in model.parameters()) / 1e6:.1f} M parameters")
     model.engine().overlap = not a.no_overlap
     trainer = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=a.denoising, grad_comm_dtype=a.grad_comm_dtype,
-                      bucket_bytes=a.bucket_mib << 20)
+                      bucket_bytes=a.bucket_mib << 20, shard_optimizer=a.shard_optimizer)
     batch = {k: v.to(dev) for k, v in synth.make_batch(B, T, Lx, Lo, len(tok), 1234 + rank, 768, denoising=a.denoising > 0).items()}
     batch["video"] = batch["video"].to(torch.bfloat16)       # features resident in HBM as bf16 (documented in DESIGN.md)
     batch["input_lens"] = (batch["input_ids"] != 0).sum(1).tolist()      # host-side lengths, as a data loader knows them
@@ -187,6 +189,7 @@ def main():
         out["data_parallel"] = {"ranks_seen_by_rccl": dist.get_world_size(), "backend": dist.get_backend(),
                                 "grad_comm_dtype": trainer.sync.comm_dtype, "bucket_mib": round(trainer.sync.chunk * (4 if trainer.sync.comm_dtype == "fp32" else 2) / 2 ** 20, 1),
                                 "collectives_per_step": trainer.sync.collectives, "wire_mb_per_step": round(trainer.sync.bytes_reduced / 1e6, 1),
+                                "optimizer": ("sharded: reduce-scatter + Adam on 1/N stripes + bf16 all-gather" if trainer.sync.shard else "replicated: all-reduce + full Adam on every rank"),
                                 "exposed_comm_ms_last_step_rank0": round(comm_ms, 3),
                                 "note": "exposed = time the main stream waited for the gradient reduction after backward had been enqueued"}
     if rank == 0 and world == 1 and not a.packing and not a.no_generate:

@@ -228,17 +228,21 @@ def _nccl_world1(rank, port, ret):
                        enc_drop=0.0, dec_drop=0.0, num_bins=cfg.num_bins, init_seed=17).to("cuda").train()
     batch = {k: v.cuda() for k, v in synth.make_batch(4, 10, 40, 12, cfg.vocab, 21, cfg.vit_dim).items()}
     res = {}
-    for dtype in ("fp32", "bf16"):
+    for dtype in ("fp32", "bf16", "fp32_sharded"):
         m_c, m_p = build(), build()
-        tr_c = Trainer(m_c, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=0.0, force_collectives=True, grad_comm_dtype=dtype,
-                       bucket_bytes=1 << 20)
+        tr_c = Trainer(m_c, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=0.0, force_collectives=True,
+                       grad_comm_dtype=dtype.split("_")[0], bucket_bytes=1 << 20, shard_optimizer=dtype.endswith("sharded"))
         tr_p = Trainer(m_p, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=0.0)
         assert tr_c.sync.active and not tr_p.sync.active
         for _ in range(2):
             tr_c.step(batch); tr_p.step(batch)
+        tr_c.gather_master()          # sharded optimizer: fp32 masters of the stripes other ranks own (none at world 1: exercises the call)
         torch.cuda.synchronize()
         d = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(m_c.parameters(), m_p.parameters()))
         res[dtype] = (d, tr_c.sync.collectives, tr_c.sync.bytes_reduced)
+        if dtype.endswith("sharded"):      # the bf16 shadow the next forward reads equals the cast of the updated masters
+            a = tr_c.eng.arena
+            res["shadow_ok"] = bool(torch.equal(a.shadow, a.master.bfloat16())) and len(tr_c.sync.buckets) >= 4 and len(tr_c.sync.replicated) >= 2
     # the collectives GradSync can use, straight on arena memory
     g = tr_c.eng.arena.grad
     n = g.numel() // 64 * 64
@@ -268,3 +272,5 @@ def test_rccl_world1_gradient_all_reduce_path():
     assert d32 <= 2 * 2.1e-3 and ncoll >= 4 and nbytes > 0
     d16, ncoll16, nbytes16 = ret["res"]["bf16"]
     assert d16 <= 2 * 2.1e-3 and nbytes16 * 2 == nbytes           # bf16 wire format: half the bytes; Adam steps differ by <= 2 lr per step
+    dsh, ncollsh, _ = ret["res"]["fp32_sharded"]                   # reduce-scatter + Adam on the owned stripes + all-gather of the bf16 shadow
+    assert dsh <= 2 * 2.1e-3 and ncollsh > ncoll and ret["res"]["shadow_ok"]

@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, shard):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     solo = dist.new_group([0])                     # a one-rank group for the single-process reference run on rank 0
@@ -33,10 +33,19 @@ def _worker(rank, world, port, ret):
     sl = slice(rank * 2, rank * 2 + 2)
     mine = {k: v[sl].cuda() for k, v in full.items()}
     model = build()
-    tr = Trainer(model, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=1.0)
-    assert tr.world == 2
+    tr = Trainer(model, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=1.0, shard_optimizer=shard, bucket_bytes=1 << 18)
+    assert tr.world == 2 and tr.sync.shard == shard
     for _ in range(2):
         losses = tr.step(mine)
+    if shard:
+        assert len(tr.sync.buckets) >= 4 and all((e - s) * 2 == n for (s, e), (_, n) in zip(tr.sync.owned, tr.sync.buckets))
+        a = model.engine().arena
+        own = torch.zeros(a.numel, dtype=torch.bool, device="cuda")
+        for s0, e0 in tr.sync.owned + tr.sync.replicated:
+            own[s0:e0] = True
+        ret[f"shadow{rank}"] = bool(torch.equal(a.shadow[own], a.master[own].bfloat16()))        # own stripes: shadow == cast(master)
+        tr.gather_master()               # the stripes the other rank updated: masters were stale, the shadow already current
+        ret[f"shadow_all{rank}"] = bool(torch.equal(a.shadow, a.master.bfloat16()))
     torch.cuda.synchronize()
     if rank == 0:
         ref = build()
@@ -65,12 +74,15 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_large_batch():
+@pytest.mark.parametrize("shard", [False, True], ids=["allreduce", "sharded_optimizer"])
+def test_two_ranks_equal_one_large_batch(shard):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + (7 if shard else 0)
+    mp.spawn(_worker, args=(world, port, ret, shard), nprocs=world, join=True)
+    if shard:
+        assert all(ret[f"shadow{r}"] and ret[f"shadow_all{r}"] for r in range(world)), dict(ret)
     print(f"DP (2 ranks) vs single process after 2 steps: worst update cosine {ret['worst']:.4f} ({ret['worst_k']}), max |dw| diff {ret['maxdiff']:.2e}")
     # Adam turns every gradient element into a step of ~lr whatever its size, so elements whose gradient is bf16/atomics-order noise
     # may step in different directions: compare update DIRECTIONS per tensor (as test_dropin_optimizer_path_matches_trainer does)

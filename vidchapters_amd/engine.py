@@ -107,7 +107,8 @@ class Engine:
         return f"t5_model.{stack}.block.{i}.layer.{2 if stack == 'decoder' else 1}.DenseReluDense."
 
     def _arena_order(self):
-        """Parameters in (approximately) the order their gradients complete during backward, q|k|v adjacent."""
+        """The weight matrices in (approximately) the order their gradients complete during backward, q|k|v adjacent; then the small
+        fp32-consumed parameters; the tied embedding last."""
         named = dict(self.model.named_parameters())
         order: List[str] = []
         c = self.cfg
@@ -134,7 +135,19 @@ class Engine:
         order += ["visual_encoder.pos_embed", "t5_model.shared.weight"]
         missing = set(named) - set(order)
         assert not missing, f"parameters without an arena slot: {sorted(missing)[:5]}"
+        # The parameters the kernels read in FP32 (norm weights, biases, the relative-position tables: all 1-D or tiny) sit together
+        # in front of the tied embedding: a data-parallel run with a sharded optimizer (train.GradSync shard=True) all-gathers only
+        # the bf16 shadow of the matrices, so these few fp32-consumed tensors form ONE contiguous range that every rank reduces
+        # and updates in full
+        small = [n for n in order if Engine.is_small_param(n, named[n])]
+        big = [n for n in order if n not in set(small) and n != "t5_model.shared.weight"]
+        order = big + small + ["t5_model.shared.weight"]
         return [(n, named[n]) for n in order]
+
+    @staticmethod
+    def is_small_param(name: str, p) -> bool:
+        """Consumed by the kernels as fp32 master values (Engine.arena.f): replicated, never sharded."""
+        return p.dim() <= 1 or name.endswith("relative_attention_bias.weight")
 
     # ------------------------------------------------------------------------------------------ small helpers
     def _bf(self, *shape) -> torch.Tensor:

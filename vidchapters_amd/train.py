@@ -38,43 +38,105 @@ def lr_at(step: int, total: int, base_lr: float, schedule: str = "", warmup_frac
     raise NotImplementedError(schedule)
 
 
+def bucket_plan(start: int, end: int, chunk: int, world: int, shard: bool) -> List[Tuple[str, int, int]]:
+    """Collectives that reduce arena[start:end]: ("rs", offset, n) = reduce-scatter of n elements (n a multiple of 64 * world, rank r
+    receives [offset + r*n/world, offset + (r+1)*n/world)), ("ar", offset, n) = all-reduce.  Pure host logic (tested on the CPU)."""
+    plan: List[Tuple[str, int, int]] = []
+    o = start
+    while o < end:
+        e = min(end, o + chunk)
+        n_sh = ((e - o) // (64 * world)) * (64 * world) if shard else 0
+        if n_sh:
+            plan.append(("rs", o, n_sh))
+        if o + n_sh < e:
+            plan.append(("ar", o + n_sh, e - o - n_sh))
+        o = e
+    return plan
+
+
 class GradSync:
-    """Bucketed asynchronous all-reduce of the gradient arena on a dedicated stream (RCCL over xGMI: backend "nccl" on ROCm).
+    """Bucketed asynchronous reduction of the gradient arena on a dedicated stream (RCCL over xGMI: backend "nccl" on ROCm).
 
     ``ready(start, end)`` hands a finished, contiguous slice of the fp32 gradient arena to the reduction: the side stream waits for
-    the producing streams through events, then issues one all-reduce per ``bucket_bytes`` of WIRE data (default 48 MiB: xGMI is
-    point to point, a ring all-reduce is bound per link, and a few tens of MB per collective keep the links streaming while the
+    the producing streams through events, then issues one collective per ``bucket_bytes`` of WIRE data (default 48 MiB: xGMI is
+    point to point, a ring collective is bound per link, and a few tens of MB per collective keep the links streaming while the
     first buckets of a slice overlap the rest of backward).  ``comm_dtype="bf16"`` halves the wire bytes: the slice is rounded into a
     bf16 staging arena, reduced there and widened back into the fp32 arena (the optimizer keeps reading fp32).  ``force=True`` issues
-    the collectives even for a one-rank group (the GPU test that loads RCCL on a single-GPU box)."""
+    the collectives even for a one-rank group (the GPU test that loads RCCL on a single-GPU box).
 
-    def __init__(self, arena, group=None, bucket_bytes: int = 48 << 20, comm_dtype: str = "fp32", force: bool = False):
+    ``shard=True`` (sharded optimizer, the SURVEY 5 design: direct reduce-scatter + all-gather instead of an all-reduce): every
+    bucket is REDUCE-SCATTERED -- rank r ends up with the summed r-th 1/world of each bucket (``owned`` ranges) -- the optimizer
+    then updates only those stripes (Adam reads and writes 8.7 GB / world per rank instead of 8.7 GB), and ``gather_shadow`` all-gathers
+    the updated bf16 SHADOW weights (0.58 GB instead of a second 1.16 GB half of the all-reduce).  Ranges handed over with
+    ``replicate=True`` (the small fp32-consumed parameters and the time-token rows, which every rank needs as fp32 masters) are
+    all-reduced and updated everywhere.  The fp32 masters of the stripes a rank does not own go stale: ``gather_master`` brings
+    them up to date for checkpoints / evaluation through the nn.Module."""
+
+    def __init__(self, arena, group=None, bucket_bytes: int = 48 << 20, comm_dtype: str = "fp32", force: bool = False, shard: bool = False):
         self.arena = arena
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
+        live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if live else 1
+        self.rank = dist.get_rank(group) if live else 0
+        self.active = self.world > 1 or (force and live)
         if comm_dtype not in ("fp32", "bf16"):
             raise ValueError(f"grad_comm_dtype must be 'fp32' or 'bf16' (got {comm_dtype!r})")
         self.comm_dtype = comm_dtype
+        self.shard = bool(shard) and self.active
         esize = 4 if comm_dtype == "fp32" else 2
-        self.chunk = max(1, bucket_bytes // esize) // 64 * 64 or 64     # elements per collective
+        unit = 64 * (self.world if self.shard else 1)                      # stripes stay 64-element (256-byte) aligned
+        self.chunk = max(unit, max(1, bucket_bytes // esize) // unit * unit)     # elements per collective
+        dev = arena.grad.device
         self.stream = torch.cuda.Stream() if self.active else None
-        self.stage = torch.empty(arena.numel, dtype=torch.bfloat16, device=arena.grad.device) if self.active and comm_dtype == "bf16" else None
+        self.stage = torch.empty(arena.numel, dtype=torch.bfloat16, device=dev) if self.active and comm_dtype == "bf16" else None
+        # gloo (the CPU-backend tests with two ranks on one GPU) has no reduce-scatter / all-gather for device tensors: staged through the host
+        self._host_staged = self.shard and live and dist.get_backend(group) == "gloo"
+        self._rs_out = torch.empty(self.chunk // self.world, dtype=torch.float32 if comm_dtype == "fp32" else torch.bfloat16, device=dev) if self.shard else None
+        self._ag_in = torch.empty(self.chunk // self.world, dtype=torch.bfloat16, device=dev) if self.shard else None
         self.works: List = []
+        self.owned: List[Tuple[int, int]] = []        # sharded mode, per step: arena ranges whose summed gradient this rank holds
+        self.replicated: List[Tuple[int, int]] = []   # ... ranges every rank holds (all-reduced)
+        self.buckets: List[Tuple[int, int]] = []      # ... (start, elements) of every reduce-scattered bucket (all-gathered after the update)
         self.collectives = 0          # statistics of the current step (reset by Trainer.step)
         self.bytes_reduced = 0
         self.exposed_ms_events = None # (start, end) events around the final wait of the last step
+
+    def begin_step(self) -> None:
+        self.collectives = self.bytes_reduced = 0
+        self.owned, self.replicated, self.buckets = [], [], []
 
     def range_of(self, first: str, last: str) -> Tuple[int, int]:
         a = self.arena
         n = 1
         for s in a.shapes[last]:
             n *= s
-        return a.offsets[first], a.offsets[last] + n
+        return a.offsets[first], (a.offsets[last] + n + 63) // 64 * 64
 
-    def ready(self, start: int, end: int, also=()) -> None:
+    # ---- collectives (device tensors; host-staged for gloo) ----------------------------------------------------------------------
+    def _reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        if self._host_staged:
+            hi = inp.cpu()
+            ho = torch.empty(out.numel(), dtype=hi.dtype)
+            if hi.dtype == torch.bfloat16:          # gloo reduces fp32
+                hi = hi.float(); ho = ho.float()
+            dist.reduce_scatter_tensor(ho, hi, op=dist.ReduceOp.SUM, group=self.group)
+            out.copy_(ho.to(out.dtype))
+        else:
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()   # stream-side dependency only
+
+    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        if self._host_staged:
+            hi = inp.cpu().view(torch.uint8)                 # a gather moves bits: bytes are a type gloo knows
+            ho = torch.empty(2 * out.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(ho, hi, group=self.group)
+            out.copy_(ho.view(torch.bfloat16))
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True).wait()
+
+    def ready(self, start: int, end: int, also=(), replicate: bool = False) -> None:
         """Gradients in arena[start:end] are final on the current stream (and on the streams in ``also``, e.g. the
-        weight-gradient stream): reduce them in the background."""
+        weight-gradient stream): reduce them in the background.  ``replicate``: keep the range whole on every rank even in sharded
+        mode (all-reduce)."""
         if not self.active or end <= start:
             return
         for st in (torch.cuda.current_stream(),) + tuple(also):
@@ -82,21 +144,36 @@ class GradSync:
             ev.record(st)
             self.stream.wait_event(ev)
         g = self.arena.grad
+        W, r = self.world, self.rank
         with torch.cuda.stream(self.stream):
-            o = start
-            while o < end:
-                e = min(end, o + self.chunk)
-                if self.stage is None:
-                    self.works.append(dist.all_reduce(g[o:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-                    self.bytes_reduced += (e - o) * 4
-                else:
-                    L.cast_bf16(g[o:e], self.stage[o:e], e - o)                      # fp32 -> bf16 (RNE) on the side stream
-                    w = dist.all_reduce(self.stage[o:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                    w.wait()                                                          # stream-side dependency only (no host block with NCCL/RCCL)
-                    g[o:e].copy_(self.stage[o:e])                                     # widen back for the fp32 optimizer
-                    self.bytes_reduced += (e - o) * 2
+            for kind, o, n in bucket_plan(start, end, self.chunk, W, self.shard and not replicate):
+                if kind == "rs":                           # reduce-scatter: this rank receives the sum of its 1/W stripe of the bucket
+                    part = n // W
+                    mine = (o + r * part, o + (r + 1) * part)
+                    if self.stage is None:
+                        self._reduce_scatter(self._rs_out[:part], g[o:o + n])
+                        self.bytes_reduced += n * 4
+                    else:
+                        L.cast_bf16(g[o:o + n], self.stage[o:o + n], n)
+                        self._reduce_scatter(self._rs_out[:part], self.stage[o:o + n])
+                        self.bytes_reduced += n * 2
+                    g[mine[0]:mine[1]].copy_(self._rs_out[:part])
+                    self.owned.append(mine)
+                    self.buckets.append((o, n))
+                else:                                      # all-reduce (unsharded mode, replicated ranges, the ragged end of a range)
+                    e = o + n
+                    if self.stage is None:
+                        self.works.append(dist.all_reduce(g[o:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                        self.bytes_reduced += n * 4
+                    else:
+                        L.cast_bf16(g[o:e], self.stage[o:e], n)                          # fp32 -> bf16 (RNE) on the side stream
+                        w = dist.all_reduce(self.stage[o:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                        w.wait()                                                          # stream-side dependency only (no host block with NCCL/RCCL)
+                        g[o:e].copy_(self.stage[o:e])                                     # widen back for the fp32 optimizer
+                        self.bytes_reduced += n * 2
+                    if self.shard:
+                        self.replicated.append((o, e))
                 self.collectives += 1
-                o = e
 
     def finish(self) -> None:
         if not self.active:
@@ -111,6 +188,35 @@ class GradSync:
         e1.record(main)
         self.exposed_ms_events = (e0, e1)
 
+    def gather_shadow(self) -> None:
+        """Sharded mode, after the optimizer updated the owned stripes: all-gather the bf16 shadow weights of every reduce-scattered
+        bucket (on the current stream: the next forward reads them)."""
+        sh = self.arena.shadow
+        W, r = self.world, self.rank
+        for o, n in self.buckets:
+            part = n // W
+            self._ag_in[:part].copy_(sh[o + r * part:o + (r + 1) * part])
+            self._all_gather(sh[o:o + n], self._ag_in[:part])
+            self.collectives += 1
+            self.bytes_reduced += n * 2
+
+    def gather_master(self) -> None:
+        """Sharded mode: bring the fp32 master weights of the stripes other ranks own up to date (checkpoints, evaluation through the
+        nn.Module, switching to an unsharded optimizer).  Uses the bucket layout of the LAST step."""
+        if not self.shard:
+            return
+        ms = self.arena.master
+        W, r = self.world, self.rank
+        for o, n in self.buckets:
+            part = n // W
+            tmp = ms[o + r * part:o + (r + 1) * part].clone()
+            if self._host_staged:
+                ho = torch.empty(n, dtype=torch.float32)
+                dist.all_gather_into_tensor(ho, tmp.cpu(), group=self.group)
+                ms[o:o + n].copy_(ho)
+            else:
+                dist.all_gather_into_tensor(ms[o:o + n], tmp, group=self.group)
+
     def exposed_ms(self) -> float:
         """Time the main stream spent waiting for the last step's reductions after backward had finished (synchronises)."""
         if self.exposed_ms_events is None:
@@ -124,7 +230,7 @@ class Trainer:
     def __init__(self, model, lr: float = 3e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  clip_max_norm: float = 1.0, generative: float = 1.0, denoising: float = 1.0, schedule: str = "",
                  fraction_warmup_steps: float = 0.1, num_training_steps: int = 1, group=None, bucket_bytes: int = 48 << 20,
-                 grad_comm_dtype: str = "fp32", force_collectives: bool = False):
+                 grad_comm_dtype: str = "fp32", force_collectives: bool = False, shard_optimizer: bool = False):
         self.model = model
         self.eng = model.engine()
         a = self.eng.arena
@@ -135,20 +241,26 @@ class Trainer:
         self.m = torch.zeros(a.numel, dtype=torch.float32, device=dev)
         self.v = torch.zeros(a.numel, dtype=torch.float32, device=dev)
         self.step_count = 0
-        self.sync = GradSync(a, group, bucket_bytes=bucket_bytes, comm_dtype=grad_comm_dtype, force=force_collectives)
+        self.sync = GradSync(a, group, bucket_bytes=bucket_bytes, comm_dtype=grad_comm_dtype, force=force_collectives, shard=shard_optimizer)
         self.world = self.sync.world
         self._sq_ws = torch.empty(1024, dtype=torch.float32, device=dev)
         self._gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._renorm_ws = torch.empty(self.eng.V + 2, dtype=torch.float32, device=dev)
-        # arena ranges in backward-completion order (engine._arena_order)
+        # arena ranges (engine._arena_order): decoder matrices | encoder matrices | ViT matrices + pos_embed | the small fp32-consumed
+        # parameters | the tied embedding, whose last rows (time tokens + the zero tail) every rank keeps whole (renorm reads them)
         names = a.names
+        small = [n for n in names if type(self.eng).is_small_param(n, a.params[n])]
         first_enc = next(i for i, n in enumerate(names) if n.startswith("t5_model.encoder."))
         first_vis = next(i for i, n in enumerate(names) if not n.startswith("t5_model."))
         self._r_dec = self.sync.range_of(names[0], names[first_enc - 1])
         self._r_enc = self.sync.range_of(names[first_enc], names[first_vis - 1])
         self._enc_first = names[first_enc]
-        self._r_shared = self.sync.range_of("t5_model.shared.weight", "t5_model.shared.weight")
         self._r_vis = self.sync.range_of(names[first_vis], "visual_encoder.pos_embed")
+        self._r_small = self.sync.range_of(small[0], small[-1])
+        sh0, sh1 = a.offsets["t5_model.shared.weight"], a.numel
+        tt0 = sh0 + ((self.eng.V - model.num_bins) * self.eng.d) // 64 * 64 if model.num_bins else sh1
+        self._r_shared, self._r_timetok = (sh0, tt0), (tt0, sh1)
+        assert self._r_dec[1] == self._r_enc[0] and self._r_enc[1] == self._r_vis[0] and self._r_vis[1] == self._r_small[0] and self._r_small[1] == sh0
 
     # ------------------------------------------------------------------------------------------------
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -164,7 +276,7 @@ class Trainer:
         overlap = eng.overlap
         eng.prepare()
         eng.arena.grad.zero_()
-        self.sync.collectives = self.sync.bytes_reduced = 0
+        self.sync.begin_step()
         losses: Dict[str, torch.Tensor] = {}
         vtape: Dict = {}
         vis, vis_ready = None, None
@@ -242,7 +354,7 @@ class Trainer:
                 # every 4 encoder layers (backward runs 11 -> 0): hand their slice to the reduction while the next layers compute,
                 # instead of one 0.45 GB all-reduce after the whole stack
                 if last and self.sync.active and i > 0 and i % 4 == 0:
-                    end = self.sync.range_of(self._enc_first, eng._ln("encoder", i, 0))[1]
+                    end = self.sync.range_of(self._enc_first, eng._sa("encoder", i) + "o.weight")[1]      # last matrix of block i in arena order
                     self.sync.ready(enc_sent[0], end, also=(eng.wstream,) if eng.overlap else ())
                     enc_sent[0] = end
 
@@ -251,6 +363,7 @@ class Trainer:
                     eng.join_wgrads()
                     self.sync.ready(enc_sent[0], self._r_enc[1])
                     self.sync.ready(*self._r_shared)
+                    self.sync.ready(*self._r_timetok, replicate=True)
 
             eng.t5_loss_backward(tape, g, after_decoder=after_decoder, after_encoder=after_encoder,
                                  encoder_layer_done=encoder_layer_done)
@@ -261,6 +374,7 @@ class Trainer:
         eng.join_wgrads()
         if m.use_video and not state.get("vis_sent"):
             self.sync.ready(*self._r_vis)
+        self.sync.ready(*self._r_small, replicate=True)       # norm weights, biases, bias tables: final only now (ViT + both stacks)
         self.sync.finish()
         self._optimizer_step(hyper_dev)
         return losses
@@ -277,11 +391,28 @@ class Trainer:
             self.step_count += 1
         lr = self._lr_of_step(self.step_count - 1) if hyper_dev is None else self.lr
         self._gnorm_sq.zero_()
-        if self.clip > 0:
-            L.sqnorm(a.grad, a.numel, self._sq_ws, self._gnorm_sq)
-        L.adam_step(a.master, self.m, self.v, a.grad, a.shadow, a.numel, lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                    max(1, self.step_count), gnorm_sq=self._gnorm_sq if self.clip > 0 else None, max_norm=self.clip,
-                    grad_scale=1.0 / self.world, hyper_dev=hyper_dev)
+        step_no = max(1, self.step_count)
+        if self.sync.shard:
+            # sharded optimizer: |g|^2 = all-reduce(sum over the stripes this rank owns) + the replicated ranges (counted once), then
+            # Adam on the owned stripes and on the replicated ranges only, then the bf16 shadow of every bucket is all-gathered
+            rng = self.sync.owned + self.sync.replicated
+            if self.clip > 0:
+                for s0, e0 in self.sync.owned:
+                    L.sqnorm(a.grad[s0:e0], e0 - s0, self._sq_ws, self._gnorm_sq)
+                dist.all_reduce(self._gnorm_sq, op=dist.ReduceOp.SUM, group=self.sync.group)
+                for s0, e0 in self.sync.replicated:
+                    L.sqnorm(a.grad[s0:e0], e0 - s0, self._sq_ws, self._gnorm_sq)
+            for s0, e0 in rng:
+                L.adam_step(a.master[s0:e0], self.m[s0:e0], self.v[s0:e0], a.grad[s0:e0], a.shadow[s0:e0], e0 - s0, lr, self.betas[0],
+                            self.betas[1], self.eps, self.wd, step_no, gnorm_sq=self._gnorm_sq if self.clip > 0 else None,
+                            max_norm=self.clip, grad_scale=1.0 / self.world, hyper_dev=hyper_dev)
+            self.sync.gather_shadow()
+        else:
+            if self.clip > 0:
+                L.sqnorm(a.grad, a.numel, self._sq_ws, self._gnorm_sq)
+            L.adam_step(a.master, self.m, self.v, a.grad, a.shadow, a.numel, lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                        step_no, gnorm_sq=self._gnorm_sq if self.clip > 0 else None, max_norm=self.clip,
+                        grad_scale=1.0 / self.world, hyper_dev=hyper_dev)
         if self.model.num_bins:
             emb = a.f("t5_model.shared.weight")
             embb = a.w("t5_model.shared.weight")
@@ -351,6 +482,12 @@ class Trainer:
         st["salt"].fill_(salt)
         st["graph"].replay()
         return st["losses"]
+
+    def gather_master(self) -> None:
+        """Sharded optimizer only: make every rank's fp32 master weights (= the nn.Module's parameters) current.  Call before
+        ``model.state_dict()`` / evaluation through the module; a no-op otherwise."""
+        self.sync.gather_master()
+        self.eng.mark_dirty()
 
     def state_dict(self) -> Dict:
         """Optimizer state for checkpoint / resume (dvc.py:310-330 saves optimizer.state_dict() next to the model): Adam moments (flat,
