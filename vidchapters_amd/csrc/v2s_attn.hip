@@ -649,9 +649,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
       mfma_settle(st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1], st[1][2], st[1][3]);
       mfma_settle(dp[0][0], dp[0][1], dp[0][2], dp[0][3], dp[1][0], dp[1][1], dp[1][2], dp[1][3]);
       const bool clean = !any_flag && !edge;
-      // bias-gradient routing: relative positions d = k - q of a 16x16 block (qb, kb) span a 31-wide range; blocks entirely in
-      // a far bucket just sum their dS (1: far-low, 2: far-high), only the near-diagonal blocks (3) resolve diagonals.  Most
-      // TILES lie entirely in one far bucket (troute != 3): decided once per tile with scalar compares.
+      // bias-gradient routing (after the dS of the whole tile are formed, below): relative positions d = k - q of a 16x16 block
+      // (qb, kb) span a 31-wide range; blocks entirely in a far bucket just sum their dS (1: far-low, 2: far-high), only the
+      // near-diagonal blocks (3) resolve diagonals.  Most TILES lie entirely in one far bucket (troute != 3): decided once per tile.
       const int troute = !want_dbias ? 0 : ((k0 + 63 - qmin) <= p.far_lo ? 1 : ((k0 - qmax) >= p.far_hi ? 2 : 3));
       bf16x8 dsf[2][2];
 #pragma unroll
@@ -660,28 +660,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
         const uint32_t rseed = rowseed[qb] ^ ((uint32_t)(k0 >> 1) * DROP_C1);
         const float ndl_q = -dl[qb], xm_q = xmask[qb], nm2_q = -m2[qb];
         const f32x2 ndl2 = {ndl_q, ndl_q}, nm22 = {nm2_q, nm2_q};
-        const int qlo = Q0 + wq0 + qb * 16;            // rows of this block: qlo .. qlo+15
-        uint32_t dw[4][2];
+        // exponent arguments x = s * sc2 - (m + log2 l) of the 16 x 64 block first (ONE clean / masked decision), in place
+        if (clean) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-          const int klo = k0 + kb * 16;
-          const int route = troute != 3 ? troute : ((klo + 15 - qlo) <= p.far_lo ? 1 : ((klo - (qlo + 15)) >= p.far_hi ? 2 : 3));
-          f32x2 x01, x23;
-          if (clean) {
-            x01 = pk_fma(f32x2{st[qb][kb][0], st[qb][kb][1]}, sc22, nm22);
-            x23 = pk_fma(f32x2{st[qb][kb][2], st[qb][kb][3]}, sc22, nm22);
-          } else {
+          for (int kb = 0; kb < 4; ++kb) {
+            const f32x2 x01 = pk_fma(f32x2{st[qb][kb][0], st[qb][kb][1]}, sc22, nm22), x23 = pk_fma(f32x2{st[qb][kb][2], st[qb][kb][3]}, sc22, nm22);
+            st[qb][kb] = f32x4{x01[0], x01[1], x23[0], x23[1]};
+          }
+        } else {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
             const uint32_t f4 = *reinterpret_cast<const uint32_t*>(s_flag + k0 + kb * 16 + 4 * g);
-            float x[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               uint32_t f = (f4 >> (8 * r)) & 0xffu;
               if (CAUSAL && (k0 + kb * 16 + 4 * g + r) > q + p.causal_off) f |= 1u;
-              x[r] = (f & 2u) ? -INFINITY : ((f & 1u) ? xm_q : fmaf(st[qb][kb][r], sc2, nm2_q));
+              st[qb][kb][r] = (f & 2u) ? -INFINITY : ((f & 1u) ? xm_q : fmaf(st[qb][kb][r], sc2, nm2_q));
             }
-            x01 = f32x2{x[0], x[1]}; x23 = f32x2{x[2], x[3]};
           }
-          const f32x2 p01 = {fast_exp2(x01[0]), fast_exp2(x01[1])}, p23 = {fast_exp2(x23[0]), fast_exp2(x23[1])};   // already divided by l
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const f32x2 p01 = {fast_exp2(st[qb][kb][0]), fast_exp2(st[qb][kb][1])}, p23 = {fast_exp2(st[qb][kb][2]), fast_exp2(st[qb][kb][3])};   // already divided by l
           f32x2 d01 = {dp[qb][kb][0], dp[qb][kb][1]}, d23 = {dp[qb][kb][2], dp[qb][kb][3]};
           if (DROP) {                                       // dropped elements: dP -> 0, so that u = -delta there
             uint32_t mlo, mhi;
@@ -691,29 +691,54 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
             d23 = f32x2{clear_if(mlo, d23[0]), clear_if(mhi, d23[1])};
           }
           const f32x2 s01 = pk_mul_t(p01, pk_fma(d01, ik2, ndl2)), s23 = pk_mul_t(p23, pk_fma(d23, ik2, ndl2));   // dS = P * (dP/(1-p) - delta)
-          if (BIAS && route != 0) {      // route is wave-uniform: one scalar branch per 16x16 block, none per element
+          st[qb][kb] = f32x4{s01[0], s01[1], s23[0], s23[1]};
+        }
+      }
+      // bias gradient.  Most tiles lie entirely in one far bucket (troute 1 / 2): their dS just sum up, no per-block decisions.
+      if (troute == 1 || troute == 2) {
+        f32x2 tsum = {0.f, 0.f};
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
+            tsum = pk_add(tsum, f32x2{st[qb][kb][0], st[qb][kb][1]});
+            tsum = pk_add(tsum, f32x2{st[qb][kb][2], st[qb][kb][3]});
+          }
+        if (troute == 1) acc_lo = pk_add(acc_lo, tsum);
+        else acc_hi = pk_add(acc_hi, tsum);
+      } else if (troute == 3) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          const int qq = wq0 + qb * 16 + li;
+          const int qlo = Q0 + wq0 + qb * 16;            // rows of this block: qlo .. qlo+15
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
+            const int klo = k0 + kb * 16;
+            const int route = (klo + 15 - qlo) <= p.far_lo ? 1 : ((klo - (qlo + 15)) >= p.far_hi ? 2 : 3);   // wave-uniform: scalar branches
             if (route == 3) {            // near-diagonal block: every element goes to its own diagonal of the window
-              const float dsv[4] = {s01[0], s01[1], s23[0], s23[1]};
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 // float -> 2^-40 fixed point without the (emulated, ~11 instruction) float->int64 conversion: adding
                 // 1.5 * 2^12 in double leaves round(ds * 2^40) (two's complement, |ds| < 2048) in the low 51 mantissa bits;
                 // the magic number's bit pattern has a zero low word, so subtracting its high word yields the integer.
-                const double md = (double)dsv[r] + 6144.0;
+                const double md = (double)st[qb][kb][r] + 6144.0;
                 const unsigned long long bits = __builtin_bit_cast(unsigned long long, md) - 0x40B8000000000000ull;
                 atomicAdd(&dbw[(k0 + kb * 16 + 4 * g + r) + 127 - qq], bits);
               }
-            } else if (route == 1) {
-              acc_lo = pk_add(acc_lo, pk_add(s01, s23));
             } else {
-              acc_hi = pk_add(acc_hi, pk_add(s01, s23));
+              const f32x2 bs = pk_add(f32x2{st[qb][kb][0], st[qb][kb][1]}, f32x2{st[qb][kb][2], st[qb][kb][3]});
+              if (route == 1) acc_lo = pk_add(acc_lo, bs);
+              else acc_hi = pk_add(acc_hi, bs);
             }
           }
-          dw[kb][0] = cvt_pk(s01[0], s01[1]);
-          dw[kb][1] = cvt_pk(s23[0], s23[1]);
         }
-        dsf[qb][0] = __builtin_bit_cast(bf16x8, make_uint4(dw[0][0], dw[0][1], dw[1][0], dw[1][1]));
-        dsf[qb][1] = __builtin_bit_cast(bf16x8, make_uint4(dw[2][0], dw[2][1], dw[3][0], dw[3][1]));
+      }
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        dsf[qb][0] = __builtin_bit_cast(bf16x8, make_uint4(cvt_pk(st[qb][0][0], st[qb][0][1]), cvt_pk(st[qb][0][2], st[qb][0][3]),
+                                                             cvt_pk(st[qb][1][0], st[qb][1][1]), cvt_pk(st[qb][1][2], st[qb][1][3])));
+        dsf[qb][1] = __builtin_bit_cast(bf16x8, make_uint4(cvt_pk(st[qb][2][0], st[qb][2][1]), cvt_pk(st[qb][2][2], st[qb][2][3]),
+                                                             cvt_pk(st[qb][3][0], st[qb][3][1]), cvt_pk(st[qb][3][2], st[qb][3][3])));
       }
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
@@ -919,25 +944,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
           u32x4 sd4 = u32x4{0u, 0u, 0u, 0u};
           if (DROP) sd4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(ms) + 192 + qb * 16 + 4 * g);
           const f32x2 nm01 = {nm4[0], nm4[1]}, nm23 = {nm4[2], nm4[3]}, nd01 = {nd4[0], nd4[1]}, nd23 = {nd4[2], nd4[3]};
+          // exponent arguments of the 16 x 32 block first (ONE clean / masked decision), in place
+          if (clean) {
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
-            const int k = K0 + wk0 + kb * 16 + li;
-            f32x2 x01, x23;
-            if (clean) {
-              x01 = pk_fma(f32x2{st[qi][kb][0], st[qi][kb][1]}, sc22, nm01);
-              x23 = pk_fma(f32x2{st[qi][kb][2], st[qi][kb][3]}, sc22, nm23);
-            } else {
-              float x[4];
+            for (int kb = 0; kb < 2; ++kb) {
+              const f32x2 x01 = pk_fma(f32x2{st[qi][kb][0], st[qi][kb][1]}, sc22, nm01), x23 = pk_fma(f32x2{st[qi][kb][2], st[qi][kb][3]}, sc22, nm23);
+              st[qi][kb] = f32x4{x01[0], x01[1], x23[0], x23[1]};
+            }
+          } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+              const int k = K0 + wk0 + kb * 16 + li;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int q = q0 + qb * 16 + 4 * g + r;
                 uint32_t f = kflag[kb];
                 if (CAUSAL && k > q + p.causal_off) f |= 1u;
-                x[r] = (f & 2u) ? -INFINITY : ((f & 1u) ? lv[r] : fmaf(st[qi][kb][r], sc2, nm4[r]));
+                st[qi][kb][r] = (f & 2u) ? -INFINITY : ((f & 1u) ? lv[r] : fmaf(st[qi][kb][r], sc2, nm4[r]));
               }
-              x01 = f32x2{x[0], x[1]}; x23 = f32x2{x[2], x[3]};
             }
-            const f32x2 p01 = {fast_exp2(x01[0]), fast_exp2(x01[1])}, p23 = {fast_exp2(x23[0]), fast_exp2(x23[1])};   // already divided by l
+          }
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            const f32x2 p01 = {fast_exp2(st[qi][kb][0]), fast_exp2(st[qi][kb][1])}, p23 = {fast_exp2(st[qi][kb][2]), fast_exp2(st[qi][kb][3])};   // already divided by l
             f32x2 pd01 = pk_mul_t(p01, ik2), pd23 = pk_mul_t(p23, ik2);
             if (DROP) {
               float pdv[4] = {pd01[0], pd01[1], pd23[0], pd23[1]};
