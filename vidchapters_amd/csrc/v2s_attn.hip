@@ -150,6 +150,11 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
   asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+__device__ __forceinline__ float vmax(float a, float b) {       // v_max_f32 without the canonicalising v_max x, x, x hipcc puts in front of fmaxf
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ float max3(float a, float b, float c) {
   float d;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
           mx = max3(mx, st[qb][2][1], st[qb][2][2]);
           mx = max3(mx, st[qb][2][3], st[qb][3][0]);
           mx = max3(mx, st[qb][3][1], st[qb][3][2]);
-          mx = fmaxf(mx, st[qb][3][3]);
+          mx = vmax(mx, st[qb][3][3]);
         } else {
           const int q = Q0 + wq0 + qb * 16 + li;
           mx = -INFINITY;
@@ -396,9 +401,9 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
             }
           }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m[qb], mx * mult);
+        mx = vmax(mx, __shfl_xor(mx, 16, 64));
+        mx = vmax(mx, __shfl_xor(mx, 32, 64));
+        const float mn = vmax(m[qb], mx * mult);
         const float alpha = fast_exp2(m[qb] - mn);
         m[qb] = mn;
         const f32x2 nmn2 = {-mn, -mn};

@@ -215,17 +215,23 @@ __device__ __forceinline__ void epilogue_chunk(const GemmP& p, float (&v)[8], in
   }
 }
 
-// epilogue of the 128x128 kernels: accumulators -> LDS (fp32 [128][128]) -> 8-wide row chunks
+// epilogue of the 128x128 kernels: accumulators -> LDS (fp32 [128][128]) -> 8-wide row chunks.  The kernels compute the tile
+// TRANSPOSED (mfma(B, A)): lane (g, li) of fragment (i, j) then holds row m = i*16 + li and the four CONSECUTIVE columns
+// n = j*16 + 4g .. +3, i.e. one ds_write_b128 per fragment instead of four ds_write_b32 whose four lane groups shared their banks
+// (16 instead of 64 LDS stores per lane).  The 16-byte chunks of a row are XOR-swizzled with (m & 7): the eight lanes one
+// ds_write_b128 pass serves (eight consecutive rows, same column chunk) and the sixteen a ds_read_b128 pass serves (one row, sixteen
+// chunks) then cover all banks.
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, const f32x4 (&acc)[4][4], int m0, int n0, int slice,
                                               int tid, int lane, int wm, int wn) {
   float* cs = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        cs[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * BN + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    for (int j = 0; j < 4; ++j) {
+      const int m = wm * 64 + i * 16 + (lane & 15);
+      const int c = (wn * 64 + j * 16 + (lane >> 4) * 4) >> 2;            // 16-byte chunk of the row
+      *reinterpret_cast<f32x4*>(cs + m * BN + ((c ^ (m & 7)) << 2)) = acc[i][j];
+    }
   __syncthreads();
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
@@ -234,8 +240,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, const 
     const int gm = m0 + row, gn = n0 + cc;
     if (gm >= p.M || gn >= p.N) continue;
     float v[8];
-    const float4 x0 = *reinterpret_cast<const float4*>(cs + row * BN + cc);
-    const float4 x1 = *reinterpret_cast<const float4*>(cs + row * BN + cc + 4);
+    const int c0 = (cc >> 2) ^ (row & 7), c1 = ((cc >> 2) + 1) ^ (row & 7);
+    const float4 x0 = *reinterpret_cast<const float4*>(cs + row * BN + (c0 << 2));
+    const float4 x1 = *reinterpret_cast<const float4*>(cs + row * BN + (c1 << 2));
     v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
     epilogue_chunk(p, v, gm, gn, slice);
   }
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmP p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // transposed: see gemm_epilogue
     }
     if (more) {
       char* da = smem + ((t + 1) & 1) * STAGE_BYTES;
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const GemmP p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // transposed: see gemm_epilogue
     }
     dma_wait();
     __syncthreads();
