@@ -241,6 +241,8 @@ class Trainer:
         self.m = torch.zeros(a.numel, dtype=torch.float32, device=dev)
         self.v = torch.zeros(a.numel, dtype=torch.float32, device=dev)
         self.step_count = 0
+        self.high_priority = True        # run step() on a high-priority stream (see step)
+        self._hi_stream = None
         self.sync = GradSync(a, group, bucket_bytes=bucket_bytes, comm_dtype=grad_comm_dtype, force=force_collectives, shard=shard_optimizer)
         self.world = self.sync.world
         self._sq_ws = torch.empty(1024, dtype=torch.float32, device=dev)
@@ -267,7 +269,24 @@ class Trainer:
         """One optimizer step on ``batch`` = {video, input_ids, output_ids[, den_input_ids, den_output_ids]}; optional
         ``input_lens`` / ``den_input_lens`` / ``output_lens`` / ``den_output_lens`` (host lists of valid lengths, e.g. from the data loader) let the padding-free
         encoder plan its rows without reading the mask back.  Returns device scalars."""
-        return self._step_impl(batch)
+        if not self.high_priority or not self.eng.overlap:
+            return self._step_impl(batch)
+        # The chain forward -> dgrad / attention backward -> optimizer is the critical path; the weight-gradient, ViT and K|V streams
+        # only fill what it leaves idle.  Issued from a HIGH-priority HIP stream its kernels win the dispatch arbitration against the
+        # side streams' (default priority): measured 56.3 -> 55.6 ms per step, interleaved (tools/prio_probe.py).
+        caller = torch.cuda.current_stream()
+        if self._hi_stream is None:
+            self._hi_stream = torch.cuda.Stream(device=self.eng.device, priority=-1)
+        self._hi_stream.wait_stream(caller)
+        with torch.cuda.stream(self._hi_stream):
+            losses = self._step_impl(batch)
+        caller.wait_stream(self._hi_stream)
+        for v in losses.values():
+            v.record_stream(caller)
+        for v in batch.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(self._hi_stream)
+        return losses
 
     def _step_impl(self, batch: Dict[str, torch.Tensor], hyper_dev: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         m, eng = self.model, self.eng
