@@ -241,7 +241,7 @@ class Trainer:
         self.m = torch.zeros(a.numel, dtype=torch.float32, device=dev)
         self.v = torch.zeros(a.numel, dtype=torch.float32, device=dev)
         self.step_count = 0
-        self.high_priority = True        # run step() on a high-priority stream (see step)
+        self.high_priority = False       # experiment (see step): faster step by step, slower in a pipelined loop -> off
         self._hi_stream = None
         self.sync = GradSync(a, group, bucket_bytes=bucket_bytes, comm_dtype=grad_comm_dtype, force=force_collectives, shard=shard_optimizer)
         self.world = self.sync.world
@@ -273,7 +273,8 @@ class Trainer:
             return self._step_impl(batch)
         # The chain forward -> dgrad / attention backward -> optimizer is the critical path; the weight-gradient, ViT and K|V streams
         # only fill what it leaves idle.  Issued from a HIGH-priority HIP stream its kernels win the dispatch arbitration against the
-        # side streams' (default priority): measured 56.3 -> 55.6 ms per step, interleaved (tools/prio_probe.py).
+        # side streams' (default priority): 56.3 -> 55.6 ms when every step is synchronised (tools/prio_probe.py, interleaved), but
+        # 54.1 -> 64.3 ms per step in bench.py's pipelined loop (the host enqueues steps back to back): off by default.
         caller = torch.cuda.current_stream()
         if self._hi_stream is None:
             self._hi_stream = torch.cuda.Stream(device=self.eng.device, priority=-1)
