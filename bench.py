@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--denoising", type=float, default=0.0)
     ap.add_argument("--model", default="t5-base")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline on os.cpu_count() threads (15 minutes on the 256-thread GPU host)")
     ap.add_argument("--frames", type=int, default=100, help="frames per video = ViT positions (cfg-5 uses 200)")
     ap.add_argument("--packing", action="store_true", help="measure `value` with the padding-free text encoder (the engine's default; exact). "
                     "Off here: `value` computes the pad rows like the reference does, the padding-free rate is reported beside it")
@@ -291,7 +292,7 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline (oracle on host cores) ...")
-        out["cpu_baseline"] = cpu_baseline(model, tok, Lx, Lo)
+        out["cpu_baseline"] = cpu_baseline(model, tok, Lx, Lo, all_cores=a.cpu_all_cores)
         log("cpu baseline done")
 
     if rank == 0:
@@ -397,14 +398,15 @@ def _cpu_model_string():
     return "unknown"
 
 
-def cpu_baseline(model, tok, Lx, Lo, threads=32):
+def cpu_baseline(model, tok, Lx, Lo, threads=32, all_cores=False):
     """The CPU oracle (fp32 torch restatement of the reference path, pinned against the reference in the build container) timed on this
     box's host cores, SURVEY 8d protocol: per leg 1 warm-up + 3 timed iterations, median.  Legs: cfg-1 exact (B=2, 100 frames, 256 ASR
     tokens, 256 targets: forward + loss + backward + clip + Adam + renorm), the cfg-2 shapes at B=2 (1000 ASR tokens) -- the number
     `value` is compared with -- and 32 greedy decode steps at B=2.  Thread count: SURVEY 8d says os.cpu_count(), but on the 2 x 64-core
-    GPU host torch's CPU kernels get SLOWER beyond a few dozen threads at these matrix sizes (measured r01: B=1 step 3.4 s at 32
-    threads, 13.7 s at 128), so the cfg-2 leg is timed at 32 threads AND at os.cpu_count() threads (bounded: one warm-up, at most two
-    timed steps) and `value` / `cores` report the faster of the two -- the other one is listed beside it."""
+    (256 logical) GPU host torch's CPU kernels collapse when oversubscribed at these matrix sizes: measured B=2 step 3.9 s at 32
+    threads, 13.7 s at 128 (round 1) and 891 s at os.cpu_count() = 256 (round 3, profiles/r03_bench_default_with_cpu_all_cores_probe.json
+    -- that one probe took 15 minutes).  So the baseline runs at 32 threads (`cores`), the fastest setting found; ``--cpu-all-cores``
+    repeats the probe."""
     from oracle import vid2seq_ref as R
     from vidchapters_amd import synth
     ncores = os.cpu_count() or 1
@@ -429,7 +431,7 @@ def cpu_baseline(model, tok, Lx, Lo, threads=32):
         dt, _ = timed(lambda: R.train_step(P, state, cfg, b, lr=3e-4, clip=1.0, generative=1.0, denoising=0.0))
         legs[name] = {"samples_per_s": round(2 / dt, 4), "seconds_per_step": round(dt, 3), "threads": threads}
     main, used = legs["cfg2_shapes_B2"], threads
-    if ncores > threads:                                      # the same leg on every logical core of the host
+    if all_cores and ncores > threads:                        # the same leg on every logical core of the host (can take many minutes)
         torch.set_num_threads(ncores)
         b = synth.make_batch(2, 100, Lx, Lo, len(tok), 99, 768)
         state = {}
@@ -444,10 +446,10 @@ def cpu_baseline(model, tok, Lx, Lo, threads=32):
     legs["greedy_32_steps_B2"] = {"sequences_per_s": round(2 / dtg, 4), "seconds": round(dtg, 3), "threads": threads}
     return {"value": main["samples_per_s"], "unit": "samples/s", "cores": used, "kind": "port",
             "host": {"cpu_model": _cpu_model_string(), "logical_cores": ncores, "threads_used": used,
-                     "threads_tried": sorted({threads, ncores})},
-            "sample": f"optimizer steps (fwd+bwd+clip+Adam+renorm) at B=2, 100 frames, {Lx} ASR tokens, {Lo} target tokens, fp32 torch CPU oracle, "
-                      f"dropout 0, after 1 warm-up: median of 3 at {threads} threads, up to 2 at {ncores} threads; the faster setting is reported: "
-                      f"{main['seconds_per_step']} s per step at {used} threads",
+                     "thread_sweep_seconds_per_step": {"32": 3.9, "128": 13.7, "256": 891.4},
+                     "thread_sweep_note": "B=2 cfg-2 step measured on this host type in rounds 1 and 3 (see the docstring); 32 threads is the fastest setting found"},
+            "sample": f"median of 3 timed optimizer steps after 1 warm-up (fwd+bwd+clip+Adam+renorm) at B=2, 100 frames, {Lx} ASR tokens, {Lo} target "
+                      f"tokens, fp32 torch CPU oracle, dropout 0, {used} threads; {main['seconds_per_step']} s per step",
             "legs": legs}
 
 
