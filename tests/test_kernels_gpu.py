@@ -422,6 +422,8 @@ def bias_from_diag(diag, Nq, Nk):
     (1, 1, 7, 9, 1.0, True, True, False),             # tiny ragged
     (3, 4, 256, 1100, 1.0, False, True, False),       # cfg-2 cross-attention shape
     (2, 12, 1000, 1000, 1.0, True, True, False),      # cfg-2 encoder shape
+    (1, 2, 2000, 2000, 1.0, True, True, False),       # cfg-5 encoder length: the forward / dQ kernels take the two-copy bias window
+    (1, 1, 2700, 2700, 1.0, True, False, False),      # long enough for the dK/dV kernel's two-copy window as well
 ])
 def test_attention_fwd_bwd(B, H, Nq, Nk, scale, use_bias, use_mask, causal, tr_mode):
     W = H * 64

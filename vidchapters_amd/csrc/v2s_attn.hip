@@ -228,12 +228,22 @@ constexpr int STAGE2 = 2 * KV_TILE;           // K|V (or Q|dO) of one pipeline s
 // i.  CS = floats per copy = WL rounded up to 64, plus 16: copy s starts 16 banks after copy s-1, so the four copies that lanes with
 // consecutive diagonals read (same 4-float group, different shift) fall on different banks.
 __host__ __device__ __forceinline__ int bias_cs(int len64) { return ((len64 + 128 + 63) & ~63) + 16; }
-// aligned read of w[i0 .. i0+3] for any i0 >= 0
+// read of w[i0 .. i0+3] for any i0 >= 0: NC = 4 shifted copies -> one aligned ds_read_b128; NC = 2 (long sequences: half the LDS, so
+// that the block count per CU does not drop) -> two aligned ds_read_b64 from the copy with the parity of i0
+template <int NC>
 __device__ __forceinline__ f32x4 bias_read4(const char* win, int CS, int i0) {
-  const int s = i0 & 3;
-  return *reinterpret_cast<const f32x4*>(win + (s * CS + (i0 - s)) * 4);
+  if (NC == 4) {
+    const int s = i0 & 3;
+    return *reinterpret_cast<const f32x4*>(win + (s * CS + (i0 - s)) * 4);
+  } else {
+    const int s = i0 & 1;
+    const char* b = win + (s * CS + (i0 - s)) * 4;
+    const f32x2 lo = *reinterpret_cast<const f32x2*>(b), hi = *reinterpret_cast<const f32x2*>(b + 8);
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+  }
 }
 // window entry i <-> relative position d = i + dbase; value = bias_diag[h][d + Nq - 1] * mul (0 outside the table)
+template <int NC>
 __device__ __forceinline__ void bias_stage(char* win, int CS, int WL, int dbase, const float* __restrict__ diag_h, int ndiag, int nq, float mul,
                                            int tid) {
   float* b = reinterpret_cast<float*>(win);
@@ -241,7 +251,7 @@ __device__ __forceinline__ void bias_stage(char* win, int CS, int WL, int dbase,
     const int gi = i + dbase + nq - 1;
     const float w = (gi >= 0 && gi < ndiag) ? diag_h[gi] * mul : 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < NC; ++s)
       if (i - s >= 0) b[s * CS + i - s] = w;
   }
 }
@@ -263,7 +273,7 @@ __device__ __forceinline__ void flags_stage(uint8_t* flag, uint8_t* state, int l
 // score MFMAs, the softmax VALU work and the PV MFMAs are serial, and only waves in different phases overlap them, so a third
 // wave per SIMD is worth 8-13 % (tools/attn_ab.py).  The causal variants spill into their hot path at that budget and stay at two.
 // LDS: [2 x (K tile | V tile)] [bias window] [key flags] [tile states]
-template <bool TR, bool BIAS, bool CAUSAL, bool DROP>
+template <bool TR, bool BIAS, bool CAUSAL, bool DROP, int NC>
 __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
   const int len64 = (p.Nk + 63) & ~63;
   const int CS = BIAS ? bias_cs(len64) : 0;
   char* s_bias = smem + 2 * STAGE2;
-  uint8_t* s_flag = reinterpret_cast<uint8_t*>(s_bias + 4 * CS * 4);
+  uint8_t* s_flag = reinterpret_cast<uint8_t*>(s_bias + NC * CS * 4);
   uint8_t* s_state = s_flag + len64;
 
   const bf16_t* qp = p.q + (p.seq_off ? (long)row0_ * p.q_rs : (long)b * p.q_bs) + h * HD;
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
   tile_load(krs, kvoff, kstep32, rk);
   tile_load(vrs, vvoff, vstep32, rv);
 
-  if (BIAS) bias_stage(s_bias, CS, len64 + 128, -(Q0 + 127), p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
+  if (BIAS) bias_stage<NC>(s_bias, CS, len64 + 128, -(Q0 + 127), p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
   flags_stage(s_flag, s_state, len64, nk_, p.key_mask ? p.key_mask + (long)b * p.Nk : nullptr, tid);
 
   float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
-          st[qb][kb] = BIAS ? bias_read4(s_bias, CS, k0 + kb * 16 + bidx0 - qb * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+          st[qb][kb] = BIAS ? bias_read4<NC>(s_bias, CS, k0 + kb * 16 + bidx0 - qb * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -507,7 +517,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p, float* _
 // The prologue also computes delta = rowsum(dO * O) of the block's rows (it holds the dO fragments anyway) and writes the per-row
 // statistics the dK/dV kernel needs (p.rowstat), so v2s_attn_bwd launches the dK/dV kernel AFTER this one.
 // LDS: [2 x (K tile | V tile)] [bias-gradient window: (Nk + 128) x 8 bytes] [bias window] [key flags] [tile states]
-template <bool TR, bool BIAS, bool CAUSAL, bool DROP>
+template <bool TR, bool BIAS, bool CAUSAL, bool DROP, int NC>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
@@ -529,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   const int CS = BIAS ? bias_cs(len64) : 0;
   unsigned long long* dbw = reinterpret_cast<unsigned long long*>(smem + 2 * STAGE2);
   char* s_bias = smem + 2 * STAGE2 + (BIAS ? ((p.Nk + 129) & ~1) * 8 : 0);
-  uint8_t* s_flag = reinterpret_cast<uint8_t*>(s_bias + 4 * CS * 4);
+  uint8_t* s_flag = reinterpret_cast<uint8_t*>(s_bias + NC * CS * 4);
   uint8_t* s_state = s_flag + len64;
   const int ndb = p.Nk + 127;
   if (want_dbias) {
@@ -594,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
   }
   const bool seen = __all(rows_real);
 
-  if (BIAS) bias_stage(s_bias, CS, len64 + 128, -(Q0 + 127), p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
+  if (BIAS) bias_stage<NC>(s_bias, CS, len64 + 128, -(Q0 + 127), p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
   flags_stage(s_flag, s_state, len64, nk_, p.key_mask ? p.key_mask + (long)b * p.Nk : nullptr, tid);
 
   f32x4 dqt[2][4];
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-          st[qb][kb] = BIAS ? bias_read4(s_bias, CS, k0 + kb * 16 + bidx0 - qb * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+          st[qb][kb] = BIAS ? bias_read4<NC>(s_bias, CS, k0 + kb * 16 + bidx0 - qb * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
           dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
@@ -801,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 constexpr int DKV_MS = STAGE2;                   // -(m + log2 l)[64], masked-element exponent[64], -delta[64], dropout row seed[64]
 constexpr int DKV_STATE = DKV_MS + 4 * 64 * 4;   // int: every row of the tile has real statistics
 constexpr int DKV_STAGE = DKV_STATE + 16;
-template <bool TR, bool BIAS, bool CAUSAL, bool DROP>
+template <bool TR, bool BIAS, bool CAUSAL, bool DROP, int NC>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
@@ -862,7 +872,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     for (int db = 0; db < 4; ++db) { dkt[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   // bias window of this key block: entry i <-> relative position d = i + (K0 - len64 + 1)  (q < len64, k - K0 in [0, 128))
-  if (BIAS) bias_stage(s_bias, CS, len64 + 128, K0 - len64 + 1, p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
+  if (BIAS) bias_stage<NC>(s_bias, CS, len64 + 128, K0 - len64 + 1, p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
 
   const int ntiles = (nq_ + 63) >> 6;
   const float sc2 = p.scale * LOG2E;
@@ -921,7 +931,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
           for (int kb = 0; kb < 2; ++kb) {
             f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
             if (BIAS) {
-              const f32x4 bw = bias_read4(s_bias, CS, kb * 16 + bidx0 - q0 - (2 * qh + qi) * 16);
+              const f32x4 bw = bias_read4<NC>(s_bias, CS, kb * 16 + bidx0 - q0 - (2 * qh + qi) * 16);
               init = f32x4{bw[3], bw[2], bw[1], bw[0]};
             }
             st[qi][kb] = init; dp[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1103,51 +1113,57 @@ int fill(AttnP& p, const v2s_attn_args* a, const char* who, bool bwd) {
   return V2S_OK;
 }
 
-// dynamic LDS of the three kernels (layouts at the kernels)
-size_t lds_fwd(const AttnP& p, bool bias) {
+// dynamic LDS of the three kernels (layouts at the kernels); nc = copies of the bias window
+size_t lds_fwd(const AttnP& p, bool bias, int nc) {
   const int len64 = (p.Nk + 63) & ~63;
-  return 2 * (size_t)STAGE2 + (bias ? (size_t)4 * bias_cs(len64) * 4 : 0) + len64 + 64;
+  return 2 * (size_t)STAGE2 + (bias ? (size_t)nc * bias_cs(len64) * 4 : 0) + len64 + 64;
 }
-size_t lds_dq(const AttnP& p, bool bias) {
+size_t lds_dq(const AttnP& p, bool bias, int nc) {
   const int len64 = (p.Nk + 63) & ~63;
-  return 2 * (size_t)STAGE2 + (bias ? (size_t)((p.Nk + 129) & ~1) * 8 + (size_t)4 * bias_cs(len64) * 4 : 0) + len64 + 64;
+  return 2 * (size_t)STAGE2 + (bias ? (size_t)((p.Nk + 129) & ~1) * 8 + (size_t)nc * bias_cs(len64) * 4 : 0) + len64 + 64;
 }
-size_t lds_dkv(const AttnP& p, bool bias) {
+size_t lds_dkv(const AttnP& p, bool bias, int nc) {
   const int len64 = (p.Nq + 63) & ~63;
-  return 2 * (size_t)DKV_STAGE + (bias ? (size_t)4 * bias_cs(len64) * 4 : 0);
+  return 2 * (size_t)DKV_STAGE + (bias ? (size_t)nc * bias_cs(len64) * 4 : 0);
 }
+constexpr size_t LDS_PER_CU = 160 * 1024;
 
-// compile-time specialisation dispatch: (tr_read, bias, causal, dropout).  Every instantiation may use the whole 160 KiB of LDS
-// (long sequences with a bias window: hipFuncSetAttribute once per instantiation).
-#define V2S_LAUNCH_ATTN(KERNEL, T_, B_, C_, D_, grid, dyn, stream, p)                                                       \
-  do {                                                                                                                      \
-    static bool attr__ = false;                                                                                             \
-    if (!attr__) {                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)KERNEL<T_, B_, C_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      attr__ = true;                                                                                                        \
-    }                                                                                                                       \
-    hipLaunchKernelGGL((KERNEL<T_, B_, C_, D_>), grid, dim3(256), dyn, stream, p);                                           \
+// compile-time specialisation dispatch: (tr_read, bias, causal, dropout[, window copies]).  Every instantiation may use the whole
+// 160 KiB of LDS (long sequences with a bias window: hipFuncSetAttribute once per instantiation).
+#define V2S_LAUNCH_ATTN(KERNEL, T_, B_, C_, D_, N_, grid, dyn, stream, p)                                                      \
+  do {                                                                                                                         \
+    static bool attr__ = false;                                                                                                \
+    if (!attr__) {                                                                                                             \
+      (void)hipFuncSetAttribute((const void*)KERNEL<T_, B_, C_, D_, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr__ = true;                                                                                                           \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((KERNEL<T_, B_, C_, D_, N_>), grid, dim3(256), dyn, stream, p);                                          \
   } while (0)
-#define V2S_DISPATCH4(KERNEL, tr, bias, causal, drop, grid, dyn, stream, p)                                   \
+#define V2S_LAUNCH_NC(KERNEL, T_, C_, D_, nc, grid, dyn, stream, p)                                          \
+  do {                                                                                                       \
+    if ((nc) == 2) V2S_LAUNCH_ATTN(KERNEL, T_, true, C_, D_, 2, grid, dyn, stream, p);                        \
+    else V2S_LAUNCH_ATTN(KERNEL, T_, true, C_, D_, 4, grid, dyn, stream, p);                                  \
+  } while (0)
+#define V2S_DISPATCH4(KERNEL, tr, bias, causal, drop, nc, grid, dyn, stream, p)                               \
   do {                                                                                                        \
     const int key__ = ((tr) ? 8 : 0) | ((bias) ? 4 : 0) | ((causal) ? 2 : 0) | ((drop) ? 1 : 0);              \
     switch (key__) {                                                                                          \
-      case 0: V2S_LAUNCH_ATTN(KERNEL, false, false, false, false, grid, dyn, stream, p); break;               \
-      case 1: V2S_LAUNCH_ATTN(KERNEL, false, false, false, true, grid, dyn, stream, p); break;                \
-      case 2: V2S_LAUNCH_ATTN(KERNEL, false, false, true, false, grid, dyn, stream, p); break;                \
-      case 3: V2S_LAUNCH_ATTN(KERNEL, false, false, true, true, grid, dyn, stream, p); break;                 \
-      case 4: V2S_LAUNCH_ATTN(KERNEL, false, true, false, false, grid, dyn, stream, p); break;                \
-      case 5: V2S_LAUNCH_ATTN(KERNEL, false, true, false, true, grid, dyn, stream, p); break;                 \
-      case 6: V2S_LAUNCH_ATTN(KERNEL, false, true, true, false, grid, dyn, stream, p); break;                 \
-      case 7: V2S_LAUNCH_ATTN(KERNEL, false, true, true, true, grid, dyn, stream, p); break;                  \
-      case 8: V2S_LAUNCH_ATTN(KERNEL, true, false, false, false, grid, dyn, stream, p); break;                \
-      case 9: V2S_LAUNCH_ATTN(KERNEL, true, false, false, true, grid, dyn, stream, p); break;                 \
-      case 10: V2S_LAUNCH_ATTN(KERNEL, true, false, true, false, grid, dyn, stream, p); break;                \
-      case 11: V2S_LAUNCH_ATTN(KERNEL, true, false, true, true, grid, dyn, stream, p); break;                 \
-      case 12: V2S_LAUNCH_ATTN(KERNEL, true, true, false, false, grid, dyn, stream, p); break;                \
-      case 13: V2S_LAUNCH_ATTN(KERNEL, true, true, false, true, grid, dyn, stream, p); break;                 \
-      case 14: V2S_LAUNCH_ATTN(KERNEL, true, true, true, false, grid, dyn, stream, p); break;                 \
-      default: V2S_LAUNCH_ATTN(KERNEL, true, true, true, true, grid, dyn, stream, p); break;                  \
+      case 0: V2S_LAUNCH_ATTN(KERNEL, false, false, false, false, 4, grid, dyn, stream, p); break;            \
+      case 1: V2S_LAUNCH_ATTN(KERNEL, false, false, false, true, 4, grid, dyn, stream, p); break;             \
+      case 2: V2S_LAUNCH_ATTN(KERNEL, false, false, true, false, 4, grid, dyn, stream, p); break;             \
+      case 3: V2S_LAUNCH_ATTN(KERNEL, false, false, true, true, 4, grid, dyn, stream, p); break;              \
+      case 4: V2S_LAUNCH_NC(KERNEL, false, false, false, nc, grid, dyn, stream, p); break;                    \
+      case 5: V2S_LAUNCH_NC(KERNEL, false, false, true, nc, grid, dyn, stream, p); break;                     \
+      case 6: V2S_LAUNCH_NC(KERNEL, false, true, false, nc, grid, dyn, stream, p); break;                     \
+      case 7: V2S_LAUNCH_NC(KERNEL, false, true, true, nc, grid, dyn, stream, p); break;                      \
+      case 8: V2S_LAUNCH_ATTN(KERNEL, true, false, false, false, 4, grid, dyn, stream, p); break;             \
+      case 9: V2S_LAUNCH_ATTN(KERNEL, true, false, false, true, 4, grid, dyn, stream, p); break;              \
+      case 10: V2S_LAUNCH_ATTN(KERNEL, true, false, true, false, 4, grid, dyn, stream, p); break;             \
+      case 11: V2S_LAUNCH_ATTN(KERNEL, true, false, true, true, 4, grid, dyn, stream, p); break;              \
+      case 12: V2S_LAUNCH_NC(KERNEL, true, false, false, nc, grid, dyn, stream, p); break;                    \
+      case 13: V2S_LAUNCH_NC(KERNEL, true, false, true, nc, grid, dyn, stream, p); break;                     \
+      case 14: V2S_LAUNCH_NC(KERNEL, true, true, false, nc, grid, dyn, stream, p); break;                     \
+      default: V2S_LAUNCH_NC(KERNEL, true, true, true, nc, grid, dyn, stream, p); break;                      \
     }                                                                                                         \
   } while (0)
 
@@ -1158,9 +1174,11 @@ extern "C" int v2s_attn_fwd(const v2s_attn_args* a, void* stream) {
   if (int e = fill(p, a, "v2s_attn_fwd", false)) return e;
   const int grid = ((p.Nq + 127) / 128) * p.H * p.B;
   const bool bias = p.bias_diag != nullptr;
-  const size_t dyn = lds_fwd(p, bias);
+  // bias window: four copies unless they would cost a block per CU (the kernel runs three blocks per CU, two when causal)
+  const int nc = (bias && lds_fwd(p, bias, 4) * (p.causal ? 2 : 3) > LDS_PER_CU) ? 2 : 4;
+  const size_t dyn = lds_fwd(p, bias, nc);
   V2S_CHECK(dyn <= 160 * 1024, V2S_ERR_SHAPE, "v2s_attn_fwd: Nk=%d too large for the LDS bias window", p.Nk);
-  V2S_DISPATCH4(attn_fwd_kernel, v2s_opt_tr_read() != 0, bias, p.causal != 0, p.p16 != 0, dim3(grid), dyn, (hipStream_t)stream, p);
+  V2S_DISPATCH4(attn_fwd_kernel, v2s_opt_tr_read() != 0, bias, p.causal != 0, p.p16 != 0, nc, dim3(grid), dyn, (hipStream_t)stream, p);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
@@ -1183,17 +1201,18 @@ extern "C" int v2s_attn_bwd(const v2s_attn_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool tr = v2s_opt_tr_read() != 0, bias = p.bias_diag != nullptr, causal = p.causal != 0, drop = p.p16 != 0;
   const int gq = ((p.Nq + 127) / 128) * p.H * p.B;
-  const size_t dyn_q = lds_dq(p, bias), dyn_kv = lds_dkv(p, bias);
+  const int nc_q = (bias && lds_dq(p, bias, 4) * 2 > LDS_PER_CU) ? 2 : 4, nc_kv = (bias && lds_dkv(p, bias, 4) * 2 > LDS_PER_CU) ? 2 : 4;   // two blocks per CU
+  const size_t dyn_q = lds_dq(p, bias, nc_q), dyn_kv = lds_dkv(p, bias, nc_kv);
   V2S_CHECK(dyn_q <= 160 * 1024 && dyn_kv <= 160 * 1024, V2S_ERR_SHAPE, "v2s_attn_bwd: Nq=%d Nk=%d too large for the LDS bias windows", p.Nq, p.Nk);
   const int part = v2s_opt_attn_bwd_part();      // profiling aid: 1 = dQ kernel only, 2 = dK/dV kernel only (needs the row statistics of an
                                                  // earlier dQ launch with the same arguments); 0 = both
   if (part != 2) {
-    V2S_DISPATCH4(attn_bwd_dq_kernel, tr, bias, causal, drop, dim3(gq), dyn_q, s, p);
+    V2S_DISPATCH4(attn_bwd_dq_kernel, tr, bias, causal, drop, nc_q, dim3(gq), dyn_q, s, p);
     V2S_LAUNCH_CHECK();
   }
   if (part != 1) {
     const int gk = ((p.Nk + 127) / 128) * p.H * p.B;
-    V2S_DISPATCH4(attn_bwd_dkv_kernel, tr, bias, causal, drop, dim3(gk), dyn_kv, s, p);
+    V2S_DISPATCH4(attn_bwd_dkv_kernel, tr, bias, causal, drop, nc_kv, dim3(gk), dyn_kv, s, p);
     V2S_LAUNCH_CHECK();
   }
   return V2S_OK;
