@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vidchapters_amd import lib as L
 dev = "cuda"
-B, H, N = 32, 12, int(sys.argv[1]) if len(sys.argv) > 1 else 1100
+B, H, N = 32, 12, int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 W = H * 64
 torch.manual_seed(0)
 q = (torch.randn(B, N, W, device=dev) * 0.5).to(torch.bfloat16); k = (torch.randn(B, N, W, device=dev) * 0.5).to(torch.bfloat16)

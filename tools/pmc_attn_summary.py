@@ -13,7 +13,8 @@ def load(d):
             dur[r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("((anon")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     return agg, dur
 a, da = load("pmc_attn_a"); b, db = load("pmc_attn_b")
-out = ["rocprofv3 --pmc over tools/attn_one.py (encoder-layer attention, B=32 H=12 N=1100, bias + mask + dropout 0.1 + dbias), 1 x MI355X; last 3 of 4 launches averaged"]
+N = int(os.environ.get("ATTN_N", "1000"))
+out = [f"rocprofv3 --pmc over tools/attn_one.py (encoder-layer attention, B=32 H=12 N={N}, bias + mask + dropout 0.1 + dbias), 1 x MI355X; last 3 of 4 launches averaged"]
 for k in a:
     if "delta" in k: continue
     va = {n: sum(x[-3:]) / 3 for n, x in a[k].items()}; vb = {n: sum(x[-3:]) / 3 for n, x in b.get(k, {}).items()}
@@ -28,7 +29,7 @@ for k in a:
     out.append(f"    wave time: parked at waitcnt/barrier {100 * va['SQ_WAIT_ANY'] / tot:4.1f} %, issue-stalled {100 * va['SQ_WAIT_INST_ANY'] / tot:4.1f} %"
                f" (of which on LDS {100 * va['SQ_WAIT_INST_LDS'] / tot:4.1f} %), issuing {100 * va['SQ_ACTIVE_INST_ANY'] / tot:4.1f} %")
     if vb:
-        nel = 32 * 12 * 1100 * 1100 / 64.0                # score elements per lane-slot (wave-level instruction counts / this = per element)
+        nel = 32 * 12 * N * N / 64.0                # score elements per lane-slot (wave-level instruction counts / this = per element)
         out.append(f"    wave-level instructions per score element: VALU {vb['SQ_INSTS_VALU'] / nel:5.2f} (+ MFMA {vb['SQ_INSTS_MFMA'] / nel:4.2f}), scalar {vb['SQ_INSTS_SALU'] / nel:5.2f},"
                    f" LDS {vb['SQ_INSTS_LDS'] / nel:4.2f}; {va['SQ_ACTIVE_INST_VALU'] * 4 / vb['SQ_INSTS_VALU']:.2f} cycles per VALU instruction;"
                    f" LDS bank-conflict cycles / LDS active cycles = {vb['SQ_LDS_BANK_CONFLICT'] / max(vb['SQ_LDS_IDX_ACTIVE'], 1):.2f}")
