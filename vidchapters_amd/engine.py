@@ -78,6 +78,7 @@ class Engine:
         # CUs those leave idle (tails, epilogues, small decoder/ViT launches).  `vstream` lets the temporal ViT (small
         # launches, independent of the T5 encoder) run beside the encoder in both directions (train.Trainer).
         self.overlap = True
+        self._fresh_grads = None  # Trainer.step only: names of the weight matrices whose gradient has been written in this step (begin_grad_step)
         self.fused_head = True    # Trainer path: LM head + CE + their backward chunk by chunk inside the forward (no [B*Lo, vocab] tensor)
         self.head_rows = 2048     # decoder rows per chunk: 264 MB of fp32 logits + 132 MB of bf16 d(logits) scratch at vocab 32200
         self.pack = True          # run the text encoder on the valid (non-pad) tokens only: exact, see _pack_plan
@@ -215,10 +216,17 @@ class Engine:
         """dW[n_out, n_in] += alpha * dy[rows, n_out]^T @ x[rows, n_in]  (fp32 accumulate into the gradient arena).
         Runs on the weight-gradient stream unless the target is the tied embedding (whose gradient is also written by
         the embedding scatter-add on the main stream)."""
+        # Trainer.step (begin_grad_step): the first weight-gradient GEMM of a matrix in a step OVERWRITES its gradient, so the 1.1 GB of
+        # matrix gradients need no memset; later contributions (second pass of the two-pass recipe, the tied embedding) accumulate
+        fresh = self._fresh_grads
+        acc = fresh is None or wname in fresh or wname == "t5_model.shared.weight"
+        if fresh is not None:
+            fresh.add(wname)
+
         def launch():
             L.gemm(dy, x, self.arena.g(wname, shape), n_out, n_in, rows, transA=True, transB=True,
                    lda=ld_dy if ld_dy is not None else n_out, ldb=ld_x if ld_x is not None else n_in, ldc=n_in,
-                   accumulate=True, alpha=alpha, workspace=self._splitk_ws())
+                   accumulate=acc, alpha=alpha, workspace=self._splitk_ws())
         if not self.overlap or (wname == "t5_model.shared.weight" and not side_ok):
             if self.overlap:      # the shared split-K workspace is owned by wstream: wait for its users first
                 torch.cuda.current_stream().wait_stream(self.wstream)
@@ -926,6 +934,22 @@ class Engine:
     def zero_grad(self) -> None:
         self.arena.grad.zero_()
         self.arena.attach_grads()
+
+    def begin_grad_step(self) -> None:
+        """Start of a native training step (Trainer): gradients of the weight MATRICES are overwritten by their first weight-gradient
+        GEMM of the step (_wgrad), so only what is accumulated with atomics or from several producers is zeroed here -- pos_embed, the
+        small fp32-consumed parameters and the tied embedding: the tail of the arena (0.1 GB instead of 1.16 GB).  Needs every matrix
+        to receive a gradient in the step: models that skip a branch (use_video / use_speech off) zero everything."""
+        a, m = self.arena, self.model
+        if not (m.use_video and m.use_speech):
+            self._fresh_grads = None
+            a.grad.zero_()
+            return
+        self._fresh_grads = set()
+        a.grad[a.offsets["visual_encoder.pos_embed"]:].zero_()
+
+    def end_grad_step(self) -> None:
+        self._fresh_grads = None
 
     def _begin_backward(self) -> None:
         """If the caller dropped the gradients (optimizer.zero_grad(set_to_none=True)) start from a zeroed arena."""

@@ -295,7 +295,7 @@ class Trainer:
         main = torch.cuda.current_stream()
         overlap = eng.overlap
         eng.prepare()
-        eng.arena.grad.zero_()
+        eng.begin_grad_step()
         self.sync.begin_step()
         losses: Dict[str, torch.Tensor] = {}
         vtape: Dict = {}
@@ -396,6 +396,7 @@ class Trainer:
             self.sync.ready(*self._r_vis)
         self.sync.ready(*self._r_small, replicate=True)       # norm weights, biases, bias tables: final only now (ViT + both stacks)
         self.sync.finish()
+        eng.end_grad_step()
         self._optimizer_step(hyper_dev)
         return losses
 
