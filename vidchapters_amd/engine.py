@@ -78,6 +78,7 @@ class Engine:
         # CUs those leave idle (tails, epilogues, small decoder/ViT launches).  `vstream` lets the temporal ViT (small
         # launches, independent of the T5 encoder) run beside the encoder in both directions (train.Trainer).
         self.overlap = True
+        self.skip_grad_memset = True
         self._fresh_grads = None  # Trainer.step only: names of the weight matrices whose gradient has been written in this step (begin_grad_step)
         self.fused_head = True    # Trainer path: LM head + CE + their backward chunk by chunk inside the forward (no [B*Lo, vocab] tensor)
         self.head_rows = 2048     # decoder rows per chunk: 264 MB of fp32 logits + 132 MB of bf16 d(logits) scratch at vocab 32200
@@ -941,7 +942,7 @@ class Engine:
         small fp32-consumed parameters and the tied embedding: the tail of the arena (0.1 GB instead of 1.16 GB).  Needs every matrix
         to receive a gradient in the step: models that skip a branch (use_video / use_speech off) zero everything."""
         a, m = self.arena, self.model
-        if not (m.use_video and m.use_speech):
+        if not (m.use_video and m.use_speech and self.skip_grad_memset):
             self._fresh_grads = None
             a.grad.zero_()
             return
