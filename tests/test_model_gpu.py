@@ -224,10 +224,10 @@ def test_greedy_vs_reference_golden(golden_dir):
     assert isinstance(text, list) and len(text) == want.shape[0] and all(isinstance(t, str) for t in text)
 
 
-@pytest.mark.parametrize("nb", [2, 3, 5, 8])
+@pytest.mark.parametrize("nb", [2, 3, 5, 8, 12])
 def test_beam_search_other_widths(golden_dir, nb):
-    """num_beams other than the default 4: 2 and 8 take the one-block-per-entry cross-attention (kv_group), 3 and 5 one block per beam
-    row; all of them the row-map instead of a cache reorder.  Reference = the fp32 oracle run here on the fixture's inputs; same bar as
+    """num_beams other than the default 4: 2 and 8 take the one-block-per-entry cross-attention (kv_group), 3, 5 and 12 one block per
+    beam row (12: the 32-candidate top-k); all of them the row-map instead of a cache reorder.  Reference = the fp32 oracle run here on the fixture's inputs; same bar as
     the golden test (valid hypotheses, >= 3/4 of the rows identical: bf16 logits can flip a near-tie)."""
     g = np.load(os.path.join(golden_dir, "small_beam.npz"))
     cfg = R.RefConfig.small()

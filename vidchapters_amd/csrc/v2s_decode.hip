@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict
 // per row: log-softmax over V fp32 logits, add the row's running beam score, keep the K best (value, token) pairs, sorted
 // descending (HF 4.28 beam_search: log_softmax + beam_scores[:, None] then topk over the beams of a batch entry; the top-2*nb
 // of a batch entry are always among the per-beam top-2*nb, which the host merges).
-// NT threads per row (1024, or 512 for K = 16: the candidate lists take NT * K * 8 bytes of LDS), 16-byte loads: the 256-thread scalar
+// NT threads per row (1024, 512 for K = 16, 128 for K = 32: the candidate lists take NT * K * 8 bytes of LDS), 16-byte loads: the 256-thread scalar
 // loop took 66 us per beam step for 256 rows (profiles/r02_decode_step.txt)
 template <int K, int NT>
 __global__ __launch_bounds__(NT) void topk_logprob_kernel(const float* __restrict__ logits, long ld, int V,
@@ -587,12 +587,13 @@ extern "C" int v2s_topk_logprob(const float* logits, int64_t ld, int32_t rows, i
                                 float* out_val, int32_t* out_idx, int32_t ban_token, const int32_t* pos_dev, int32_t min_length, const float* row_lse,
                                 void* stream) {
   V2S_CHECK(logits && out_val && out_idx && rows > 0 && V > 0, V2S_ERR_ARG, "v2s_topk_logprob: bad args");
-  V2S_CHECK(K == 2 || K == 4 || K == 8 || K == 16, V2S_ERR_ARG, "v2s_topk_logprob: K must be 2, 4, 8 or 16 (got %d)", K);
+  V2S_CHECK(K == 2 || K == 4 || K == 8 || K == 16 || K == 32, V2S_ERR_ARG, "v2s_topk_logprob: K must be 2, 4, 8, 16 or 32 (got %d)", K);
   hipStream_t s = (hipStream_t)stream;
   if (K == 2) hipLaunchKernelGGL((topk_logprob_kernel<2, 1024>), dim3(rows), dim3(1024), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
   else if (K == 4) hipLaunchKernelGGL((topk_logprob_kernel<4, 1024>), dim3(rows), dim3(1024), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
   else if (K == 8) hipLaunchKernelGGL((topk_logprob_kernel<8, 1024>), dim3(rows), dim3(1024), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
-  else hipLaunchKernelGGL((topk_logprob_kernel<16, 512>), dim3(rows), dim3(512), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
+  else if (K == 16) hipLaunchKernelGGL((topk_logprob_kernel<16, 512>), dim3(rows), dim3(512), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
+  else hipLaunchKernelGGL((topk_logprob_kernel<32, 128>), dim3(rows), dim3(128), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);   // 9..16 beams
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

@@ -1132,9 +1132,9 @@ class Engine:
         B, S, d = mem.shape
         nb = num_beams
         R = B * nb
-        if not 1 <= nb <= 8:
-            raise ValueError(f"num_beams must be in [1, 8] on the HIP path (got {nb})")
-        K = next(k for k in (2, 4, 8, 16) if k >= 2 * nb)     # per-beam candidate lists are sorted: a longer list only adds entries
+        if not 1 <= nb <= 16:
+            raise ValueError(f"num_beams must be in [1, 16] on the HIP path (got {nb})")
+        K = next(k for k in (2, 4, 8, 16, 32) if k >= 2 * nb)     # per-beam candidate lists are sorted: a longer list only adds entries
                                                               # the merge never reaches, so any num_beams uses the next instantiated size
         inner, H, nl = self.inner, self.H, c.n_dec
         mem2 = mem.view(B * S, d)
