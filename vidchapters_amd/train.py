@@ -200,22 +200,26 @@ class GradSync:
             self.collectives += 1
             self.bytes_reduced += n * 2
 
-    def gather_master(self) -> None:
-        """Sharded mode: bring the fp32 master weights of the stripes other ranks own up to date (checkpoints, evaluation through the
-        nn.Module, switching to an unsharded optimizer).  Uses the bucket layout of the LAST step."""
+    def gather_stripes(self, buf: torch.Tensor) -> None:
+        """Sharded mode: all-gather an fp32 arena-shaped buffer whose owned stripes are current on every rank (master weights, Adam
+        moments) so that it is whole everywhere.  Collective: every rank calls it.  Uses the bucket layout of the LAST step."""
         if not self.shard:
             return
-        ms = self.arena.master
         W, r = self.world, self.rank
         for o, n in self.buckets:
             part = n // W
-            tmp = ms[o + r * part:o + (r + 1) * part].clone()
+            tmp = buf[o + r * part:o + (r + 1) * part].clone()
             if self._host_staged:
                 ho = torch.empty(n, dtype=torch.float32)
                 dist.all_gather_into_tensor(ho, tmp.cpu(), group=self.group)
-                ms[o:o + n].copy_(ho)
+                buf[o:o + n].copy_(ho)
             else:
-                dist.all_gather_into_tensor(ms[o:o + n], tmp, group=self.group)
+                dist.all_gather_into_tensor(buf[o:o + n], tmp, group=self.group)
+
+    def gather_master(self) -> None:
+        """Sharded mode: bring the fp32 master weights of the stripes other ranks own up to date (checkpoints, evaluation through the
+        nn.Module, switching to an unsharded optimizer)."""
+        self.gather_stripes(self.arena.master)
 
     def exposed_ms(self) -> float:
         """Time the main stream spent waiting for the last step's reductions after backward had finished (synchronises)."""
@@ -512,7 +516,10 @@ class Trainer:
 
     def state_dict(self) -> Dict:
         """Optimizer state for checkpoint / resume (dvc.py:310-330 saves optimizer.state_dict() next to the model): Adam moments (flat,
-        arena order), step count, and the dropout stream position so that a resumed run draws the masks the uninterrupted one would."""
+        arena order), step count, and the dropout stream position so that a resumed run draws the masks the uninterrupted one would.
+        With a sharded optimizer this is a COLLECTIVE (every rank calls it): the moments of the other ranks' stripes are gathered first."""
+        self.sync.gather_stripes(self.m)
+        self.sync.gather_stripes(self.v)
         return {"step_count": self.step_count, "exp_avg": self.m, "exp_avg_sq": self.v, "dropout_rng": self.eng.rng_state(),
                 "arena_names": list(self.eng.arena.names)}
 
