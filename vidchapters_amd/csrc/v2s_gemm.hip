@@ -41,7 +41,7 @@ struct GemmP {
   float rms_eps;         // > 0: fused RMSNorm row scale (skinny kernel only)
   int order;             // tile walk: 0 = row-major with adjacent K slices, GM > 0 = grouped (tile_coords)
   int row0;              // rows of this launch are rows row0.. of the caller's matrix (dropout mask index; v2s_gemm splits rows over two launches)
-  int dbg;               // profiling aid (option "gemm_dbg"): 1 = p8 epilogue without the global store, 2 = p8 without epilogue
+  int dbg;               // profiling aid (option "gemm_dbg"): 1 = epilogue without post-ops and global store, 2 = no epilogue (128x128 and 8-phase kernels; results invalid)
 };
 
 // swizzle of the [k][row] (transposed-operand) LDS image: XOR the 32-byte column chunk with bits of k
@@ -224,6 +224,13 @@ __device__ __forceinline__ void epilogue_chunk(const GemmP& p, float (&v)[8], in
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, const f32x4 (&acc)[4][4], int m0, int n0, int slice,
                                               int tid, int lane, int wm, int wn) {
   float* cs = reinterpret_cast<float*>(smem);
+  if (p.dbg == 2) {                               // ablation (option gemm_dbg): main loop only (accumulators kept live; results invalid)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -244,6 +251,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, const 
     const float4 x0 = *reinterpret_cast<const float4*>(cs + row * BN + (c0 << 2));
     const float4 x1 = *reinterpret_cast<const float4*>(cs + row * BN + (c1 << 2));
     v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+    if (p.dbg == 1) {                             // ablation: everything but the post-ops and the global store
+      asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+      continue;
+    }
     epilogue_chunk(p, v, gm, gn, slice);
   }
 }
