@@ -17,7 +17,7 @@ SHAPES = [  # (kind, M, N, K, what)
     ("NN", 32000, 3072, 768, "enc wo dgrad"), ("NN", 32000, 768, 3072, "enc wi dgrad"), ("NT", 35200, 1536, 768, "cross K|V fwd"),
     ("NN", 35200, 768, 1536, "cross K|V dgrad"), ("NT", 8192, 2304, 768, "dec QKV fwd"), ("NT", 8192, 768, 768, "dec O fwd"),
     ("NT", 8192, 3072, 768, "dec wi fwd"), ("NT", 8192, 768, 3072, "dec wo fwd"), ("NN", 8192, 768, 2304, "dec QKV dgrad"),
-    ("NN", 8192, 3072, 768, "dec wo dgrad"), ("NT", 2048, 32256, 768, "LM head chunk fwd (fp32 out)"), ("NN", 2048, 768, 32256, "LM head chunk dgrad"),
+    ("NN", 8192, 3072, 768, "dec wo dgrad"), ("NT", 2048, 32256, 768, "LM head chunk fwd (fp32 out)"), ("NN", 2048, 768, 32256, "LM head chunk dgrad (split-K fp32 + cast)"),
     ("NT", 3200, 2304, 768, "ViT QKV fwd"), ("NT", 3200, 2048, 768, "ViT fc1 fwd"), ("NT", 3200, 768, 2048, "ViT fc2 fwd"),
     ("TN", 768, 768, 32000, "enc O wgrad (fp32 out)"), ("TN", 2304, 768, 32000, "enc QKV wgrad"), ("TN", 3072, 768, 32000, "enc wi wgrad"),
     ("TN", 768, 3072, 32000, "enc wo wgrad"), ("TN", 1536, 768, 35200, "cross K|V wgrad"), ("TN", 2304, 768, 8192, "dec QKV wgrad"),
@@ -29,7 +29,8 @@ SHAPES = [  # (kind, M, N, K, what)
 def make(kind, M, N, K):
     g = torch.Generator(device=dev); g.manual_seed(M * 7 + N * 3 + K)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
-    f32 = kind == "TN" or N >= 32000
+    head_dgrad = kind == "NN" and K >= 32000          # the engine runs it split-K into fp32 + one cast to bf16 (Engine.t5_loss_forward)
+    f32 = kind == "TN" or N >= 32000 or head_dgrad
     C = torch.zeros(M, N, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
     if kind == "NT":
         A, B, kw = rn(M, K), rn(N, K), {}
@@ -37,14 +38,20 @@ def make(kind, M, N, K):
     elif kind == "NN":
         A, B, kw = rn(M, K), rn(K, N), dict(transB=True)
         At, Bt = A, B
+        if head_dgrad:
+            kw["workspace"] = torch.empty(96 << 20, dtype=torch.uint8, device=dev)
     else:
         A, B, kw = rn(K, M), rn(K, N), dict(transA=True, transB=True)
         At, Bt = A.t(), B
         kw["workspace"] = torch.empty(96 << 20, dtype=torch.uint8, device=dev)
     Cv = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)       # the vendor side writes bf16 (torch.mm has no fp32-out bf16 GEMM)
 
+    Cb = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if head_dgrad else None
+
     def ours():
         L.gemm(A, B, C, M, N, K, **kw)
+        if head_dgrad:
+            L.cast_bf16(C.view(-1), Cb.view(-1), M * N)
 
     def vendor():
         torch.mm(At, Bt, out=Cv)

@@ -1481,6 +1481,8 @@ static int p8_auto(const v2s_gemm_args* a, bool deferred_ok) {
   }
   if (deferred_ok && a->K <= 1536) return 256;          // p8_decide turns deferred_ok into the deferred form
   if (a->K >= 1024 || a->transA) return 256;
+  // LM-head logits (fp32 output, N = 32200): 2048x32200x768 136 -> 126 us, 1024 rows 71 -> 66 (tools/gemm_vendor_ab.py shapes, round 3)
+  if (a->c_dtype == V2S_F32 && a->N >= 8192 && !a->transB) return 256;
   return 0;
 }
 
