@@ -1,5 +1,6 @@
-"""Same-process A/B of the GEMM kernels of two builds of the library on the shapes of the cfg-2 train step (forward NT, dgrad NN,
-wgrad TN).  usage: python tools/gemm_lib_ab.py libA.so libB.so"""
+"""Same-process A/B of GEMM epilogue variants from two builds of the library (shapes of the step whose epilogue reads a global
+operand: the ReLU-mask source of the wo dgrad, the residual of the O / wo projections, bias + GELU' of the ViT).
+usage: python tools/gemm_lib_ab.py libA.so libB.so[@gemm_big=0]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,21 +8,14 @@ from vidchapters_amd import lib as L
 dev = "cuda"
 paths = sys.argv[1:] or [L.LIB_PATH]
 
-def use(path):
+def use(spec):
+    """spec = lib.so[@option=value[,option=value]]"""
+    path, _, opts = spec.partition("@")
     L.LIB_PATH = os.path.abspath(path); L._LIB = None; L.lib()
-
-def make(kind, M, N, K):
-    if kind == "NT":   # y[M,N] = x[M,K] w[N,K]^T
-        A = torch.randn(M, K, device=dev).to(torch.bfloat16); B = torch.randn(N, K, device=dev).to(torch.bfloat16); kw = dict(transB=False)
-    elif kind == "NN": # dx[M,N] = dy[M,K] w[K,N]
-        A = torch.randn(M, K, device=dev).to(torch.bfloat16); B = torch.randn(K, N, device=dev).to(torch.bfloat16); kw = dict(transB=True)
-    else:              # dw[M,N] = dy[K,M]^T x[K,N]
-        A = torch.randn(K, M, device=dev).to(torch.bfloat16); B = torch.randn(K, N, device=dev).to(torch.bfloat16); kw = dict(transA=True, transB=True)
-    fp32 = kind == "TN"
-    C = torch.zeros(M, N, device=dev, dtype=torch.float32 if fp32 else torch.bfloat16)
-    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
-    def run(): L.gemm(A, B, C, M, N, K, workspace=ws, **kw)
-    return run
+    for k, v in (("gemm_big", 1), ("gemm_p8", 1), ("gemm_dma", 2)):       # options live in the loaded library: back to the defaults first
+        L.set_option(k, v)
+    for kv in filter(None, opts.split(",")):
+        k, v = kv.split("="); L.set_option(k, int(v))
 
 def t(f, n=20):
     for _ in range(3): f()
@@ -31,21 +25,31 @@ def t(f, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-SHAPES = [("NT", 32000, 768, 768), ("NT", 32000, 2304, 768), ("NT", 32000, 3072, 768), ("NT", 32000, 768, 3072), ("NT", 8192, 768, 768),
-          ("NT", 8192, 3072, 768), ("NT", 8192, 768, 3072), ("NT", 3200, 2304, 768), ("NT", 3200, 768, 2048), ("NT", 8192, 32200, 768),
-          ("NN", 32000, 768, 768), ("NN", 32000, 768, 2304), ("NN", 32000, 768, 3072), ("NN", 32000, 3072, 768), ("NN", 8192, 768, 3072),
-          ("NN", 8192, 768, 32200), ("TN", 768, 768, 32000), ("TN", 2304, 768, 32000), ("TN", 3072, 768, 32000), ("TN", 768, 3072, 32000),
-          ("TN", 768, 768, 8192), ("TN", 3072, 768, 8192), ("TN", 32200, 768, 8192)]
-tot = {p: 0.0 for p in paths}
-for kind, M, N, K in SHAPES:
-    use(paths[0]); run = make(kind, M, N, K)
-    best = {p: 1e9 for p in paths}; names = {}
+CASES = [("enc wo dgrad relu-mask+drop", "NN", 32000, 3072, 768, "dact"), ("enc wo dgrad bare", "NN", 32000, 3072, 768, ""),
+         ("enc O fwd residual+drop", "NT", 32000, 768, 768, "res"), ("enc O fwd bare", "NT", 32000, 768, 768, ""),
+         ("enc wo fwd residual+drop", "NT", 32000, 768, 3072, "res"), ("enc wo fwd bare", "NT", 32000, 768, 3072, ""),
+         ("dec wo dgrad relu-mask+drop", "NN", 8192, 3072, 768, "dact"), ("dec O fwd residual+drop", "NT", 8192, 768, 768, "res"),
+         ("dec wo fwd residual+drop", "NT", 8192, 768, 3072, "res"), ("ViT fc2 fwd residual", "NT", 3200, 768, 2048, "res"),
+         ("ViT fc1 dgrad gelu'", "NN", 3200, 2048, 768, "dgelu")]
+for name, kind, M, N, K, ep in CASES:
+    torch.manual_seed(0)
+    A = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
+    B = (torch.randn(*((K, N) if kind == "NN" else (N, K)), device=dev) * 0.5).to(torch.bfloat16)
+    Z = torch.relu(torch.randn(M, N, device=dev)).to(torch.bfloat16) if ep in ("dact", "dgelu") else None
+    R = torch.randn(M, N, device=dev).to(torch.bfloat16) if ep == "res" else None
+    outs = {}
+    res = {p: [] for p in paths}
+    kern = ""
     for rep in range(3):
         for p in paths:
-            use(p); best[p] = min(best[p], t(run)); names[p] = L.lib().v2s_last_gemm_kernel().decode()
-    line = f"{kind} {M:6d}x{N:6d}x{K:6d}"
-    for p in paths:
-        tot[p] += best[p]
-        line += f" | {os.path.basename(p)[:12]:12s} {best[p]:7.1f} us {2.0 * M * N * K / best[p] / 1e6:6.1f} TF/s {names[p][:34]:34s}"
-    print(line)
-print("sum:", {os.path.basename(p): round(v, 1) for p, v in tot.items()})
+            use(p)
+            Cc = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            kw = dict(transB=(kind == "NN"), ldb=N if kind == "NN" else K)
+            if ep == "dact": kw.update(dact=L.ACT_RELU, z=Z, dropout_p=0.1, dropout_seed=3)
+            if ep == "dgelu": kw.update(dact=L.ACT_GELU, z=Z)
+            if ep == "res": kw.update(residual=R, dropout_p=0.1 if M > 4000 else 0.0, dropout_seed=3)
+            f = lambda: L.gemm(A, B, Cc, M, N, K, **kw)
+            res[p].append(t(f)); outs[p] = Cc
+            kern = L.lib().v2s_last_gemm_kernel().decode()
+    same = all(torch.equal(outs[paths[0]], outs[p]) for p in paths)
+    print(f"{name:30s} {kind} {M}x{N}x{K} [{kern}] " + "  ".join(f"{min(res[p]):7.1f} us" for p in paths) + ("  identical" if same else "  DIFFERENT"))

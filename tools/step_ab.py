@@ -1,6 +1,6 @@
 """Interleaved A/B of library options on the full cfg-2 train step: one model / trainer / batch, the option settings alternate step
 by step, HIP-event time per step, median per setting (separate bench.py runs differ by +-2-3 % from box to box and run to run).
-usage: python tools/step_ab.py "gemm_p8=0" "gemm_p8=1" [--steps 12] [--model t5-base]"""
+usage: python tools/step_ab.py "gemm_p8=0" "gemm_p8=1" [--steps 12] [--model t5-base]      (also "lib=path/to/other_build.so")"""
 import sys, os, statistics, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -31,6 +31,9 @@ def apply(setting):
         k, v = kv.split("=")
         if k.startswith("eng:"):
             setattr(model.engine(), k[4:], int(v))
+            continue
+        if k == "lib":                       # another build of the library (same ABI): "lib=tools/lib_head.so"
+            L.LIB_PATH = os.path.abspath(v); L._LIB = None; L.lib()
             continue
         defaults.setdefault(k, L.get_option(k))
         L.set_option(k, int(v))

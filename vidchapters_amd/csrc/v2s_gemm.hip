@@ -151,7 +151,9 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rowbase, int ks
 
 // ---- epilogue shared by both main loops: accumulators -> LDS (fp32 [128][128]) -> vector post-ops -> global
 // post-ops + store of ONE 8-wide row chunk (gm, gn..gn+7) whose raw accumulators are in v[]
-__device__ __forceinline__ void epilogue_chunk(const GemmP& p, float (&v)[8], int gm, int gn, int slice) {
+// AHEAD: ``gop`` is the chunk of the epilogue's global operand (z if dact is set, else the residual) fetched ahead by the caller
+template <bool AHEAD = false>
+__device__ __forceinline__ void epilogue_chunk(const GemmP& p, float (&v)[8], int gm, int gn, int slice, uint4 gop = uint4{0, 0, 0, 0}) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
   if (p.bias) {
@@ -169,7 +171,9 @@ __device__ __forceinline__ void epilogue_chunk(const GemmP& p, float (&v)[8], in
   }
   if (p.dact != V2S_ACT_NONE) {
     float zf[8];
-    unpack8(*reinterpret_cast<const uint4*>(p.z + (long)gm * p.ldz + gn), zf);
+    uint4 zr;
+    if constexpr (AHEAD) zr = gop; else zr = *reinterpret_cast<const uint4*>(p.z + (long)gm * p.ldz + gn);
+    unpack8(zr, zf);
     if (p.dact == V2S_ACT_RELU) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = zf[j] > 0.f ? v[j] : 0.f;
@@ -190,7 +194,9 @@ __device__ __forceinline__ void epilogue_chunk(const GemmP& p, float (&v)[8], in
   }
   if (p.residual) {
     float rf[8];
-    unpack8(*reinterpret_cast<const uint4*>(p.residual + (long)gm * p.ldr + gn), rf);
+    uint4 rr;
+    if (AHEAD && p.dact == V2S_ACT_NONE) rr = gop; else rr = *reinterpret_cast<const uint4*>(p.residual + (long)gm * p.ldr + gn);
+    unpack8(rr, rf);
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] += rf[j];
   }
@@ -221,8 +227,28 @@ __device__ __forceinline__ void epilogue_chunk(const GemmP& p, float (&v)[8], in
 // (16 instead of 64 LDS stores per lane).  The 16-byte chunks of a row are XOR-swizzled with (m & 7): the eight lanes one
 // ds_write_b128 pass serves (eight consecutive rows, same column chunk) and the sixteen a ds_read_b128 pass serves (one row, sixteen
 // chunks) then cover all banks.
+// The epilogue's ONE global operand (the ReLU / GELU mask source z, or the residual): its eight 16-byte chunks per lane are requested
+// before the accumulators are staged, so that their latency runs under the staging and the barrier -- instead of once per write-out
+// iteration.  (Requested before the main loop they cost what they save, 59.0 vs 53.8 us on 32000x768x768; requested at the last
+// K-step with that step's vmcnt(0) dropped, the changed loop shape costs the main loop 10-30 %.) (dec wo dgrad with the ReLU
+// mask 58.6 -> 52.9 us, enc wo fwd with residual + dropout 171 -> 164, enc O fwd 59.1 -> 53.8; tools/gemm_lib_ab.py)
+__device__ __forceinline__ bool epilogue_prefetch(const GemmP& p, int m0, int n0, int tid, uint4 (&gop)[8]) {
+  const bf16_t* gsrc = p.dact != V2S_ACT_NONE ? p.z : p.residual;
+  const long gld = p.dact != V2S_ACT_NONE ? p.ldz : p.ldr;
+  const bool ahead = gsrc != nullptr && p.dbg == 0 && p.splitk == 1;
+  if (ahead) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int c = tid + it * NTHREADS;
+      const int gm = m0 + (c >> 4), gn = n0 + (c & 15) * 8;
+      gop[it] = (gm < p.M && gn < p.N) ? *reinterpret_cast<const uint4*>(gsrc + (long)gm * gld + gn) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  return ahead;
+}
+
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, const f32x4 (&acc)[4][4], int m0, int n0, int slice,
-                                              int tid, int lane, int wm, int wn) {
+                                              int tid, int lane, int wm, int wn, const uint4 (&gop)[8], bool ahead) {
   float* cs = reinterpret_cast<float*>(smem);
   if (p.dbg == 2) {                               // ablation (option gemm_dbg): main loop only (accumulators kept live; results invalid)
 #pragma unroll
@@ -240,6 +266,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, const 
       *reinterpret_cast<f32x4*>(cs + m * BN + ((c ^ (m & 7)) << 2)) = acc[i][j];
     }
   __syncthreads();
+  if (ahead) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int c = tid + it * NTHREADS;
+      const int row = c >> 4, cc = (c & 15) * 8;
+      const int gm = m0 + row, gn = n0 + cc;
+      if (gm >= p.M || gn >= p.N) continue;
+      float v[8];
+      const int c0 = (cc >> 2) ^ (row & 7), c1 = ((cc >> 2) + 1) ^ (row & 7);
+      const float4 x0 = *reinterpret_cast<const float4*>(cs + row * BN + (c0 << 2));
+      const float4 x1 = *reinterpret_cast<const float4*>(cs + row * BN + (c1 << 2));
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+      epilogue_chunk<true>(p, v, gm, gn, slice, gop[it]);
+    }
+    return;
+  }
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
     const int c = tid + it * NTHREADS;
@@ -315,7 +357,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmP p) {
     __syncthreads();
   }
 
-  gemm_epilogue(p, smem, acc, m0, n0, slice, tid, lane, wm, wn);
+  uint4 gop[8];
+  const bool ahead = epilogue_prefetch(p, m0, n0, tid, gop);
+  gemm_epilogue(p, smem, acc, m0, n0, slice, tid, lane, wm, wn, gop, ahead);
 }
 
 // ---- LDS-DMA main loop (K a multiple of 64): tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR
@@ -451,7 +495,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const GemmP p) {
     dma_wait();
     __syncthreads();
   }
-  gemm_epilogue(p, smem, acc, m0, n0, slice, tid, lane, wm, wn);
+  uint4 gop[8];
+  const bool ahead = epilogue_prefetch(p, m0, n0, tid, gop);
+  gemm_epilogue(p, smem, acc, m0, n0, slice, tid, lane, wm, wn, gop, ahead);
 }
 
 // =====================================================================================================================
@@ -566,7 +612,24 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmP p) {
   constexpr int IPP = 64 / WM / 16;                 // fragments per wave per pass: 2 (WM=2) or 1 (WM=4)
   constexpr int NPASS = MI / IPP;                   // 4
   constexpr int CPR = BN2 / 8;                      // 8-wide chunks per row
+  constexpr int NIT = 64 * CPR / 512;               // 8-wide chunks per lane per pass: 4 | 2
+  // one global operand (ReLU / GELU mask source, or the residual): the chunks of pass ps + 1 are requested before the write-out of
+  // pass ps (those of pass 0 before the first staging), see gemm_epilogue
+  const bf16_t* gsrc = p.dact != V2S_ACT_NONE ? p.z : p.residual;
+  const long gld = p.dact != V2S_ACT_NONE ? p.ldz : p.ldr;
+  const bool ahead = gsrc != nullptr;
+  uint4 gop[NIT], gnext[NIT];
+  auto fetch = [&](int ps, uint4 (&g)[NIT]) {
 #pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = tid + it * 512;
+      const int lr = c / CPR, cc = (c % CPR) * 8;
+      const int gm = m0 + (lr / (IPP * 16)) * (MI * 16) + ps * (IPP * 16) + lr % (IPP * 16), gn = n0 + cc;
+      g[it] = (gm < p.M && gn < p.N) ? *reinterpret_cast<const uint4*>(gsrc + (long)gm * gld + gn) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if (ahead) fetch(0, gop);
+#pragma clang loop unroll(full)                     // acc[] is indexed by ps: a rolled loop would put the accumulators in scratch
   for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
     for (int ii = 0; ii < IPP; ++ii)
@@ -576,17 +639,36 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmP p) {
         for (int r = 0; r < 4; ++r)
           cs[(wm * (IPP * 16) + ii * 16 + (lane >> 4) * 4 + r) * BN2 + wn * 64 + j * 16 + (lane & 15)] = acc[ps * IPP + ii][j][r];
     __syncthreads();
+    if (ahead) {
+      if (ps + 1 < NPASS) fetch(ps + 1, gnext);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = tid + it * 512;
+        const int lr = c / CPR, cc = (c % CPR) * 8;
+        const int gm = m0 + (lr / (IPP * 16)) * (MI * 16) + ps * (IPP * 16) + lr % (IPP * 16), gn = n0 + cc;
+        if (gm < p.M && gn < p.N) {
+          float v[8];
+          const float4 x0 = *reinterpret_cast<const float4*>(cs + lr * BN2 + cc);
+          const float4 x1 = *reinterpret_cast<const float4*>(cs + lr * BN2 + cc + 4);
+          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+          epilogue_chunk<true>(p, v, gm, gn, slice, gop[it]);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) gop[it] = gnext[it];
+    } else {
 #pragma unroll 1
-    for (int c = tid; c < 64 * CPR; c += 512) {
-      const int lr = c / CPR, cc = (c % CPR) * 8;                 // local row in the 64-row staging block
-      const int w = lr / (IPP * 16), rr = lr % (IPP * 16);        // owning wave row, row inside its IPP*16 rows
-      const int gm = m0 + w * (MI * 16) + ps * (IPP * 16) + rr, gn = n0 + cc;
-      if (gm >= p.M || gn >= p.N) continue;
-      float v[8];
-      const float4 x0 = *reinterpret_cast<const float4*>(cs + lr * BN2 + cc);
-      const float4 x1 = *reinterpret_cast<const float4*>(cs + lr * BN2 + cc + 4);
-      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-      epilogue_chunk(p, v, gm, gn, slice);
+      for (int c = tid; c < 64 * CPR; c += 512) {
+        const int lr = c / CPR, cc = (c % CPR) * 8;                 // local row in the 64-row staging block
+        const int w = lr / (IPP * 16), rr = lr % (IPP * 16);        // owning wave row, row inside its IPP*16 rows
+        const int gm = m0 + w * (MI * 16) + ps * (IPP * 16) + rr, gn = n0 + cc;
+        if (gm >= p.M || gn >= p.N) continue;
+        float v[8];
+        const float4 x0 = *reinterpret_cast<const float4*>(cs + lr * BN2 + cc);
+        const float4 x1 = *reinterpret_cast<const float4*>(cs + lr * BN2 + cc + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        epilogue_chunk(p, v, gm, gn, slice);
+      }
     }
     __syncthreads();
   }
@@ -924,7 +1006,24 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmP p) {
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
+  // one global operand (ReLU / GELU mask source, or the residual): the chunks of pass ps + 1 are requested before the write-out of
+  // pass ps (those of pass 0 before the first staging), see gemm_epilogue
+  constexpr int NIT = ROWS_PASS * CPR / 512;        // 8-wide chunks per lane per pass
+  const bf16_t* gsrc = p.dact != V2S_ACT_NONE ? p.z : p.residual;
+  const long gld = p.dact != V2S_ACT_NONE ? p.ldz : p.ldr;
+  const bool ahead = gsrc != nullptr && p.dbg == 0;
+  uint4 gop[NIT], gnext[NIT];
+  auto fetch = [&](int ps, uint4 (&g)[NIT]) {
 #pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = tid + it * 512;
+      const int lr = c / CPR, cc = (c % CPR) * 8;
+      const int gm = m0 + (lr >> 5) * (MI * 16) + ps * 32 + (lr & 31), gn = n0 + cc;
+      g[it] = (gm < p.M && gn < p.N) ? *reinterpret_cast<const uint4*>(gsrc + (long)gm * gld + gn) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if (ahead) fetch(0, gop);
+#pragma clang loop unroll(full)                     // acc[] is indexed by ps
   for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
@@ -932,20 +1031,39 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmP p) {
       for (int j = 0; j < 4; ++j)
         *reinterpret_cast<f32x4*>(cs + (wm * 32 + ii * 16 + (lane & 15)) * PB + wn * 64 + j * 16 + (lane >> 4) * 4) = acc[ps * 2 + ii][j];
     __syncthreads();
-#pragma unroll 1
-    for (int c = tid; c < ROWS_PASS * CPR; c += 512) {
-      const int lr = c / CPR, cc = (c % CPR) * 8;
-      const int gm = m0 + (lr >> 5) * (MI * 16) + ps * 32 + (lr & 31), gn = n0 + cc;
-      if (gm >= p.M || gn >= p.N) continue;
-      float v[8];
-      const float4 x0 = *reinterpret_cast<const float4*>(cs + lr * PB + cc);
-      const float4 x1 = *reinterpret_cast<const float4*>(cs + lr * PB + cc + 4);
-      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-      if (p.dbg == 1) {                           // ablation: everything but the global store
-        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-        continue;
+    if (ahead) {
+      if (ps + 1 < NPASS) fetch(ps + 1, gnext);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = tid + it * 512;
+        const int lr = c / CPR, cc = (c % CPR) * 8;
+        const int gm = m0 + (lr >> 5) * (MI * 16) + ps * 32 + (lr & 31), gn = n0 + cc;
+        if (gm < p.M && gn < p.N) {
+          float v[8];
+          const float4 x0 = *reinterpret_cast<const float4*>(cs + lr * PB + cc);
+          const float4 x1 = *reinterpret_cast<const float4*>(cs + lr * PB + cc + 4);
+          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+          epilogue_chunk<true>(p, v, gm, gn, slice, gop[it]);
+        }
       }
-      epilogue_chunk(p, v, gm, gn, slice);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) gop[it] = gnext[it];
+    } else {
+#pragma unroll 1
+      for (int c = tid; c < ROWS_PASS * CPR; c += 512) {
+        const int lr = c / CPR, cc = (c % CPR) * 8;
+        const int gm = m0 + (lr >> 5) * (MI * 16) + ps * 32 + (lr & 31), gn = n0 + cc;
+        if (gm >= p.M || gn >= p.N) continue;
+        float v[8];
+        const float4 x0 = *reinterpret_cast<const float4*>(cs + lr * PB + cc);
+        const float4 x1 = *reinterpret_cast<const float4*>(cs + lr * PB + cc + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        if (p.dbg == 1) {                           // ablation: everything but the global store
+          asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+          continue;
+        }
+        epilogue_chunk(p, v, gm, gn, slice);
+      }
     }
     if (ps + 1 < NPASS) __syncthreads();
   }
@@ -1644,7 +1762,8 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     const long t2 = (long)((a->M + 255) / 256) * ((a->N + bn2 - 1) / bn2);
     const bool transposed = a->transA || a->transB;
     // forward and dgrad: wide output AND enough 256x256 tiles (dgrad 8192x3072x768: 74 vs 60 us -> 128x128); weight gradients: wide
-    const bool use256 = a->transA ? wide : (wide && t2 >= 1200);
+    // (a dgrad whose epilogue reads the activation mask stays on the 128x128 tiles: 32000x3072x768 with the ReLU mask 245 vs 227 us)
+    const bool use256 = a->transA ? wide : (wide && t2 >= 1200 && a->dact == V2S_ACT_NONE);
     if (big_mode == 2) { if (t2 >= 240) { bm = 256; bn = bn2; } }
     else if (use256 && (t2 >= 240 || (plain_split && t2 >= 8))) { bm = 256; bn = bn2; }
   }
