@@ -347,15 +347,26 @@ int v2s_ban_token(float* scores, int64_t ld, int32_t rows, int32_t V, int32_t to
 int v2s_span_corrupt(const int64_t* ids, int64_t ld_ids, const int32_t* lens, const uint8_t* noise, int64_t ld_noise, int32_t B,
                      int32_t max_len, int64_t num_text_tokens, int64_t eos, int64_t* den_in, int64_t ld_in, int64_t* den_out,
                      int64_t ld_out, int32_t* out_lens, void* stream);
-/* one nucleus-sampling step (HF 4.28 sample(): temperature + top-p warpers + multinomial; call site vid2seq.py:150-162 with
- * do_sample=use_nucleus_sampling): per row, softmax(logits / temperature), keep the most probable tokens whose preceding mass is
- * < top_p, draw from the renormalised kept set with a counter-based uniform number (seed, row, *pos_dev) -- torch's RNG stream is not
- * reproducible, so parity is distributional.  Finished rows emit pad; the token is also written to seq_out[row][*pos_dev + 1] when
- * seq_out != NULL.  EOS has probability 0 while *pos_dev + 1 < min_length (MinLengthLogitsProcessor).  probs_out (optional,
- * [rows][V]) receives the filtered, renormalised distribution (tests). */
+/* one nucleus-sampling step (HF 4.28 sample(): temperature + top-k + top-p warpers + multinomial; call site vid2seq.py:150-162 with
+ * do_sample=use_nucleus_sampling): per row, softmax(logits / temperature), keep the top_k most probable tokens (0 = no top-k filter;
+ * HF's generation default top_k = 50 is in force whenever do_sample is set -- the reference never overrides it), of those the most
+ * probable ones whose preceding mass is < top_p, draw from the renormalised kept set with a counter-based uniform number (seed, row,
+ * *pos_dev) -- torch's RNG stream is not reproducible, so parity is distributional.  Finished rows emit pad; the token is also written
+ * to seq_out[row][*pos_dev + 1] when seq_out != NULL.  EOS has probability 0 while *pos_dev + 1 < min_length
+ * (MinLengthLogitsProcessor).  probs_out (optional, [rows][V]) receives the filtered, renormalised distribution (tests). */
 int v2s_topp_sample_step(const float* logits, int64_t ld, int32_t rows, int32_t V, float top_p, float temperature, uint32_t seed,
                          int64_t* next_tok, int32_t* unfinished, int32_t eos_id, int32_t pad_id, int64_t* seq_out, int64_t seq_ld,
-                         const int32_t* pos_dev, float* probs_out, int32_t min_length, void* stream);
+                         const int32_t* pos_dev, float* probs_out, int32_t min_length, int32_t top_k, void* stream);
+/* candidates of one beam-sample step (HF 4.28 beam_sample(): do_sample with num_beams > 1 at the call site vid2seq.py:150-162).
+ * Per beam row: score = (log_softmax(logits) [row_lse: a processor rewrote the logits against that normaliser; EOS banned while
+ * *pos_dev + 1 < min_length] + beam_scores[row]) / temperature, kept set = TopK(max(top_k, 2)) then TopP(top_p, keep >= 2) of the
+ * row; HF draws 2 * num_beams tokens without replacement from the softmax over all kept scores of a batch entry = the largest
+ * keys score + Gumbel noise (counter-based hash of seed, *pos_dev, row, token).  The kernel writes the K kept candidates of each row
+ * with the largest keys, sorted by key: out_val (scores), out_tok, out_key, each [rows][K]; unused slots hold -inf / 0 / -inf.
+ * K in [1, 64], top_k in [0, 64] (0 = 64: a row's kept list has 64 slots). */
+int v2s_beam_sample_cand(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const float* beam_scores, float top_p,
+                         float temperature, int32_t top_k, uint32_t seed, float* out_val, int32_t* out_tok, float* out_key,
+                         int32_t ban_token, const int32_t* pos_dev, int32_t min_length, const float* row_lse, void* stream);
 /* *ctr += delta (one thread; closes a captured decode step) */
 int v2s_counter_add(int32_t* ctr, int32_t delta, void* stream);
 

@@ -345,14 +345,66 @@ def vid2seq_forward(P: Params, cfg: RefConfig, video, input_ids, input_mask, out
 
 
 @torch.no_grad()
-def top_p_probs(logits: torch.Tensor, top_p: float, temperature: float = 1.0) -> torch.Tensor:
-    """The distribution HF 4.28 sample() draws from: TemperatureLogitsWarper then TopPLogitsWarper (min_tokens_to_keep=1), softmax."""
-    scores = logits.float() / temperature
-    sl, si = torch.sort(scores, descending=False, dim=-1)
-    remove = sl.softmax(-1).cumsum(-1) <= (1 - top_p)
-    remove[..., -1:] = False
-    scores = scores.masked_fill(remove.scatter(-1, si, remove), -float("inf"))
-    return scores.softmax(-1)
+def warp_scores(scores: torch.Tensor, top_p: float, temperature: float = 1.0, top_k: int = 0, min_keep: int = 1) -> torch.Tensor:
+    """HF 4.28 logits warpers in the order ``_get_logits_warper`` builds them: TemperatureLogitsWarper, TopKLogitsWarper (skipped for
+    top_k == 0; HF's generation default is 50), TopPLogitsWarper (skipped for top_p == 1).  ``min_keep`` = ``min_tokens_to_keep``: 1 for
+    sample(), 2 for beam_sample().  Returns the warped scores, removed entries at -inf."""
+    scores = scores.float() / temperature
+    if top_k:
+        k = min(max(top_k, min_keep), scores.shape[-1])
+        scores = scores.masked_fill(scores < torch.topk(scores, k)[0][..., -1, None], -float("inf"))
+    if top_p < 1.0:
+        sl, si = torch.sort(scores, descending=False, dim=-1)
+        remove = sl.softmax(-1).cumsum(-1) <= (1 - top_p)
+        remove[..., -min_keep:] = False
+        scores = scores.masked_fill(remove.scatter(-1, si, remove), -float("inf"))
+    return scores
+
+
+def top_p_probs(logits: torch.Tensor, top_p: float, temperature: float = 1.0, top_k: int = 0) -> torch.Tensor:
+    """The distribution HF 4.28 sample() draws from: temperature, top-k, top-p warpers (min_tokens_to_keep=1), softmax."""
+    return warp_scores(logits, top_p, temperature, top_k, 1).softmax(-1)
+
+
+def hash32(x):
+    """v2s_hash32 (vidchapters_amd/csrc/v2s_common.h) on numpy uint32 arrays / Python ints."""
+    import numpy as np
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF; x ^= x >> 16
+    return x
+
+
+def beam_sample_gumbel(seed: int, step: int, rows: int, V: int) -> torch.Tensor:
+    """The Gumbel noise of v2s_beam_sample_cand for every (row, token) of one step: a counter-based hash of (seed, step, row, token)
+    -> 24-bit uniform u -> -log(-log u).  Test infrastructure for the beam-sample restatement below (torch's multinomial stream, which
+    HF 4.28 beam_sample draws from, cannot be reproduced on the device: the kernel's own noise is restated instead)."""
+    import numpy as np
+    r = hash32((np.arange(rows, dtype=np.uint64) * 0x9E3779B1 + step * 0x85EBCA6B + 0x1234567) & 0xFFFFFFFF)
+    t = hash32((np.arange(V, dtype=np.uint64) * 0xC2B2AE35 + 0x27D4EB2F) & 0xFFFFFFFF)
+    h = hash32((seed & 0xFFFFFFFF) ^ r[:, None] ^ t[None, :])
+    u = ((h >> 8).astype(np.float64) + 0.5) / 16777216.0
+    return torch.from_numpy(-np.log(-np.log(u))).float()
+
+
+def beam_sample_step(logits: torch.Tensor, beam_scores: torch.Tensor, num_beams: int, top_p: float, temperature: float, top_k: int,
+                     noise: torch.Tensor, ban_token: int = -1):
+    """One step of HF 4.28 beam_sample() up to the scorer: log_softmax -> (MinLength ban) -> + beam score -> warpers (min_keep 2) ->
+    2*num_beams draws WITHOUT replacement from the softmax over an entry's nb*V warped scores, expressed as the largest keys
+    score + noise (Gumbel top-k = successive multinomial draws without replacement) -> sorted by score.  Returns (scores, tokens,
+    beam indices), each [B, 2*nb]."""
+    R_, V = logits.shape
+    B = R_ // num_beams
+    sc = torch.log_softmax(logits.float(), -1)
+    if ban_token >= 0:
+        sc[:, ban_token] = -float("inf")
+    sc = warp_scores(sc + beam_scores[:, None], top_p, temperature, top_k, 2)
+    key = (sc + noise).view(B, num_beams * V)
+    flat = sc.view(B, num_beams * V)
+    drawn = torch.topk(key, 2 * num_beams, dim=1)[1]
+    val = torch.gather(flat, 1, drawn)
+    val, order = torch.sort(val, descending=True, dim=1, stable=True)
+    drawn = torch.gather(drawn, 1, order)
+    return val, drawn % V, drawn // V
 
 
 def repetition_penalty_(scores: torch.Tensor, seq: torch.Tensor, penalty: float) -> None:

@@ -826,21 +826,26 @@ def test_topp_sampling_step_distribution():
     rows, V, ld = 6, 612, 616
     g = torch.Generator().manual_seed(3)
     logits = torch.zeros(rows, ld); logits[:, :V] = torch.randn(rows, V, generator=g) * 2.5; logits[:, V:] = 50.0
-    for top_p, temp in ((0.9, 1.0), (0.5, 0.7)):
-        want = R.top_p_probs(logits[:, :V], top_p, temp)
+    for top_p, temp, top_k in ((0.9, 1.0, 0), (0.5, 0.7, 0), (0.95, 1.2, 50), (1.0, 1.0, 7)):
+        want = R.top_p_probs(logits[:, :V], top_p, temp, top_k)
         probs = torch.zeros(rows, V, device=DEV)
         nxt = torch.zeros(rows, dtype=torch.long, device=DEV); unf = torch.ones(rows, dtype=torch.int32, device=DEV)
-        L.topp_sample_step(logits.to(DEV), ld, rows, V, top_p, temp, 1, nxt, unf, -1, 0, probs_out=probs)
+        L.topp_sample_step(logits.to(DEV), ld, rows, V, top_p, temp, 1, nxt, unf, -1, 0, probs_out=probs, top_k=top_k)
         got = probs.cpu()
         edge = ((got > 0) != (want > 0)).sum().item()          # ties at the nucleus boundary may fall either way
         assert edge <= rows and (got - want).abs().max() < 2e-3
+        if top_k:
+            assert ((got > 0).sum(1) <= top_k).all() and (top_p < 1.0 or ((got > 0).sum(1) == top_k).all())
         counts = torch.zeros(rows, V)
-        n_draw = 3000
+        n_draw = 3000 if top_k in (0, 7) else 300
         lg = logits.to(DEV)
         for sd in range(n_draw):
             unf.fill_(1)
-            L.topp_sample_step(lg, ld, rows, V, top_p, temp, 1000 + sd, nxt, unf, -1, 0)
+            L.topp_sample_step(lg, ld, rows, V, top_p, temp, 1000 + sd, nxt, unf, -1, 0, top_k=top_k)
             counts[torch.arange(rows), nxt.cpu()] += 1
+        if n_draw < 3000:
+            assert (counts[got == 0] == 0).all()
+            continue
         assert (counts[got == 0] == 0).all()                  # never outside the nucleus
         freq = counts / n_draw
         assert (freq - got).abs().max() < 0.04, float((freq - got).abs().max())
@@ -853,6 +858,49 @@ def test_topp_sampling_step_distribution():
     unf.fill_(1)
     L.topp_sample_step(big.to(DEV), ld, rows, V, 0.9, 1.0, 7, nxt, unf, 1, 0, seq_out=seq, seq_ld=8, pos_dev=pos, min_length=5)
     assert (nxt.cpu() != 1).all()
+
+
+def test_beam_sample_candidates_vs_oracle():
+    """v2s_beam_sample_cand against the oracle's restatement of one HF 4.28 beam_sample step (log-softmax, EOS ban, beam score,
+    temperature / top-k / top-p warpers with min_tokens_to_keep 2, draws without replacement as the largest score + Gumbel keys) with
+    the kernel's own counter-based noise restated on the host: kept sets, scores and keys per row, and -- after the host merge
+    (beam.BeamScorer ordering) -- the same 2*nb (score, token, beam) triples per entry."""
+    from oracle import vid2seq_ref as R
+    B, nb, V, ld, K = 3, 4, 1500, 1504, 8
+    rows = B * nb
+    g = torch.Generator().manual_seed(9)
+    logits = torch.zeros(rows, ld); logits[:, :V] = torch.randn(rows, V, generator=g) * 3; logits[:, V:] = 60.0
+    bscore = torch.randn(rows, generator=g) * 2
+    pos = torch.tensor([3], dtype=torch.int32, device=DEV)
+    for top_p, temp, top_k, min_length in ((0.9, 1.0, 50, 1), (0.6, 0.7, 50, 9), (1.0, 1.3, 5, 1), (0.05, 1.0, 50, 1)):
+        ban = 1 if 3 + 1 < min_length else -1
+        val = torch.zeros(rows, K, device=DEV); key = torch.zeros(rows, K, device=DEV); tok = torch.zeros(rows, K, dtype=torch.int32, device=DEV)
+        L.beam_sample_cand(logits.to(DEV), ld, rows, V, K, bscore.to(DEV), top_p, temp, top_k, 77, val, tok, key, ban_token=1, pos_dev=pos,
+                           min_length=min_length)
+        val, key, tok = val.cpu(), key.cpu(), tok.cpu().long()
+        sc = torch.log_softmax(logits[:, :V], -1)
+        if ban >= 0:
+            sc[:, ban] = -float("inf")
+        w = R.warp_scores(sc + bscore[:, None], top_p, temp, top_k, 2)
+        noise = R.beam_sample_gumbel(77, 3, rows, V)
+        kept = torch.isfinite(w).sum(1)
+        assert (kept >= 2).all()
+        if top_p <= 0.05:
+            assert (kept == 2).all()                          # min_tokens_to_keep
+        for r in range(rows):
+            n = min(int(kept[r]), K)
+            wk, wi = torch.topk(w[r] + noise[r], n)
+            assert tok[r, :n].tolist() == wi.tolist(), (r, tok[r], wi)
+            assert (val[r, :n] - w[r, wi]).abs().max() < 2e-4 and (key[r, :n] - wk).abs().max() < 2e-3
+            assert torch.isinf(key[r, n:]).all() and torch.isinf(val[r, n:]).all()
+        # host merge == the oracle's joint draw
+        from vidchapters_amd.beam import BeamScorer
+        scorer = BeamScorer(B, nb, 1.0, -5, 0, 0, 8, sample=True)
+        new_tok, src, _ = scorer.advance(val.numpy(), tok.numpy().astype(np.int32), key.numpy())
+        wv, wt, wb = R.beam_sample_step(logits[:, :V], bscore, nb, top_p, temp, top_k, noise, ban_token=ban)
+        assert new_tok.reshape(B, nb).tolist() == wt[:, :nb].tolist()
+        assert src.reshape(B, nb).tolist() == (wb[:, :nb] + torch.arange(B)[:, None] * nb).tolist()
+        assert np.abs(scorer.scores - wv[:, :nb].numpy()).max() < 2e-4
 
 
 def test_decode_kernels():

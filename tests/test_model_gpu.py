@@ -493,6 +493,56 @@ def test_generate_with_nucleus_sampling_runs():
     assert torch.equal(greedy[:, :n], samp[:, :n])
 
 
+def test_generate_beam_sample_vs_oracle():
+    """generate(use_nucleus_sampling=True, num_beams=4) = HF 4.28 beam_sample (vid2seq.py:150-162 forwards do_sample together with
+    num_beams): strings come back, a call is reproducible for a given sampling seed and differs for another, num_captions expands the
+    rows; and, step by step along the engine's trajectory, the oracle's restatement of beam_sample (warpers + draws without replacement
+    as Gumbel keys, the kernel's noise restated on the host) reproduces the beam scores and the final sequences."""
+    from vidchapters_amd.beam import BeamScorer
+    cfg = R.RefConfig.small()
+    model = build(cfg, 21).eval()
+    P = synth.init_params(R.param_shapes(cfg), 21, cfg.d_model, cfg.inner, cfg.d_ff)
+    b = synth.make_batch(4, cfg.num_features, 24, 12, cfg.vocab, 21, cfg.vit_dim)
+    video, ids = b["video"].to(DEV), tok(b["input_ids"])
+    nb, max_new, top_p, temp, top_k = 4, 10, 0.9, 0.8, 50
+    model.sampling_seed = 100
+    t1 = model.generate(video, ids, use_nucleus_sampling=True, num_beams=nb, max_length=max_new, top_p=top_p, temperature=temp)
+    model.sampling_seed = 100
+    t2 = model.generate(video, ids, use_nucleus_sampling=True, num_beams=nb, max_length=max_new, top_p=top_p, temperature=temp)
+    t3 = model.generate(video, ids, use_nucleus_sampling=True, num_beams=nb, max_length=max_new, top_p=top_p, temperature=temp)
+    assert len(t1) == 4 and all(isinstance(x, str) for x in t1) and t1 == t2 and t1 != t3
+    caps = model.generate(video, ids, use_nucleus_sampling=True, num_beams=2, max_length=6, num_captions=2)
+    assert len(caps) == 8
+    # Along the engine's own trajectory (a free-running fp32 oracle diverges at the first near-tied key, and HF's accumulation of
+    # temperature-scaled scores amplifies any difference by 1/T per step): record the logits / beam scores / step counter every step
+    # hands to the kernel, recompute that step with the oracle (warpers, keys from the restated noise) and drive a second host scorer
+    # with it -- beam scores of every following step, and the final sequences, must agree.
+    import vidchapters_amd.engine as E
+    seed, rec, orig = 555, [], E.L.beam_sample_cand
+
+    def spy(logits, ld, rows, V, K, bscore, *a, **kw):
+        rec.append((logits.view(-1, ld)[:rows, :V].float().cpu().clone(), bscore.cpu().clone(), int(kw["pos_dev"].item())))
+        return orig(logits, ld, rows, V, K, bscore, *a, **kw)
+    E.L.beam_sample_cand = spy
+    try:
+        got = model.engine().beam_search(video, ids, num_beams=nb, max_new_tokens=max_new, sample=(top_p, temp, seed, top_k), use_graph=False).cpu()
+    finally:
+        E.L.beam_sample_cand = orig
+    B = 4
+    sc = BeamScorer(B, nb, 1.0, cfg.eos_id, cfg.pad_id, cfg.dec_start_id, max_new + 1, sample=True)
+    assert [r[2] for r in rec] == list(range(len(rec)))
+    for t, (logits, bscore, pos) in enumerate(rec):
+        assert np.abs(bscore.numpy() - sc.scores.reshape(-1)).max() < 1e-3, t
+        noise = R.beam_sample_gumbel(seed, pos, B * nb, logits.shape[1])
+        w = R.warp_scores(torch.log_softmax(logits, -1) + bscore[:, None], top_p, temp, top_k, 2)
+        kk, ki = torch.topk(w + noise, 2 * nb, dim=1)
+        _, _, finished = sc.advance(torch.gather(w, 1, ki).numpy(), ki.numpy().astype(np.int32), kk.numpy())
+        assert finished == (t == len(rec) - 1)
+    want = torch.from_numpy(sc.finalize(1))
+    print(f"beam-sample: {len(rec)} steps; hip {got[0].tolist()} oracle {want[0].tolist()}")
+    assert got.shape == want.shape and torch.equal(got, want)
+
+
 def test_greedy_min_length_and_sampled_num_captions_vs_oracle():
     """generate(num_beams=1, min_length=k) (EOS banned by v2s_ban_token from the device step counter, inside the replayed graph) against
     the oracle's greedy loop (itself checked against the installed transformers), and num_captions > 1 with nucleus sampling (HF expands

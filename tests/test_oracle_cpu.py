@@ -111,15 +111,49 @@ def test_oracle_repetition_penalty_vs_golden(golden_dir):
 
 
 def test_oracle_top_p_filter_equals_installed_hf_warpers():
-    """oracle.top_p_probs == softmax after the installed transformers' TemperatureLogitsWarper + TopPLogitsWarper (un-vendored in the
-    reference: 4.28 itself cannot be imported here)."""
-    from transformers.generation.logits_process import TemperatureLogitsWarper, TopPLogitsWarper
+    """oracle.top_p_probs / warp_scores == the installed transformers' TemperatureLogitsWarper + TopKLogitsWarper + TopPLogitsWarper
+    (un-vendored in the reference: 4.28 itself cannot be imported here), for sample() (min_tokens_to_keep 1) and beam_sample() (2)."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
     g = torch.Generator().manual_seed(0)
     for V, tp, T in ((612, 0.9, 1.0), (4000, 0.9, 1.0), (500, 0.5, 0.7), (100, 0.95, 1.3)):
         lg = torch.randn(5, V, generator=g) * 3
         sc = TemperatureLogitsWarper(T)(None, lg.clone()) if T != 1.0 else lg.clone()
         ref = TopPLogitsWarper(top_p=tp)(None, sc).softmax(-1)
         assert torch.equal(R.top_p_probs(lg, tp, T), ref)
+        for top_k, keep in ((50, 1), (50, 2), (1, 2), (7, 1)):
+            sc = TemperatureLogitsWarper(T)(None, lg.clone()) if T != 1.0 else lg.clone()
+            sc = TopKLogitsWarper(top_k=top_k, min_tokens_to_keep=keep)(None, sc)
+            ref = TopPLogitsWarper(top_p=tp, min_tokens_to_keep=keep)(None, sc)
+            assert torch.equal(R.warp_scores(lg, tp, T, top_k, keep), ref)
+            if keep == 1:
+                assert torch.equal(R.top_p_probs(lg, tp, T, top_k), ref.softmax(-1))
+
+
+def test_host_beam_scorer_sampled_candidates():
+    """BeamScorer.advance with sampling keys == the oracle's beam_sample_step on the same scores and noise: per entry the 2*nb
+    candidates with the largest keys, ordered by score; all beams start at score 0."""
+    from vidchapters_amd.beam import BeamScorer
+    B, nb, V, K = 3, 4, 97, 8
+    g = torch.Generator().manual_seed(5)
+    sc = BeamScorer(B, nb, 1.0, 1, 0, 0, 6, sample=True)
+    assert (sc.scores == 0).all()
+    for step in range(3):
+        logits = torch.randn(B * nb, V, generator=g) * 2
+        noise = R.beam_sample_gumbel(11, step, B * nb, V)
+        bs = torch.from_numpy(sc.scores.reshape(-1).copy())
+        val, tok, beam = R.beam_sample_step(logits, bs, nb, 0.9, 0.8, 10, noise)
+        # what the device kernel hands over: per row, the K kept candidates with the largest keys
+        w = R.warp_scores(torch.log_softmax(logits, -1) + bs[:, None], 0.9, 0.8, 10, 2)
+        key = w + noise
+        kk, ki = torch.topk(key, K, dim=1)
+        cand_val = torch.gather(w, 1, ki).numpy()
+        prev = sc.seqs.copy()
+        new_tok, src, _ = sc.advance(cand_val, ki.numpy().astype(np.int32), kk.numpy())
+        for b in range(B):
+            want = [(int(t), int(b * nb + r)) for t, r in zip(tok[b], beam[b]) if int(t) != 1][:nb]
+            got = list(zip(new_tok.reshape(B, nb)[b].tolist(), src.reshape(B, nb)[b].tolist()))
+            assert got == want
+        assert np.array_equal(sc.seqs[:, :sc.cur_len - 1], prev[src][:, :sc.cur_len - 1])
 
 
 def test_host_beam_scorer_matches_oracle(golden_dir):

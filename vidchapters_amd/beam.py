@@ -4,6 +4,11 @@ Mirrors what the reference gets from ``transformers==4.28.0`` ``BeamSearchScorer
 ``Vid2Seq.generate`` (model/vid2seq.py:150-162) runs with ``num_beams>1, do_sample=False, early_stopping=False,
 num_return_sequences=1``.  The device produces, for every live beam, its 2*num_beams best continuations
 (``v2s_topk_logprob``); everything here is small integer/float bookkeeping on numpy arrays.
+
+With ``do_sample=True`` (HF 4.28 ``beam_sample``) the device sends sampled candidates instead (``v2s_beam_sample_cand``: warped
+scores + Gumbel keys): an entry's 2*num_beams continuations are the candidates with the largest keys (= HF's multinomial draw
+without replacement from the softmax over the entry's warped scores), then ordered by score like HF's ``torch.sort`` of the draws;
+all beams start with score 0 (beam_sample does not mask beams 1.. with -1e9: the sampling tells them apart).
 """
 from __future__ import annotations
 
@@ -39,7 +44,8 @@ class _Heap:
 
 
 class BeamScorer:
-    def __init__(self, batch: int, num_beams: int, length_penalty: float, eos_id: int, pad_id: int, start_id: int, max_length: int):
+    def __init__(self, batch: int, num_beams: int, length_penalty: float, eos_id: int, pad_id: int, start_id: int, max_length: int,
+                 sample: bool = False):
         self.B, self.nb, self.eos, self.pad, self.max_length = batch, num_beams, eos_id, pad_id, max_length
         self.heaps = [_Heap(num_beams, length_penalty) for _ in range(batch)]
         self.done = np.zeros(batch, dtype=bool)
@@ -47,16 +53,23 @@ class BeamScorer:
         self.seqs[:, 0] = start_id
         self.cur_len = 1
         self.scores = np.zeros((batch, num_beams), dtype=np.float32)
-        self.scores[:, 1:] = -1e9
+        if not sample:
+            self.scores[:, 1:] = -1e9
 
-    def advance(self, cand_val: np.ndarray, cand_tok: np.ndarray):
+    def advance(self, cand_val: np.ndarray, cand_tok: np.ndarray, cand_key: np.ndarray = None):
         """cand_val/cand_tok: [B*nb, K] per-beam sorted candidates.  Returns (tokens [B*nb] int64, source rows [B*nb] int32,
-        finished) and updates ``self.scores`` / ``self.seqs``."""
+        finished) and updates ``self.scores`` / ``self.seqs``.  ``cand_key`` (beam-sample): the 2*nb candidates of an entry are the
+        ones with the largest keys, ordered by value."""
         B, nb = self.B, self.nb
         K = cand_val.shape[1]
         val = cand_val.reshape(B, nb * K)
         tok = cand_tok.reshape(B, nb * K)
-        order = np.argsort(-val, axis=1, kind="stable")[:, :2 * nb]
+        if cand_key is None:
+            order = np.argsort(-val, axis=1, kind="stable")[:, :2 * nb]
+        else:
+            drawn = np.argsort(-cand_key.reshape(B, nb * K), axis=1, kind="stable")[:, :2 * nb]
+            by_val = np.argsort(-np.take_along_axis(val, drawn, 1), axis=1, kind="stable")
+            order = np.take_along_axis(drawn, by_val, 1)
         tok_sel = np.take_along_axis(tok, order, 1)
         val_sel = np.take_along_axis(val, order, 1)
         src_sel = (np.arange(B, dtype=np.int64)[:, None] * nb + order // K).astype(np.int32)

@@ -441,10 +441,25 @@ __device__ __forceinline__ float block_sum256(float v, float* red, int tid) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// bit pattern of the k-th largest of V non-negative floats in LDS (non-negative floats order like their bit patterns): bisection on
+// the 31 value bits, count(x >= T) per step -- exact, ties at the k-th value included (HF TopKLogitsWarper removes only scores strictly
+// below the k-th).  red: >= 4 floats of LDS scratch.  All 256 threads call it.
+__device__ __forceinline__ uint32_t kth_largest_bits(const float* pr, int V, int k, float* red, int tid) {
+  uint32_t lo = 0u, hi = 0x7f800001u;     // count(>= lo) >= k (V >= k), count(>= hi) = 0 < k
+  while (hi - lo > 1u) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    float c = 0.f;
+    for (int i = tid; i < V; i += 256) c += __float_as_uint(pr[i]) >= mid ? 1.f : 0.f;
+    c = block_sum256(c, red, tid);
+    if (c >= (float)k) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 __global__ __launch_bounds__(256) void topp_sample_kernel(const float* __restrict__ logits, long ld, int V, float top_p, float inv_temp,
                                                           uint32_t seed, long* __restrict__ next_tok, int* __restrict__ unfinished, int eos_id,
                                                           int pad_id, long* __restrict__ seq_out, long seq_ld, const int* __restrict__ pos_dev,
-                                                          float* __restrict__ probs_out, int min_length) {
+                                                          float* __restrict__ probs_out, int min_length, int top_k) {
   extern __shared__ float pr[];          // V probabilities (unnormalised), then 256 + 8 floats of scratch
   float* part = pr + V;
   float* red = part + 256;
@@ -461,6 +476,11 @@ __global__ __launch_bounds__(256) void topp_sample_kernel(const float* __restric
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float s = 0.f;
   for (int i = tid; i < V; i += 256) { const float e = i == ban ? 0.f : __expf((z[i] - m) * inv_temp); pr[i] = e; s += e; }
+  if (top_k > 0 && top_k < V) {           // TopKLogitsWarper (HF generation default top_k = 50 applies whenever do_sample is set)
+    const uint32_t kth = kth_largest_bits(pr, V, top_k, red, tid);
+    s = 0.f;
+    for (int i = tid; i < V; i += 256) { const float e = __float_as_uint(pr[i]) >= kth ? pr[i] : 0.f; pr[i] = e; s += e; }
+  }
   const float Z = block_sum256(s, red, tid);
   // bisection: G(tau) = mass of tokens with p > tau; invariant G(lo) >= top_p > G(hi)
   float lo = -1.f, hi = 1.f;             // p_max = exp(0)/Z <= 1
@@ -515,6 +535,92 @@ __global__ __launch_bounds__(256) void topp_sample_kernel(const float* __restric
     next_tok[row] = tok;
     unfinished[row] = un && (tok != eos_id);
     if (seq_out) seq_out[(long)row * seq_ld + *pos_dev + 1] = tok;
+  }
+}
+
+// ---- beam-sample step (vid2seq.py:150-162 with do_sample=True AND num_beams > 1: HF 4.28 beam_sample()).  Per beam row:
+//   scores = log_softmax(logits) -> processors (the caller's repetition penalty via row_lse; MinLength bans EOS) -> + beam score
+//   -> warpers: / temperature, TopK(top_k, keep >= 2), TopP(top_p, keep >= 2)
+// HF then draws 2*nb tokens WITHOUT replacement from the softmax over the nb * V warped scores of a batch entry, and sorts the
+// draws by score.  Drawing without replacement from weights exp(score) = taking the largest keys score + Gumbel noise, so the
+// kernel emits, per row, its K (>= 2*nb) kept candidates with the largest keys (sorted by key): [score | token | key]; the host
+// merges the nb rows of an entry by key and orders the winners by score (beam.BeamScorer.advance).  The noise is a counter-based
+// hash of (seed, step, row, token): torch's multinomial stream cannot be reproduced, the distribution is the same.
+// One block per row; the row's tempered, unnormalised probabilities live in LDS; the kept set has at most 64 members (top_k <= 64).
+__device__ __forceinline__ float beam_sample_gumbel(uint32_t seed, int step, int row, int tok) {
+  const uint32_t h = v2s_hash32(seed ^ v2s_hash32((uint32_t)row * 0x9E3779B1u + (uint32_t)step * 0x85EBCA6Bu + 0x1234567u) ^
+                                v2s_hash32((uint32_t)tok * 0xC2B2AE35u + 0x27D4EB2Fu));
+  const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  return -logf(-logf(u));
+}
+
+__global__ __launch_bounds__(256) void beam_sample_cand_kernel(const float* __restrict__ logits, long ld, int V, const float* __restrict__ beam_scores,
+                                                               float top_p, float inv_temp, int top_k, int min_keep, uint32_t seed,
+                                                               float* __restrict__ out_val, int* __restrict__ out_tok, float* __restrict__ out_key,
+                                                               int K, int ban_tok, const int* __restrict__ pos_dev, int min_length,
+                                                               const float* __restrict__ row_lse) {
+  extern __shared__ float pr[];          // V tempered probabilities (unnormalised), then 8 floats of scratch, then the kept list
+  float* red = pr + V;
+  int* s_tok = reinterpret_cast<int*>(red + 8);      // [64]
+  int* s_cnt = s_tok + 64;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* z = logits + (long)row * ld;
+  const int step = pos_dev ? *pos_dev : 0;
+  const int ban = (ban_tok >= 0 && step + 1 < min_length) ? ban_tok : -1;
+  float m = -INFINITY;
+  for (int i = tid; i < V; i += 256) m = fmaxf(m, z[i]);
+  m = wave_max(m);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s1 = 0.f;                         // log_softmax normaliser: over ALL tokens, untempered (the processors come after it)
+  for (int i = tid; i < V; i += 256) {
+    const float d = z[i] - m;
+    s1 += __expf(d);
+    pr[i] = i == ban ? 0.f : __expf(d * inv_temp);
+  }
+  s1 = block_sum256(s1, red, tid);
+  const float lse = row_lse ? row_lse[row] : m + logf(s1);
+  if (tid == 0) *s_cnt = 0;
+  const int k = top_k > 0 && top_k < 64 ? top_k : 64;
+  const uint32_t kth = k < V ? kth_largest_bits(pr, V, k < min_keep ? min_keep : k, red, tid) : 0u;
+  __syncthreads();
+  for (int i = tid; i < V; i += 256) {
+    const float e = pr[i];
+    if (e > 0.f && __float_as_uint(e) >= kth) {
+      const int slot = atomicAdd(s_cnt, 1);
+      if (slot < 64) s_tok[slot] = i;
+    }
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  const int n = min(*s_cnt, 64), lane = tid;
+  const int tok = lane < n ? s_tok[lane] : 0x7fffffff;
+  const float e = lane < n ? pr[tok] : 0.f;
+  // rank by probability (descending; equal values: lower token first) and the mass in front of each member
+  int rank = 0;
+  float before = 0.f, Zk = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float ei = __shfl(e, i, 64);
+    const int ti = __shfl(tok, i, 64);
+    const bool ahead = ei > e || (ei == e && ti < tok);
+    rank += ahead ? 1 : 0;
+    before += ahead ? ei : 0.f;
+    Zk += ei;
+  }
+  const bool keep = lane < n && (before < top_p * Zk || rank < min_keep);
+  const float base = beam_scores ? beam_scores[row] : 0.f;
+  const float score = keep ? ((z[tok] - lse) + base) * inv_temp : -INFINITY;
+  const float key = keep ? score + beam_sample_gumbel(seed, step, row, tok) : -INFINITY;
+  int krank = 0;
+  for (int i = 0; i < 64; ++i) {
+    const float ki = __shfl(key, i, 64);
+    krank += (ki > key || (ki == key && i < lane)) ? 1 : 0;
+  }
+  if (krank < K) {
+    const long o = (long)row * K + krank;
+    out_val[o] = score; out_tok[o] = keep ? tok : 0; out_key[o] = key;
   }
 }
 
@@ -635,8 +741,8 @@ extern "C" int v2s_ban_token(float* scores, int64_t ld, int32_t rows, int32_t V,
 
 extern "C" int v2s_topp_sample_step(const float* logits, int64_t ld, int32_t rows, int32_t V, float top_p, float temperature, uint32_t seed,
                                     int64_t* next_tok, int32_t* unfinished, int32_t eos_id, int32_t pad_id, int64_t* seq_out, int64_t seq_ld,
-                                    const int32_t* pos_dev, float* probs_out, int32_t min_length, void* stream) {
-  V2S_CHECK(logits && next_tok && unfinished && rows > 0 && V > 0, V2S_ERR_ARG, "v2s_topp_sample_step: bad args");
+                                    const int32_t* pos_dev, float* probs_out, int32_t min_length, int32_t top_k, void* stream) {
+  V2S_CHECK(logits && next_tok && unfinished && rows > 0 && V > 0 && top_k >= 0, V2S_ERR_ARG, "v2s_topp_sample_step: bad args");
   V2S_CHECK(top_p > 0.f && top_p <= 1.f && temperature > 0.f, V2S_ERR_ARG, "v2s_topp_sample_step: top_p in (0,1], temperature > 0");
   V2S_CHECK(!seq_out || pos_dev, V2S_ERR_ARG, "v2s_topp_sample_step: seq_out needs pos_dev");
   const size_t dyn = ((size_t)V + 256 + 8) * sizeof(float);
@@ -644,7 +750,24 @@ extern "C" int v2s_topp_sample_step(const float* logits, int64_t ld, int32_t row
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)topp_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   hipLaunchKernelGGL(topp_sample_kernel, dim3(rows), dim3(256), dyn, (hipStream_t)stream, logits, (long)ld, V, top_p, 1.0f / temperature, seed,
-                     (long*)next_tok, unfinished, eos_id, pad_id, (long*)seq_out, (long)seq_ld, pos_dev, probs_out, min_length);
+                     (long*)next_tok, unfinished, eos_id, pad_id, (long*)seq_out, (long)seq_ld, pos_dev, probs_out, min_length, top_k);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_beam_sample_cand(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const float* beam_scores, float top_p,
+                                    float temperature, int32_t top_k, uint32_t seed, float* out_val, int32_t* out_tok, float* out_key,
+                                    int32_t ban_token, const int32_t* pos_dev, int32_t min_length, const float* row_lse, void* stream) {
+  V2S_CHECK(logits && out_val && out_tok && out_key && rows > 0 && V > 0, V2S_ERR_ARG, "v2s_beam_sample_cand: bad args");
+  V2S_CHECK(K >= 1 && K <= 64, V2S_ERR_ARG, "v2s_beam_sample_cand: K must be in [1, 64] (got %d)", K);
+  V2S_CHECK(top_p > 0.f && top_p <= 1.f && temperature > 0.f && top_k >= 0 && top_k <= 64, V2S_ERR_ARG,
+            "v2s_beam_sample_cand: top_p in (0,1], temperature > 0, top_k in [0, 64] (0 = 64: the kept list of a row has 64 slots)");
+  const size_t dyn = ((size_t)V + 8) * sizeof(float) + 65 * sizeof(int);
+  V2S_CHECK(dyn <= 160 * 1024, V2S_ERR_SHAPE, "v2s_beam_sample_cand: vocabulary %d too large for the LDS row buffer", V);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)beam_sample_cand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(beam_sample_cand_kernel, dim3(rows), dim3(256), dyn, (hipStream_t)stream, logits, (long)ld, V, beam_scores, top_p,
+                     1.0f / temperature, top_k, 2, seed, out_val, out_tok, out_key, K, ban_token, pos_dev, min_length, row_lse);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

@@ -1021,8 +1021,8 @@ class Engine:
         step-dependent quantity (cache position, number of keys, bias row, output column) is read by the kernels from a
         device-resident step counter, so the same graph serves all steps.  The all-rows-finished test of HF is evaluated
         every 8 replays; the returned tensor is trimmed to exactly the length HF would have produced.
-        ``sample=(top_p, temperature, seed)`` switches the token choice from argmax to nucleus sampling (same loop and stopping
-        rule as HF's sample()); ``min_length`` bans EOS while the decoder sequence is shorter (HF MinLengthLogitsProcessor)."""
+        ``sample=(top_p, temperature, seed[, top_k])`` switches the token choice from argmax to sampling (temperature, top-k, top-p
+        warpers; same loop and stopping rule as HF's sample()); ``min_length`` bans EOS while the decoder sequence is shorter (HF MinLengthLogitsProcessor)."""
         a, c = self.arena, self.cfg
         mem, mem_mask = self.encode(video, input_tokenized)
         B, S, d = mem.shape
@@ -1085,9 +1085,10 @@ class Engine:
                 L.repetition_penalty(logits, self.ldv, B, self.V, seq, repetition_penalty, pos_dev=pos)
             if sample is None and min_length > 1 and eos >= 0:      # MinLengthLogitsProcessor of greedy_search (sampling: inside the sampling kernel)
                 L.ban_token(logits, self.ldv, B, self.V, c.eos_id, pos, min_length)
-            if sample is not None:                  # nucleus sampling (HF sample(): processors, then temperature / top-p warpers, multinomial)
+            if sample is not None:                  # HF sample(): processors, then temperature / top-k / top-p warpers, multinomial
                 L.topp_sample_step(logits, self.ldv, B, self.V, sample[0], sample[1], sample[2], nxt, unfinished, eos, c.pad_id,
-                                   seq_out=seq, seq_ld=maxlen + 1, pos_dev=pos, min_length=min_length)
+                                   seq_out=seq, seq_ld=maxlen + 1, pos_dev=pos, min_length=min_length,
+                                   top_k=sample[3] if len(sample) > 3 else 0)
             else:
                 L.argmax_step_seq(logits, self.ldv, B, self.V, nxt, unfinished, eos, c.pad_id, seq, maxlen + 1, pos)
             L.counter_add(pos, 1)
@@ -1118,8 +1119,11 @@ class Engine:
 
     @torch.no_grad()
     def beam_search(self, video, input_tokenized, num_beams: int, max_new_tokens: int, length_penalty: float = 1.0,
-                    use_graph: bool = True, min_length: int = 1, repetition_penalty: float = 1.0, num_return: int = 1) -> torch.Tensor:
+                    use_graph: bool = True, min_length: int = 1, repetition_penalty: float = 1.0, num_return: int = 1,
+                    sample=None) -> torch.Tensor:
         """HF-4.28 beam_search + BeamSearchScorer semantics (call site vid2seq.py:150-162) on static caches.
+        ``sample=(top_p, temperature, seed, top_k)`` turns the step into HF's beam_sample (do_sample with num_beams > 1): the
+        candidates of a row come from ``v2s_beam_sample_cand`` (warped scores + Gumbel keys) instead of ``v2s_topk_logprob``.
         The encoder memory is NOT replicated per beam: cross K/V are projected once per batch entry and the nb beams of an
         entry read the same rows (``kv_group``).  A step = decoder forward for B*nb rows -> ``v2s_topk_logprob`` (log-softmax +
         running beam score + per-beam top 2*nb), captured as a hipGraph; the host merges the candidates (beam.BeamScorer) and
@@ -1153,16 +1157,18 @@ class Engine:
         # down, [candidate values f32 | candidate tokens i32] up
         h2d = torch.zeros(4 * R, dtype=torch.int32, device=self.device)
         pins = self._ws.setdefault("beam_pinned", {})          # pinned staging is allocated once per (rows, K): hipHostMalloc costs ms
-        if (R, K) not in pins:
-            pins[(R, K)] = (torch.zeros(4 * R, dtype=torch.int32).pin_memory(), torch.zeros(2, R, K, dtype=torch.int32).pin_memory())
-        h2d_host, cand_host = pins[(R, K)]
+        NP = 3 if sample is not None else 2                    # candidate planes: values, tokens (, sampling keys)
+        if (R, K, NP) not in pins:
+            pins[(R, K, NP)] = (torch.zeros(4 * R, dtype=torch.int32).pin_memory(), torch.zeros(NP, R, K, dtype=torch.int32).pin_memory())
+        h2d_host, cand_host = pins[(R, K, NP)]
         nxt = h2d[:2 * R].view(torch.long)
         nxt.fill_(c.dec_start_id)
         pos = torch.zeros(1, dtype=torch.int32, device=self.device)
         bscore = h2d[2 * R:3 * R].view(torch.float32)
         src_dev = h2d[3 * R:]
-        cand = torch.zeros(2, R, K, dtype=torch.int32, device=self.device)
+        cand = torch.zeros(NP, R, K, dtype=torch.int32, device=self.device)
         cand_val, cand_tok = cand[0].view(torch.float32), cand[1]
+        cand_key = cand[2].view(torch.float32) if sample is not None else None
         h_tok, h_score, h_src = (h2d_host[:2 * R].view(torch.long).numpy(), h2d_host[2 * R:3 * R].view(torch.float32).numpy(),
                                  h2d_host[3 * R:].numpy())
         logits = self._f32(R, self.ldv)
@@ -1211,11 +1217,15 @@ class Engine:
                 L.gemm(n, E, logits, R, self.V, d, ldc=self.ldv, alpha=d ** -0.5, decode=True)
             if rp:          # processor on the log-probabilities (beam_search): rewrites the logits against the stored row lse
                 L.repetition_penalty(logits, self.ldv, R, self.V, hist, repetition_penalty, pos_dev=pos, row_lse=row_lse)
-            L.topk_logprob(logits, self.ldv, R, self.V, K, bscore, cand_val, cand_tok, ban_token=c.eos_id, pos_dev=pos,
-                           min_length=min_length, row_lse=row_lse if rp else None)
+            if sample is not None:
+                L.beam_sample_cand(logits, self.ldv, R, self.V, K, bscore, sample[0], sample[1], sample[3], sample[2], cand_val, cand_tok,
+                                   cand_key, ban_token=c.eos_id, pos_dev=pos, min_length=min_length, row_lse=row_lse if rp else None)
+            else:
+                L.topk_logprob(logits, self.ldv, R, self.V, K, bscore, cand_val, cand_tok, ban_token=c.eos_id, pos_dev=pos,
+                               min_length=min_length, row_lse=row_lse if rp else None)
             L.counter_add(pos, 1)
 
-        scorer = BeamScorer(B, nb, length_penalty, c.eos_id, c.pad_id, c.dec_start_id, max_new_tokens + 1)
+        scorer = BeamScorer(B, nb, length_penalty, c.eos_id, c.pad_id, c.dec_start_id, max_new_tokens + 1, sample=sample is not None)
         if rp:
             hist.copy_(torch.from_numpy(scorer.seqs))
         bscore.copy_(torch.from_numpy(scorer.scores.reshape(-1)))
@@ -1235,7 +1245,8 @@ class Engine:
                 graph.replay()
             cand_host.copy_(cand, non_blocking=True)
             torch.cuda.current_stream().synchronize()
-            tok, src, finished = scorer.advance(cand_host[0].view(torch.float32).numpy(), cand_host[1].numpy())
+            tok, src, finished = scorer.advance(cand_host[0].view(torch.float32).numpy(), cand_host[1].numpy(),
+                                                cand_host[2].view(torch.float32).numpy() if sample is not None else None)
             if finished:
                 break
             h_tok[:] = tok; h_score[:] = scorer.scores.reshape(-1); h_src[:] = src

@@ -100,7 +100,8 @@ SYMBOLS = {
     "v2s_scale_cols": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "v2s_span_corrupt": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "v2s_topk_logprob": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
-    "v2s_topp_sample_step": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _f32, _u32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "v2s_topp_sample_step": (C.c_int, [_vp, _i64, _i32, _i32, _f32, _f32, _u32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp]),
+    "v2s_beam_sample_cand": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _f32, _f32, _i32, _u32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "v2s_repetition_penalty": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),
     "v2s_kv_gather": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "v2s_ban_token": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
@@ -496,7 +497,18 @@ def scale_cols(W, w, out, rows, cols):
 
 
 def topp_sample_step(logits, ld, rows, V, top_p, temperature, seed, next_tok, unfinished, eos_id, pad_id, seq_out=None, seq_ld=0, pos_dev=None,
-                     probs_out=None, min_length=0):
+                     probs_out=None, min_length=0, top_k=0):
     _check(lib().v2s_topp_sample_step(logits.data_ptr(), ld, rows, V, top_p, temperature, seed & 0xFFFFFFFF, next_tok.data_ptr(),
-                                      unfinished.data_ptr(), eos_id, pad_id, ptr(seq_out), seq_ld, ptr(pos_dev), ptr(probs_out), min_length, stream_ptr()),
+                                      unfinished.data_ptr(), eos_id, pad_id, ptr(seq_out), seq_ld, ptr(pos_dev), ptr(probs_out), min_length,
+                                      top_k, stream_ptr()),
            "v2s_topp_sample_step")
+
+
+def beam_sample_cand(logits, ld, rows, V, K, beam_scores, top_p, temperature, top_k, seed, out_val, out_tok, out_key, ban_token=-1,
+                     pos_dev=None, min_length=0, row_lse=None):
+    _need(out_val, torch.float32, "beam_sample_cand out_val"); _need(out_tok, torch.int32, "beam_sample_cand out_tok")
+    _need(out_key, torch.float32, "beam_sample_cand out_key")
+    _check(lib().v2s_beam_sample_cand(logits.data_ptr(), ld, rows, V, K, ptr(beam_scores), top_p, temperature, top_k, seed & 0xFFFFFFFF,
+                                      out_val.data_ptr(), out_tok.data_ptr(), out_key.data_ptr(), ban_token, ptr(pos_dev), min_length,
+                                      ptr(row_lse), stream_ptr()),
+           "v2s_beam_sample_cand")

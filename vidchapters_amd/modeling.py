@@ -321,16 +321,22 @@ class Vid2Seq(nn.Module):
                  top_p=0.9, repetition_penalty=1.0, length_penalty=1.0, num_captions=1, temperature=1):
         eng = self.engine()
         if use_nucleus_sampling:
-            # HF sample(): multinomial draws from the top-p filtered softmax.  The draws use a counter-based generator keyed on
-            # self.sampling_seed (torch's global RNG stream cannot be reproduced): same distribution, different samples.
-            if num_beams > 1:       # HF 4.28 would run beam-sample (multinomial beam search) for do_sample with num_beams > 1
-                raise NotImplementedError("nucleus sampling with num_beams > 1 (HF beam-sample) is not implemented; use num_beams <= 1")
+            # HF sample() / beam_sample(): multinomial draws from the warped softmax (temperature, top-k, top-p).  The draws use a
+            # counter-based generator keyed on self.sampling_seed (torch's global RNG stream cannot be reproduced): same distribution,
+            # different samples.  top_k: the call site (vid2seq.py:150-162) never passes one, so HF's generation default of 50 is in
+            # force whenever do_sample is set; ``self.sampling_top_k`` overrides it (0 = no top-k filter).
             if num_captions > 1:    # HF: num_return_sequences expands every input row num_captions times and samples them independently
                 video = video.repeat_interleave(num_captions, 0)
                 input_tokenized = {k: v.repeat_interleave(num_captions, 0) for k, v in input_tokenized.items()}
             self.sampling_seed = (getattr(self, "sampling_seed", 0) + 1) & 0xFFFFFFFF
-            toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length, repetition_penalty=repetition_penalty,
-                              sample=(float(top_p), float(temperature), self.sampling_seed), min_length=min_length)
+            top_k = int(getattr(self, "sampling_top_k", 50))
+            sample = (float(top_p), float(temperature), self.sampling_seed, top_k)
+            if num_beams > 1:       # HF 4.28 beam_sample: one best hypothesis per (expanded) input row
+                toks = eng.beam_search(video, input_tokenized, num_beams=num_beams, max_new_tokens=max_length, length_penalty=length_penalty,
+                                       min_length=min_length, repetition_penalty=repetition_penalty, num_return=1, sample=sample)
+            else:
+                toks = eng.greedy(video, input_tokenized, max_new_tokens=max_length, repetition_penalty=repetition_penalty,
+                                  sample=sample, min_length=min_length)
             return batch_decode_spaced(self.t5_tokenizer, toks, skip_special_tokens=True)
         if num_captions != 1 and num_beams <= 1:
             raise ValueError("num_captions > 1 needs beam search (HF: greedy search returns one sequence)")
