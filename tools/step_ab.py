@@ -14,6 +14,7 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--model", default="t5-base")
 ap.add_argument("--frames", type=int, default=100)
 ap.add_argument("--asr", type=int, default=1000)
+ap.add_argument("--block", type=int, default=1, help="time blocks of this many back-to-back steps (pipelined like bench.py) instead of single synchronised steps")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 tok = SyntheticTokenizer(32100, 100)
@@ -32,6 +33,9 @@ def apply(setting):
         if k.startswith("eng:"):
             setattr(model.engine(), k[4:], int(v))
             continue
+        if k.startswith("tr:"):              # Trainer attribute, e.g. "tr:defer_adam=1"
+            setattr(tr, k[3:], int(v))
+            continue
         if k == "lib":                       # another build of the library (same ABI): "lib=tools/lib_head.so"
             L.LIB_PATH = os.path.abspath(v); L._LIB = None; L.lib()
             continue
@@ -45,8 +49,11 @@ for i in range(a.steps):
     for s in a.settings:
         apply(s)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); tr.step(batch); e1.record(); torch.cuda.synchronize()
-        times[s].append(e0.elapsed_time(e1))
+        e0.record()
+        for _ in range(a.block):
+            tr.step(batch)
+        e1.record(); torch.cuda.synchronize()
+        times[s].append(e0.elapsed_time(e1) / a.block)
 for s in a.settings:
     med = statistics.median(times[s])
     print(f"{s:40s} median {med:7.2f} ms  min {min(times[s]):7.2f}  -> {32 / med * 1e3:6.1f} samples/s")
