@@ -25,7 +25,10 @@ def t(f, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-CASES = [("enc wo dgrad relu-mask+drop", "NN", 32000, 3072, 768, "dact"), ("enc wo dgrad bare", "NN", 32000, 3072, 768, ""),
+CASES = [("enc QKV fwd (deferred)", "NT", 32000, 2304, 768, ""), ("enc wi fwd relu+drop (deferred)", "NT", 32000, 3072, 768, "act"),
+         ("enc wi fwd bare (deferred)", "NT", 32000, 3072, 768, ""), ("cross K|V fwd (deferred)", "NT", 35200, 1536, 768, ""),
+         ("t5-large wi fwd relu+drop", "NT", 16000, 4096, 1024, "act"),
+         ("enc wo dgrad relu-mask+drop", "NN", 32000, 3072, 768, "dact"), ("enc wo dgrad bare", "NN", 32000, 3072, 768, ""),
          ("enc O fwd residual+drop", "NT", 32000, 768, 768, "res"), ("enc O fwd bare", "NT", 32000, 768, 768, ""),
          ("enc wo fwd residual+drop", "NT", 32000, 768, 3072, "res"), ("enc wo fwd bare", "NT", 32000, 768, 3072, ""),
          ("dec wo dgrad relu-mask+drop", "NN", 8192, 3072, 768, "dact"), ("dec O fwd residual+drop", "NT", 8192, 768, 768, "res"),
@@ -45,6 +48,7 @@ for name, kind, M, N, K, ep in CASES:
             use(p)
             Cc = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             kw = dict(transB=(kind == "NN"), ldb=N if kind == "NN" else K)
+            if ep == "act": kw.update(act=L.ACT_RELU, dropout_p=0.1, dropout_seed=3)
             if ep == "dact": kw.update(dact=L.ACT_RELU, z=Z, dropout_p=0.1, dropout_seed=3)
             if ep == "dgelu": kw.update(dact=L.ACT_GELU, z=Z)
             if ep == "res": kw.update(residual=R, dropout_p=0.1 if M > 4000 else 0.0, dropout_seed=3)
