@@ -10,7 +10,8 @@ from vidchapters_amd import lib as L
 # gemm_dma_kernel<false, true>: dx = dy @ W (transB), N < 1024 or fewer than 1200 256x256 tiles
 SHAPES_DGRAD = [(32000, 768, 3072, 12), (32000, 768, 2304, 12), (35200, 768, 1536, 12), (32000, 768, 768, 12), (8192, 768, 768, 36),
                 (8192, 768, 3072, 12), (8192, 768, 2304, 12), (8192, 3072, 768, 12), (3200, 768, 2304, 12), (3200, 768, 2048, 12),
-                (3200, 2048, 768, 12), (3200, 768, 768, 12)]
+                (3200, 2048, 768, 12), (3200, 768, 768, 12),
+                (32000, 3072, 768, 12, "dact")]      # round 3: the encoder wo dgrad with its ReLU-mask operand stays on the 128x128 tiles
 # gemm_dma_kernel<false, false>: y = x @ W^T (forward): encoder qkv/o/wo, every decoder and ViT projection, cross K/V
 SHAPES_NT = [(32000, 2304, 768, 12), (32000, 768, 768, 12), (32000, 768, 3072, 12), (35200, 1536, 768, 12), (8192, 2304, 768, 12),
              (8192, 768, 768, 36), (8192, 3072, 768, 12), (8192, 768, 3072, 12), (3200, 2304, 768, 12), (3200, 768, 768, 12),
@@ -20,12 +21,15 @@ SHAPES = SHAPES_NT if VARIANT == "nt" else SHAPES_DGRAD
 if __name__ == "__main__":
     dev = "cuda"
     names = []
-    for M, N, K, _ in SHAPES:
+    for M, N, K, _, *ep in SHAPES:
         A = torch.randn(M, K, device=dev).to(torch.bfloat16)
         B = torch.randn((N, K) if VARIANT == "nt" else (K, N), device=dev).to(torch.bfloat16)
         C = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        kw = {}
+        if ep == ["dact"]:                       # d(hidden) masked by the saved dropout(relu(.)) activations, 1/(1-p) scale
+            kw = dict(dact=L.ACT_RELU, z=torch.relu(torch.randn(M, N, device=dev)).to(torch.bfloat16), dropout_p=0.1, dropout_seed=3)
         for _ in range(3):
-            L.gemm(A, B, C, M, N, K, transB=(VARIANT != "nt"))
+            L.gemm(A, B, C, M, N, K, transB=(VARIANT != "nt"), **kw)
         names.append(L.lib().v2s_last_gemm_kernel().decode())
     torch.cuda.synchronize()
     print(json.dumps(names))

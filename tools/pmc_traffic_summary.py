@@ -14,12 +14,12 @@ def per_dispatch(counter):
 f, w = per_dispatch("FETCH_SIZE"), per_dispatch("WRITE_SIZE")
 assert len(f) == len(w) == 3 * len(SHAPES), (len(f), len(w))
 shapes, tot_t, tot_a, tot_n = [], 0.0, 0.0, 0
-for i, (M, N, K, cnt) in enumerate(SHAPES):
+for i, (M, N, K, cnt, *ep) in enumerate(SHAPES):
     name = f[3 * i + 2][0]
     fetch_kb = f[3 * i + 2][1]; write_kb = w[3 * i + 2][1]          # third (warm) launch of the shape
     traffic = (2.0 * fetch_kb + write_kb) * 1024
-    alg = 2.0 * (M * K + K * N + M * N)
-    shapes.append({"M": M, "N": N, "K": K, "launches_per_step": cnt, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+    alg = 2.0 * (M * K + K * N + M * N) + (2.0 * M * N if ep == ["dact"] else 0.0)      # + the mask operand z
+    shapes.append({"M": M, "N": N, "K": K, "epilogue": ep[0] if ep else "", "launches_per_step": cnt, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
                    "traffic_bytes": traffic, "algorithmic_bytes": alg, "ratio": round(traffic / alg, 3)})
     tot_t += traffic * cnt; tot_a += alg * cnt; tot_n += cnt
 kern = name.replace("void (anonymous namespace)::", "").split("((anonymous")[0]
