@@ -223,6 +223,177 @@ void decode_attn_kernel(const DecP p) {
   }
 }
 
+// ---- grouped cross-attention on the matrix pipe (round 3): the G (<= 16) beams of a batch entry against the entry's encoder K/V.
+// The packed-FMA form above is VALU-bound at G = 4 (48 us per layer for 54 MB of K/V: 0.09 of the HBM roofline over a beam step);
+// here the scores of a 32-key chunk are two 16 x 16 x 32 MFMA pairs  S^T[key][query] = K[key][d] . Q^T[d][query]  (queries padded
+// to 16 columns), and the output is accumulated TRANSPOSED,  O^T[d][query] += V^T[d][key] . P^T[key][query],  so that a lane keeps
+// all its values for ONE query (column = lane & 15): the running max / sum / rescale of the online softmax are lane-local, only the
+// chunk maximum crosses the four key groups of a query (two shuffles).
+//   * K fragments come straight from global memory (A operand: row = key, 8 consecutive d per lane = one 16-byte load); the key a
+//     fragment row stands for is chosen so that the accumulator a lane ends up with -- rows 4g..4g+3 of the chunk's two tiles --
+//     are the 8 CONSECUTIVE keys 8g..8g+7: exactly the B-operand layout P^T needs, no data movement between the two products;
+//   * V goes through a wave-private 4 KB LDS tile ([key][d], 32-byte groups XOR-swizzled) and comes back as the A operand V^T
+//     through ds_read_tr16_b64 (the transposing LDS read of gfx950), like the [k][row] operands of the GEMM kernels;
+//   * P is split into bf16 hi + lo parts (two MFMAs per d tile): the products carry ~16 mantissa bits like the fp32 FMAs above.
+// One block (4 waves) per (entry, head), the waves take the 32-key chunks round robin and are merged through LDS at the end.
+// Mask semantics as above (masked key = -3e38; keys past the last valid one are not visited when the row has a valid key).
+__device__ __forceinline__ int dtr_g(int k) { return (k & 3); }      // 32-byte-group swizzle of the V tile (4 groups per 128-byte row)
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attn_mfma_kernel(const DecP p, int G) {
+  // per wave: V tile [32 keys][64 d] bf16 (one buffer: LDS serves a wave's operations in order); merge buffers; NW waves: the
+  // kernel is a latency-bound HBM stream (192 blocks at 16 entries x 12 heads), so the bytes in flight are what counts
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  char (*s_v)[4096] = reinterpret_cast<char (*)[4096]>(dsm);
+  float (*s_o)[16][64] = reinterpret_cast<float (*)[16][64]>(dsm + NW * 4096);
+  float (*s_m)[16] = reinterpret_cast<float (*)[16]>(dsm + NW * 4096 + NW * 4096);
+  float (*s_l)[16] = s_m + NW;
+  __shared__ __attribute__((aligned(8))) uint8_t s_valid[4096 + 64];
+  __shared__ int s_last;
+  const int bh = blockIdx.x, h = bh % p.H, ent = bh / p.H;
+  const int b0 = ent * G;                                              // first query row of the entry; its K/V row = ent
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane & 15, g = lane >> 4;
+  const int Nk = p.Nk;
+  const bool has_mask = p.key_mask != nullptr;
+  if (tid == 0) s_last = -1;
+  __syncthreads();
+  if (has_mask) {
+    int last = -1;
+    for (int k = tid; k < Nk; k += NW * 64) {
+      const uint8_t mv = p.key_mask[(long)ent * p.mask_ld + k];
+      s_valid[k] = mv;
+      if (mv) last = k;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+    if (lane == 0 && last >= 0) atomicMax(&s_last, last);
+  } else {
+    for (int k = tid; k < Nk; k += NW * 64) s_valid[k] = 1;
+  }
+  for (int k = Nk + tid; k < ((Nk + 63) & ~63); k += NW * 64) s_valid[k] = 1;      // chunk tail (those keys score -inf anyway)
+  __syncthreads();
+  const bool skipm = has_mask && s_last >= 0;                        // masked keys weigh exactly 0: their K/V rows are not fetched
+  const int Nvis = skipm ? s_last + 1 : Nk;
+  // Q^T as the B operand: column = query (zero beyond G), 8 consecutive d per lane
+  bf16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (q < G) v = *reinterpret_cast<const uint4*>(p.q + (long)(b0 + q) * p.q_bs + h * 64 + ks * 32 + g * 8);
+    qf[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+  const bf16_t* kbase = p.k + (long)ent * p.kv_bs + h * 64;
+  const bf16_t* vbase = p.v + (long)ent * p.kv_bs + h * 64;
+  const int nchunk = (Nvis + 31) >> 5;
+  uint4 kr[2][2], vr[4];
+  auto load_chunk = [&](int ch) {
+    const int kc = ch * 32;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int key = kc + (q >> 2) * 8 + 4 * t + (q & 3);            // fragment row q of tile t stands for this key
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        kr[t][ks] = (key < Nvis && !(skipm && s_valid[key] == 0)) ? *reinterpret_cast<const uint4*>(kbase + (long)key * p.kv_rs + ks * 32 + g * 8)
+                                                                   : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = lane + 64 * i, key = kc + (idx >> 3), c16 = idx & 7;
+      vr[i] = (key < Nvis && !(skipm && s_valid[key] == 0)) ? *reinterpret_cast<const uint4*>(vbase + (long)key * p.kv_rs + c16 * 8)
+                                                             : make_uint4(0, 0, 0, 0);
+    }
+  };
+  float m = -INFINITY, l = 0.f;
+  f32x4 ot[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wave < nchunk) load_chunk(wave);
+  for (int ch = wave; ch < nchunk; ch += NW) {
+    const int kc = ch * 32;
+    char* vt = s_v[wave];
+    // stage V (this wave's tile)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = lane + 64 * i, kk = idx >> 3, c16 = idx & 7;
+      *reinterpret_cast<uint4*>(vt + kk * 128 + (((c16 >> 1) ^ dtr_g(kk)) << 5) + ((c16 & 1) << 4)) = vr[i];
+    }
+    const bf16x8 k00 = __builtin_bit_cast(bf16x8, kr[0][0]), k01 = __builtin_bit_cast(bf16x8, kr[0][1]);
+    const bf16x8 k10 = __builtin_bit_cast(bf16x8, kr[1][0]), k11 = __builtin_bit_cast(bf16x8, kr[1][1]);
+    if (ch + NW < nchunk) load_chunk(ch + NW);                           // next chunk in flight under this one's arithmetic
+    f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k00, qf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k01, qf[1], s0, 0, 0, 0);
+    f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k10, qf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k11, qf[1], s1, 0, 0, 0);
+    // lane (q, g): scores of keys kc + 8g + e, e = 0..7 (s0 = e 0..3, s1 = e 4..7)
+    const uint2 vm = *reinterpret_cast<const uint2*>(s_valid + kc + 8 * g);
+    float sv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int key = kc + 8 * g + e;
+      const bool ok = (((e < 4 ? vm.x : vm.y) >> (8 * (e & 3))) & 0xffu) != 0;
+      const float d = (e < 4 ? s0[e & 3] : s1[e & 3]) * p.scale;
+      sv[e] = key < Nvis ? (ok ? d : -3.0e38f) : -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);                                      // > -inf: a visited chunk has at least one key < Nvis
+    const float alpha = __expf(m - mn);                                 // exp(-inf) = 0 on the first chunk
+    float pr[8], ps = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pr[e] = __expf(sv[e] - mn); ps += pr[e]; }
+    l = l * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { ot[dt][0] *= alpha; ot[dt][1] *= alpha; ot[dt][2] *= alpha; ot[dt][3] *= alpha; }
+    // P^T as the B operand, hi + lo bf16 parts
+    uint4 ph, pl;
+    {
+      float lo[8];
+      uint32_t hb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { hb[e] = f2bf(pr[e]); lo[e] = pr[e] - __uint_as_float(hb[e] << 16); }
+      ph = make_uint4(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16));
+      pl = make_uint4(pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(lo[4], lo[5]), pack2bf(lo[6], lo[7]));
+    }
+    const bf16x8 pfh = __builtin_bit_cast(bf16x8, ph), pfl = __builtin_bit_cast(bf16x8, pl);
+    // V^T fragments (row = d, 8 consecutive keys per lane) through the transposing LDS read
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0): this wave's V tile is in LDS (wave-private: no barrier)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int kk = g * 8 + (q >> 2), dm = dt * 16 + (q & 3) * 4, kk1 = kk + 4;
+      const s16x4 vlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((V2S_LDS s16x4*)(vt + kk * 128 + (((dm >> 4) ^ dtr_g(kk)) << 5) + ((dm & 15) << 1)));
+      const s16x4 vhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((V2S_LDS s16x4*)(vt + kk1 * 128 + (((dm >> 4) ^ dtr_g(kk1)) << 5) + ((dm & 15) << 1)));
+      const s16x8 vv = {vlo[0], vlo[1], vlo[2], vlo[3], vhi[0], vhi[1], vhi[2], vhi[3]};
+      const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+      ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfh, ot[dt], 0, 0, 0);
+      ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfl, ot[dt], 0, 0, 0);
+    }
+  }
+  // merge: the four key groups of a query hold partial sums (same m), then the four waves through LDS
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (g == 0) { s_m[wave][q] = m; s_l[wave][q] = l; }
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_o[wave][q][dt * 16 + 4 * g + r] = ot[dt][r];
+  __syncthreads();
+  for (int t = tid; t < G * 64; t += NW * 64) {
+    const int qq = t >> 6, d = t & 63;
+    float mm = -INFINITY;
+    for (int w = 0; w < NW; ++w) mm = fmaxf(mm, s_m[w][qq]);
+    float ll = 0.f, oo = 0.f;
+    for (int w = 0; w < NW; ++w) {
+      const float a = (s_m[w][qq] == -INFINITY) ? 0.f : __expf(s_m[w][qq] - mm);
+      ll += s_l[w][qq] * a;
+      oo += s_o[w][qq][d] * a;
+    }
+    p.o[(long)(b0 + qq) * p.o_bs + h * 64 + d] = f2bf(oo / ll);
+  }
+}
+
 // one 1024-thread block per row: 16-byte loads, the whole row (V ~ 32k fp32 = 128 KiB) in flight in two rounds -- the earlier
 // 256-thread scalar loop took 39.5 us per step for 64 rows (latency-bound; profiles/r02_decode_step.txt)
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, long ld, int V, long* __restrict__ next_tok,
@@ -641,6 +812,29 @@ extern "C" int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream) {
   V2S_CHECK(!a->new_k || (a->new_v && a->pos_dev && a->kv_group <= 1 && (a->new_bs % 8) == 0), V2S_ERR_ARG,
             "v2s_decode_attn: the fused cache append needs new_v, pos_dev and one KV row per batch entry");
   // the beams of a batch entry share a block (K/V fetched once) when they divide evenly; any other group size keeps one block per row
+  // the beams of a batch entry against its encoder K/V on the matrix pipe: any group size 2..16 (no bias, no cache append, no row map)
+  if (a->kv_group >= 2 && a->kv_group <= 16 && (a->B % a->kv_group) == 0 && !a->new_k && !a->bias_row && !a->pos_dev && !a->row_map &&
+      a->Nk <= 4096 && (a->kv_rs % 8) == 0 && v2s_opt_gemm_skinny() != 3) {
+    // waves per block: enough bytes in flight for the HBM stream at few blocks (16 entries x 12 heads = 192 blocks on 256 CUs).  Per layer,
+    // twelve K|V buffers in rotation (tools/decode_xattn_ab.py): 16 entries x 4 beams 29.9 us packed-FMA, 20.5 / 16.1 / 18.1 at 4 / 8 / 16
+    // waves; 64 x 4: 49.9 -> 43.4 / 45.2 / 53.0; 16 x 12 beams: 57.6 -> 16.4
+    const unsigned nblk = (unsigned)(p.B / a->kv_group * p.H);
+    const int nw_opt = v2s_opt_gemm_skinny();        // A/B hook (tools/decode_ab.py): gemm_skinny = 5 | 6 | 7 -> 4 | 8 | 16 waves
+    const int nw = nw_opt == 5 ? 4 : (nw_opt == 6 ? 8 : (nw_opt == 7 ? 16 : (nblk >= 512 ? 4 : 8)));
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)decode_attn_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + 4.1 KB static
+      (void)hipFuncSetAttribute((const void*)decode_attn_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + 4.1 KB static
+      (void)hipFuncSetAttribute((const void*)decode_attn_mfma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + 4.1 KB static
+      attr = true;
+    }
+    const size_t dyn = (size_t)nw * (4096 + 4096 + 128);
+    if (nw == 4) hipLaunchKernelGGL(decode_attn_mfma_kernel<4>, dim3(nblk), dim3(256), dyn, (hipStream_t)stream, p, (int)a->kv_group);
+    else if (nw == 8) hipLaunchKernelGGL(decode_attn_mfma_kernel<8>, dim3(nblk), dim3(512), dyn, (hipStream_t)stream, p, (int)a->kv_group);
+    else hipLaunchKernelGGL(decode_attn_mfma_kernel<16>, dim3(nblk), dim3(1024), dyn, (hipStream_t)stream, p, (int)a->kv_group);
+    V2S_LAUNCH_CHECK();
+    return V2S_OK;
+  }
   const int G = (a->kv_group == 2 || a->kv_group == 4 || a->kv_group == 8) && (a->B % a->kv_group) == 0 && !a->new_k ? a->kv_group : 1;
   const dim3 grid((unsigned)(p.B / G * p.H));
   hipStream_t s = (hipStream_t)stream;
