@@ -26,6 +26,21 @@ SHAPES = [  # (kind, M, N, K, what)
 ]
 
 
+# cfg-5 exact (t5-large: d = 1024, ff = 4096, 16 heads; B = 32, 200 frames, 2000 ASR tokens, 256 targets): `--large`
+SHAPES_LARGE = [
+    ("NT", 64000, 3072, 1024, "enc QKV fwd"), ("NT", 64000, 1024, 1024, "enc O fwd"), ("NT", 64000, 4096, 1024, "enc wi fwd"),
+    ("NT", 64000, 1024, 4096, "enc wo fwd"), ("NN", 64000, 1024, 1024, "enc O dgrad"), ("NN", 64000, 1024, 3072, "enc QKV dgrad"),
+    ("NN", 64000, 4096, 1024, "enc wo dgrad"), ("NN", 64000, 1024, 4096, "enc wi dgrad"), ("NT", 70400, 2048, 1024, "cross K|V fwd"),
+    ("NN", 70400, 1024, 2048, "cross K|V dgrad"), ("NT", 8192, 3072, 1024, "dec QKV fwd"), ("NT", 8192, 1024, 1024, "dec O fwd"),
+    ("NT", 8192, 4096, 1024, "dec wi fwd"), ("NT", 8192, 1024, 4096, "dec wo fwd"), ("NN", 8192, 1024, 3072, "dec QKV dgrad"),
+    ("NN", 8192, 4096, 1024, "dec wo dgrad"), ("NN", 8192, 1024, 4096, "dec wi dgrad"),
+    ("TN", 1024, 1024, 64000, "enc O wgrad (fp32 out)"), ("TN", 3072, 1024, 64000, "enc QKV wgrad"), ("TN", 4096, 1024, 64000, "enc wi wgrad"),
+    ("TN", 1024, 4096, 64000, "enc wo wgrad"), ("TN", 2048, 1024, 70400, "cross K|V wgrad"), ("TN", 3072, 1024, 8192, "dec QKV wgrad"),
+]
+if "--large" in sys.argv:
+    SHAPES = SHAPES_LARGE
+
+
 def make(kind, M, N, K):
     g = torch.Generator(device=dev); g.manual_seed(M * 7 + N * 3 + K)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
