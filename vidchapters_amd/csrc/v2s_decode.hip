@@ -458,8 +458,7 @@ __global__ __launch_bounds__(NT) void topk_logprob_kernel(const float* __restric
   constexpr int NW = NT / 64;
   __shared__ float sv[NT * K];
   __shared__ int si[NT * K];
-  __shared__ float red_m[NW], red_s[NW], best_v[NW];
-  __shared__ int best_t[NW], best_o[NW];
+  __shared__ float red_m[NW], red_s[NW];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* z = logits + (long)row * ld;
   // HF MinLengthLogitsProcessor: EOS is not a candidate while the decoder sequence (start token + decoded) is shorter than min_length
@@ -511,25 +510,39 @@ __global__ __launch_bounds__(NT) void topk_logprob_kernel(const float* __restric
   for (int w = 0; w < NW; ++w) S += red_m[w] == -INFINITY ? 0.f : red_s[w] * __expf(red_m[w] - M);
   const float lse = row_lse ? row_lse[row] : M + logf(S);      // a processor may have rewritten logits against a stored lse
   const float base = beam_scores ? beam_scores[row] : 0.f;
-  // K rounds of block-wide argmax over the heads of the NT sorted lists
-  int head = 0;
-  for (int r = 0; r < K; ++r) {
-    float v = head < K ? sv[tid * K + head] : -INFINITY;
-    int t = head < K ? si[tid * K + head] : 0x7fffffff;
-    int owner = tid;
+  // two-level merge of the NT sorted lists (same order everywhere: value descending, equal values lower token first).  Level 1: every
+  // wave extracts the K best of its 64 lists, wave-synchronous -- the earlier K rounds of BLOCK-wide argmax paid two barriers and a
+  // serial scan over the waves per round (38 us per 64-row beam step, most of it here); level 2: wave 0 merges the NW wave lists.
+  __shared__ float wv[NW * K];
+  __shared__ int wt[NW * K];
+  auto wave_best = [&](float& v, int& t, int& owner) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float v2 = __shfl_xor(v, o, 64); const int t2 = __shfl_xor(t, o, 64); const int o2 = __shfl_xor(owner, o, 64);
       if (v2 > v || (v2 == v && t2 < t)) { v = v2; t = t2; owner = o2; }
     }
-    __syncthreads();
-    if (lane == 0) { best_v[wave] = v; best_t[wave] = t; best_o[wave] = owner; }
-    __syncthreads();
-    float bv = best_v[0]; int bt = best_t[0], bo = best_o[0];
-    for (int w = 1; w < NW; ++w)
-      if (best_v[w] > bv || (best_v[w] == bv && best_t[w] < bt)) { bv = best_v[w]; bt = best_t[w]; bo = best_o[w]; }
-    if (tid == bo) ++head;
-    if (tid == 0) { out_val[(long)row * K + r] = bv - lse + base; out_idx[(long)row * K + r] = bt; }
+  };
+  int head = 0;
+  for (int r = 0; r < K; ++r) {
+    float v = head < K ? sv[tid * K + head] : -INFINITY;
+    int t = head < K ? si[tid * K + head] : 0x7fffffff;
+    int owner = lane;
+    wave_best(v, t, owner);
+    if (lane == owner) ++head;
+    if (lane == 0) { wv[wave * K + r] = v; wt[wave * K + r] = t; }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    int head2 = 0;
+    for (int r = 0; r < K; ++r) {
+      const bool live = lane < NW && head2 < K;
+      float v = live ? wv[lane * K + head2] : -INFINITY;
+      int t = live ? wt[lane * K + head2] : 0x7fffffff;
+      int owner = lane;
+      wave_best(v, t, owner);
+      if (lane == owner) ++head2;
+      if (lane == 0) { out_val[(long)row * K + r] = v - lse + base; out_idx[(long)row * K + r] = t; }
+    }
   }
 }
 
