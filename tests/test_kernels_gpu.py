@@ -938,7 +938,7 @@ def test_decode_kernels():
     assert torch.equal(o2, o3)
     # beams of a batch entry share the encoder K/V (kv_group): one block per (entry, head) scores all of them (2 / 4 / 8), any other
     # group size keeps one block per row; both against a per-row reference
-    for grp in (2, 3, 4, 8):
+    for grp in (2, 3, 4, 8, 12, 16):           # (round 3: every width 2..16 runs the MFMA kernel -- scores and P.V on the matrix pipe)
         Bq = B2 * grp
         q4 = rnd(Bq, W, seed=31 + grp, scale=0.5)
         s4 = torch.einsum("bghd,bkhd->bghk", q4.float().view(B2, grp, H, 64), k2.float().view(B2, Nk2, H, 64))
@@ -948,6 +948,13 @@ def test_decode_kernels():
         L.decode_attn(Bq, H, Nk2, q4, W, k2p, v2p, Nk2 * W, W, o4, W, key_mask=mask2.to(torch.uint8).contiguous(), mask_ld=Nk2, kv_group=grp)
         assert torch.isfinite(o4.float()).all()
         assert relerr(o4, ref4) < 1e-2, grp
+        if grp in (4, 16):                      # no key mask at all, and a key count that is not a multiple of the 32-key chunk
+            Nk3 = 333
+            s5 = torch.einsum("bghd,bkhd->bghk", q4.float().view(B2, grp, H, 64), k2[:, :Nk3].float().view(B2, Nk3, H, 64))
+            ref5 = torch.einsum("bghk,bkhd->bghd", torch.softmax(s5, -1), v2[:, :Nk3].float().view(B2, Nk3, H, 64)).reshape(Bq, W)
+            o5 = torch.empty(Bq, W, dtype=torch.bfloat16, device=DEV)
+            L.decode_attn(Bq, H, Nk3, q4, W, k2, v2, Nk2 * W, W, o5, W, kv_group=grp)
+            assert relerr(o5, ref5) < 1e-2, grp
     # beam search without moving the cache: key k of row b is read from cache row row_map[b][k]; the step's own key comes from the
     # projection output, is appended to cache row b, and row_map[b][pos] becomes b
     Bm, maxlen, pv = 6, 40, 17
