@@ -761,6 +761,29 @@ def test_topk_logprob_and_kv_gather(K):
     assert torch.equal(idx.cpu().long(), ri2) and (val.cpu().double() - rv2).abs().max() < 1e-5
     L.topk_logprob(logits.to(DEV), ld, rows, V, K, bs.to(DEV), val, idx, ban_token=ban, pos_dev=pos, min_length=3)
     assert torch.equal(idx.cpu().long(), ri)
+    if K <= 8:
+        # the 1024-thread threshold path (aligned rows of <= 32768 logits: candidates = elements >= the K-th largest thread maximum),
+        # with rows that overflow its 64-slot list (flat row, a wide plateau of equal maxima) falling back to the sorted-list path;
+        # equal values: lower token first
+        rows2, V2, ld2 = 9, 32200, 32256
+        lg2 = torch.zeros(rows2, ld2)
+        lg2[:, :V2] = torch.randn(rows2, V2, generator=g) * 3
+        lg2[:, V2:] = 1e9
+        lg2[5, :V2] = 0.25                                           # flat: every element ties
+        lg2[6, 100:400] = 50.0                                       # 300 equal maxima
+        lg2[7, 7] = lg2[7, 31000] = 60.0                             # a tie between far-apart columns
+        bs2 = torch.randn(rows2, generator=g)
+        val2 = torch.zeros(rows2, K, device=DEV); idx2 = torch.zeros(rows2, K, dtype=torch.int32, device=DEV)
+        L.topk_logprob(lg2.to(DEV), ld2, rows2, V2, K, bs2.to(DEV), val2, idx2)
+        ref3 = torch.log_softmax(lg2[:, :V2].double(), -1) + bs2[:, None].double()
+        order = torch.argsort(-lg2[:, :V2].double(), dim=1, stable=True)[:, :K]          # value descending, lower token first
+        assert torch.equal(idx2.cpu().long(), order)
+        assert (val2.cpu().double() - torch.gather(ref3, 1, order)).abs().max() < 1e-5
+        ban2 = int(order[0, 0]); ref4 = lg2[:, :V2].double().clone(); ref4[:, ban2] = -float("inf")
+        order4 = torch.argsort(-ref4, dim=1, stable=True)[:, :K]
+        L.topk_logprob(lg2.to(DEV), ld2, rows2, V2, K, bs2.to(DEV), val2, idx2, ban_token=ban2, pos_dev=pos, min_length=4)
+        assert torch.equal(idx2.cpu().long(), order4)
+        assert (val2.cpu().double() - torch.gather(ref3, 1, order4)).abs().max() < 1e-5
     # gather
     B, maxlen, W, n = 6, 20, 256, 13
     src = rnd(B, maxlen, W, seed=5); dst = torch.zeros_like(src)

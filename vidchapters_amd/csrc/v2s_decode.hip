@@ -463,6 +463,111 @@ __global__ __launch_bounds__(NT) void topk_logprob_kernel(const float* __restric
   const float* z = logits + (long)row * ld;
   // HF MinLengthLogitsProcessor: EOS is not a candidate while the decoder sequence (start token + decoded) is shorter than min_length
   const int ban = (ban_tok >= 0 && (pos_dev ? *pos_dev + 1 : 0) < min_length) ? ban_tok : -1;
+  // Fast path (1024 threads, rows of <= 32768 aligned fp32): the per-thread sorted lists below cost ~12 us of a 64-row step -- with
+  // 32 elements per thread some lane of every wave inserts at nearly every element, so the whole wave runs the 8-deep insertion
+  // each time.  Here a thread only tracks its maximum; the K-th largest of the 1024 thread maxima is a lower bound T of the row's
+  // K-th largest value (K distinct elements >= T exist), so the candidates are the elements >= T: K plus a handful.  They are
+  // appended to a 64-slot list and ranked by one wave.  Rows that overflow the list (flat rows, masses of ties) take the general
+  // path below.
+  if constexpr (NT == 1024) {
+    const bool al = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
+    if (al && (V & 3) == 0 && V <= NT * 32) {
+      __shared__ float c_v[64];
+      __shared__ int c_i[64];
+      __shared__ int c_n;
+      __shared__ float c_thr;
+      __shared__ float tw[NW * K];
+      float4 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = tid * 4 + u * NT * 4;
+        q[u] = i < V ? *reinterpret_cast<const float4*>(z + i) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      }
+      float fm = -INFINITY, fs = 0.f, tmax = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = tid * 4 + u * NT * 4;
+        const float mx = fmaxf(fmaxf(q[u].x, q[u].y), fmaxf(q[u].z, q[u].w));
+        if (mx > -INFINITY) {
+          const float mn = fmaxf(fm, mx);
+          fs = fs * __expf(fm - mn) + ((__expf(q[u].x - mn) + __expf(q[u].y - mn)) + (__expf(q[u].z - mn) + __expf(q[u].w - mn)));
+          fm = mn;
+        }
+        tmax = fmaxf(tmax, fmaxf(fmaxf(i == ban ? -INFINITY : q[u].x, i + 1 == ban ? -INFINITY : q[u].y),
+                                 fmaxf(i + 2 == ban ? -INFINITY : q[u].z, i + 3 == ban ? -INFINITY : q[u].w)));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(fm, o, 64), s2 = __shfl_xor(fs, o, 64);
+        const float mn = fmaxf(fm, m2);
+        fs = (fm == -INFINITY ? 0.f : fs * __expf(fm - mn)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mn));
+        fm = mn;
+      }
+      if (lane == 0) { red_m[wave] = fm; red_s[wave] = fs; }
+      // level 1: the K largest thread maxima of this wave (values only), descending
+      {
+        float v = tmax;
+        for (int r = 0; r < K; ++r) {
+          const float wm = wave_max(v);
+          const unsigned long long hit = __ballot(v == wm);
+          if (lane == (int)__ffsll((long long)hit) - 1) v = -INFINITY;
+          if (lane == 0) tw[wave * K + r] = wm;
+        }
+      }
+      if (tid == 0) c_n = 0;
+      __syncthreads();
+      float M = red_m[0];
+      for (int w = 1; w < NW; ++w) M = fmaxf(M, red_m[w]);
+      float S = 0.f;
+      for (int w = 0; w < NW; ++w) S += red_m[w] == -INFINITY ? 0.f : red_s[w] * __expf(red_m[w] - M);
+      const float lse = row_lse ? row_lse[row] : M + logf(S);
+      const float base = beam_scores ? beam_scores[row] : 0.f;
+      if (wave == 0) {                       // level 2: lane w walks the sorted list of wave w; the K-th extraction is the threshold
+        int head = 0;
+        float wm = -INFINITY;
+        for (int r = 0; r < K; ++r) {
+          const bool live = lane < NW && head < K;
+          const float v = live ? tw[lane * K + head] : -INFINITY;
+          wm = wave_max(v);
+          const unsigned long long hit = __ballot(live && v == wm);
+          if (hit != 0ull && lane == (int)__ffsll((long long)hit) - 1) ++head;
+        }
+        if (lane == 0) c_thr = wm;
+      }
+      __syncthreads();
+      const float T = c_thr;
+      if (T > -INFINITY) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = tid * 4 + u * NT * 4;
+          const float e[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (e[c] >= T && i + c != ban) {
+              const int slot = atomicAdd(&c_n, 1);
+              if (slot < 64) { c_v[slot] = e[c]; c_i[slot] = i + c; }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const int n = c_n;
+      if (T > -INFINITY && n >= K && n <= 64) {
+        if (wave == 0) {
+          const float v = lane < n ? c_v[lane] : -INFINITY;
+          const int t = lane < n ? c_i[lane] : 0x7fffffff;
+          int rank = 0;
+          for (int j = 0; j < n; ++j) {
+            const float vj = c_v[j]; const int tj = c_i[j];
+            rank += (vj > v || (vj == v && tj < t)) ? 1 : 0;
+          }
+          if (lane < n && rank < K) { out_val[(long)row * K + rank] = v - lse + base; out_idx[(long)row * K + rank] = t; }
+        }
+        return;
+      }
+      __syncthreads();                       // overflow: the general path (re-reads the row)
+    }
+  }
   float tv[K]; int ti[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
