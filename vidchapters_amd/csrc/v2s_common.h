@@ -43,6 +43,7 @@ int v2s_opt_gemm_split(); // 1 = split-K slice count from the rounds x length co
 int v2s_opt_gemm_p8();   // 8-phase ping-pong 256-row kernel: 0 = never, 1 = where it measured faster (default), 2 = 256x256 wherever legal, 3 = 256x128 wherever legal
 int v2s_opt_ce_fused();  // reserved
 int v2s_opt_gemm_dbg();  // profiling aid for the 8-phase kernel: 1 = epilogue without the global store, 2 = no epilogue (results invalid)
+int v2s_opt_gemm_ps();   // persistent 128x128 kernel with write-out waves: 0 = never, 1 = where it measured faster (default), 2 = wherever legal, 3 = wherever legal with more tiles than block slots
 int v2s_opt_gemm_big();  // 0 = never, 1 = 256x256/256x128 tiles where they pay (default), 2 = 256x128 only, 3 = 4-wave 256x128x32 ring kernel for every variant
 
 // ---------------------------------------------------------------- device helpers

@@ -1308,6 +1308,201 @@ __global__ __launch_bounds__(512, 2) void gemm_p8d_kernel(const GemmP p) {
 }
 
 // =====================================================================================================================
+// Persistent 128 x 128 x 64 kernel with DEDICATED WRITE-OUT WAVES ("ps", round 4).
+// Where a K = 768 launch of gemm_dma_kernel loses its time (tools/gemm_k_sweep.py, round 3): the main loop alone runs at 1180 TF/s, a
+// launch costs a fixed 19-20 us on top, 10 us of it the acknowledgement of the output stores -- gfx950 counts loads and stores in ONE
+// in-order vmcnt queue, so a wave that stores cannot pass its next DMA wait (persistent kernel) or retire (non-persistent kernel)
+// before the HBM write burst has been acknowledged.  Here the waves that compute never store and never read an epilogue operand:
+//   * block = 8 waves, two per SIMD: waves 0-3 are the compute waves of gemm_dma_kernel (2 x 2 grid of 64 x 64 wave tiles, two-stage
+//     LDS-DMA ring), waves 4-7 are write-out waves; <= 128 VGPRs and 80 KiB of LDS, so TWO blocks per CU like the kernel it replaces;
+//   * a block walks its tiles (ids blockIdx.x + k * gridDim.x); the first stage of tile k+1 is requested during the last K-step of
+//     tile k, so only the block's first tile pays a prologue;
+//   * hand-off at the end of a tile, four quarters of 32 rows (fragment row q of all four compute waves) through a 16 KiB fp32
+//     staging block: barrier A_q (staging free) - compute waves dump acc[q][*] (4 ds_write_b128 per lane) - barrier B_q (staging
+//     full) - write-out waves read their two 8-wide row chunks into registers and run the usual epilogue (epilogue_chunk: bias /
+//     activation / mask / dropout / residual / fp32 or bf16 store) on them WHILE the compute waves dump the next quarter or have
+//     moved on to the next tile; the global operand of the epilogue (z or residual) is prefetched by the write-out waves during the
+//     tile's main loop (eight 16-byte loads per lane).  The write-out waves' loads, stores and their acknowledgements live on their
+//     own vmcnt queues.
+// Barrier protocol (s_barrier counts every wave of the block, so both roles execute the same sequence): per tile nk K-step
+// barriers, then A_0 B_0 A_1 B_1 A_2 B_2 A_3 B_3.  Raw s_barrier from asm with a "memory" clobber (a compiler fence): __syncthreads()
+// would add s_waitcnt vmcnt(0) and make the write-out waves wait for their stores at every K-step.
+// LDS hazards: ring as in gemm_dma_kernel (a slot is refilled after the barrier that follows its last read); staging written only
+// between A_q and B_q (lgkmcnt(0) before B_q), read only between B_q and A_q+1 (lgkmcnt(0) before A_q+1; after B_3 the next A_0 is
+// nk barriers away).  Results are bit-identical to gemm_dma_kernel (same K order, same fp32 epilogue arithmetic).
+constexpr int PS_RING = 2 * STAGE_BYTES;          // 64 KiB
+constexpr int PS_STG = 32 * BN * 4;               // 16 KiB
+constexpr int PS_LDS = PS_RING + PS_STG;          // 80 KiB
+#define PS_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define PS_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <bool TB>
+__device__ __forceinline__ void ps_compute(const GemmP& p, char* smem, int wave, int lane, int nmy, int G_) {
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = p.tilesM * p.tilesN;
+  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
+  const int nk = p.K / BK;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 4096);
+  uint32_t oa[4], ob[4];
+  auto setup = [&](int k) __attribute__((always_inline)) {
+    int tm, tn, sl;
+    tile_coords(p, xcd_remap((int)blockIdx.x + k * G_, ntiles), tm, tn, sl);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      oa[i] = dma_lane_off<false>(p.lda, tm * BM, p.M, M8, wave * 4 + i, lane);
+      ob[i] = dma_lane_off<TB>(p.ldb, tn * BN, p.N, N8, wave * 4 + i, lane);
+    }
+  };
+  const long stepA = (long)BK * 2, stepB = TB ? (long)BK * p.ldb * 2 : (long)BK * 2;
+  const char* ga = reinterpret_cast<const char*>(p.A);
+  const char* gb = reinterpret_cast<const char*>(p.B);
+  setup(0);
+  dma_issue8(oa, ob, ga, gb, sbase);
+  int slot = 0;                                     // ring slot (0 | 1) of the stage the next K-step reads
+  float* cs = reinterpret_cast<float*>(smem + PS_RING);
+  // staging address of this lane's fragment chunks: local row wm*16 + (lane & 15), 16-byte chunk (wn*64 + j*16 + (lane >> 4)*4) / 4
+  const int srow = wm * 16 + (lane & 15);
+  for (int k = 0; k < nmy; ++k) {
+    for (int t = 0; t < nk; ++t) {
+      dma_wait();
+      PS_BARRIER();
+      if (t + 1 < nk) {
+        ga += stepA; gb += stepB;
+        dma_issue8(oa, ob, ga, gb, sbase + (slot ^ 1) * STAGE_BYTES);
+      } else if (k + 1 < nmy) {                     // first stage of the next tile
+        setup(k + 1);
+        ga = reinterpret_cast<const char*>(p.A); gb = reinterpret_cast<const char*>(p.B);
+        dma_issue8(oa, ob, ga, gb, sbase + (slot ^ 1) * STAGE_BYTES);
+      }
+      const char* sa = smem + slot * STAGE_BYTES;
+      const char* sb = sa + A_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = read_frag<false, true>(sa, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB, true>(sb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // transposed: see gemm_epilogue
+      }
+      slot ^= 1;
+    }
+#pragma clang loop unroll(full)                     // acc[] is indexed by q
+    for (int q = 0; q < 4; ++q) {
+      PS_BARRIER();                                 // A_q: the write-out waves hold the previous quarter in registers
+      if (p.dbg != 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = (wn * 64 + j * 16 + (lane >> 4) * 4) >> 2;
+          *reinterpret_cast<f32x4*>(cs + srow * BN + ((c ^ (srow & 7)) << 2)) = acc[q][j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[q][j]));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      PS_LGKM0();
+      PS_BARRIER();                                 // B_q: quarter q is in the staging block
+    }
+  }
+}
+
+__device__ __forceinline__ void ps_store(const GemmP& p, char* smem, int sl, int nmy, int G_) {
+  const int ntiles = p.tilesM * p.tilesN;
+  const int nk = p.K / BK;
+  const float* cs = reinterpret_cast<const float*>(smem + PS_RING);
+  const bf16_t* gsrc = p.dact != V2S_ACT_NONE ? p.z : p.residual;
+  const long gld = p.dact != V2S_ACT_NONE ? p.ldz : p.ldr;
+  const bool ahead = gsrc != nullptr;
+  // this lane's two 8-wide chunks of a quarter: c = sl + it*256 -> local row c >> 4, columns (c & 15)*8 .. +7
+  int lr[2], cc[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) { const int c = sl + it * 256; lr[it] = c >> 4; cc[it] = (c & 15) * 8; }
+  for (int k = 0; k < nmy; ++k) {
+    int tm, tn, slc;
+    tile_coords(p, xcd_remap((int)blockIdx.x + k * G_, ntiles), tm, tn, slc);
+    const int m0 = tm * BM, n0 = tn * BN;
+    auto grow = [&](int q, int it) __attribute__((always_inline)) { return m0 + (lr[it] >> 4) * 64 + q * 16 + (lr[it] & 15); };
+    uint4 gop[8];
+    if (ahead) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int gm = grow(q, it), gn = n0 + cc[it];
+          gop[q * 2 + it] = (gm < p.M && gn < p.N) ? *reinterpret_cast<const uint4*>(gsrc + (long)gm * gld + gn) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    for (int t = 0; t < nk; ++t) PS_BARRIER();
+    float v[2][8];
+    auto fetch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int c0 = (cc[it] >> 2) ^ (lr[it] & 7), c1 = ((cc[it] >> 2) + 1) ^ (lr[it] & 7);
+        const float4 x0 = *reinterpret_cast<const float4*>(cs + lr[it] * BN + (c0 << 2));
+        const float4 x1 = *reinterpret_cast<const float4*>(cs + lr[it] * BN + (c1 << 2));
+        v[it][0] = x0.x; v[it][1] = x0.y; v[it][2] = x0.z; v[it][3] = x0.w; v[it][4] = x1.x; v[it][5] = x1.y; v[it][6] = x1.z; v[it][7] = x1.w;
+      }
+      PS_LGKM0();
+    };
+    auto epi = [&](auto Qc) __attribute__((always_inline)) {
+      constexpr int q = decltype(Qc)::value;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int gm = grow(q, it), gn = n0 + cc[it];
+        if (gm < p.M && gn < p.N) {
+          if (ahead) epilogue_chunk<true>(p, v[it], gm, gn, 0, gop[q * 2 + it]);
+          else epilogue_chunk<false>(p, v[it], gm, gn, 0);
+        }
+      }
+    };
+    if (p.dbg == 2) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) PS_BARRIER();
+      continue;
+    }
+    PS_BARRIER();                                   // A_0
+    PS_BARRIER();                                   // B_0
+    fetch();
+    PS_BARRIER();                                   // A_1: quarter 0 is in registers, the compute waves may overwrite the staging block
+    epi(std::integral_constant<int, 0>{});
+    PS_BARRIER();                                   // B_1
+    fetch();
+    PS_BARRIER();                                   // A_2
+    epi(std::integral_constant<int, 1>{});
+    PS_BARRIER();                                   // B_2
+    fetch();
+    PS_BARRIER();                                   // A_3
+    epi(std::integral_constant<int, 2>{});
+    PS_BARRIER();                                   // B_3
+    fetch();
+    epi(std::integral_constant<int, 3>{});
+  }
+}
+
+template <bool TB>
+__global__ __launch_bounds__(512, 4) void gemm_ps_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // ring (64 KiB) + fp32 staging (16 KiB)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = p.tilesM * p.tilesN;
+  const int G_ = gridDim.x;
+  const int nmy = (ntiles - (int)blockIdx.x + G_ - 1) / G_;          // tiles of this block: ids blockIdx.x + k * gridDim.x
+  if (wave < 4) ps_compute<TB>(p, smem, wave, lane, nmy, G_);
+  else ps_store(p, smem, tid - 256, nmy, G_);
+}
+
+// =====================================================================================================================
 // Skinny GEMM for cached decoding (M <= 64 rows: one token per live sequence / beam): C[M][N] = A[M][K] . B[N][K]^T.
 // The weight matrix B is the only real traffic (read once); the 128-wide tiles above would occupy 6..24 CUs for it.  Here a block
 // owns 16 output columns: its 4 waves split K four ways, each streaming its [16][K/4] weight slab straight from HBM into MFMA
@@ -1604,6 +1799,12 @@ static int p8_auto(const v2s_gemm_args* a, bool deferred_ok) {
   return 0;
 }
 
+// Shapes the persistent write-out-wave kernel takes by default (gemm_ps = 1).  Rules from tools/gemm_ps_ab.py (profiles/r04_gemm_ps_ab.txt).
+static bool ps_auto(const v2s_gemm_args* a, long t128, int slots, int p8, bool p8d) {
+  (void)a; (void)p8; (void)p8d;
+  return t128 > slots;
+}
+
 // Which form of the 8-phase kernel runs this problem: p8 = tile width (0 = none), p8d = deferred-epilogue persistent form.
 static void p8_decide(const v2s_gemm_args* a, bool tr, int& p8, bool& p8d) {
   p8 = 0; p8d = false;
@@ -1780,6 +1981,23 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
   bool p8d = false;
   if (p8_force != 0) p8_decide(a, tr, p8, p8d);
   if (p8) { bm = 256; bn = p8; w4 = false; }
+  // persistent 128 x 128 kernel with write-out waves (gemm_ps_kernel): forward / dgrad shapes with more tiles than the chip has block
+  // slots (a block must walk >= 2 tiles for its write-out to run under a main loop), any epilogue, never split-K
+  bool ps = false;
+  {
+    const int ps_mode = v2s_opt_gemm_ps();
+    const long t128 = (long)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+    const int slots = 2 * num_cus();
+    const bool ps_ok = ps_mode != 0 && p8_force != 0 && tr && !a->transA && (a->K % BK) == 0 && a->M >= 8 && a->N >= 8 &&
+                       !(plain_split && t128 < 768) && (long)a->M * a->lda < (1L << 30) &&
+                       (a->transB ? 64 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 30);
+    if (ps_ok) {
+      if (ps_mode == 2) ps = true;
+      else if (ps_mode == 3) ps = t128 > slots;
+      else ps = ps_auto(a, t128, slots, p8, p8d);
+    }
+    if (ps) { bm = BM; bn = BN; p8 = 0; p8d = false; w4 = false; }
+  }
   p.tilesM = (a->M + bm - 1) / bm; p.tilesN = (a->N + bn - 1) / bn;
   // split-K: weight-gradient GEMMs have few output tiles (768x768 -> 36) but a huge contraction (all tokens);
   // slice K so that the chip is filled.  Only for fp32 outputs with a plain epilogue; partials go to the workspace.
@@ -1812,7 +2030,20 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     }
   }
   const unsigned nblocks = (unsigned)(p.tilesM * p.tilesN * p.splitk);
-  if (p8d) {
+  if (ps && p.splitk == 1) {
+    static bool attr_ps = false;
+    if (!attr_ps) {
+      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+      attr_ps = true;
+    }
+    const int slots = 2 * num_cus();
+    const int nt = p.tilesM * p.tilesN;
+    const dim3 grid((unsigned)(nt < slots ? nt : slots)), block(512);
+    g_last_gemm = a->transB ? "gemm_ps_kernel<true>" : "gemm_ps_kernel<false>";
+    if (!a->transB) hipLaunchKernelGGL((gemm_ps_kernel<false>), grid, block, PS_LDS, s, p);
+    else hipLaunchKernelGGL((gemm_ps_kernel<true>), grid, block, PS_LDS, s, p);
+  } else if (p8d) {
     static bool attr8d = false;
     const int ncu = num_cus();
     if (!attr8d) {
