@@ -39,6 +39,10 @@ if "--large" in sys.argv:
     CASES = CASES[:4] + LARGE
 if "--quick" in sys.argv:
     CASES = CASES[:9]
+NST = 4
+for a_ in sys.argv:
+    if a_.startswith("--nst="):
+        NST = int(a_[6:])
 
 
 def timed(f, n):
@@ -70,6 +74,7 @@ def main():
         if ep == "biasres": kw.update(bias=bias, residual=R)
         odt = torch.float32 if ep == "f32" else torch.bfloat16
         outs, kern, fns = {}, {}, {}
+        L.set_option("gemm_ps_nst", NST)
         for mode in (0, 2):
             L.set_option("gemm_ps", mode)
             Cc = torch.full((M, N), float("nan"), dtype=odt, device=dev)
@@ -98,7 +103,7 @@ def main():
         print(f"{name:30s} {kind} {M:6d}x{N:6d}x{K:6d} {o:8.1f} {fl / o / 1e6:6.0f} {kern[0]:34s} {s:8.1f} {fl / s / 1e6:6.0f}  {o / s:6.3f}"
               + ("" if same else f"   DIFFERENT ({kern[2]})"), flush=True)
         bad += 0 if same else 1
-    L.set_option("gemm_ps", 1)
+    L.set_option("gemm_ps", 0)
     print(f"sum (M >= 3200): old {tot[0]:.0f} us, ps {tot[1]:.0f} us, old/ps {tot[0] / max(tot[1], 1e-9):.3f};  {bad} case(s) differ")
     sys.exit(1 if bad else 0)
 

@@ -1330,18 +1330,23 @@ __global__ __launch_bounds__(512, 2) void gemm_p8d_kernel(const GemmP p) {
 // LDS hazards: ring as in gemm_dma_kernel (a slot is refilled after the barrier that follows its last read); staging written only
 // between A_q and B_q (lgkmcnt(0) before B_q), read only between B_q and A_q+1 (lgkmcnt(0) before A_q+1; after B_3 the next A_0 is
 // nk barriers away).  Results are bit-identical to gemm_dma_kernel (same K order, same fp32 epilogue arithmetic).
-constexpr int PS_RING = 2 * STAGE_BYTES;          // 64 KiB
-constexpr int PS_STG = 32 * BN * 4;               // 16 KiB
-constexpr int PS_LDS = PS_RING + PS_STG;          // 80 KiB
+constexpr int PS_STG = 32 * BN * 4;               // 16 KiB fp32 staging block behind the ring
+template <int NST> struct PS { static constexpr int RING = NST * STAGE_BYTES, LDS = RING + PS_STG; };   // NST = 2: 80 KiB (two blocks per CU), 4: 144 KiB (one)
 #define PS_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define PS_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <bool TB>
+// Ring of NST stages, prefetch distance NST - 1 K-steps.  Ablation (tools/gemm_ps_ablate.py, 32000x768x768): a K-step of the two-stage
+// ring takes 1.04 us per block = the issued -> landed latency of its ONE prefetched stage (MFMA time 0.25 us): the main loop is bound
+// by latency x bytes in flight, and the output stores cost their 8 us (of 50) by lengthening that latency, on whichever wave they are
+// issued.  The DMA stream never stops at a tile edge (the issue pointer runs NST - 1 stages ahead of the compute pointer, into the
+// block's next tile); counted waits: stage s has landed once at most 8 x (groups issued after it) loads of this wave are outstanding.
+template <bool TB, int NST>
 __device__ __forceinline__ void ps_compute(const GemmP& p, char* smem, int wave, int lane, int nmy, int G_) {
   const int wm = wave >> 1, wn = wave & 1;
   const int ntiles = p.tilesM * p.tilesN;
   const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
   const int nk = p.K / BK;
+  const int total = nmy * nk;                       // stages of this block
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1361,24 +1366,34 @@ __device__ __forceinline__ void ps_compute(const GemmP& p, char* smem, int wave,
   const long stepA = (long)BK * 2, stepB = TB ? (long)BK * p.ldb * 2 : (long)BK * 2;
   const char* ga = reinterpret_cast<const char*>(p.A);
   const char* gb = reinterpret_cast<const char*>(p.B);
+  int iss = 0, it = 0, ik = 0, islot = 0;           // issue stream: stages issued, K-step inside its tile, its tile, ring slot of the next issue
+  auto issue = [&]() __attribute__((always_inline)) {
+    dma_issue8(oa, ob, ga, gb, sbase + islot * STAGE_BYTES);
+    islot = islot + 1 == NST ? 0 : islot + 1;
+    ++iss;
+    if (++it == nk) {
+      it = 0; ++ik;
+      if (ik < nmy) { setup(ik); ga = reinterpret_cast<const char*>(p.A); gb = reinterpret_cast<const char*>(p.B); }
+    } else {
+      ga += stepA; gb += stepB;
+    }
+  };
   setup(0);
-  dma_issue8(oa, ob, ga, gb, sbase);
-  int slot = 0;                                     // ring slot (0 | 1) of the stage the next K-step reads
-  float* cs = reinterpret_cast<float*>(smem + PS_RING);
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (iss < total) issue();
+  int slot = 0, s = 0;                              // ring slot and index of the stage the next K-step reads
+  float* cs = reinterpret_cast<float*>(smem + PS<NST>::RING);
   // staging address of this lane's fragment chunks: local row wm*16 + (lane & 15), 16-byte chunk (wn*64 + j*16 + (lane >> 4)*4) / 4
   const int srow = wm * 16 + (lane & 15);
   for (int k = 0; k < nmy; ++k) {
     for (int t = 0; t < nk; ++t) {
-      dma_wait();
-      PS_BARRIER();
-      if (t + 1 < nk) {
-        ga += stepA; gb += stepB;
-        dma_issue8(oa, ob, ga, gb, sbase + (slot ^ 1) * STAGE_BYTES);
-      } else if (k + 1 < nmy) {                     // first stage of the next tile
-        setup(k + 1);
-        ga = reinterpret_cast<const char*>(p.A); gb = reinterpret_cast<const char*>(p.B);
-        dma_issue8(oa, ob, ga, gb, sbase + (slot ^ 1) * STAGE_BYTES);
-      }
+      const int ahead = iss - s - 1;                // DMA groups issued after stage s: NST - 2 in steady state, fewer at the block's end
+      if (NST == 2 || ahead <= 0) dma_wait_n<0>();
+      else if (NST == 3 || ahead == 1) dma_wait_n<8>();
+      else dma_wait_n<16>();
+      PS_BARRIER();                                 // stage s landed for every wave; every wave has finished reading stage s - 1
+      if (iss < total) issue();                     // into the slot of stage s - 1
       const char* sa = smem + slot * STAGE_BYTES;
       const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -1394,7 +1409,15 @@ __device__ __forceinline__ void ps_compute(const GemmP& p, char* smem, int wave,
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // transposed: see gemm_epilogue
       }
-      slot ^= 1;
+      slot = slot + 1 == NST ? 0 : slot + 1;
+      ++s;
+    }
+    if (p.dbg == 3) {                               // ablation: no hand-off (main loops back to back; results invalid)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+      continue;
     }
 #pragma clang loop unroll(full)                     // acc[] is indexed by q
     for (int q = 0; q < 4; ++q) {
@@ -1417,10 +1440,10 @@ __device__ __forceinline__ void ps_compute(const GemmP& p, char* smem, int wave,
   }
 }
 
-__device__ __forceinline__ void ps_store(const GemmP& p, char* smem, int sl, int nmy, int G_) {
+__device__ __forceinline__ void ps_store(const GemmP& p, char* smem, int ring_bytes, int sl, int nmy, int G_) {
   const int ntiles = p.tilesM * p.tilesN;
   const int nk = p.K / BK;
-  const float* cs = reinterpret_cast<const float*>(smem + PS_RING);
+  const float* cs = reinterpret_cast<const float*>(smem + ring_bytes);
   const bf16_t* gsrc = p.dact != V2S_ACT_NONE ? p.z : p.residual;
   const long gld = p.dact != V2S_ACT_NONE ? p.ldz : p.ldr;
   const bool ahead = gsrc != nullptr;
@@ -1460,12 +1483,15 @@ __device__ __forceinline__ void ps_store(const GemmP& p, char* smem, int sl, int
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int gm = grow(q, it), gn = n0 + cc[it];
-        if (gm < p.M && gn < p.N) {
+        if (p.dbg == 1) {                            // ablation: everything but the post-ops and the global store
+          asm volatile("" ::"v"(v[it][0]), "v"(v[it][1]), "v"(v[it][2]), "v"(v[it][3]), "v"(v[it][4]), "v"(v[it][5]), "v"(v[it][6]), "v"(v[it][7]));
+        } else if (gm < p.M && gn < p.N) {
           if (ahead) epilogue_chunk<true>(p, v[it], gm, gn, 0, gop[q * 2 + it]);
           else epilogue_chunk<false>(p, v[it], gm, gn, 0);
         }
       }
     };
+    if (p.dbg == 3) continue;
     if (p.dbg == 2) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) PS_BARRIER();
@@ -1490,16 +1516,165 @@ __device__ __forceinline__ void ps_store(const GemmP& p, char* smem, int sl, int
   }
 }
 
-template <bool TB>
+template <bool TB, int NST>
 __global__ __launch_bounds__(512, 4) void gemm_ps_kernel(const GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];        // ring (64 KiB) + fp32 staging (16 KiB)
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // ring (NST x 32 KiB) + fp32 staging (16 KiB)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = p.tilesM * p.tilesN;
   const int G_ = gridDim.x;
   const int nmy = (ntiles - (int)blockIdx.x + G_ - 1) / G_;          // tiles of this block: ids blockIdx.x + k * gridDim.x
-  if (wave < 4) ps_compute<TB>(p, smem, wave, lane, nmy, G_);
-  else ps_store(p, smem, tid - 256, nmy, G_);
+  if (wave < 4) ps_compute<TB, NST>(p, smem, wave, lane, nmy, G_);
+  else ps_store(p, smem, PS<NST>::RING, tid - 256, nmy, G_);
+}
+
+// =====================================================================================================================
+// 256 x 192 tile, FOUR waves with 128 x 96 WAVE TILES ("wt", round 4): 192 accumulators per lane in AGPRs (one wave per SIMD owns the
+// unified 512-register file), fragments double-buffered in VGPRs.  NT only (B = [N][K] weights).
+// Why: the ablation of the 128 x 128 kernels (tools/gemm_ps_ablate.py) and the LDS arithmetic behind it.  A 64 x 64 wave tile reads
+// 8 KiB of fragments per 16 MFMAs (256 matrix-pipe clocks): eight such waves ask for 256 B/clk, the whole LDS read bandwidth of a CU,
+// and the LDS-DMA path for 64 B/clk, the whole vector-L1 bandwidth -- both saturate at the rate the matrix pipe would run at, so
+// those kernels sit at ~50 % of it whatever the prefetch depth (a deeper ring, a persistent walk and write-out waves: all +-0).
+// The 128 x 64 wave tiles of the 8-phase kernel ask for 192 B/clk (75 %).  A 128 x 96 wave tile reads 14 KiB per 48 MFMAs: four waves
+// = 75 B/clk (29 %) of LDS and 37 B/clk of L1 -- and 192 divides every N of t5-base (768, 1536, 2304, 3072), 768 -> 500 tiles = 1.95
+// rounds of the chip instead of 375 = 1.46 (the vendor library picks 256 x 192 for these shapes too).
+// Loop (ONE barrier per 32-wide K stage; 48 MFMAs = 768 matrix-pipe clocks per wave and stage): the fragments of stage s are in
+// registers when iteration s starts (read during iteration s-1); the iteration waits for its own fragment reads (the slot they came
+// from is free once every wave has passed the barrier), waits for stage s+1 with a counted vmcnt, passes the barrier, refills the slot
+// of stage s with stage s+NST (NST-1 stages in flight), issues the fragment reads of stage s+1 into the second register set and runs
+// the 48 MFMAs of stage s under them.  The lgkmcnt waits are BUILTINS pinned by sched_barriers: an asm wait is invisible to the
+// compiler's scoreboard, which then puts its own lgkmcnt(0) in front of the first MFMA -- behind the next stage's reads.
+template <int NST>
+struct WT {
+  static constexpr int BM2 = 256, BN2 = 192;
+  static constexpr int A_B = BM2 * 32 * 2, B_B = BN2 * 32 * 2, STG = A_B + B_B;     // 16 + 12 = 28 KiB per stage
+  static constexpr int LDS = NST * STG > 33 * 1024 ? NST * STG : 33 * 1024;           // ring; the epilogue stages 32 x 196 floats in it
+  static constexpr int PER = 7;                                                        // DMA instructions per wave and stage
+};
+__device__ __forceinline__ void wt_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }    // lgkmcnt(0) only
+
+template <int NST>
+__global__ __launch_bounds__(256, 1) void gemm_wt_kernel(const GemmP p) {
+  using G = WT<NST>;
+  constexpr int A_B = G::A_B, STG = G::STG, PER = G::PER;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = p.tilesM * p.tilesN;
+  int tm, tn, slice;
+  tile_coords(p, xcd_remap(blockIdx.x, nwg), tm, tn, slice);
+  const int m0 = tm * 256, n0 = tn * 192;
+  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
+  const int nst = p.K / 32;                                          // >= NST (dispatcher)
+
+  f32x4 acc[8][6];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint32_t oa[4], ob[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) oa[i] = p8_lane_off<256, false>(p.lda, m0, p.M, M8, wave * 4 + i, lane);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ob[i] = p8_lane_off<192, false>(p.ldb, n0, p.N, N8, wave * 3 + i, lane);
+  const char* ga = reinterpret_cast<const char*>(p.A);
+  const char* gb = reinterpret_cast<const char*>(p.B);
+  const uint32_t sbase = lds_addr(smem);
+  const uint32_t dstA = __builtin_amdgcn_readfirstlane(sbase + wave * 4096);
+  const uint32_t dstB = __builtin_amdgcn_readfirstlane(sbase + A_B + wave * 3072);
+  int islot = 0, iss = 0;
+  auto issue = [&]() __attribute__((always_inline)) {
+    p8_dma2(oa[0], oa[1], ga, dstA + islot);
+    p8_dma2(oa[2], oa[3], ga, dstA + islot + 2048);
+    p8_dma2(ob[0], ob[1], gb, dstB + islot);
+    p8_dma1(ob[2], gb, dstB + islot + 2048);
+    ga += 64; gb += 64; ++iss;
+    islot = islot + STG == NST * STG ? 0 : islot + STG;
+  };
+  const int arow = wm * 128, brow = wn * 96;
+  bf16x8 af[8], bfr[6];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) issue();                             // stages 0 .. NST-1
+  dma_wait_n<PER * (NST - 1)>();
+  P8_BARRIER();
+#pragma unroll
+  for (int j = 0; j < 6; ++j) bfr[j] = read_frag_w4<192, false>(smem + A_B, brow + j * 16, lane);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) af[i] = read_frag_w4<256, false>(smem, arow + i * 16, lane);
+  int rslot = STG;                                                   // ring slot (byte offset) of stage s + 1
+#pragma unroll 1
+  for (int s = 0; s < nst; ++s) {
+    wt_lgkm0();                                                      // fragments of stage s are in registers: its slot may be refilled after the barrier
+    const int after = nst - 2 - s;                                   // stages after stage s + 1 that exist (in flight: min(after, NST - 2))
+    if (after >= NST - 2) dma_wait_n<PER * (NST - 2)>();
+    else if (NST > 3 && after == 2) dma_wait_n<PER * 2>();
+    else if (after == 1) dma_wait_n<PER>();
+    else dma_wait_n<0>();
+    P8_BARRIER();
+    if (iss < nst) issue();                                          // stage s + NST into the slot of stage s
+    // fragments of stage s + 1 (after the last stage: a stale slot, never used): B into a second set, A row i in place right
+    // behind the last MFMA that reads row i of stage s
+    const char* sa = smem + rslot;
+    const char* sb = sa + A_B;
+    bf16x8 bn[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bn[j] = read_frag_w4<192, false>(sb, brow + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      af[i] = read_frag_w4<256, false>(sa, arow + i * 16, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bfr[j] = bn[j];
+    // issue order of this region: the six B reads, then per A row its six MFMAs followed by the row's refill read -- the fragment reads
+    // of the next stage run under the MFMAs of this one (left alone, the scheduler sinks every read below the last MFMA)
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    rslot = rslot + STG == NST * STG ? 0 : rslot + STG;
+  }
+  __syncthreads();                                                   // every wave is done with the ring
+
+  if (p.dbg == 2) {                                                  // ablation: main loop only (accumulators kept live; results invalid)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) asm volatile("" ::"a"(acc[i][j]));
+    return;
+  }
+  // epilogue: eight passes; pass ps = fragment row ps of every wave = tile rows {wm*128 + ps*16 + 0..15}, 32 rows x 192 columns through
+  // an fp32 staging block [32][192 + 4] (transposed accumulators: one ds_write_b128 per fragment), then 8-wide row chunks
+  constexpr int PB = 192 + 4;
+  float* cs = reinterpret_cast<float*>(smem);
+#pragma clang loop unroll(full)                                      // acc[] is indexed by ps
+  for (int ps = 0; ps < 8; ++ps) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      *reinterpret_cast<f32x4*>(cs + (wm * 16 + (lane & 15)) * PB + wn * 96 + j * 16 + (lane >> 4) * 4) = acc[ps][j];
+    __syncthreads();
+#pragma unroll 1
+    for (int c = tid; c < 32 * 24; c += 256) {
+      const int lr = c / 24, cc = (c % 24) * 8;
+      const int gm = m0 + (lr >> 4) * 128 + ps * 16 + (lr & 15), gn = n0 + cc;
+      if (gm >= p.M || gn >= p.N) continue;
+      float v[8];
+      const float4 x0 = *reinterpret_cast<const float4*>(cs + lr * PB + cc);
+      const float4 x1 = *reinterpret_cast<const float4*>(cs + lr * PB + cc + 4);
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+      if (p.dbg == 1) {
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        continue;
+      }
+      epilogue_chunk(p, v, gm, gn, slice);
+    }
+    if (ps + 1 < 8) __syncthreads();
+  }
 }
 
 // =====================================================================================================================
@@ -1805,6 +1980,12 @@ static bool ps_auto(const v2s_gemm_args* a, long t128, int slots, int p8, bool p
   return t128 > slots;
 }
 
+// Shapes the 128 x 128-wave-tile kernel takes by default (gemm_w128 = 1).
+static bool w128_auto(const v2s_gemm_args* a) {
+  (void)a;
+  return false;
+}
+
 // Which form of the 8-phase kernel runs this problem: p8 = tile width (0 = none), p8d = deferred-epilogue persistent form.
 static void p8_decide(const v2s_gemm_args* a, bool tr, int& p8, bool& p8d) {
   p8 = 0; p8d = false;
@@ -1983,18 +2164,28 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
   if (p8) { bm = 256; bn = p8; w4 = false; }
   // persistent 128 x 128 kernel with write-out waves (gemm_ps_kernel): forward / dgrad shapes with more tiles than the chip has block
   // slots (a block must walk >= 2 tiles for its write-out to run under a main loop), any epilogue, never split-K
+  // 4-wave 128 x 128-wave-tile kernel (gemm_w128_kernel): option gemm_w128 = 2 wherever legal, 1 = where it measured faster
+  bool w128 = false;
+  {
+    const int wmode = v2s_opt_gemm_w128();
+    const bool w_ok = wmode != 0 && p8_force != 0 && tr && !a->transA && !a->transB && (a->K % 32) == 0 && a->K >= 160 && a->M >= 256 && a->N >= 96 &&
+                      !plain_split && (long)a->M * a->lda < (1L << 30) && (long)a->N * a->ldb < (1L << 30);
+    if (w_ok && (wmode == 2 || (wmode == 1 && v2s_opt_gemm_p8() == 1 && w128_auto(a)))) { w128 = true; bm = 256; bn = 192; p8 = 0; p8d = false; w4 = false; }
+  }
   bool ps = false;
+  int ps_nst = v2s_opt_gemm_ps_nst();
+  if (ps_nst < 2 || ps_nst > 4) ps_nst = 2;
   {
     const int ps_mode = v2s_opt_gemm_ps();
     const long t128 = (long)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
-    const int slots = 2 * num_cus();
-    const bool ps_ok = ps_mode != 0 && p8_force != 0 && tr && !a->transA && (a->K % BK) == 0 && a->M >= 8 && a->N >= 8 &&
+    const int slots = (ps_nst == 2 ? 2 : 1) * num_cus();
+    const bool ps_ok = ps_mode != 0 && !w128 && p8_force != 0 && tr && !a->transA && (a->K % BK) == 0 && a->M >= 8 && a->N >= 8 &&
                        !(plain_split && t128 < 768) && (long)a->M * a->lda < (1L << 30) &&
                        (a->transB ? 64 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 30);
     if (ps_ok) {
       if (ps_mode == 2) ps = true;
       else if (ps_mode == 3) ps = t128 > slots;
-      else ps = ps_auto(a, t128, slots, p8, p8d);
+      else ps = v2s_opt_gemm_p8() == 1 && ps_auto(a, t128, slots, p8, p8d);      // a forced 8-phase mode (tests, A/B tools) keeps its kernel
     }
     if (ps) { bm = BM; bn = BN; p8 = 0; p8d = false; w4 = false; }
   }
@@ -2030,19 +2221,40 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     }
   }
   const unsigned nblocks = (unsigned)(p.tilesM * p.tilesN * p.splitk);
-  if (ps && p.splitk == 1) {
+  if (w128 && p.splitk == 1) {
+    static bool attr_w = false;
+    if (!attr_w) {
+      (void)hipFuncSetAttribute((const void*)gemm_wt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WT<4>::LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_wt_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, WT<5>::LDS);
+      attr_w = true;
+    }
+    const dim3 grid(nblocks), block(256);
+    const bool five = v2s_opt_gemm_ps_nst() == 5 && a->K >= 160;
+    g_last_gemm = five ? "gemm_wt_kernel<5>" : "gemm_wt_kernel<4>";
+    if (five) hipLaunchKernelGGL((gemm_wt_kernel<5>), grid, block, WT<5>::LDS, s, p);
+    else hipLaunchKernelGGL((gemm_wt_kernel<4>), grid, block, WT<4>::LDS, s, p);
+  } else if (ps && p.splitk == 1) {
     static bool attr_ps = false;
     if (!attr_ps) {
-      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PS<2>::LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PS<2>::LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, PS<3>::LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, PS<3>::LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PS<4>::LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PS<4>::LDS);
       attr_ps = true;
     }
-    const int slots = 2 * num_cus();
+    const int nst = ps_nst;
+    const int slots = (nst == 2 ? 2 : 1) * num_cus();
     const int nt = p.tilesM * p.tilesN;
     const dim3 grid((unsigned)(nt < slots ? nt : slots)), block(512);
-    g_last_gemm = a->transB ? "gemm_ps_kernel<true>" : "gemm_ps_kernel<false>";
-    if (!a->transB) hipLaunchKernelGGL((gemm_ps_kernel<false>), grid, block, PS_LDS, s, p);
-    else hipLaunchKernelGGL((gemm_ps_kernel<true>), grid, block, PS_LDS, s, p);
+    static const char* names_ps[3][2] = {{"gemm_ps_kernel<false, 2>", "gemm_ps_kernel<true, 2>"}, {"gemm_ps_kernel<false, 3>", "gemm_ps_kernel<true, 3>"},
+                                         {"gemm_ps_kernel<false, 4>", "gemm_ps_kernel<true, 4>"}};
+    g_last_gemm = names_ps[nst - 2][a->transB ? 1 : 0];
+#define V2S_PS(NST_) do { if (!a->transB) hipLaunchKernelGGL((gemm_ps_kernel<false, NST_>), grid, block, PS<NST_>::LDS, s, p); \
+                          else hipLaunchKernelGGL((gemm_ps_kernel<true, NST_>), grid, block, PS<NST_>::LDS, s, p); } while (0)
+    if (nst == 2) V2S_PS(2); else if (nst == 3) V2S_PS(3); else V2S_PS(4);
+#undef V2S_PS
   } else if (p8d) {
     static bool attr8d = false;
     const int ncu = num_cus();
