@@ -32,7 +32,10 @@ extern "C" {
 #define V2S_BF16 0
 #define V2S_F32 1
 
-#define V2S_ABI_VERSION 2
+/* 3 (round 4): v2s_attn_bwd's `delta` became a [B][H][Nq][4] workspace it WRITES, v2s_topp_sample_step gained top_k, dact=RELU with
+ * dropout expects z = the post-dropout activation (round 3 changes that a version-2 caller would corrupt memory with);
+ * + v2s_rowsumsq_range / v2s_timetoken_renorm_sq, options gemm_ps / gemm_ps_nst / gemm_w128 */
+#define V2S_ABI_VERSION 3
 
 int v2s_version(void);
 const char* v2s_last_error(void);
@@ -277,6 +280,14 @@ int v2s_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
  * mean(row-norm of those rows)/mean(row-norm of rows [0,V-num_bins)); shadow refreshed. ws: V+2 floats */
 int v2s_timetoken_renorm(float* emb, void* emb_bf16, int32_t V, int32_t d, int32_t num_bins, float* ws,
                          void* stream);
+/* The same renorm for a SHARDED data-parallel optimizer (train.GradSync shard=True), where a rank's fp32 values of the frozen rows
+ * are current only inside the stripes it owns: v2s_rowsumsq_range adds, per row, the squares of the elements whose flat index
+ * row*d + c lies in [f0, f1) to sumsq[row] (the caller all-reduces the per-rank partial sums of the frozen rows);
+ * v2s_timetoken_renorm_sq then takes the frozen rows' norms from text_sumsq[0 .. V-num_bins) and reads only the time-token rows
+ * (whole on every rank) from emb.  Same arithmetic as v2s_timetoken_renorm otherwise (dvc.py:118-126). */
+int v2s_rowsumsq_range(const float* emb, int32_t V, int32_t d, int64_t f0, int64_t f1, float* sumsq, void* stream);
+int v2s_timetoken_renorm_sq(float* emb, void* emb_bf16, int32_t V, int32_t d, int32_t num_bins, const float* text_sumsq, float* ws,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Greedy decoding helpers (HF 4.28 greedy_search, call site vid2seq.py:150-162)

@@ -38,21 +38,43 @@ def _worker(rank, world, port, ret, shard):
     for _ in range(2):
         losses = tr.step(mine)
     if shard:
+        # the masters of the other rank's stripes are stale now -- saving / re-casting them must fail loudly, not silently
+        seen = model.engine().arena._seen_version
+        for what, fn in (("model.state_dict", model.state_dict), ("trainer.state_dict", tr.state_dict),
+                         ("mark_dirty + prepare", lambda: (model.engine().mark_dirty(), model.engine().prepare()))):
+            try:
+                fn()
+                ret[f"guard_{what}{rank}"] = False
+            except RuntimeError:
+                ret[f"guard_{what}{rank}"] = True
+        model.engine().arena._seen_version = seen      # undo mark_dirty
+        for _ in range(2):                # two more steps: the time-token renorm must keep the replicas identical (stale frozen-row norms would not)
+            losses = tr.step(mine)
+        a = model.engine().arena
+        V, d, nb = model.engine().V, model.engine().d, cfg.num_bins
+        emb = a.f("t5_model.shared.weight").view(-1, d)
+        ret[f"tt{rank}"] = emb[V - nb:V].detach().cpu().clone()
+    if shard:
         assert len(tr.sync.buckets) >= 4 and all((e - s) * 2 == n for (s, e), (_, n) in zip(tr.sync.owned, tr.sync.buckets))
         a = model.engine().arena
         own = torch.zeros(a.numel, dtype=torch.bool, device="cuda")
         for s0, e0 in tr.sync.owned + tr.sync.replicated:
             own[s0:e0] = True
         ret[f"shadow{rank}"] = bool(torch.equal(a.shadow[own], a.master[own].bfloat16()))        # own stripes: shadow == cast(master)
-        tr.gather_master()               # the stripes the other rank updated: masters were stale, the shadow already current
+        tr.prepare_checkpoint()          # collective: masters (+ Adam moments) of the stripes the other rank updated; the shadow was already current
         ret[f"shadow_all{rank}"] = bool(torch.equal(a.shadow, a.master.bfloat16()))
+        sd, osd = model.state_dict(), tr.state_dict()       # now legal on any single rank
+        ret[f"ckpt{rank}"] = len(sd) > 0 and osd["step_count"] == 4
+        emb = a.f("t5_model.shared.weight").view(-1, d)
+        nrm = emb.norm(dim=1)
+        ret[f"ratio{rank}"] = float(nrm[V - nb:V].mean() / nrm[:V - nb].mean())     # dvc.py:120-126 leaves the two mean norms equal
     torch.cuda.synchronize()
     if rank == 0:
         ref = build()
         tr1 = Trainer(ref, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=1.0, group=solo)
         assert tr1.world == 1
         allb = {k: v.cuda() for k, v in full.items()}
-        for _ in range(2):
+        for _ in range(4 if shard else 2):
             tr1.step(allb)
         torch.cuda.synchronize()
         worst, worst_k, maxdiff = 1.0, "", 0.0
@@ -82,8 +104,13 @@ def test_two_ranks_equal_one_large_batch(shard):
     port = 29500 + (os.getpid() % 2000) + (7 if shard else 0)
     mp.spawn(_worker, args=(world, port, ret, shard), nprocs=world, join=True)
     if shard:
-        assert all(ret[f"shadow{r}"] and ret[f"shadow_all{r}"] for r in range(world)), dict(ret)
+        assert all(ret[f"shadow{r}"] and ret[f"shadow_all{r}"] and ret[f"ckpt{r}"] for r in range(world)), {k: v for k, v in ret.items() if not torch.is_tensor(v)}
+        assert all(ret[f"guard_{w}{r}"] for r in range(world) for w in ("model.state_dict", "trainer.state_dict", "mark_dirty + prepare")), \
+            {k: v for k, v in ret.items() if k.startswith("guard")}
+        assert torch.equal(ret["tt0"], ret["tt1"]), "time-token rows differ between the ranks of a sharded-optimizer run"
+        assert all(abs(ret[f"ratio{r}"] - 1.0) < 1e-5 for r in range(world)), (ret["ratio0"], ret["ratio1"])
     print(f"DP (2 ranks) vs single process after 2 steps: worst update cosine {ret['worst']:.4f} ({ret['worst_k']}), max |dw| diff {ret['maxdiff']:.2e}")
     # Adam turns every gradient element into a step of ~lr whatever its size, so elements whose gradient is bf16/atomics-order noise
     # may step in different directions: compare update DIRECTIONS per tensor (as test_dropin_optimizer_path_matches_trainer does)
-    assert ret["worst"] > 0.93 and ret["maxdiff"] <= 2 * 2.1 * 1e-3      # measured r02: 0.9466 (block-0 bias table), 3.97e-3
+    steps = 4 if shard else 2
+    assert ret["worst"] > (0.90 if shard else 0.93) and ret["maxdiff"] <= steps * 2.1 * 1e-3      # measured r02 (2 steps): 0.9466 (block-0 bias table), 3.97e-3

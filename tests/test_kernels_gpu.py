@@ -926,6 +926,28 @@ def test_beam_sample_candidates_vs_oracle():
         assert np.abs(scorer.scores - wv[:, :nb].numpy()).max() < 2e-4
 
 
+def test_beam_sample_candidates_plateau_is_deterministic():
+    """a plateau of ties at the k-th value puts more than 64 candidates at or above it; the kept 64 must not depend on
+    atomic arrival order: everything strictly above the plateau plus the LOWEST token ids of the ties, identical from run to run."""
+    rows, V, ld, K = 4, 3000, 3008, 8
+    logits = torch.zeros(rows, ld)
+    logits[:, :V] = 1.0                                   # plateau over the whole vocabulary ...
+    logits[:, 100:110] = 5.0                              # ... with ten tokens strictly above it
+    logits[:, V:] = 60.0
+    bscore = torch.zeros(rows)
+    pos = torch.tensor([3], dtype=torch.int32, device=DEV)
+    outs = []
+    for _ in range(3):
+        val = torch.zeros(rows, K, device=DEV); key = torch.zeros(rows, K, device=DEV); tok = torch.zeros(rows, K, dtype=torch.int32, device=DEV)
+        L.beam_sample_cand(logits.to(DEV), ld, rows, V, K, bscore.to(DEV), 1.0, 1.0, 50, 77, val, tok, key, ban_token=1, pos_dev=pos, min_length=1)
+        outs.append((val.cpu(), tok.cpu(), key.cpu()))
+    for v, t, k in outs[1:]:
+        assert torch.equal(t, outs[0][1]) and torch.equal(v, outs[0][0]) and torch.equal(k, outs[0][2])
+    tok = outs[0][1].long()
+    allowed = set(range(100, 110)) | set(range(0, 54))    # the ten above the plateau + the 54 lowest token ids of the ties = 64 kept
+    assert all(int(x) in allowed for x in tok.flatten()), tok
+
+
 def test_decode_kernels():
     B, H, Nk = 3, 4, 333
     W = H * 64

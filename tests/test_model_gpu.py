@@ -596,6 +596,46 @@ def test_fused_lm_head_equals_unfused():
     assert worst > 0.9995
 
 
+def test_skip_grad_memset_equals_zeroed_arena_and_survives_an_exception():
+    """the skip-grad-memset path (a matrix's first weight-gradient GEMM of a step overwrites its gradient) against a zeroed
+    arena: identical gradients over two two-pass steps; and an exception inside a step must leave overwrite mode (Trainer's try/finally),
+    so that a later autograd-path backward accumulates again."""
+    cfg = R.RefConfig.small()
+    b = {k: v.to(DEV) for k, v in synth.make_batch(3, 10, 40, 23, cfg.vocab, 31, cfg.vit_dim, denoising=True).items()}
+    res = {}
+    for skip in (True, False):
+        model = build(cfg, 13).train()
+        model.engine().skip_grad_memset = skip
+        tr = Trainer(model, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=1.0)
+        for _ in range(2):
+            tr.step(b)
+        res[skip] = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()}
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]) or cos(res[True][k], res[False][k]) > 0.99999, k
+    model = build(cfg, 13).train()
+    tr = Trainer(model, lr=1e-3)
+    bad = dict(b); bad["output_ids"] = b["output_ids"][:1]            # batch-size mismatch: the step raises somewhere inside
+    with pytest.raises(Exception):
+        tr.step(bad)
+    assert model.engine()._fresh_grads is None
+
+
+def test_beam_sample_rejects_top_k_outside_the_kept_list():
+    """beam-sample keeps at most 64 warped candidates per beam row; sampling_top_k = 0 ("no filter") or > 64 would be truncated,
+    i.e. a different distribution from HF's beam_sample -- generate() refuses it instead (greedy-loop sampling has no such limit)."""
+    cfg = R.RefConfig.small()
+    model = build(cfg, 7).eval()
+    b = synth.make_batch(2, 10, 24, 12, cfg.vocab, 7, cfg.vit_dim)
+    video, ids = b["video"].to(DEV), tok(b["input_ids"])
+    for k in (0, 65):
+        model.sampling_top_k = k
+        with pytest.raises(ValueError):
+            model.generate(video, ids, use_nucleus_sampling=True, num_beams=4, max_length=6)
+        assert len(model.generate(video, ids, use_nucleus_sampling=True, num_beams=0, max_length=6)) == 2
+    model.sampling_top_k = 50
+    assert len(model.generate(video, ids, use_nucleus_sampling=True, num_beams=4, max_length=6)) == 2
+
+
 def test_captured_step_equals_eager_steps():
     """Trainer.step_graph: the whole step (three streams, ~2500 launches at full size) replayed from one hipGraph; batch, dropout salt and
     Adam's lr / bias corrections are read from device memory.  Without dropout three graph-path steps (eager warm-up, capture, replay)

@@ -471,7 +471,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(so, name), f"{name} declared in include/vid2seq_hip.h but not exported"
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
     l = L.lib()
-    assert l.v2s_version() == 2
+    assert l.v2s_version() == L.ABI_VERSION == int(re.search(r"#define V2S_ABI_VERSION (\d+)", header).group(1))
     assert l.v2s_set_option(b"no_such_option", 1) != 0 and b"unknown option" in l.v2s_last_error()
     # argument validation happens on the host before any launch: exercisable without a GPU
     a = L.GemmArgs()

@@ -108,5 +108,8 @@ class ParamArena:
         # Parameters (optimizer.step, div_, load_state_dict) show up there, not on the arena tensor
         v = self.master._version + sum(self.params[n]._version for n in self.names)
         if force or v != self._seen_version:
+            guard = getattr(self, "stale_guard", None)
+            if guard is not None and not force:      # sharded optimizer: never re-cast stale foreign stripes over the gathered shadow
+                guard("refresh of the bf16 shadow weights from the fp32 masters (a Parameter was modified in place, or mark_dirty())")
             L.cast_bf16(self.master, self.shadow, self.numel)
             self._seen_version = v

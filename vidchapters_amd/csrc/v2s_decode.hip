@@ -883,6 +883,32 @@ __global__ __launch_bounds__(256) void beam_sample_cand_kernel(const float* __re
     }
   }
   __syncthreads();
+  if (*s_cnt > 64) {
+    // more than 64 candidates at or above the k-th value: a plateau of ties AT that value.  Keep everything strictly above it (fewer
+    // than k <= 64 entries) and, of the ties, the LOWEST token ids -- the slots above were handed out in atomic arrival order, which
+    // would make the kept set depend on scheduling
+    __syncthreads();
+    if (tid == 0) *s_cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < V; i += 256) {
+      const float e = pr[i];
+      if (e > 0.f && __float_as_uint(e) > kth) s_tok[atomicAdd(s_cnt, 1)] = i;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      int base = *s_cnt;
+      for (int i0 = 0; i0 < V && base < 64; i0 += 64) {
+        const int i = i0 + tid;
+        const bool tie = i < V && pr[i] > 0.f && __float_as_uint(pr[i]) == kth;
+        const unsigned long long bal = __ballot(tie);
+        const int before = __popcll(bal & ((1ull << tid) - 1ull));
+        if (tie && base + before < 64) s_tok[base + before] = i;
+        base += __popcll(bal);
+      }
+      if (tid == 0) *s_cnt = min(base, 64);
+    }
+    __syncthreads();
+  }
   if (tid >= 64) return;
   const int n = min(*s_cnt, 64), lane = tid;
   const int tok = lane < n ? s_tok[lane] : 0x7fffffff;

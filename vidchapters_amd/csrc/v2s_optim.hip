@@ -103,6 +103,33 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
   s = wave_sum(s);
   if (lane == 0) ws[2 + row] = sqrtf(s);
 }
+// one wavefront per embedding row: sumsq[row] += sum of squares of the row's elements whose FLAT index (row * d + c) lies in [f0, f1).
+// Sharded optimizer: a rank's fp32 master values are current only inside the stripes it owns, so the frozen-row norms of the
+// time-token renorm are assembled from per-rank partial sums (all-reduced by the caller) instead of read from stale masters.
+__global__ __launch_bounds__(256) void rowsumsq_range_kernel(const float* __restrict__ emb, int row_lo, int row_hi, int d, long f0, long f1,
+                                                            float* __restrict__ sumsq) {
+  const int row = row_lo + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= row_hi) return;
+  const long base = (long)row * d;
+  const int c0 = (int)max(0L, f0 - base), c1 = (int)min((long)d, f1 - base);
+  float s = 0.f;
+  for (int c = c0 + lane; c < c1; c += 64) { const float x = emb[base + c]; s += x * x; }
+  s = wave_sum(s);
+  if (lane == 0 && c1 > c0) sumsq[row] += s;
+}
+// ws[2 + row] = sqrt(text_sumsq[row]) for the frozen rows (the time-token rows are whole on every rank: rownorm_kernel on them)
+__global__ __launch_bounds__(256) void rownorm_from_sumsq_kernel(const float* __restrict__ text_sumsq, int n, float* __restrict__ ws) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < n) ws[2 + r] = sqrtf(text_sumsq[r]);
+}
+__global__ __launch_bounds__(256) void rownorm_rows_kernel(const float* __restrict__ emb, int row_lo, int row_hi, int d, float* __restrict__ ws) {
+  const int row = row_lo + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= row_hi) return;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) { const float x = emb[(long)row * d + c]; s += x * x; }
+  s = wave_sum(s);
+  if (lane == 0) ws[2 + row] = sqrtf(s);
+}
 __global__ __launch_bounds__(1024) void renorm_means_kernel(float* __restrict__ ws, int V, int nb) {
   __shared__ float a[1024], b[1024];
   float sa = 0.f, sb = 0.f;
@@ -172,6 +199,30 @@ extern "C" int v2s_timetoken_renorm(float* emb, void* emb_bf16, int32_t V, int32
   V2S_CHECK(emb && ws && V > num_bins && num_bins > 0 && d > 0, V2S_ERR_ARG, "v2s_timetoken_renorm: bad args V=%d bins=%d", V, num_bins);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(rownorm_kernel, dim3((V + 3) / 4), dim3(256), 0, s, emb, V, d, ws);
+  V2S_LAUNCH_CHECK();
+  hipLaunchKernelGGL(renorm_means_kernel, dim3(1), dim3(1024), 0, s, ws, V, num_bins);
+  V2S_LAUNCH_CHECK();
+  hipLaunchKernelGGL(renorm_scale_kernel, dim3((num_bins * d + 255) / 256), dim3(256), 0, s, emb, (bf16_t*)emb_bf16, V, d, num_bins, ws);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_rowsumsq_range(const float* emb, int32_t V, int32_t d, int64_t f0, int64_t f1, float* sumsq, void* stream) {
+  V2S_CHECK(emb && sumsq && V > 0 && d > 0 && f0 >= 0 && f1 <= (int64_t)V * d, V2S_ERR_ARG, "v2s_rowsumsq_range: bad args V=%d d=%d range [%ld, %ld)", V, d, (long)f0, (long)f1);
+  if (f1 <= f0) return V2S_OK;
+  const int row_lo = (int)(f0 / d), row_hi = (int)((f1 - 1) / d) + 1;
+  hipLaunchKernelGGL(rowsumsq_range_kernel, dim3((row_hi - row_lo + 3) / 4), dim3(256), 0, (hipStream_t)stream, emb, row_lo, row_hi, d, (long)f0, (long)f1, sumsq);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_timetoken_renorm_sq(float* emb, void* emb_bf16, int32_t V, int32_t d, int32_t num_bins, const float* text_sumsq, float* ws,
+                                       void* stream) {
+  V2S_CHECK(emb && ws && text_sumsq && V > num_bins && num_bins > 0 && d > 0, V2S_ERR_ARG, "v2s_timetoken_renorm_sq: bad args V=%d bins=%d", V, num_bins);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(rownorm_from_sumsq_kernel, dim3((V - num_bins + 255) / 256), dim3(256), 0, s, text_sumsq, V - num_bins, ws);
+  V2S_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rownorm_rows_kernel, dim3((num_bins + 3) / 4), dim3(256), 0, s, emb, V - num_bins, V, d, ws);
   V2S_LAUNCH_CHECK();
   hipLaunchKernelGGL(renorm_means_kernel, dim3(1), dim3(1024), 0, s, ws, V, num_bins);
   V2S_LAUNCH_CHECK();

@@ -952,6 +952,25 @@ class Engine:
         a.grad[a.offsets["visual_encoder.pos_embed"]:].zero_()
 
     def end_grad_step(self) -> None:
+        """End of a completed native step: every weight matrix must have received its (overwriting) first weight-gradient GEMM --
+        a matrix that did not would keep the PREVIOUS step's gradient (its memset was skipped)."""
+        fresh = self._fresh_grads
+        if fresh is not None:
+            a = self.arena
+            end = a.offsets["visual_encoder.pos_embed"]
+            def covered(n):          # fused projections: one weight-gradient GEMM writes q|k|v (cross-attention: k|v)
+                if n in fresh:
+                    return True
+                if n.endswith("SelfAttention.k.weight") or n.endswith("SelfAttention.v.weight"):
+                    return n[:-len("k.weight")] + "q.weight" in fresh
+                return n.endswith("EncDecAttention.v.weight") and n[:-len("v.weight")] + "k.weight" in fresh
+            missing = [n for n in a.names if a.offsets[n] < end and a.params[n].dim() >= 2 and not covered(n)]
+            assert not missing, f"skip_grad_memset: no weight gradient was written for {missing[:4]} in this step"
+        self._fresh_grads = None
+
+    def abort_grad_step(self) -> None:
+        """Leave overwrite mode whatever happened (Trainer wraps the step body in try/finally): after an exception inside a step the
+        autograd-path backward must accumulate again instead of overwriting."""
         self._fresh_grads = None
 
     def _begin_backward(self) -> None:

@@ -58,6 +58,8 @@ class DecodeAttnArgs(C.Structure):
                 ("kv_group", _i32), ("new_k", _vp), ("new_v", _vp), ("new_bs", _i64), ("row_map", _vp), ("row_map_ld", _i64)]
 
 
+ABI_VERSION = 3   # V2S_ABI_VERSION this binding was written against (include/vid2seq_hip.h)
+
 #: every symbol include/vid2seq_hip.h declares (checked by tests/test_oracle_cpu.py::test_c_abi_exports_every_declared_symbol)
 SYMBOLS = {
     "v2s_version": (C.c_int, []),
@@ -91,6 +93,8 @@ SYMBOLS = {
     "v2s_adam_step": (C.c_int, [C.POINTER(AdamArgs), _vp]),
     "v2s_cast_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "v2s_timetoken_renorm": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "v2s_rowsumsq_range": (C.c_int, [_vp, _i32, _i32, _i64, _i64, _vp, _vp]),
+    "v2s_timetoken_renorm_sq": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "v2s_decode_attn": (C.c_int, [C.POINTER(DecodeAttnArgs), _vp]),
     "v2s_argmax_step": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "v2s_argmax_step_seq": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
@@ -123,7 +127,11 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        # ABI handshake: the argument structs defined above must have the size the library was compiled with
+        # ABI handshake: the version this binding was written against, then the argument-struct sizes
+        got = int(l.v2s_version())
+        if got != ABI_VERSION:
+            raise RuntimeError(f"ABI mismatch: {LIB_PATH} reports V2S_ABI_VERSION {got}, this binding needs {ABI_VERSION} "
+                               "(rebuild the library: vidchapters_amd/csrc/build.sh)")
         for cname, ctype in (("v2s_gemm_args", GemmArgs), ("v2s_attn_args", AttnArgs), ("v2s_adam_args", AdamArgs),
                              ("v2s_decode_attn_args", DecodeAttnArgs)):
             want = int(l.v2s_sizeof(cname.encode()))
@@ -430,6 +438,16 @@ def cast_bf16(src, dst, n):
 def timetoken_renorm(emb, emb_bf16, V, d, num_bins, ws):
     _check(lib().v2s_timetoken_renorm(emb.data_ptr(), ptr(emb_bf16), V, d, num_bins, ws.data_ptr(), stream_ptr()),
            "v2s_timetoken_renorm")
+
+
+def rowsumsq_range(emb, V, d, f0, f1, sumsq):
+    """sumsq[row] += sum of squares of the elements of ``emb`` ([V, d] fp32) whose flat index lies in [f0, f1)."""
+    _check(lib().v2s_rowsumsq_range(emb.data_ptr(), V, d, f0, f1, sumsq.data_ptr(), stream_ptr()), "v2s_rowsumsq_range")
+
+
+def timetoken_renorm_sq(emb, emb_bf16, V, d, num_bins, text_sumsq, ws):
+    _check(lib().v2s_timetoken_renorm_sq(emb.data_ptr(), ptr(emb_bf16), V, d, num_bins, text_sumsq.data_ptr(), ws.data_ptr(), stream_ptr()),
+           "v2s_timetoken_renorm_sq")
 
 
 def decode_attn(B, H, Nk, q, q_bs, k, v, kv_bs, kv_rs, o, o_bs, bias_row=None, bias_ld=0, key_mask=None, mask_ld=0, scale=1.0,

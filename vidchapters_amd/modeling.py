@@ -331,6 +331,11 @@ class Vid2Seq(nn.Module):
             self.sampling_seed = (getattr(self, "sampling_seed", 0) + 1) & 0xFFFFFFFF
             top_k = int(getattr(self, "sampling_top_k", 50))
             sample = (float(top_p), float(temperature), self.sampling_seed, top_k)
+            if num_beams > 1 and not (1 <= top_k <= 64):
+                # v2s_beam_sample_cand keeps at most 64 warped candidates per beam row: HF's default top_k = 50 fits, "no top-k filter"
+                # (0) or a wider k would be truncated to 64 -- a different distribution from HF's beam_sample, so refuse it
+                raise ValueError(f"beam-sample (use_nucleus_sampling with num_beams > 1) supports 1 <= sampling_top_k <= 64 (got {top_k}); "
+                                 "use num_beams <= 1 for an unrestricted nucleus")
             if num_beams > 1:       # HF 4.28 beam_sample: one best hypothesis per (expanded) input row
                 toks = eng.beam_search(video, input_tokenized, num_beams=num_beams, max_new_tokens=max_length, length_penalty=length_penalty,
                                        min_length=min_length, repetition_penalty=repetition_penalty, num_return=1, sample=sample)

@@ -100,6 +100,10 @@ class GradSync:
         self.collectives = 0          # statistics of the current step (reset by Trainer.step)
         self.bytes_reduced = 0
         self.exposed_ms_events = None # (start, end) events around the final wait of the last step
+        # sharded mode: after an optimizer step the fp32 masters / Adam moments of the stripes OTHER ranks own are out of date on this
+        # rank until gather_master() / gather_stripes() (collectives) bring them in; consumers check the flags instead of reading stale data
+        self.masters_stale = False
+        self.moments_stale = False
 
     def begin_step(self) -> None:
         self.collectives = self.bytes_reduced = 0
@@ -220,6 +224,7 @@ class GradSync:
         """Sharded mode: bring the fp32 master weights of the stripes other ranks own up to date (checkpoints, evaluation through the
         nn.Module, switching to an unsharded optimizer)."""
         self.gather_stripes(self.arena.master)
+        self.masters_stale = False
 
     def exposed_ms(self) -> float:
         """Time the main stream spent waiting for the last step's reductions after backward had finished (synchronises)."""
@@ -252,6 +257,13 @@ class Trainer:
         self._sq_ws = torch.empty(1024, dtype=torch.float32, device=dev)
         self._gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._renorm_ws = torch.empty(self.eng.V + 2, dtype=torch.float32, device=dev)
+        self._text_sumsq = torch.zeros(self.eng.V, dtype=torch.float32, device=dev) if self.sync.shard else None
+        if self.sync.shard:
+            # stale-master guards (sharded optimizer): a re-cast of the bf16 shadow from the masters (an in-place torch update of a
+            # Parameter, mark_dirty, load_state_dict) or a state_dict() of the module would silently use the (world-1)/world stale
+            # matrices -- fail loudly instead; gather_master() (a collective: every rank) makes them current
+            a.stale_guard = self._stale_guard
+            model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self._stale_guard("model.state_dict()"))
         # arena ranges (engine._arena_order): decoder matrices | encoder matrices | ViT matrices + pos_embed | the small fp32-consumed
         # parameters | the tied embedding, whose last rows (time tokens + the zero tail) every rank keeps whole (renorm reads them)
         names = a.names
@@ -267,6 +279,11 @@ class Trainer:
         tt0 = sh0 + ((self.eng.V - model.num_bins) * self.eng.d) // 64 * 64 if model.num_bins else sh1
         self._r_shared, self._r_timetok = (sh0, tt0), (tt0, sh1)
         assert self._r_dec[1] == self._r_enc[0] and self._r_enc[1] == self._r_vis[0] and self._r_vis[1] == self._r_small[0] and self._r_small[1] == sh0
+
+    def _stale_guard(self, what: str) -> None:
+        if self.sync.masters_stale:
+            raise RuntimeError(f"{what}: the fp32 master weights of the stripes other ranks own are stale (sharded optimizer). Call "
+                               "Trainer.gather_master() on EVERY rank first (it is a collective), then save / evaluate / update.")
 
     # ------------------------------------------------------------------------------------------------
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -300,6 +317,15 @@ class Trainer:
         overlap = eng.overlap
         eng.prepare()
         eng.begin_grad_step()
+        try:
+            return self._step_body(batch, hyper_dev)
+        finally:
+            eng.abort_grad_step()        # no-op after a completed step; after an exception: later backward calls accumulate again
+
+    def _step_body(self, batch: Dict[str, torch.Tensor], hyper_dev: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        m, eng = self.model, self.eng
+        main = torch.cuda.current_stream()
+        overlap = eng.overlap
         self.sync.begin_step()
         losses: Dict[str, torch.Tensor] = {}
         vtape: Dict = {}
@@ -438,11 +464,38 @@ class Trainer:
             L.adam_step(a.master, self.m, self.v, a.grad, a.shadow, a.numel, lr, self.betas[0], self.betas[1], self.eps, self.wd,
                         step_no, gnorm_sq=self._gnorm_sq if self.clip > 0 else None, max_norm=self.clip,
                         grad_scale=1.0 / self.world, hyper_dev=hyper_dev)
+        if self.sync.shard:
+            self.sync.masters_stale = self.sync.moments_stale = self.sync.world > 1
         if self.model.num_bins:
             emb = a.f("t5_model.shared.weight")
             embb = a.w("t5_model.shared.weight")
-            for _ in range(2):      # dvc.py:120-126 renormalises `shared` and then `lm_head` -- the same tied tensor
-                L.timetoken_renorm(emb, embb, eng.V, eng.d, self.model.num_bins, self._renorm_ws)
+            if self.sync.shard:
+                # the frozen (text) rows are reduce-scattered: this rank's fp32 masters are current only inside its own stripes, so
+                # their norms come from per-rank partial row sums of squares (owned stripes: all-reduced; replicated ranges: added once,
+                # locally).  The time-token rows are whole on every rank (replicated range).  One all-reduce of V floats per step.
+                V, d, nb = eng.V, eng.d, self.model.num_bins
+                sh0 = a.offsets["t5_model.shared.weight"]
+                t1 = sh0 + (V - nb) * d                                    # end of the frozen rows (arena offset)
+                sq = self._text_sumsq
+                sq.zero_()
+                for s0, e0 in self.sync.owned:
+                    lo, hi = max(s0, sh0), min(e0, t1)
+                    if lo < hi:
+                        L.rowsumsq_range(emb, V, d, lo - sh0, hi - sh0, sq)
+                if self.sync.world > 1:
+                    if self.sync._host_staged:
+                        h = sq.cpu(); dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.sync.group); sq.copy_(h)
+                    else:
+                        dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.sync.group)
+                for s0, e0 in self.sync.replicated:
+                    lo, hi = max(s0, sh0), min(e0, t1)
+                    if lo < hi:
+                        L.rowsumsq_range(emb, V, d, lo - sh0, hi - sh0, sq)
+                for _ in range(2):  # dvc.py:120-126 twice on the tied tensor: the frozen rows do not change in between
+                    L.timetoken_renorm_sq(emb, embb, V, d, nb, sq, self._renorm_ws)
+            else:
+                for _ in range(2):      # dvc.py:120-126 renormalises `shared` and then `lm_head` -- the same tied tensor
+                    L.timetoken_renorm(emb, embb, eng.V, eng.d, self.model.num_bins, self._renorm_ws)
 
     # ------------------------------------------------------------------------------------------------ captured step
     def step_graph(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -514,12 +567,26 @@ class Trainer:
         self.sync.gather_master()
         self.eng.mark_dirty()
 
+    def prepare_checkpoint(self) -> None:
+        """Sharded optimizer only (a no-op otherwise): COLLECTIVE -- every rank calls it -- that makes the fp32 masters and both Adam
+        moments whole on every rank, so that ``model.state_dict()`` and ``Trainer.state_dict()`` can then be taken by any single rank
+        (dvc.py:310-330 saves from the main process only)."""
+        if not self.sync.shard:
+            return
+        self.gather_master()
+        self.sync.gather_stripes(self.m)
+        self.sync.gather_stripes(self.v)
+        self.sync.moments_stale = False
+
     def state_dict(self) -> Dict:
         """Optimizer state for checkpoint / resume (dvc.py:310-330 saves optimizer.state_dict() next to the model): Adam moments (flat,
         arena order), step count, and the dropout stream position so that a resumed run draws the masks the uninterrupted one would.
-        With a sharded optimizer this is a COLLECTIVE (every rank calls it): the moments of the other ranks' stripes are gathered first."""
-        self.sync.gather_stripes(self.m)
-        self.sync.gather_stripes(self.v)
+        With a sharded optimizer call :meth:`prepare_checkpoint` on every rank first (this method itself is NOT a collective and raises on
+        stale moments instead of deadlocking a main-process-only save)."""
+        if self.sync.shard and self.sync.moments_stale:
+            raise RuntimeError("Trainer.state_dict(): the Adam moments of the stripes other ranks own are stale (sharded optimizer). Call "
+                               "Trainer.prepare_checkpoint() on EVERY rank first (a collective); the usual `if is_main_process(): "
+                               "save(trainer.state_dict())` of dvc.py:310-330 then works unchanged.")
         return {"step_count": self.step_count, "exp_avg": self.m, "exp_avg_sq": self.v, "dropout_rng": self.eng.rng_state(),
                 "arena_names": list(self.eng.arena.names)}
 
