@@ -875,11 +875,107 @@ def case_greedy_full(v2s, B=2, T=100, L=1000, max_new=24, seed=2026):
     npz("full_cfg4_greedy.npz", **arrs)
 
 
+def case_beam_full(v2s, B=2, T=100, L=1000, nb=4, max_new=16, seed=2027):
+    """The callers' DEFAULT decode mode (num_beams=4, vid2seq.py:104, args.py:306-311) at the reference's own sizes (t5-base, 100
+    frames, 1000 ASR tokens): the restated 4.28 beam search (R.beam_search_core) driven by the REFERENCE's own cached forward
+    (its past_key_values, reordered like modeling_t5.py:1771-1793), against (a) the pure oracle R.beam_generate and (b) the installed
+    transformers' generate(num_beams=4) on the same weights.  Weights: synthetic init with a ``sharp`` x sharper embedding and the EOS
+    row at ``fac`` x the greedy favourite's row (EOS competes, finished hypotheses appear), like the small beam fixture.  Two variants:
+    plain (2x), and repetition_penalty 1.3 (3x; one entry ends in EOS early).  A random-init model decides most beam steps by less
+    than bf16 noise, so the fixture stores the reference's whole TRAJECTORY: per step and entry the 2*nb + 1 best candidate scores /
+    tokens / source beams and the step's decisions (next tokens, scores, source rows) -- the HIP engine is driven along these
+    decisions (teacher forcing) and its candidates are compared step by step; the final tokens are stored as well."""
+    import transformers
+    from transformers.modeling_outputs import BaseModelOutput
+    cfg = R.RefConfig()
+    print(f"[full_cfg4 beam] B={B} T={T} L={L} num_beams={nb} {max_new} new tokens (reference fp32 CPU, cached decoding)")
+    batch = synth.make_batch(B, T, L, 8, cfg.vocab, seed, cfg.vit_dim)
+    batch["output_ids"] = torch.ones(B, 2, dtype=torch.long)
+    arrs = {"seed": seed, "B": B, "T": T, "L": L, "num_beams": nb, "max_new": max_new}
+
+    def norm(x):
+        x = x.tolist()
+        x = x[:x.index(1) + 1] if 1 in x else x
+        while x and x[-1] == 0:
+            x.pop()
+        return x
+    for tag, pen, fac, sharp in (("", 1.0, 1.0, 2.0), ("_rp", 1.3, 1.0, 3.0)):
+        P = oracle_params(cfg, seed, grad=False)
+        E = P["t5_model.shared.weight"] * sharp
+        P["t5_model.shared.weight"] = E
+        g = R.greedy_generate(P, cfg, batch["video"], batch["input_ids"], batch["input_ids"] != 0, 4)
+        fav = int(torch.mode(g[:, 1:].flatten()).values)
+        E[1] = E[fav] * fac
+        m = build_ref_model(v2s, cfg, P).eval()
+        with torch.no_grad():
+            _, _, mem, atts = ref_logits(m, batch)
+            memr, attr = mem.repeat_interleave(nb, 0), atts.repeat_interleave(nb, 0)
+            state = {"past": None}
+
+            def step_logp(seq, bidx):
+                past = state["past"]
+                if past is not None:
+                    past = m.t5_model._reorder_cache(past, bidx)                       # the reference's own cache reorder
+                step = seq if past is None else seq[:, -1:]
+                o = m.t5_model(encoder_outputs=BaseModelOutput(last_hidden_state=memr), attention_mask=attr, decoder_input_ids=step,
+                               past_key_values=past, use_cache=True, return_dict=True)
+                state["past"] = o.past_key_values
+                return torch.log_softmax(o.logits[:, -1].float(), -1)
+            tr_ref, tr_or = [], []
+            V = E.shape[0]
+            out_ref = R.beam_search_core(step_logp, B, nb, V, cfg.eos_id, cfg.pad_id, cfg.dec_start_id, max_new + 1, 1.0,
+                                         repetition_penalty=pen, trace=tr_ref)
+            out_or = R.beam_generate(P, cfg, batch["video"], batch["input_ids"], batch["input_ids"] != 0, nb, max_new, 1.0,
+                                     repetition_penalty=pen, trace=tr_or)
+            assert out_ref.shape == out_or.shape and torch.equal(out_ref, out_or), (out_ref, out_or)
+            dmax = max(float((a["scores"] - b["scores"]).abs().max()) for a, b in zip(tr_ref, tr_or))
+            print(f"  penalty {pen}: OK  oracle beam search == beam search over the reference's cached forward: tokens identical, "
+                  f"candidate scores to {dmax:.2e}")
+            assert dmax < 2e-3
+            # the scorer against the installed transformers (HF's own T5 class, same weights, the reference's memory)
+            hf = transformers.T5ForConditionalGeneration(transformers.T5Config(
+                vocab_size=cfg.vocab, d_model=cfg.d_model, d_kv=cfg.d_kv, d_ff=cfg.d_ff, num_layers=cfg.n_enc,
+                num_decoder_layers=cfg.n_dec, num_heads=cfg.heads, feed_forward_proj="relu", dropout_rate=0.0,
+                tie_word_embeddings=True, pad_token_id=0, eos_token_id=1, decoder_start_token_id=0))
+            sd = {k[len("t5_model."):]: v for k, v in P.items() if k.startswith("t5_model.")}
+            for a in ("encoder.embed_tokens.weight", "decoder.embed_tokens.weight", "lm_head.weight"):
+                sd[a] = sd["shared.weight"]
+            hf.load_state_dict(sd, strict=False); hf.eval()
+            ref = hf.generate(encoder_outputs=BaseModelOutput(last_hidden_state=mem), attention_mask=atts, num_beams=nb, do_sample=False,
+                              max_new_tokens=max_new, min_length=1, length_penalty=1.0, early_stopping=False, repetition_penalty=pen)
+        same_hf = [norm(out_ref[i]) == norm(ref[i]) for i in range(B)]
+        print(f"  {'OK ' if all(same_hf) else 'DIFF'} installed-HF {transformers.__version__} generate(num_beams={nb}, repetition_penalty={pen}) "
+              f"agrees on {sum(same_hf)}/{B} rows")
+        scores = torch.stack([t["scores"] for t in tr_ref], 1)                        # [B, steps, 2*nb + 1]
+        cut = scores[:, :, nb - 1] - scores[:, :, nb]                                 # gap at the beam cut (ignoring EOS candidates)
+        n_eos = sum(1 in norm(out_ref[i]) for i in range(B))
+        print(f"  rows: {[norm(out_ref[i]) for i in range(B)]}; {n_eos} end in EOS; {scores.shape[1]} steps; gap at the beam cut: min "
+              f"{float(cut.min()):.4f}, median {float(cut.median()):.4f}")
+        pad = torch.zeros(B, max_new + 1, dtype=torch.long)
+        pad[:, :out_ref.shape[1]] = out_ref
+        steps = scores.shape[1]
+        def padsteps(x):
+            o = torch.zeros(B, max_new, x.shape[2], dtype=x.dtype)
+            o[:, :steps] = x
+            return o
+        arrs.update({"tokens" + tag: pad, "steps" + tag: steps, "fav" + tag: fav, "fac" + tag: np.float32(fac), "sharp" + tag: np.float32(sharp),
+                     "hf_same" + tag: np.array(same_hf),
+                     "next_scores" + tag: padsteps(torch.stack([t["next_scores"] for t in tr_ref], 1)),
+                     "next_tokens" + tag: padsteps(torch.stack([t["next_tokens"] for t in tr_ref], 1)),
+                     "next_src" + tag: padsteps(torch.stack([t["next_src"] for t in tr_ref], 1)),
+                     "done" + tag: torch.stack([t["done"] for t in tr_ref], 1),
+                     "cand_scores" + tag: padsteps(scores), "cand_tokens" + tag: padsteps(torch.stack([t["tokens"] for t in tr_ref], 1)),
+                     "cand_beams" + tag: padsteps(torch.stack([t["beams"] for t in tr_ref], 1))})
+    arrs["penalty"] = 1.3
+    npz("full_cfg4_beam4.npz", **arrs)
+
+
 def case_shapes(v2s):
     case_shape(v2s, "full_cfg2", R.RefConfig(), B=2, T=100, L=1000, Lo=256, seed=2024)
     large = R.RefConfig(d_model=1024, d_kv=64, heads=16, d_ff=4096, n_enc=24, n_dec=24, num_features=200)
     case_shape(v2s, "large_cfg5", large, B=1, T=200, L=2000, Lo=256, seed=2025)
     case_greedy_full(v2s)
+    case_beam_full(v2s)
 
 
 def main():
@@ -887,6 +983,7 @@ def main():
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-eval", action="store_true", help="regenerate tests/golden/eval_metrics.json only")
     ap.add_argument("--only-shapes", action="store_true", help="regenerate the big-shape goldens (cfg-2 shape, t5-large / cfg-5 shape) only")
+    ap.add_argument("--only-beam-full", action="store_true", help="regenerate tests/golden/full_cfg4_beam4.npz only")
     a = ap.parse_args()
     if a.only_eval:
         case_schedule()
@@ -897,6 +994,9 @@ def main():
     mt5, v2s, vit = load_reference()
     if a.only_shapes:
         case_shapes(v2s)
+        return
+    if a.only_beam_full:
+        case_beam_full(v2s)
         return
     case_functions(mt5)
     case_parse()

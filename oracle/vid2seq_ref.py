@@ -473,7 +473,8 @@ class _BeamHyps:
 
 @torch.no_grad()
 def beam_search_core(step_logp, B: int, nb: int, V: int, eos_id: int, pad_id: int, start_id: int, max_length: int,
-                     length_penalty: float = 1.0, min_length: int = 1, repetition_penalty: float = 1.0, num_return_sequences: int = 1):
+                     length_penalty: float = 1.0, min_length: int = 1, repetition_penalty: float = 1.0, num_return_sequences: int = 1,
+                     trace: Optional[list] = None):
     """transformers==4.28.0 GenerationMixin.beam_search + BeamSearchScorer (early_stopping=False) over an arbitrary next-token model:
     ``step_logp(seq, beam_idx)`` returns log-softmax scores [B*nb, V] for the sequences ``seq`` ([B*nb, len]); ``beam_idx`` (None at the
     first call) is the row permutation that produced ``seq`` from the previous call's rows (for reordering a cache)."""
@@ -491,7 +492,10 @@ def beam_search_core(step_logp, B: int, nb: int, V: int, eos_id: int, pad_id: in
         if seq.shape[-1] < min_length:                         # MinLengthLogitsProcessor (applied to the log-probs in 4.28 beam_search)
             logp[:, eos_id] = -float("inf")
         logp = logp + beam_scores[:, None]
-        top_s, top_i = torch.topk(logp.view(B, nb * V), 2 * nb, dim=1, largest=True, sorted=True)
+        top_s, top_i = torch.topk(logp.view(B, nb * V), 2 * nb + 1, dim=1, largest=True, sorted=True)
+        if trace is not None:       # goldens: the 2*nb + 1 best candidate scores of every entry (gaps = how firmly the step was decided)
+            trace.append({"scores": top_s.clone(), "tokens": (top_i % V).clone(), "beams": (top_i // V).clone()})
+        top_s, top_i = top_s[:, :2 * nb], top_i[:, :2 * nb]
         nidx, ntok = top_i // V, top_i % V
         cur_len = seq.shape[-1]
         new_scores = torch.zeros(B, nb); new_tok = torch.zeros(B, nb, dtype=torch.long); new_idx = torch.zeros(B, nb, dtype=torch.long)
@@ -513,6 +517,8 @@ def beam_search_core(step_logp, B: int, nb: int, V: int, eos_id: int, pad_id: in
                     break
             done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len)
         beam_scores, bt, bidx = new_scores.view(-1), new_tok.view(-1), new_idx.view(-1)
+        if trace is not None:       # the step's decisions: next tokens / scores / source rows of the nb beams, and which entries are done
+            trace[-1].update(next_scores=new_scores.clone(), next_tokens=new_tok.clone(), next_src=new_idx.clone(), done=torch.tensor(done))
         seq = torch.cat([seq[bidx], bt[:, None]], -1)
         if all(done) or seq.shape[-1] >= max_length:
             break
@@ -536,7 +542,8 @@ def beam_search_core(step_logp, B: int, nb: int, V: int, eos_id: int, pad_id: in
 
 
 def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_beams: int = 4, max_new_tokens: int = 256,
-                  length_penalty: float = 1.0, min_length: int = 1, repetition_penalty: float = 1.0, num_return_sequences: int = 1):
+                  length_penalty: float = 1.0, min_length: int = 1, repetition_penalty: float = 1.0, num_return_sequences: int = 1,
+                  trace: Optional[list] = None):
     """vid2seq.py:150-162 with num_beams>1, do_sample=False, early_stopping=False, num_return_sequences=1:
     transformers==4.28.0 GenerationMixin.beam_search + BeamSearchScorer (un-vendored dependency -> restated from the
     published algorithm; *parity unpinned by reference tests*, cross-checked against the installed transformers'
@@ -557,7 +564,7 @@ def beam_generate(P: Params, cfg: RefConfig, video, input_ids, input_mask, num_b
         return torch.log_softmax(lm_logits(P, cfg, h[:, -1:]).squeeze(1).float(), dim=-1)
 
     return beam_search_core(step_logp, B, nb, V, cfg.eos_id, cfg.pad_id, cfg.dec_start_id, max_new_tokens + 1, length_penalty,
-                            min_length, repetition_penalty, num_return_sequences)
+                            min_length, repetition_penalty, num_return_sequences, trace=trace)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -249,6 +249,81 @@ def test_cfg4_greedy_vs_reference_cached_decoding(golden_dir):
     assert checked >= 60            # measured: 25 + 25 + 20 + 25 of 4 x 25
 
 
+def test_cfg4_beam4_vs_reference_trajectory(golden_dir):
+    """The callers' default decode mode (num_beams=4, vid2seq.py:104,150-162) at cfg-4's real shapes (t5-base, 100 frames + 1000 ASR
+    tokens: S = 1100 memory keys, the MFMA grouped cross-attention, row-map reorders) against tests/golden/full_cfg4_beam4.npz = the
+    restated 4.28 beam search driven by the REFERENCE's own cached forward (oracle/make_golden.py:case_beam_full; == the pure oracle,
+    == the installed transformers' generate on the same weights).  A random-init model decides many beam steps by less than bf16
+    noise, so the engine is TEACHER-FORCED along the reference's decisions and compared step by step: every one of the reference's
+    2*nb best candidates of an entry must be among the engine's candidates with the same score (tolerance below), in the same rank
+    wherever the reference's neighbouring gaps exceed twice the tolerance.  The free-running result must equal the reference's
+    tokens unless the reference itself decided a step before the divergence by less than the tolerance."""
+    g = np.load(os.path.join(golden_dir, "full_cfg4_beam4.npz"))
+    B, T, L, nb, max_new, seed = (int(g[k]) for k in ("B", "T", "L", "num_beams", "max_new", "seed"))
+    R = B * nb
+    TOL = 0.08                       # |log-prob + beam score| difference per candidate; measured below
+    b = synth.make_batch(B, T, L, 8, 32200, seed, 768)
+    video, ids = b["video"].to(DEV), b["input_ids"].to(DEV)
+    inp = {"input_ids": ids, "attention_mask": ids != 0}
+    for tag, pen in (("", 1.0), ("_rp", float(g["penalty"]))):
+        model = Vid2Seq("t5-base", tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
+                        init_seed=seed, device=DEV).eval()
+        with torch.no_grad():
+            E = model.t5_model.shared.weight
+            E.mul_(float(g["sharp" + tag]))
+            E[1] = E[int(g["fav" + tag])] * float(g["fac" + tag])
+        steps = int(g["steps" + tag])
+        cs, ct, cb = g["cand_scores" + tag], g["cand_tokens" + tag], g["cand_beams" + tag]
+        ns, nt, nsrc, done = g["next_scores" + tag], g["next_tokens" + tag], g["next_src" + tag], g["done" + tag]
+        seqs = np.zeros((R, max_new + 1), dtype=np.int64)
+        teacher = []
+        for t in range(steps - 1):
+            src = nsrc[:, t].reshape(-1).astype(np.int32)
+            seqs = seqs[src]
+            seqs[:, t + 1] = nt[:, t].reshape(-1)
+            teacher.append((nt[:, t].reshape(-1), ns[:, t].reshape(-1).astype(np.float32), src, seqs.copy()))
+        rec = model.engine().beam_search(video, inp, num_beams=nb, max_new_tokens=max_new, repetition_penalty=pen, teacher=teacher)
+        assert len(rec) == steps
+        worst, checked, order_checked = 0.0, 0, 0
+        for t in range(steps):
+            val, tok = rec[t]
+            for e in range(B):
+                if t > 0 and bool(done[e, t - 1]):
+                    continue
+                merged = sorted(((float(val[e * nb + r, k]), r, int(tok[e * nb + r, k])) for r in range(nb) for k in range(val.shape[1])
+                                 if np.isfinite(val[e * nb + r, k])), key=lambda x: -x[0])
+                for j in range(2 * nb):
+                    want = (int(cb[e, t, j]), int(ct[e, t, j]))
+                    hit = [i for i, (v, r, k) in enumerate(merged) if (r, k) == want]
+                    if not hit:      # a row's list holds K = 2*nb candidates: one that the reference ranks within 2*TOL of its (2*nb + 1)-th may drop out
+                        assert float(cs[e, t, j] - cs[e, t, 2 * nb]) < 2 * TOL, (tag, t, e, j, want, merged[:10], cs[e, t].tolist())
+                        continue
+                    diff = abs(merged[hit[0]][0] - float(cs[e, t, j]))
+                    worst = max(worst, diff)
+                    assert diff < TOL, (tag, t, e, j, merged[hit[0]], float(cs[e, t, j]))
+                    checked += 1
+                    gap_up = float(cs[e, t, j - 1] - cs[e, t, j]) if j else 1e9
+                    gap_dn = float(cs[e, t, j] - cs[e, t, j + 1])
+                    if min(gap_up, gap_dn) > 2 * TOL:
+                        assert hit[0] == j, (tag, t, e, j, hit[0], merged[:10], cs[e, t].tolist())
+                        order_checked += 1
+        print(f"cfg-4 beam-4{tag}: {checked} reference candidates over {steps} steps found with |score diff| <= {worst:.4f}; {order_checked} firm ranks identical")
+        assert checked >= (2 * nb - 1) * (steps if tag == '' else steps // 2) and order_checked >= 4
+        # free run
+        want = torch.from_numpy(g["tokens" + tag])
+        got = model.engine().beam_search(video, inp, num_beams=nb, max_new_tokens=max_new, repetition_penalty=pen).cpu()
+        gp = torch.zeros_like(want); gp[:, :got.shape[1]] = got
+        for e in range(B):
+            diff = (gp[e] != want[e]).nonzero()
+            if len(diff) == 0:
+                print(f"  free-running row {e}: identical to the reference's hypothesis")
+                continue
+            n = int(diff[0])
+            gaps = np.abs(cs[e, :steps, :nb] - cs[e, :steps, 1:nb + 1]).min()
+            print(f"  free-running row {e}: differs from token {n} on; the reference's smallest gap among its {nb + 1} best candidates of a step: {gaps:.4f}")
+            assert gaps < TOL, (tag, e, n, gp[e].tolist(), want[e].tolist())
+
+
 def _nccl_world1(rank, port, ret):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")

@@ -1139,7 +1139,7 @@ class Engine:
     @torch.no_grad()
     def beam_search(self, video, input_tokenized, num_beams: int, max_new_tokens: int, length_penalty: float = 1.0,
                     use_graph: bool = True, min_length: int = 1, repetition_penalty: float = 1.0, num_return: int = 1,
-                    sample=None) -> torch.Tensor:
+                    sample=None, teacher=None) -> torch.Tensor:
         """HF-4.28 beam_search + BeamSearchScorer semantics (call site vid2seq.py:150-162) on static caches.
         ``sample=(top_p, temperature, seed, top_k)`` turns the step into HF's beam_sample (do_sample with num_beams > 1): the
         candidates of a row come from ``v2s_beam_sample_cand`` (warped scores + Gumbel keys) instead of ``v2s_topk_logprob``.
@@ -1148,7 +1148,11 @@ class Engine:
         running beam score + per-beam top 2*nb), captured as a hipGraph; the host merges the candidates (beam.BeamScorer) and
         sends back next tokens, scores and source rows.  The self-attention cache is never moved: a [rows][maxlen] ``row_map`` says
         which cache row holds each (beam, position) key, and a beam reorder permutes the rows of that table (v2s_decode_attn
-        row_map) -- HF copies every cached K/V row (modeling_t5.py:1771-1793), 12 layers x rows x len x 3 KB per step."""
+        row_map) -- HF copies every cached K/V row (modeling_t5.py:1771-1793), 12 layers x rows x len x 3 KB per step.
+        ``teacher`` (parity tests at real shapes, tests/test_configs_gpu.py): a list of per-step decisions (tokens int64 [rows],
+        scores float32 [rows], source rows int32 [rows], optionally the decoder ids so far [rows, maxlen + 1] for the repetition
+        penalty) taken from a reference trajectory: the engine then FOLLOWS them instead of its own scorer -- same kernels, same graph,
+        same row-map reorders -- and returns the per-step candidates [(values [rows, K], tokens [rows, K])] it would have scored."""
         from .beam import BeamScorer
         a, c = self.arena, self.cfg
         mem, mem_mask = self.encode(video, input_tokenized)
@@ -1250,7 +1254,8 @@ class Engine:
         bscore.copy_(torch.from_numpy(scorer.scores.reshape(-1)))
         identity = np.arange(R, dtype=np.int32)
         graph = None
-        for t in range(maxlen):
+        recorded = []
+        for t in range(maxlen if teacher is None else min(maxlen, len(teacher) + 1)):
             if t == 0 or not use_graph:
                 step()
             else:
@@ -1264,6 +1269,18 @@ class Engine:
                 graph.replay()
             cand_host.copy_(cand, non_blocking=True)
             torch.cuda.current_stream().synchronize()
+            if teacher is not None:
+                recorded.append((cand_host[0].view(torch.float32).numpy().copy(), cand_host[1].numpy().copy()))
+                if t >= len(teacher):
+                    break
+                tt = teacher[t]
+                h_tok[:] = tt[0]; h_score[:] = tt[1]; h_src[:] = tt[2]
+                h2d.copy_(h2d_host, non_blocking=True)
+                if rp:
+                    hist.copy_(torch.as_tensor(tt[3]))
+                if not np.array_equal(np.asarray(tt[2], dtype=np.int32), identity):
+                    row_map.copy_(row_map.index_select(0, src_dev))
+                continue
             tok, src, finished = scorer.advance(cand_host[0].view(torch.float32).numpy(), cand_host[1].numpy(),
                                                 cand_host[2].view(torch.float32).numpy() if sample is not None else None)
             if finished:
@@ -1274,6 +1291,8 @@ class Engine:
                 hist.copy_(torch.from_numpy(scorer.seqs))
             if not np.array_equal(src, identity):
                 row_map.copy_(row_map.index_select(0, src_dev))
+        if teacher is not None:
+            return recorded
         if not 1 <= num_return <= nb:
             raise ValueError(f"num_captions must be in [1, num_beams] (got {num_return})")
         return torch.from_numpy(scorer.finalize(num_return)).to(self.device)
