@@ -470,6 +470,94 @@ def test_attention_fwd_bwd(B, H, Nq, Nk, scale, use_bias, use_mask, causal, tr_m
         assert c > 0.999 and e < 3e-2
 
 
+def test_fp32_io_debug_mode_norm_ce_attention():
+    """SURVEY 8c "tolerances to state": with fp32 activations in and out (library option fp32_io) the norm, cross-entropy and
+    attention entry points must agree with fp32 torch to <= 1e-4 -- the debug mode that separates a kernel bug from bf16 rounding.
+    (Norms / CE: the product kernels instantiated for fp32 I/O; attention: fp32-arithmetic reference kernels with the product
+    kernels' semantics, incl. the dropout mask function, compared here with torch and with the MFMA kernels.)"""
+    F = torch.nn.functional
+    g = torch.Generator(device="cpu").manual_seed(11)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    worst = {}
+    with L.fp32_io():
+        # ---- RMSNorm / LayerNorm forward + backward (with the fused residual-gradient add)
+        rows, cols, eps = 333, 768, 1e-6
+        for ln in (False, True):
+            x, w, b, dy, da = rn(rows, cols), rn(cols) * 0.2 + 1.0, rn(cols) * 0.1, rn(rows, cols), rn(rows, cols)
+            y = torch.empty_like(x); rstd = torch.empty(rows, device=DEV); mean = torch.empty(rows, device=DEV)
+            dx = torch.empty_like(x); dw = torch.zeros(cols, device=DEV); db = torch.zeros(cols, device=DEV)
+            xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            if ln:
+                L.layernorm_fwd(x, w, b, y, mean, rstd, rows, cols, 1e-5)
+                L.layernorm_bwd(x, w, mean, rstd, dy, dx, da, dw, db, rows, cols)
+                ref = F.layer_norm(xr, (cols,), wr, br, 1e-5)
+            else:
+                L.rmsnorm_fwd(x, w, y, rstd, rows, cols, eps)
+                L.rmsnorm_bwd(x, w, rstd, dy, dx, da, dw, rows, cols)
+                ref = wr * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps))
+            ref.backward(dy)
+            tag = "layernorm" if ln else "rmsnorm"
+            worst[tag] = max(relerr(y, ref), relerr(dx, xr.grad + da), relerr(dw, wr.grad), relerr(db, br.grad) if ln else 0.0)
+        # ---- cross-entropy (label smoothing, ignore_index) forward + backward with fp32 d(logits)
+        R_, V, ld, sm = 37, 1000, 1000, 0.1
+        logits = rn(R_, ld, sc=3.0)
+        labels = torch.randint(0, V, (R_,), generator=g).to(DEV); labels[::5] = -100
+        row = torch.empty(R_, 2, device=DEV); ls = torch.zeros(1, device=DEV); cnt = torch.zeros(1, device=DEV)
+        L.ce_fwd(logits, ld, labels, R_, V, sm, row, ls, cnt)
+        lr = logits.clone().requires_grad_(True)
+        want = F.cross_entropy(lr, labels, ignore_index=-100, label_smoothing=sm)
+        want.backward()
+        gs = (1.0 / cnt).contiguous()
+        dl = torch.empty(R_, ld, device=DEV)
+        L.ce_bwd(logits, ld, labels, row, R_, V, sm, gs, dl, ld)
+        worst["ce"] = max(abs(float(ls / cnt) - float(want)) / abs(float(want)), relerr(dl, lr.grad))
+        # ---- attention: bias + key mask (with a fully masked row) / causal; torch fp32 reference
+        for (B, H, Nq, Nk, scale, use_bias, use_mask, causal, drop) in ((2, 3, 70, 90, 1.0, True, True, False, 0.0), (2, 2, 65, 65, 1.0, True, False, True, 0.0),
+                                                                     (1, 2, 50, 50, 0.125, False, False, False, 0.0)):
+            W = H * 64
+            q, k, v, d_o = rn(B, Nq, W, sc=0.5), rn(B, Nk, W, sc=0.5), rn(B, Nk, W), rn(B, Nq, W)
+            mask = None
+            if use_mask:
+                mask = torch.arange(Nk, device=DEV)[None, :] < torch.tensor([Nk - 5, 0], device=DEV)[:, None]      # batch entry 1: NO visible key
+            diag = rn(H, Nq + Nk - 1) if use_bias else None
+            o = torch.empty(B, Nq, W, device=DEV); ml = torch.empty(B, H, Nq, 2, device=DEV)
+            a = L.attn_args(B, H, Nq, Nk, q, k, v, o, (Nq * W, W), (Nk * W, W), (Nk * W, W), (Nq * W, W), ml=ml, scale=scale, bias_diag=diag,
+                            key_mask=mask.to(torch.uint8).contiguous() if mask is not None else None, causal=causal, dropout_p=drop, dropout_seed=5)
+            L.attn_fwd(a)
+            qf, kf, vf = (t.view(B, -1, H, 64).clone().requires_grad_(True) for t in (q, k, v))
+            df = diag.clone().requires_grad_(True) if use_bias else None
+            ref = attn_ref(qf, kf, vf, scale, bias_from_diag(df, Nq, Nk) if use_bias else None, mask, causal, 0)
+            ref.backward(d_o.view(B, Nq, H, 64))
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            delta = torch.empty(B, H, Nq, 4, device=DEV)
+            ddiag = torch.zeros(H, Nq + Nk - 1, device=DEV) if use_bias else None
+            L.attn_bwd(a, d_o, (Nq * W, W), delta, dq, dk, dv, (Nq * W, W), (Nk * W, W), (Nk * W, W), dbias_diag=ddiag)
+            e = max(relerr(o.view(B, Nq, H, 64), ref), relerr(dq.view(B, Nq, H, 64), qf.grad), relerr(dk.view(B, Nk, H, 64), kf.grad),
+                    relerr(dv.view(B, Nk, H, 64), vf.grad), relerr(ddiag, df.grad) if use_bias else 0.0)
+            worst[f"attention {Nq}x{Nk}" + (" causal" if causal else "")] = e
+    print("fp32_io debug mode, worst relative error vs fp32 torch:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert all(v <= 1e-4 for v in worst.values()), worst
+    # the MFMA kernels against the fp32 reference kernels on the same inputs, with attention dropout: same mask function -> same kept set
+    B, H, N, W = 2, 2, 130, 128
+    qkv = rnd(B, N, 3 * W, seed=1, scale=0.5); d_o = rnd(B, N, W, seed=2)
+    diag = rnd(H, 2 * N - 1, seed=3, dtype=torch.float32)
+    st3, st1 = (N * 3 * W, 3 * W), (N * W, W)
+    o16 = torch.empty(B, N, W, dtype=torch.bfloat16, device=DEV); ml = torch.empty(B, H, N, 2, device=DEV)
+    a16 = L.attn_args(B, H, N, N, qkv, qkv[..., W:], qkv[..., 2 * W:], o16, st3, st3, st3, st1, ml=ml, bias_diag=diag, dropout_p=0.1, dropout_seed=9)
+    L.attn_fwd(a16)
+    dqkv16 = torch.zeros_like(qkv); delta = torch.empty(B, H, N, 4, device=DEV)
+    L.attn_bwd(a16, d_o, st1, delta, dqkv16, dqkv16[..., W:], dqkv16[..., 2 * W:], st3, st3, st3)
+    with L.fp32_io():
+        q32 = qkv.float(); o32 = torch.empty(B, N, W, device=DEV); ml2 = torch.empty(B, H, N, 2, device=DEV)
+        a32 = L.attn_args(B, H, N, N, q32, q32[..., W:], q32[..., 2 * W:], o32, st3, st3, st3, st1, ml=ml2, bias_diag=diag, dropout_p=0.1, dropout_seed=9)
+        L.attn_fwd(a32)
+        dqkv32 = torch.zeros(B, N, 3 * W, device=DEV)
+        L.attn_bwd(a32, d_o.float(), st1, delta, dqkv32, dqkv32[..., W:], dqkv32[..., 2 * W:], st3, st3, st3)
+    e_o, c_g = relerr(o16, o32), cos(dqkv16, dqkv32)
+    print(f"  MFMA bf16 kernels vs fp32 reference kernels with dropout 0.1: O relerr {e_o:.2e}, d(qkv) cosine {c_g:.5f}")
+    assert e_o < 2e-2 and c_g > 0.999
+
+
 @pytest.mark.parametrize("N,H,drop", [(200, 3, 0.0), (1000, 4, 0.1), (70, 2, 0.1)])
 def test_attention_packed_equals_padded(N, H, drop):
     """Packed ("varlen", seq_off) self-attention == the padded + key-masked call on every row that exists: forward output,

@@ -195,7 +195,7 @@ __device__ __forceinline__ void mfma_settle(f32x4& a0, f32x4& a1, f32x4& a2, f32
 //   dQ:      d = sat16(draw - Ts) is negative <=> drop; the two sign bits, spread to 32 bits (v_ashrrev_i32 31 / v_bfe_i32 15,1),
 //            clear the fp32 dP elements (v_bfi_b32) before the packed fma that forms dP / keep - delta;
 //   dK/dV:   a lane owns ONE key and four rows, so the pair does not help; it evaluates its half with one 32-bit compare:
-//            mul_lo(a, k odd ? C2 : C2 << 16) moves the half into the top 16 bits, kept <=> (int32) >= Ts << 16.
+//            mul24(a, C2) << (k odd ? 0 : 16) moves the half into the top 16 bits, kept <=> (int32) >= Ts << 16.
 // Same definition in all three kernels (forward mask == backward mask; tests extract it from the forward and replay it).
 constexpr uint32_t DROP_C1 = 0x9E3779B1u, DROP_C2 = 0x00EBCA77u, DROP_M24 = 0x00FFFFFFu;
 __device__ __forceinline__ uint32_t drop_rowseed(uint32_t seed, uint32_t rowid) { return v2s_hash32(seed ^ (rowid * 0x9E3779B1u)) & DROP_M24; }
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     }
     kflag[kb] = (k >= nk_) ? 2u : ((p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0) ? 1u : 0u);
     kc[kb] = drop_pairhash((uint32_t)k >> 1);
-    cmul[kb] = (k & 1) ? DROP_C2 : (DROP_C2 << 16);      // moves this key's 16-bit half of the pair hash into the top half
+    cmul[kb] = (k & 1) ? 0u : 16u;                       // shift that moves this key's 16-bit half of the pair hash into the top half
   }
   const bool keys_clean = __all(kflag[0] == 0u && kflag[1] == 0u);
   const int kmin = K0 + wk0, kmax = kmin + 31;
@@ -987,7 +987,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
               float pdv[4] = {pd01[0], pd01[1], pd23[0], pd23[1]};
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                pdv[r] = ((int32_t)((sd4[r] ^ kc[kb]) * cmul[kb]) >= p.ts32) ? pdv[r] : 0.f;
+                pdv[r] = ((int32_t)(__umul24(sd4[r] ^ kc[kb], DROP_C2) << cmul[kb]) >= p.ts32) ? pdv[r] : 0.f;   // full-rate 24-bit multiply + shift
+                                                                                                              // (a 32-bit v_mul_lo_u32 by a per-lane constant is quarter rate)
               pd01 = f32x2{pdv[0], pdv[1]}; pd23 = f32x2{pdv[2], pdv[3]};
             }
             // dS = Pd * dP - P * delta
@@ -1039,6 +1040,194 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
         u.y = pack2bf(dvt[kb][db][2], dvt[kb][db][3]);
         *reinterpret_cast<uint2*>(dvp + db * 16 + 4 * g) = u;
       }
+    }
+  }
+}
+
+// ====================================================================================== fp32 reference-grade kernels (option "fp32_io")
+// Debug mode for parity work (<= 1e-4 against an fp32 reference): q / k / v / o / dO / dq / dk / dv are FP32 buffers with
+// the same element strides, every product and the softmax run in fp32 FMA arithmetic (no MFMA, no bf16 anywhere).  Same semantics as
+// the kernels above: score = scale * q.k + bias_diag[h][k - q + Nq - 1]; masked keys / the causal future are REPLACED by a huge
+// negative constant (a row without a visible key is uniform over its keys), gradients flow straight through the replacement like the
+// reference's `scores + mask` (modeling_t5.py:559); the dropout mask is the same counter-based function (drop_* above), so a masked
+// run here can be compared with the MFMA kernels element for element.  Dense layout only (no seq_off packing).  Slow by design.
+__device__ __forceinline__ bool f32_keep(uint32_t rowseed24, int k, int ts) {
+  const uint32_t h = __umul24(rowseed24 ^ drop_pairhash((uint32_t)k >> 1), DROP_C2);
+  const int draw = (k & 1) ? (int)(short)(h >> 16) : (int)(short)(h & 0xffffu);
+  return draw >= ts;
+}
+__device__ __forceinline__ float f32_block_max(float v, float* red, int tid) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float f32_block_sum(float v, float* red, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+// scores of row q into prob[] (natural domain), returns the row maximum
+__device__ __forceinline__ float f32_scores(const AttnP& p, const float* K, const float* sq, const float* bias_h, const uint8_t* mask_b, int q,
+                                            float* prob, float* red, int tid) {
+  float mx = -INFINITY;
+  for (int k = tid; k < p.Nk; k += 256) {
+    const float* kr = K + (long)k * p.k_rs;
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < HD; ++d) s = fmaf(sq[d], kr[d], s);
+    s *= p.scale;
+    if (bias_h) s += bias_h[k - q + p.Nq - 1];
+    if ((mask_b && mask_b[k] == 0) || (p.causal && k > q + p.causal_off)) s = MASKED2;
+    prob[k] = s;
+    mx = fmaxf(mx, s);
+  }
+  return f32_block_max(mx, red, tid);
+}
+
+__global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* prob = reinterpret_cast<float*>(smem);            // [Nk]
+  float* part = prob + ((p.Nk + 3) & ~3);                  // [4][64]
+  __shared__ float sq[HD], red[4];
+  const int tid = threadIdx.x;
+  const int q = blockIdx.x % p.Nq, bh = blockIdx.x / p.Nq, h = bh % p.H, b = bh / p.H;
+  const float* Q = reinterpret_cast<const float*>(p.q) + (long)b * p.q_bs + (long)q * p.q_rs + h * HD;
+  const float* K = reinterpret_cast<const float*>(p.k) + (long)b * p.k_bs + h * HD;
+  const float* V = reinterpret_cast<const float*>(p.v) + (long)b * p.v_bs + h * HD;
+  if (tid < HD) sq[tid] = Q[tid];
+  __syncthreads();
+  const float* bias_h = p.bias_diag ? p.bias_diag + (long)h * (p.Nq + p.Nk - 1) : nullptr;
+  const uint8_t* mask_b = p.key_mask ? p.key_mask + (long)b * p.Nk : nullptr;
+  const float m = f32_scores(p, K, sq, bias_h, mask_b, q, prob, red, tid);
+  float l = 0.f;
+  for (int k = tid; k < p.Nk; k += 256) { const float e = __expf(prob[k] - m); prob[k] = e; l += e; }
+  l = f32_block_sum(l, red, tid);
+  const uint32_t rs = p.p16 ? drop_rowseed(v2s_salted(p.seed, p.salt), (uint32_t)((b * p.H + h) * p.Nq + q)) : 0u;
+  const int ts = (int)p.p16 - 32768;
+  const int d = tid & 63, sl = tid >> 6;
+  float acc = 0.f;
+  for (int k = sl; k < p.Nk; k += 4) {
+    const float pd = (!p.p16 || f32_keep(rs, k, ts)) ? prob[k] : 0.f;
+    acc = fmaf(pd, V[(long)k * p.v_rs + d], acc);
+  }
+  part[sl * HD + d] = acc;
+  __syncthreads();
+  if (tid < HD) {
+    const float o = ((part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid])) * (p.p16 ? p.inv_keep : 1.0f) / l;
+    reinterpret_cast<float*>(p.o)[(long)b * p.o_bs + (long)q * p.o_rs + h * HD + tid] = o;
+  }
+  if (tid == 0 && p.ml) {
+    float* mp = p.ml + (((long)(b * p.H + h)) * p.Nq + q) * 2;
+    mp[0] = m * LOG2E; mp[1] = l;
+  }
+}
+
+// dQ (+ dbias) per query row; writes (m, l, delta) to rowstat for the dK/dV kernel
+__global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* prob = reinterpret_cast<float*>(smem);            // [Nk] p
+  float* dsv = prob + ((p.Nk + 3) & ~3);                   // [Nk] dS
+  float* part = dsv + ((p.Nk + 3) & ~3);                   // [4][64]
+  __shared__ float sq[HD], sdo[HD], red[4];
+  const int tid = threadIdx.x;
+  const int q = blockIdx.x % p.Nq, bh = blockIdx.x / p.Nq, h = bh % p.H, b = bh / p.H;
+  const float* Q = reinterpret_cast<const float*>(p.q) + (long)b * p.q_bs + (long)q * p.q_rs + h * HD;
+  const float* DO = reinterpret_cast<const float*>(p.d_o) + (long)b * p.do_bs + (long)q * p.do_rs + h * HD;
+  const float* K = reinterpret_cast<const float*>(p.k) + (long)b * p.k_bs + h * HD;
+  const float* V = reinterpret_cast<const float*>(p.v) + (long)b * p.v_bs + h * HD;
+  if (tid < HD) { sq[tid] = Q[tid]; sdo[tid] = DO[tid]; }
+  __syncthreads();
+  const float* bias_h = p.bias_diag ? p.bias_diag + (long)h * (p.Nq + p.Nk - 1) : nullptr;
+  const uint8_t* mask_b = p.key_mask ? p.key_mask + (long)b * p.Nk : nullptr;
+  const float m = f32_scores(p, K, sq, bias_h, mask_b, q, prob, red, tid);
+  float l = 0.f;
+  for (int k = tid; k < p.Nk; k += 256) { const float e = __expf(prob[k] - m); prob[k] = e; l += e; }
+  l = f32_block_sum(l, red, tid);
+  const uint32_t rs = p.p16 ? drop_rowseed(v2s_salted(p.seed, p.salt), (uint32_t)((b * p.H + h) * p.Nq + q)) : 0u;
+  const int ts = (int)p.p16 - 32768;
+  const float ik = p.p16 ? p.inv_keep : 1.0f;
+  float dl = 0.f;
+  for (int k = tid; k < p.Nk; k += 256) {
+    const float* vr = V + (long)k * p.v_rs;
+    float dp = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < HD; ++d) dp = fmaf(sdo[d], vr[d], dp);
+    dp = (!p.p16 || f32_keep(rs, k, ts)) ? dp * ik : 0.f;
+    const float pk = prob[k] / l;
+    prob[k] = pk;
+    dsv[k] = dp;
+    dl = fmaf(pk, dp, dl);
+  }
+  dl = f32_block_sum(dl, red, tid);                        // delta = sum_k P * dP_eff = rowsum(dO * O)
+  for (int k = tid; k < p.Nk; k += 256) {
+    const float ds = prob[k] * (dsv[k] - dl);
+    dsv[k] = ds;
+    if (p.dbias_diag) atomicAdd(p.dbias_diag + (long)h * (p.Nq + p.Nk - 1) + (k - q + p.Nq - 1), ds);
+  }
+  __syncthreads();
+  const int d = tid & 63, sl = tid >> 6;
+  float acc = 0.f;
+  for (int k = sl; k < p.Nk; k += 4) acc = fmaf(dsv[k], K[(long)k * p.k_rs + d], acc);
+  part[sl * HD + d] = acc;
+  __syncthreads();
+  if (tid < HD)
+    reinterpret_cast<float*>(p.dq)[(long)b * p.dq_bs + (long)q * p.dq_rs + h * HD + tid] =
+        ((part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid])) * p.scale;
+  if (tid == 0) *reinterpret_cast<float4*>(p.rowstat + (((long)(b * p.H + h)) * p.Nq + q) * 4) = make_float4(m, l, dl, 0.f);
+}
+
+// dK, dV per key: every thread walks a slice of the query rows, 2 x 64 accumulators reduced over the block in rounds of 32 values
+__global__ __launch_bounds__(256) void attn_f32_bwd_dkv_kernel(const AttnP p) {
+  __shared__ float sk[HD], sv[HD], red[256][33];
+  const int tid = threadIdx.x;
+  const int k = blockIdx.x % p.Nk, bh = blockIdx.x / p.Nk, h = bh % p.H, b = bh / p.H;
+  const float* Qb = reinterpret_cast<const float*>(p.q) + (long)b * p.q_bs + h * HD;
+  const float* DOb = reinterpret_cast<const float*>(p.d_o) + (long)b * p.do_bs + h * HD;
+  const float* Kr = reinterpret_cast<const float*>(p.k) + (long)b * p.k_bs + (long)k * p.k_rs + h * HD;
+  const float* Vr = reinterpret_cast<const float*>(p.v) + (long)b * p.v_bs + (long)k * p.v_rs + h * HD;
+  if (tid < HD) { sk[tid] = Kr[tid]; sv[tid] = Vr[tid]; }
+  __syncthreads();
+  const float* bias_h = p.bias_diag ? p.bias_diag + (long)h * (p.Nq + p.Nk - 1) : nullptr;
+  const bool kmasked = p.key_mask && p.key_mask[(long)b * p.Nk + k] == 0;
+  const int ts = (int)p.p16 - 32768;
+  const float ik = p.p16 ? p.inv_keep : 1.0f;
+  float dk[HD], dv[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+  for (int q = tid; q < p.Nq; q += 256) {
+    const float* qr = Qb + (long)q * p.q_rs;
+    const float* dor = DOb + (long)q * p.do_rs;
+    const float4 st = *reinterpret_cast<const float4*>(p.rowstat + (((long)(b * p.H + h)) * p.Nq + q) * 4);     // m, l, delta
+    float s = 0.f, dp = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < HD; ++d) { s = fmaf(qr[d], sk[d], s); dp = fmaf(dor[d], sv[d], dp); }
+    s *= p.scale;
+    if (bias_h) s += bias_h[k - q + p.Nq - 1];
+    if (kmasked || (p.causal && k > q + p.causal_off)) s = MASKED2;
+    const float pk = __expf(s - st.x) / st.y;
+    const bool keep = !p.p16 || f32_keep(drop_rowseed(v2s_salted(p.seed, p.salt), (uint32_t)((b * p.H + h) * p.Nq + q)), k, ts);
+    const float pd = keep ? pk * ik : 0.f;
+    const float ds = pk * ((keep ? dp * ik : 0.f) - st.z) * p.scale;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { dk[d] = fmaf(ds, qr[d], dk[d]); dv[d] = fmaf(pd, dor[d], dv[d]); }
+  }
+  float* dkp = reinterpret_cast<float*>(p.dk) + (long)b * p.dk_bs + (long)k * p.dk_rs + h * HD;
+  float* dvp = reinterpret_cast<float*>(p.dv) + (long)b * p.dv_bs + (long)k * p.dv_rs + h * HD;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {                             // values r*32 .. r*32+31 of the 128 (dk | dv) per round
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { const int v = r * 32 + j; red[tid][j] = v < HD ? dk[v] : dv[v - HD]; }
+    __syncthreads();
+    if (tid < 32) {
+      float t = 0.f;
+      for (int i = 0; i < 256; ++i) t += red[i][tid];
+      const int v = r * 32 + tid;
+      if (v < HD) dkp[v] = t; else dvp[v - HD] = t;
     }
   }
 }
@@ -1172,6 +1361,13 @@ constexpr size_t LDS_PER_CU = 160 * 1024;
 extern "C" int v2s_attn_fwd(const v2s_attn_args* a, void* stream) {
   AttnP p;
   if (int e = fill(p, a, "v2s_attn_fwd", false)) return e;
+  if (v2s_opt_fp32_io()) {                // debug mode: fp32 buffers, fp32 arithmetic
+    V2S_CHECK(!p.seq_off && !p.kv_seq_off, V2S_ERR_ARG, "v2s_attn_fwd: the fp32_io debug kernels take the dense layout only");
+    const size_t dyn = ((size_t)((p.Nk + 3) & ~3) + 4 * HD) * sizeof(float);
+    hipLaunchKernelGGL(attn_f32_fwd_kernel, dim3((unsigned)(p.B * p.H * p.Nq)), dim3(256), dyn, (hipStream_t)stream, p);
+    V2S_LAUNCH_CHECK();
+    return V2S_OK;
+  }
   const int grid = ((p.Nq + 127) / 128) * p.H * p.B;
   const bool bias = p.bias_diag != nullptr;
   // bias window: four copies unless they would cost a block per CU (the kernel runs three blocks per CU, two when causal)
@@ -1199,6 +1395,15 @@ extern "C" int v2s_attn_bwd(const v2s_attn_args* a, void* stream) {
   V2S_CHECK(a->delta != nullptr, V2S_ERR_ARG, "v2s_attn_bwd: the row-statistics workspace `delta` (fp32 [B][H][Nq][4]) is missing");
   V2S_CHECK(((uintptr_t)a->delta & 15) == 0, V2S_ERR_ALIGN, "v2s_attn_bwd: `delta` must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  if (v2s_opt_fp32_io()) {                // debug mode: fp32 buffers, fp32 arithmetic (dbias_diag is accumulated with float atomics)
+    V2S_CHECK(!p.seq_off && !p.kv_seq_off, V2S_ERR_ARG, "v2s_attn_bwd: the fp32_io debug kernels take the dense layout only");
+    const size_t dyn = ((size_t)2 * ((p.Nk + 3) & ~3) + 4 * HD) * sizeof(float);
+    hipLaunchKernelGGL(attn_f32_bwd_dq_kernel, dim3((unsigned)(p.B * p.H * p.Nq)), dim3(256), dyn, s, p);
+    V2S_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_f32_bwd_dkv_kernel, dim3((unsigned)(p.B * p.H * p.Nk)), dim3(256), 0, s, p);
+    V2S_LAUNCH_CHECK();
+    return V2S_OK;
+  }
   const bool tr = v2s_opt_tr_read() != 0, bias = p.bias_diag != nullptr, causal = p.causal != 0, drop = p.p16 != 0;
   const int gq = ((p.Nq + 127) / 128) * p.H * p.B;
   const int nc_q = (bias && lds_dq(p, bias, 4) * 2 > LDS_PER_CU) ? 2 : 4, nc_kv = (bias && lds_dkv(p, bias, 4) * 2 > LDS_PER_CU) ? 2 : 4;   // two blocks per CU

@@ -169,16 +169,25 @@ __global__ __launch_bounds__(1024) void ce_reduce_kernel(const float* __restrict
   if (threadIdx.x == 0) { *loss_sum += a[0]; *count += c[0]; }
 }
 
+__device__ __forceinline__ void ce_st8(bf16_t* p, const float* f) { *reinterpret_cast<uint4*>(p) = pack8(f); }
+__device__ __forceinline__ void ce_st8(float* p, const float* f) {
+  *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+__device__ __forceinline__ void ce_st1(bf16_t* p, float f) { *p = f2bf(f); }
+__device__ __forceinline__ void ce_st1(float* p, float f) { *p = f; }
+template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ labels,
                                                      const float* __restrict__ row_out, int V, float eps,
-                                                     const float* __restrict__ gscale, bf16_t* __restrict__ dl, long ldd) {
+                                                     const float* __restrict__ gscale, T* __restrict__ dl, long ldd) {
   const int row = blockIdx.x, tid = threadIdx.x;
   const long y = labels[row];
-  bf16_t* d = dl + (long)row * ldd;
+  T* d = dl + (long)row * ldd;
   const int n8 = V >> 3;
   for (int i = V + tid; i < ldd; i += 256) d[i] = 0;     // row padding (ragged V): keep it zero for the dgrad GEMM
   if (y < 0) {
-    for (int i = tid; i < n8; i += 256) *reinterpret_cast<uint4*>(d + i * 8) = make_uint4(0, 0, 0, 0);
+    const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < n8; i += 256) ce_st8(d + i * 8, z8);
     for (int i = n8 * 8 + tid; i < V; i += 256) d[i] = 0;
     return;
   }
@@ -195,12 +204,12 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
       if (i * 8 + j == y) pr -= (1.f - eps);
       f[j] = pr * g;
     }
-    *reinterpret_cast<uint4*>(d + i * 8) = pack8(f);
+    ce_st8(d + i * 8, f);
   }
   for (int i = n8 * 8 + tid; i < V; i += 256) {
     float pr = __expf(z[i] - lse) - sm;
     if (i == y) pr -= (1.f - eps);
-    d[i] = f2bf(pr * g);
+    ce_st1(d + i, pr * g);
   }
 }
 
@@ -277,8 +286,12 @@ extern "C" int v2s_ce_bwd(const float* logits, int64_t ld, const int64_t* labels
                           int32_t V, float eps, const float* gscale, void* dlogits, int64_t ldd, void* stream) {
   V2S_CHECK(rows > 0 && V > 0 && (ld % 4) == 0 && (ldd % 8) == 0 && ldd >= V, V2S_ERR_SHAPE,
             "v2s_ce_bwd: bad shape rows=%d V=%d ld=%ld ldd=%ld (ldd must be a multiple of 8 >= V)", rows, V, (long)ld, (long)ldd);
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, (const long*)labels, row_lse,
-                     V, eps, gscale, (bf16_t*)dlogits, (long)ldd);
+  if (v2s_opt_fp32_io())                  // debug mode: fp32 d(logits)
+    hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, (const long*)labels, row_lse,
+                       V, eps, gscale, (float*)dlogits, (long)ldd);
+  else
+    hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, (const long*)labels, row_lse,
+                       V, eps, gscale, (bf16_t*)dlogits, (long)ldd);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

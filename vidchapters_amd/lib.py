@@ -168,6 +168,30 @@ def get_option(name: str) -> int:
     return int(lib().v2s_get_option(name.encode()))
 
 
+_FP32_IO = False
+
+
+class fp32_io:
+    """Debug context (library option "fp32_io"): inside it the norm / cross-entropy-backward / attention entry points
+    take and return FP32 activations (attention: fp32-arithmetic reference kernels).  Parity tests only -- the product path never
+    enters it; GEMMs are not affected (their fp32-output form exists already)."""
+
+    def __enter__(self):
+        global _FP32_IO
+        set_option("fp32_io", 1); _FP32_IO = True
+        return self
+
+    def __exit__(self, *exc):
+        global _FP32_IO
+        set_option("fp32_io", 0); _FP32_IO = False
+        return False
+
+
+def _need_act(t: torch.Tensor, what: str) -> None:
+    """An activation operand: bf16, or fp32 inside the fp32_io debug context."""
+    _need(t, torch.float32 if _FP32_IO else torch.bfloat16, what)
+
+
 def _need(t: torch.Tensor, dtype, what: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"{what}: tensor must live on the GPU (HIP path has no CPU fallback)")
@@ -265,7 +289,7 @@ def colsum(X: torch.Tensor, M: int, N: int, out: torch.Tensor, accumulate=True, 
 
 # --------------------------------------------------------------------------------------------- norms
 def rmsnorm_fwd(x, w, y, rstd, rows, cols, eps):
-    _need(x, torch.bfloat16, "rmsnorm x"); _need(w, torch.float32, "rmsnorm w")
+    _need_act(x, "rmsnorm x"); _need(w, torch.float32, "rmsnorm w")
     _check(lib().v2s_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows, cols, eps, stream_ptr()),
            "v2s_rmsnorm_fwd")
 
@@ -282,7 +306,7 @@ def rmsnorm_bwd(x, w, rstd, dy, dx, dx_add, dw, rows, cols, dx_drop=None, dropou
 
 
 def layernorm_fwd(x, w, b, y, mean, rstd, rows, cols, eps):
-    _need(x, torch.bfloat16, "layernorm x")
+    _need_act(x, "layernorm x")
     _check(lib().v2s_layernorm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                    rows, cols, eps, stream_ptr()), "v2s_layernorm_fwd")
 
