@@ -42,6 +42,32 @@ def log(msg):
         print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def rccl_choices(path: str) -> dict:
+    """Summary of what RCCL logged for this rank (NCCL_DEBUG=INFO, subsystems INIT,GRAPH,TUNING): the (collective size -> algorithm,
+    protocol) choices, ring / tree channel counts.  Best effort: a missing or differently formatted log yields {"log": ...} only."""
+    import re
+    info = {"log": path}
+    try:
+        txt = open(path, errors="replace").read()
+    except OSError:
+        return info
+    algo = {0: "Tree", 1: "Ring", 2: "CollNetDirect", 3: "CollNetChain", 4: "NVLS", 5: "NVLSTree"}
+    proto = {0: "LL", 1: "LL128", 2: "Simple"}
+    seen = {}
+    for m in re.finditer(r"(?:(\w+): )?(\d+) Bytes -> Algo (\d+) proto (\d+)", txt):
+        key = f"{m.group(1) or 'coll'} {algo.get(int(m.group(3)), m.group(3))}/{proto.get(int(m.group(4)), m.group(4))}"
+        lo, hi, n = seen.get(key, (1 << 62, 0, 0))
+        seen[key] = (min(lo, int(m.group(2))), max(hi, int(m.group(2))), n + 1)
+    if seen:
+        info["algo_proto"] = {k: {"bytes_min": v[0], "bytes_max": v[1], "calls": v[2]} for k, v in sorted(seen.items())}
+    m = re.search(r"(\d+) coll channels.*?(\d+) p2p channels", txt)
+    if m:
+        info["coll_channels"], info["p2p_channels"] = int(m.group(1)), int(m.group(2))
+    info["rings_connected"] = "Connected all rings" in txt
+    info["trees_connected"] = "Connected all trees" in txt
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,7 +91,8 @@ def main():
     ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the data-parallel gradient all-reduce")
     ap.add_argument("--bucket-mib", type=int, default=48, help="wire bytes per gradient all-reduce (MiB)")
     ap.add_argument("--shard-optimizer", action="store_true", help="data parallel: reduce-scatter the gradient buckets, Adam on the local 1/N "
-                    "stripes, all-gather the bf16 shadow weights (train.GradSync shard=True) instead of all-reduce + full Adam on every rank")
+                    "stripes, all-gather the bf16 shadow weights under the next forward (train.GradSync shard=True): the DEFAULT for N > 1")
+    ap.add_argument("--replicated-optimizer", action="store_true", help="data parallel: all-reduce + full Adam on every rank instead")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -76,6 +103,10 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
+        # which algorithm / protocol RCCL picks for the step's collectives (ring vs tree, LL / LL128 / Simple) decides what the per-link
+        # xGMI bandwidth buys: ask the library to log its choices (TUNING subsystem) and summarise them in the JSON line
+        if "NCCL_DEBUG" not in os.environ:
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING", NCCL_DEBUG_FILE=f"/tmp/v2s_rccl_{os.getpid()}_rank{rank}.log")
         backend = os.environ.get("V2S_DIST_BACKEND", "nccl")   # "nccl" == RCCL on ROCm; "gloo" lets two ranks share one GPU to
         if backend == "nccl":                                  # exercise the multi-rank control flow where only one GPU exists
             dist.init_process_group("nccl", device_id=dev)
@@ -93,7 +124,7 @@ def main():
     log(f"model built: {sum(p.numel() for p in model.parameters()) / 1e6:.1f} M parameters")
     model.engine().overlap = not a.no_overlap
     trainer = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=a.denoising, grad_comm_dtype=a.grad_comm_dtype,
-                      bucket_bytes=a.bucket_mib << 20, shard_optimizer=a.shard_optimizer)
+                      bucket_bytes=a.bucket_mib << 20, shard_optimizer=(False if a.replicated_optimizer else (True if a.shard_optimizer else None)))
     batch = {k: v.to(dev) for k, v in synth.make_batch(B, T, Lx, Lo, len(tok), 1234 + rank, 768, denoising=a.denoising > 0).items()}
     batch["video"] = batch["video"].to(torch.bfloat16)       # features resident in HBM as bf16 (documented in DESIGN.md)
     batch["input_lens"] = (batch["input_ids"] != 0).sum(1).tolist()      # host-side lengths, as a data loader knows them
@@ -192,6 +223,9 @@ def main():
                                 "collectives_per_step": trainer.sync.collectives, "wire_mb_per_step": round(trainer.sync.bytes_reduced / 1e6, 1),
                                 "optimizer": ("sharded: reduce-scatter + Adam on 1/N stripes + bf16 all-gather" if trainer.sync.shard else "replicated: all-reduce + full Adam on every rank"),
                                 "exposed_comm_ms_last_step_rank0": round(comm_ms, 3),
+                                "shadow_allgather": ("on the communication stream under the next step's forward (per-group events)" if trainer.sync.shard and trainer.overlap_gather
+                                                     else ("on the main stream after Adam" if trainer.sync.shard else "none")),
+                                "rccl": rccl_choices(os.environ.get("NCCL_DEBUG_FILE", "")),
                                 "note": "exposed = time the main stream waited for the gradient reduction after backward had been enqueued"}
     if rank == 0 and world == 1 and not a.packing and not a.no_generate:
         # the same step with the engine's default padding-free text encoder (pad-token rows are not computed; exact, see

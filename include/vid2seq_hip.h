@@ -64,7 +64,8 @@ int64_t v2s_sizeof(const char* struct_name);
 /* Device-resident dropout salt: while set, every launch that draws a dropout mask (GEMM epilogues, attention, embedding, v2s_dropout)
  * uses seed ^ *dev_word instead of its by-value seed.  The pointer is read when a launch is ENQUEUED and travels as a kernel argument,
  * so a training step captured into a hipGraph draws new masks on every replay once the caller changes the word between replays
- * (vidchapters_amd.train.Trainer.step_graph).  NULL restores the by-value seeds. */
+ * (vidchapters_amd.train.Trainer.step_graph).  NULL restores the by-value seeds.  The setting is PER HOST THREAD (it applies to the
+ * launches the calling thread enqueues): no process-global mutable state besides the read-mostly tuning options above. */
 int v2s_set_seed_salt(const uint32_t* dev_word);
 
 /* ------------------------------------------------------------------------------------------------

@@ -46,9 +46,13 @@ int v2s_opt_gemm_ps_nst() { return opt(O_GEMM_PS_NST); }
 int v2s_opt_gemm_w128() { return opt(O_GEMM_W128); }
 int v2s_opt_fp32_io() { return opt(O_FP32_IO); }
 
-static std::atomic<const uint32_t*> g_seed_salt{nullptr};
-const uint32_t* v2s_seed_salt() { return g_seed_salt.load(std::memory_order_relaxed); }
-extern "C" int v2s_set_seed_salt(const uint32_t* dev_word) { g_seed_salt.store(dev_word); return V2S_OK; }
+// Dropout seed salt of the launches ENQUEUED BY THE CALLING THREAD (a device word XOR-ed into every by-value seed, so that a captured
+// hipGraph draws new masks per replay).  Thread-local, not process-global: a capture running on one host thread
+// cannot leak its salt into the eager launches another thread enqueues for another engine; on one thread the owner sets it around its
+// capture and clears it (Trainer.step_graph).  The tuning options above stay process-wide by design: read-mostly A/B knobs.
+static thread_local const uint32_t* g_seed_salt = nullptr;
+const uint32_t* v2s_seed_salt() { return g_seed_salt; }
+extern "C" int v2s_set_seed_salt(const uint32_t* dev_word) { g_seed_salt = dev_word; return V2S_OK; }
 
 extern "C" int v2s_version(void) { return V2S_ABI_VERSION; }
 extern "C" const char* v2s_last_error(void) { return g_err; }

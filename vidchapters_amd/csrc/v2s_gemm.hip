@@ -1613,30 +1613,37 @@ __global__ __launch_bounds__(256, 1) void gemm_wt_kernel(const GemmP p) {
     else if (after == 1) dma_wait_n<PER>();
     else dma_wait_n<0>();
     P8_BARRIER();
-    if (iss < nst) issue();                                          // stage s + NST into the slot of stage s
-    // fragments of stage s + 1 (after the last stage: a stale slot, never used): B into a second set, A row i in place right
-    // behind the last MFMA that reads row i of stage s
+    // fragments of stage s + 1 (after the last stage: a stale slot, never used).  Issue order: B (second register set) and the LAST two
+    // A rows (second set) first, the MFMAs of row 0, the DMA of stage s + NST (into the slot of stage s), then per A row its refill
+    // read (in place, right behind the last MFMA that read it) and the next row's six MFMAs; the iteration ends with twelve MFMAs
+    // and no read behind them, so that the lgkmcnt(0) at the top of the next iteration finds every read complete
     const char* sa = smem + rslot;
     const char* sb = sa + A_B;
-    bf16x8 bn[6];
+    bf16x8 bn[6], an6, an7;
 #pragma unroll
     for (int j = 0; j < 6; ++j) bn[j] = read_frag_w4<192, false>(sb, brow + j * 16, lane);
+    an6 = read_frag_w4<256, false>(sa, arow + 6 * 16, lane);
+    an7 = read_frag_w4<256, false>(sa, arow + 7 * 16, lane);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int j = 0; j < 6; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[0], acc[0][j], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    if (iss < nst) issue();
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+      if (i <= 6) af[i - 1] = read_frag_w4<256, false>(sa, arow + (i - 1) * 16, lane);
 #pragma unroll
       for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      af[i] = read_frag_w4<256, false>(sa, arow + i * 16, lane);
     }
+#pragma unroll
+    for (int i = 1; i <= 6; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    af[6] = an6; af[7] = an7;
 #pragma unroll
     for (int j = 0; j < 6; ++j) bfr[j] = bn[j];
-    // issue order of this region: the six B reads, then per A row its six MFMAs followed by the row's refill read -- the fragment reads
-    // of the next stage run under the MFMAs of this one (left alone, the scheduler sinks every read below the last MFMA)
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
     rslot = rslot + STG == NST * STG ? 0 : rslot + STG;
   }
   __syncthreads();                                                   // every wave is done with the ring

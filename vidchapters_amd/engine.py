@@ -89,6 +89,7 @@ class Engine:
         self.vstream = torch.cuda.Stream(device=device)
         self.kstream = torch.cuda.Stream(device=device)   # cross-attention K|V projections of all decoder layers (forward) / the d(memory) chain (backward)
         self.overlap_kv = True    # see decoder_forward / _cross_attn_bwd
+        self.shadow_events = None # sharded optimizer: {"vit" | "enc" | "dec": event after which that group's bf16 shadow weights are whole}
         self.arena.refresh_shadow(force=True)
 
     # ------------------------------------------------------------------------------------------ names / arena order
@@ -566,6 +567,7 @@ class Engine:
         self.kstream.wait_stream(main)
         out = []
         with torch.cuda.stream(self.kstream):
+            self.wait_shadow("dec")
             for i in range(self.cfg.n_dec):
                 kv = self._bf(Mk, 2 * inner)
                 L.gemm(mem, a.w(self._ca(i) + "k.weight", (2 * inner, d)), kv, Mk, 2 * inner, d)
@@ -579,6 +581,7 @@ class Engine:
     def decoder_forward(self, dec_ids, dec_mask_u8, mem, S: int, mem_mask_u8, p: float, tape, pack=None, kpack=None):
         """``pack`` = (seq_off, rows, tok_rows, B, Lo) from _pack_plan_dec: ``dec_ids`` is then the 1-D packed id vector and the result
         has ``rows`` rows."""
+        self.wait_shadow("dec")
         if pack is not None:
             B, Lo, M = pack[3], pack[4], pack[1]
             ahead = self._cross_kv_ahead(mem, kpack[1] if kpack is not None else B * S)
@@ -636,6 +639,7 @@ class Engine:
         a, m = self.arena, self.model
         B, T, C = video.shape
         assert C == self.vd, f"feature dim {C} != embed_dim {self.vd}"
+        self.wait_shadow("vit")
         M, p = B * T, (m.vis_drop if m.training else 0.0)
         if video.dtype != torch.bfloat16:          # fp32 (the reference's features), fp16, fp64, ...: through fp32 to bf16
             xb = self._bf(M, C)
@@ -759,6 +763,7 @@ class Engine:
         pe, pd = (m.enc_drop if train else 0.0), (m.dec_drop if train else 0.0)
         B = output_ids.shape[0]
         enc_tape, dec_tape = ([], []) if tape is not None else (None, None)
+        self.wait_shadow("enc")             # encoder matrices + the tied embedding (the decoder's arrive under the encoder forward)
         parts, masks = [], []
         T = 0
         if m.use_video:
@@ -911,9 +916,22 @@ class Engine:
         return dvis
 
     # ========================================================================================== public forward
-    def prepare(self) -> None:
-        """Bring the bf16 shadow weights up to date and make sure param.grad views exist."""
+    def prepare(self, wait_shadow: bool = True) -> None:
+        """Bring the bf16 shadow weights up to date and make sure param.grad views exist.  ``wait_shadow``: also wait (on the current
+        stream) for a sharded optimizer's in-flight all-gather of the shadow weights; Trainer.step passes False and lets the forward
+        wait group by group instead (wait_shadow("vit" | "enc" | "dec")), so that the decoder's gather overlaps the encoder forward."""
         self.arena.refresh_shadow()
+        if wait_shadow and self.shadow_events:
+            for ev in self.shadow_events.values():
+                torch.cuda.current_stream().wait_event(ev)
+            self.shadow_events = None
+
+    def wait_shadow(self, group: str) -> None:
+        """Current stream waits until the shadow weights of ``group`` ("vit", "enc" = encoder + tied embedding, "dec") are whole
+        (sharded data-parallel optimizer: their all-gather runs on the communication stream behind the previous step's Adam)."""
+        ev = self.shadow_events.get(group) if self.shadow_events else None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def forward(self, video, input_tokenized, output_tokenized):
         m = self.model

@@ -204,6 +204,31 @@ class GradSync:
             self.collectives += 1
             self.bytes_reduced += n * 2
 
+    def gather_shadow_async(self, groups) -> Dict[str, torch.cuda.Event]:
+        """gather_shadow on the communication stream, in the order the next forward needs the weights.  ``groups`` = [(name, start, end)]
+        arena ranges in need order (encoder + embedding, ViT, decoder); returns {name: event recorded behind the group's last bucket}.
+        The stream waits for the current stream (the Adam launches) first; nothing on the main stream waits here."""
+        sh = self.arena.shadow
+        W, r = self.world, self.rank
+        ev0 = torch.cuda.Event()
+        ev0.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev0)
+        events: Dict[str, torch.cuda.Event] = {}
+        with torch.cuda.stream(self.stream):
+            for name, g0, g1 in groups:
+                for o, n in self.buckets:
+                    if not (g0 <= o < g1):
+                        continue
+                    part = n // W
+                    self._ag_in[:part].copy_(sh[o + r * part:o + (r + 1) * part])
+                    self._all_gather(sh[o:o + n], self._ag_in[:part])
+                    self.collectives += 1
+                    self.bytes_reduced += n * 2
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                events[name] = ev
+        return events
+
     def gather_stripes(self, buf: torch.Tensor) -> None:
         """Sharded mode: all-gather an fp32 arena-shaped buffer whose owned stripes are current on every rank (master weights, Adam
         moments) so that it is whole everywhere.  Collective: every rank calls it.  Uses the bucket layout of the LAST step."""
@@ -239,7 +264,10 @@ class Trainer:
     def __init__(self, model, lr: float = 3e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  clip_max_norm: float = 1.0, generative: float = 1.0, denoising: float = 1.0, schedule: str = "",
                  fraction_warmup_steps: float = 0.1, num_training_steps: int = 1, group=None, bucket_bytes: int = 48 << 20,
-                 grad_comm_dtype: str = "fp32", force_collectives: bool = False, shard_optimizer: bool = False):
+                 grad_comm_dtype: str = "fp32", force_collectives: bool = False, shard_optimizer: Optional[bool] = None):
+        """``shard_optimizer``: None (default) = sharded whenever the group has more than one rank (reduce-scatter + Adam on the owned
+        1/N stripes + overlapped bf16 all-gather: less wire traffic and 1/N of the optimizer's HBM traffic per rank), True / False force it.
+        With a sharded optimizer call :meth:`prepare_checkpoint` (a collective) before ``model.state_dict()`` / ``Trainer.state_dict()``."""
         self.model = model
         self.eng = model.engine()
         a = self.eng.arena
@@ -251,7 +279,10 @@ class Trainer:
         self.v = torch.zeros(a.numel, dtype=torch.float32, device=dev)
         self.step_count = 0
         self.high_priority = False       # experiment (see step): faster step by step, slower in a pipelined loop -> off
+        self.overlap_gather = True       # sharded optimizer: all-gather the bf16 shadow on the communication stream under the next forward
         self._hi_stream = None
+        if shard_optimizer is None:
+            shard_optimizer = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.sync = GradSync(a, group, bucket_bytes=bucket_bytes, comm_dtype=grad_comm_dtype, force=force_collectives, shard=shard_optimizer)
         self.world = self.sync.world
         self._sq_ws = torch.empty(1024, dtype=torch.float32, device=dev)
@@ -315,7 +346,7 @@ class Trainer:
         assert m.training, "call model.train() first"
         main = torch.cuda.current_stream()
         overlap = eng.overlap
-        eng.prepare()
+        eng.prepare(wait_shadow=False)      # the forward waits for a pending shadow all-gather group by group (Engine.wait_shadow)
         eng.begin_grad_step()
         try:
             return self._step_body(batch, hyper_dev)
@@ -427,6 +458,7 @@ class Trainer:
         self.sync.ready(*self._r_small, replicate=True)       # norm weights, biases, bias tables: final only now (ViT + both stacks)
         self.sync.finish()
         eng.end_grad_step()
+        eng.shadow_events = None            # every group was waited for during this step's forward
         self._optimizer_step(hyper_dev)
         return losses
 
@@ -457,7 +489,6 @@ class Trainer:
                 L.adam_step(a.master[s0:e0], self.m[s0:e0], self.v[s0:e0], a.grad[s0:e0], a.shadow[s0:e0], e0 - s0, lr, self.betas[0],
                             self.betas[1], self.eps, self.wd, step_no, gnorm_sq=self._gnorm_sq if self.clip > 0 else None,
                             max_norm=self.clip, grad_scale=1.0 / self.world, hyper_dev=hyper_dev)
-            self.sync.gather_shadow()
         else:
             if self.clip > 0:
                 L.sqnorm(a.grad, a.numel, self._sq_ws, self._gnorm_sq)
@@ -496,6 +527,18 @@ class Trainer:
             else:
                 for _ in range(2):      # dvc.py:120-126 renormalises `shared` and then `lm_head` -- the same tied tensor
                     L.timetoken_renorm(emb, embb, eng.V, eng.d, self.model.num_bins, self._renorm_ws)
+        if self.sync.shard:
+            # all-gather of the updated bf16 shadow stripes: LAST collective of the step (the process group runs collectives in issue
+            # order: the renorm's small all-reduce above must not queue behind 0.5 GB of gathers), on the communication stream, in
+            # the order the next forward needs the weights -- encoder + embedding, ViT, decoder -- with an event per group: the next
+            # step's encoder forward (~8 ms) runs while the decoder's 0.2 GB are still on the wire (Engine.wait_shadow)
+            if self.overlap_gather:
+                groups = [("enc", self._r_enc[0], self._r_enc[1]), ("enc", self._r_shared[0], self._r_shared[1]),
+                          ("vit", self._r_vis[0], self._r_vis[1]), ("dec", self._r_dec[0], self._r_dec[1])]
+                # one event per name: "enc" is recorded twice (after the encoder range and after the embedding): keep the later one
+                eng.shadow_events = self.sync.gather_shadow_async(groups)
+            else:
+                self.sync.gather_shadow()
 
     # ------------------------------------------------------------------------------------------------ captured step
     def step_graph(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
