@@ -297,8 +297,8 @@ def main():
                         out["roofline"]["traffic_unit"] = "bytes per launch (PMC, offline: profiles/" + fn + ")"
                         out["roofline"]["algorithmic_bytes_per_launch"] = round(pj["algorithmic"])
                         # the PMC passes ran on the launch mix of the day they were taken: say so if this run's mix differs
-                        out["roofline"]["traffic_matches_this_launch_mix"] = (pj.get("launches_per_step") == n and
-                                                                               abs(pj["algorithmic"] * 0 + work / n - 47.1e9) / 47.1e9 < 0.02)
+                        fl = sum(2.0 * sh["M"] * sh["N"] * sh["K"] * sh["launches_per_step"] for sh in pj.get("shapes", [])) / max(1, pj.get("launches_per_step", 1))
+                        out["roofline"]["traffic_matches_this_launch_mix"] = bool(pj.get("launches_per_step") == n and abs(fl - work / n) < 0.02 * fl)
         except OSError:
             pass
         out["kernel_breakdown_note"] = ("HIP-event pairs around each launch on the launch stream; at ~2500 launches per step this leg is host-bound, so "
