@@ -1972,6 +1972,10 @@ static int p8_auto(const v2s_gemm_args* a, bool deferred_ok) {
     const long rounds = (t256 + ncu - 1) / ncu;
     const bool full_rounds = v2s_opt_gemm_p8() != 5 && t256 * 100 >= rounds * ncu * 92 && a->K >= 1024 && !a->transA;
     if (full_rounds) return 256;
+    // split-K weight gradients with a long contraction and >= 24 output tiles (tools/gemm_wgrad_ab.py, round 4; us 4-wave ring or 8-wave
+    // 256-row kernel / 8-phase): 2304x768x32000 124.9 / 120.5, 768x3072x32000 155.2 / 145.1, 3072x768x32000 159.6 / 158.4; smaller outputs
+    // (768x768, 1536x768) and the K = 8192 / 3200 decoder and ViT shapes lose 5-30 %
+    if (a->transA && a->workspace && t256 >= 24 && a->K >= 16384) return 256;
     return (a->transA && t256 >= 256 && a->K >= 4096) ? 256 : 0;
   }
   if (deferred_ok && a->K <= 1536) return 256;          // p8_decide turns deferred_ok into the deferred form

@@ -225,6 +225,9 @@ class Engine:
         if fresh is not None:
             fresh.add(wname)
 
+        if getattr(self, "dbg_skip_wgrad", 0):     # timing probe (tools/step_ab.py "eng:dbg_skip_wgrad=1"): what the weight-gradient stream costs the step
+            return
+
         def launch():
             L.gemm(dy, x, self.arena.g(wname, shape), n_out, n_in, rows, transA=True, transB=True,
                    lda=ld_dy if ld_dy is not None else n_out, ldb=ld_x if ld_x is not None else n_in, ldc=n_in,
