@@ -121,6 +121,12 @@ typedef struct v2s_gemm_args {
 } v2s_gemm_args;
 
 int v2s_gemm(const v2s_gemm_args* args, void* stream);
+/* GROUPED weight gradients: `count` (<= 16) problems of ONE shape in one launch -- C[i][M][N] (+)= alpha * A[i]^T B[i] with A[i] = [K][lda]
+ * (dY), B[i] = [K][ldb] (X), fp32 C -- e.g. the same projection's weight gradient of every decoder layer, whose operands live in
+ * separate allocations.  `args` carries the shape, leading dimensions, alpha and accumulate (transA = transB = 1, c_dtype = V2S_F32, no
+ * epilogue, its A / B / C pointers are ignored); K a multiple of 64.  Whole-K tiles, no split-K, no reduction: deterministic.
+ * (modeling_t5.py:304-311,528-536 autograd weight gradients of the decoder / ViT layers.) */
+int v2s_gemm_grouped(const v2s_gemm_args* args, int32_t count, const void* const* A, const void* const* B, void* const* C, void* stream);
 /* symbol of the kernel variant the calling thread's last v2s_gemm dispatched (for profiling: matches rocprofv3 kernel names) */
 const char* v2s_last_gemm_kernel(void);
 

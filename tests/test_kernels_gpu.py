@@ -470,6 +470,25 @@ def test_attention_fwd_bwd(B, H, Nq, Nk, scale, use_bias, use_mask, causal, tr_m
         assert c > 0.999 and e < 3e-2
 
 
+@pytest.mark.parametrize("M,N,K,G,acc", [(768, 768, 512, 12, False), (136, 264, 192, 3, True), (2304, 768, 256, 16, False)])
+def test_gemm_grouped_weight_gradients(M, N, K, G, acc):
+    """v2s_gemm_grouped: G weight gradients of one shape (dY^T X, fp32 out) in one launch == the single launches / fp32 torch."""
+    As = [rnd(K, M, seed=10 + i, scale=0.5) for i in range(G)]
+    Bs = [rnd(K, N, seed=40 + i, scale=0.5) for i in range(G)]
+    init = [rnd(M, N, seed=70 + i, dtype=torch.float32) for i in range(G)]
+    Cs = [t.clone() for t in init]
+    L.gemm_grouped(As, Bs, Cs, M, N, K, accumulate=acc)
+    assert L.lib().v2s_last_gemm_kernel().decode() == "gemm_dma_grouped_kernel"
+    for a, b, c, c0 in zip(As, Bs, Cs, init):
+        ref = a.float().t() @ b.float() + (c0 if acc else 0)
+        assert relerr(c, ref) < 2e-5
+        single = c0.clone()
+        L.gemm(a, b, single, M, N, K, transA=True, transB=True, accumulate=acc)
+        assert torch.equal(single, c)          # same kernel body, same K order (no split-K without a workspace)
+    with pytest.raises(ValueError):
+        L.gemm_grouped(As[:1] * 17, Bs[:1] * 17, Cs[:1] * 17, M, N, K)
+
+
 def test_fp32_io_debug_mode_norm_ce_attention():
     """SURVEY 8c "tolerances to state": with fp32 activations in and out (library option fp32_io) the norm, cross-entropy and
     attention entry points must agree with fp32 torch to <= 1e-4 -- the debug mode that separates a kernel bug from bf16 rounding.

@@ -438,13 +438,12 @@ __device__ __forceinline__ void dma_issue8(const uint32_t (&oa)[4], const uint32
 }
 
 template <bool TA, bool TB>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const GemmP p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+__device__ __forceinline__ void gemm_dma_body(const GemmP& p, const int bid, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nwg = p.tilesM * p.tilesN * p.splitk;
-  const int id0 = xcd_remap(blockIdx.x, nwg);
+  const int id0 = xcd_remap(bid, nwg);
   int tm, tn, slice;
   tile_coords(p, id0, tm, tn, slice);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -498,6 +497,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const GemmP p) {
   uint4 gop[8];
   const bool ahead = epilogue_prefetch(p, m0, n0, tid, gop);
   gemm_epilogue(p, smem, acc, m0, n0, slice, tid, lane, wm, wn, gop, ahead);
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const GemmP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  gemm_dma_body<TA, TB>(p, blockIdx.x, smem);
+}
+
+// GROUPED weight gradients (round 4): up to V2S_GEMM_GROUP_MAX problems of ONE shape -- the same projection of the twelve decoder (or
+// ViT) layers, whose operands live in separate allocations -- in one launch: block -> (problem, tile).  A 768 x 768 x 8192 weight gradient
+// has 36 output tiles; alone it needs split-K (plus a reduce launch) to occupy the chip and runs at 370 TF/s, twelve of them fill it
+// with whole-K tiles and no reduction (tools/gemm_group_ab.py).  The pointers travel in the kernel arguments.
+constexpr int GEMM_GROUP_MAX = 16;
+struct GemmGrp {
+  GemmP p;
+  const bf16_t* A[GEMM_GROUP_MAX];
+  const bf16_t* B[GEMM_GROUP_MAX];
+  void* C[GEMM_GROUP_MAX];
+};
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_grouped_kernel(const GemmGrp g) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  const int per = g.p.tilesM * g.p.tilesN * g.p.splitk;
+  const int gi = __builtin_amdgcn_readfirstlane((int)blockIdx.x / per);
+  GemmP p = g.p;
+  p.A = g.A[gi]; p.B = g.B[gi]; p.C = g.C[gi];
+  gemm_dma_body<true, true>(p, (int)blockIdx.x - gi * per, smem);
 }
 
 // =====================================================================================================================
@@ -2025,6 +2050,35 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
 // into whole rounds of 256 x 256 tiles plus a remainder on the 128 x 128 kernels was measured and did not pay: 132.1 vs 133.1 us
 // on 32000 x 2304 x 768, nothing on the N = 768 shapes.)
 extern "C" int v2s_gemm(const v2s_gemm_args* a, void* stream) { return gemm_impl(a, stream, 0, -1); }
+
+extern "C" int v2s_gemm_grouped(const v2s_gemm_args* a, int32_t count, const void* const* A, const void* const* B, void* const* C, void* stream) {
+  V2S_CHECK(a && A && B && C, V2S_ERR_ARG, "v2s_gemm_grouped: null args");
+  V2S_CHECK(count >= 1 && count <= GEMM_GROUP_MAX, V2S_ERR_ARG, "v2s_gemm_grouped: 1..%d problems per call (got %d)", GEMM_GROUP_MAX, count);
+  V2S_CHECK(a->transA && a->transB && a->c_dtype == V2S_F32 && !a->bias && !a->act && !a->dact && !a->pre && !a->residual && a->dropout_p == 0.f &&
+                a->rms_eps <= 0.f, V2S_ERR_ARG, "v2s_gemm_grouped: weight-gradient form only (transA = transB = 1, fp32 C, plain epilogue)");
+  V2S_CHECK(a->M > 0 && a->N > 0 && a->K > 0 && (a->K % BK) == 0 && (a->M % 8) == 0 && (a->N % 8) == 0, V2S_ERR_SHAPE,
+            "v2s_gemm_grouped: M, N multiples of 8 and K a multiple of %d (got %d %d %d)", BK, a->M, a->N, a->K);
+  V2S_CHECK((a->lda % 8) == 0 && (a->ldb % 8) == 0 && (a->ldc % 8) == 0 && a->lda >= a->M && a->ldb >= a->N && a->ldc >= a->N, V2S_ERR_ALIGN,
+            "v2s_gemm_grouped: leading dimensions must be multiples of 8 covering the rows");
+  V2S_CHECK(64 * a->lda + a->M < (1L << 31) && 64 * a->ldb + a->N < (1L << 31), V2S_ERR_SHAPE, "v2s_gemm_grouped: operand rows too long for 32-bit lane offsets");
+  GemmGrp g;
+  GemmP& p = g.p;
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.A = nullptr; p.B = nullptr; p.lda = a->lda; p.ldb = a->ldb; p.C = nullptr; p.ldc = a->ldc; p.c_f32 = 1; p.accumulate = a->accumulate;
+  p.alpha = a->alpha; p.bias = nullptr; p.act = 0; p.pre = nullptr; p.dact = 0; p.z = nullptr; p.ldz = 0; p.residual = nullptr; p.ldr = 0;
+  p.p16 = 0; p.inv_keep = 1.f; p.seed = 0; p.salt = nullptr; p.rms_eps = 0.f;
+  p.order = v2s_opt_gemm_order(); p.dbg = 0; p.row0 = 0;
+  p.tilesM = (a->M + BM - 1) / BM; p.tilesN = (a->N + BN - 1) / BN; p.splitk = 1; p.kper = a->K; p.ws = nullptr;
+  for (int i = 0; i < count; ++i) {
+    V2S_CHECK(A[i] && B[i] && C[i] && ((((uintptr_t)A[i] | (uintptr_t)B[i] | (uintptr_t)C[i]) & 15) == 0), V2S_ERR_ALIGN, "v2s_gemm_grouped: problem %d: null or misaligned pointer", i);
+    g.A[i] = (const bf16_t*)A[i]; g.B[i] = (const bf16_t*)B[i]; g.C[i] = C[i];
+  }
+  for (int i = count; i < GEMM_GROUP_MAX; ++i) { g.A[i] = g.A[0]; g.B[i] = g.B[0]; g.C[i] = g.C[0]; }
+  g_last_gemm = "gemm_dma_grouped_kernel";
+  hipLaunchKernelGGL(gemm_dma_grouped_kernel, dim3((unsigned)(p.tilesM * p.tilesN * count)), dim3(NTHREADS), 0, (hipStream_t)stream, g);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
 
 static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_force) {
   V2S_CHECK(a != nullptr, V2S_ERR_ARG, "v2s_gemm: null args");

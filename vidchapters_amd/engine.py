@@ -89,6 +89,9 @@ class Engine:
         self.vstream = torch.cuda.Stream(device=device)
         self.kstream = torch.cuda.Stream(device=device)   # cross-attention K|V projections of all decoder layers (forward) / the d(memory) chain (backward)
         self.overlap_kv = True    # see decoder_forward / _cross_attn_bwd
+        self.group_wgrads = True  # decoder / ViT weight gradients of one projection across the layers as ONE grouped launch (_wgrad, flush_wgrads)
+        self.group_flush_layers = 4  # ... every this many decoder layers (the launches then run beside the NEXT layers' under-filled 8192-row kernels)
+        self._wgrad_groups: Dict = {}
         self.shadow_events = None # sharded optimizer: {"vit" | "enc" | "dec": event after which that group's bf16 shadow weights are whole}
         self.arena.refresh_shadow(force=True)
 
@@ -214,7 +217,7 @@ class Engine:
 
     # linear helpers ------------------------------------------------------------------------------------------
     def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, wname: str, n_out: int, n_in: int, rows: int, ld_dy=None, ld_x=None,
-               alpha: float = 1.0, shape=None, side_ok: bool = False) -> None:
+               alpha: float = 1.0, shape=None, side_ok: bool = False, group: Optional[str] = None) -> None:
         """dW[n_out, n_in] += alpha * dy[rows, n_out]^T @ x[rows, n_in]  (fp32 accumulate into the gradient arena).
         Runs on the weight-gradient stream unless the target is the tied embedding (whose gradient is also written by
         the embedding scatter-add on the main stream)."""
@@ -226,6 +229,13 @@ class Engine:
             fresh.add(wname)
 
         if getattr(self, "dbg_skip_wgrad", 0):     # timing probe (tools/step_ab.py "eng:dbg_skip_wgrad=1"): what the weight-gradient stream costs the step
+            return
+        # ``group``: the same projection of every decoder / ViT layer (short contraction: 8192 / 3200 rows, 36-144 output tiles each) is
+        # collected and launched as ONE grouped GEMM when the stack's backward is done (flush_wgrads): whole-K tiles of twelve problems
+        # fill the chip without split-K and its reduce launches (v2s_gemm_grouped)
+        if group is not None and self.group_wgrads and alpha == 1.0 and rows % 64 == 0 and n_out % 8 == 0 and n_in % 8 == 0:
+            key = (group, n_out, n_in, rows, ld_dy if ld_dy is not None else n_out, ld_x if ld_x is not None else n_in, acc)
+            self._wgrad_groups.setdefault(key, []).append((dy, x, self.arena.g(wname, shape)))
             return
 
         def launch():
@@ -244,6 +254,28 @@ class Engine:
             launch()
         dy.record_stream(self.wstream)
         x.record_stream(self.wstream)
+
+    def flush_wgrads(self) -> None:
+        """Launch the collected weight-gradient groups (see _wgrad) on the weight-gradient stream, behind everything the current stream
+        has enqueued so far (every member's operands were produced on it)."""
+        groups, self._wgrad_groups = self._wgrad_groups, {}
+        if not groups:
+            return
+        cur = torch.cuda.current_stream()
+        if self.overlap:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self.wstream.wait_event(ev)
+        with torch.cuda.stream(self.wstream if self.overlap else cur):
+            for (_, n_out, n_in, rows, ld_dy, ld_x, acc), items in groups.items():
+                for i in range(0, len(items), 16):
+                    part = items[i:i + 16]
+                    L.gemm_grouped([t[0] for t in part], [t[1] for t in part], [t[2] for t in part], n_out, n_in, rows,
+                                   lda=ld_dy, ldb=ld_x, ldc=n_in, accumulate=acc)
+        if self.overlap:
+            for items in groups.values():
+                for dy, x, _ in items:
+                    dy.record_stream(self.wstream); x.record_stream(self.wstream)
 
     def join_wgrads(self) -> None:
         """Make the current stream wait for every weight-gradient GEMM issued so far."""
@@ -369,7 +401,8 @@ class Engine:
         sa = self._sa(r.stack, r.i)
         if df is None:
             df = self._drop(dh, r.p, r.seed_o)
-        self._wgrad(df, r.ctx, sa + "o.weight", d, inner, M)
+        grp = "dec.sa." if r.stack == "decoder" else None           # the encoder's (32000-row contraction) stay single launches
+        self._wgrad(df, r.ctx, sa + "o.weight", d, inner, M, group=grp and grp + "o")
         dctx = self._dgrad(df, a.w(sa + "o.weight"), M, inner, d)
         dqkv = self._bf(M, 3 * inner)
         delta = self._f32(B, self.H, N, 4)       # row statistics handed from the dQ to the dK/dV kernel (v2s_attn_bwd workspace)
@@ -377,7 +410,7 @@ class Engine:
         self._lut(N, N, r.stack == "encoder")
         L.attn_bwd(r.args, dctx, (N * inner, inner), delta, dqkv, dqkv[:, inner:], dqkv[:, 2 * inner:], st, st, st,
                    dbias_diag=dbias_diag, far=self._far[(N, N, r.stack == "encoder")])
-        self._wgrad(dqkv, r.n, sa + "q.weight", 3 * inner, d, M, shape=(3 * inner, d))
+        self._wgrad(dqkv, r.n, sa + "q.weight", 3 * inner, d, M, shape=(3 * inner, d), group=grp and grp + "qkv")
         dn = self._dgrad(dqkv, a.w(sa + "q.weight", (3 * inner, d)), M, d, 3 * inner)
         return self._norm_bwd_next(r.h, self._ln(r.stack, r.i, 0), r.rstd, dn, dh, M, nxt)
 
@@ -388,7 +421,7 @@ class Engine:
         ca = self._ca(r.i)
         if df is None:
             df = self._drop(dh, r.p, r.seed_o)
-        self._wgrad(df, r.ctx, ca + "o.weight", d, inner, Mq)
+        self._wgrad(df, r.ctx, ca + "o.weight", d, inner, Mq, group="dec.ca.o")
         dctx = self._dgrad(df, a.w(ca + "o.weight"), Mq, inner, d)
         dq = self._bf(Mq, inner); dkv = self._bf(Mk, 2 * inner)
         if r.k_real < Mk:
@@ -396,7 +429,7 @@ class Engine:
         delta = self._f32(B, self.H, Nq, 4)
         kst = (S * 2 * inner, 2 * inner)
         L.attn_bwd(r.args, dctx, (Nq * inner, inner), delta, dq, dkv, dkv[:, inner:], (Nq * inner, inner), kst, kst)
-        self._wgrad(dq, r.n, ca + "q.weight", inner, d, Mq)
+        self._wgrad(dq, r.n, ca + "q.weight", inner, d, Mq, group="dec.ca.q")
         dn = self._dgrad(dq, a.w(ca + "q.weight"), Mq, d, inner)
         self._wgrad(dkv, r.mem, ca + "k.weight", 2 * inner, d, Mk, shape=(2 * inner, d))
         # dmem accumulates over the decoder layers (residual add in the GEMM epilogue, in place).  Nothing in the decoder's backward
@@ -421,11 +454,12 @@ class Engine:
         fp = self._ffp(r.stack, r.i)
         if df is None:
             df = self._drop(dh, r.p, r.seed_o)
-        self._wgrad(df, r.u, fp + "wo.weight", d, ff, M)
+        grp = "dec.ff." if r.stack == "decoder" else None
+        self._wgrad(df, r.u, fp + "wo.weight", d, ff, M, group=grp and grp + "wo")
         # (timing probe, round 3: without the ReLU-mask operand z this launch would take the deferred-epilogue kernel and the step
         # 55.48 -> 54.33 ms; a byte mask written by the wi forward would have to be packed inside that kernel's slack-free write-out phases)
         du = self._dgrad(df, a.w(fp + "wo.weight"), M, ff, d, dact=L.ACT_RELU, z=r.u, dropout_p=r.p, dropout_seed=r.seed_u)
-        self._wgrad(du, r.n, fp + "wi.weight", ff, d, M)
+        self._wgrad(du, r.n, fp + "wi.weight", ff, d, M, group=grp and grp + "wi")
         dn = self._dgrad(du, a.w(fp + "wi.weight"), M, d, ff)
         return self._norm_bwd_next(r.h, self._ln(r.stack, r.i, 2 if r.stack == "decoder" else 1), r.rstd, dn, dh, M, nxt)
 
@@ -629,10 +663,13 @@ class Engine:
                 first_cross = False
             elif r.kind == "self":
                 dh, df = self._self_attn_bwd(r, dh, ddiag, df, nxt)
+                if stack == "decoder" and r.i % self.group_flush_layers == 0:
+                    self.flush_wgrads()               # the collected decoder layers' weight gradients: one grouped launch per projection
                 if layer_done is not None:        # all parameter gradients of block r.i are enqueued (except block 0's bias table)
                     layer_done(r.i)
             elif r.kind == "embed":
                 self._embed_bwd(r, dh)
+        self.flush_wgrads()
         L.bias_bucket_bwd(ddiag, lut, a.g(self._sa(stack, 0) + "relative_attention_bias.weight"), self.H, 2 * nq - 1,
                           self.cfg.buckets)
 
@@ -722,24 +759,25 @@ class Engine:
         for idx, r in enumerate(recs):
             pre = r.pre
             L.colsum(df2, M, C, a.g(pre + "mlp.fc2.bias"))
-            self._wgrad(df2, r.u, pre + "mlp.fc2.weight", C, mlp, M)
+            self._wgrad(df2, r.u, pre + "mlp.fc2.weight", C, mlp, M, group="vit.fc2")
             du = self._dgrad(df2, a.w(pre + "mlp.fc2.weight"), M, mlp, C, dact=L.ACT_GELU, z=r.upre, dropout_p=p,
                              dropout_seed=r.seed_u)
             L.colsum(du, M, mlp, a.g(pre + "mlp.fc1.bias"))
-            self._wgrad(du, r.n2, pre + "mlp.fc1.weight", mlp, C, M)
+            self._wgrad(du, r.n2, pre + "mlp.fc1.weight", mlp, C, M, group="vit.fc1")
             dn2 = self._dgrad(du, a.w(pre + "mlp.fc1.weight"), M, C, mlp)
             dx1, df1 = ln_bwd(r.x1, pre + "norm2.", r.mean2, r.rstd2, dn2, dx, r.seed_p)
             L.colsum(df1, M, C, a.g(pre + "attn.proj.bias"))
-            self._wgrad(df1, r.ctx, pre + "attn.proj.weight", C, C, M)
+            self._wgrad(df1, r.ctx, pre + "attn.proj.weight", C, C, M, group="vit.proj")
             dctx = self._dgrad(df1, a.w(pre + "attn.proj.weight"), M, C, C)
             dqkv = self._bf(M, 3 * C); delta = self._f32(B, Hh, T, 4)
             st = (T * 3 * C, 3 * C)
             L.attn_bwd(r.args, dctx, (T * C, C), delta, dqkv, dqkv[:, C:], dqkv[:, 2 * C:], st, st, st)
             L.colsum(dqkv, M, 3 * C, a.g(pre + "attn.qkv.bias"))
-            self._wgrad(dqkv, r.n1, pre + "attn.qkv.weight", 3 * C, C, M)
+            self._wgrad(dqkv, r.n1, pre + "attn.qkv.weight", 3 * C, C, M, group="vit.qkv")
             dn1 = self._dgrad(dqkv, a.w(pre + "attn.qkv.weight"), M, C, 3 * C)
             nseed = recs[idx + 1].seed_2 if idx + 1 < len(recs) else tape["seed0"]      # next block's fc2 dropout, or the input dropout
             dx, df2 = ln_bwd(r.x, pre + "norm1.", r.mean1, r.rstd1, dn1, dx1, nseed)
+        self.flush_wgrads()
         dx = df2                                                   # = dropout(dx; seed0), vit.py:126
         gpos = a.g("visual_encoder.pos_embed", (m.num_features, C))
         if tape["idx"] is None:
@@ -993,6 +1031,7 @@ class Engine:
         """Leave overwrite mode whatever happened (Trainer wraps the step body in try/finally): after an exception inside a step the
         autograd-path backward must accumulate again instead of overwriting."""
         self._fresh_grads = None
+        self._wgrad_groups = {}
 
     def _begin_backward(self) -> None:
         """If the caller dropped the gradients (optimizer.zero_grad(set_to_none=True)) start from a zeroed arena."""

@@ -101,6 +101,7 @@ SYMBOLS = {
     "v2s_kv_append": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "v2s_counter_add": (C.c_int, [_vp, _i32, _vp]),
     "v2s_last_gemm_kernel": (C.c_char_p, []),
+    "v2s_gemm_grouped": (C.c_int, [C.POINTER(GemmArgs), _i32, _vp, _vp, _vp, _vp]),
     "v2s_scale_cols": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "v2s_span_corrupt": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "v2s_topk_logprob": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
@@ -279,6 +280,38 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_out: torch.Tensor, M: int, N: int, 
             kind += f":{M}x{N}x{K}" + (":drop" if dropout_p > 0 else "") + (":res" if residual is not None else "") + \
                     (":act" if act or dact else "") + (":bias" if bias is not None else "") + (":f32" if a.c_dtype == V2S_F32 else "")
         kt.end(kind, 2.0 * M * N * K, e0)
+
+
+def gemm_grouped(As, Bs, Cs, M: int, N: int, K: int, *, lda=None, ldb=None, ldc=None, accumulate=False, alpha=1.0) -> None:
+    """Cs[i][M, N] (+)= alpha * As[i]^T @ Bs[i] (As[i]: bf16 [K, lda], Bs[i]: bf16 [K, ldb], Cs[i]: fp32) for up to 16 problems of one shape
+    in ONE launch (v2s_gemm_grouped: the same weight gradient of many layers)."""
+    n = len(As)
+    if not (n == len(Bs) == len(Cs) and 1 <= n <= 16):
+        raise ValueError(f"gemm_grouped: 1..16 problems with one A, B and C each (got {n}, {len(Bs)}, {len(Cs)})")
+    for t in As + Bs:
+        _need(t, torch.bfloat16, "gemm_grouped operand")
+    for t in Cs:
+        _need(t, torch.float32, "gemm_grouped C")
+    a = GemmArgs()
+    a.M, a.N, a.K = M, N, K
+    a.transA, a.transB = 1, 1
+    a.lda = lda if lda is not None else M
+    a.ldb = ldb if ldb is not None else N
+    a.ldc = ldc if ldc is not None else N
+    a.c_dtype = V2S_F32
+    a.accumulate = int(accumulate)
+    a.alpha = alpha
+    arr = C.c_void_p * n
+    pa, pb, pc = arr(*[t.data_ptr() for t in As]), arr(*[t.data_ptr() for t in Bs]), arr(*[t.data_ptr() for t in Cs])
+    kt = KernelTimer.active
+    if kt is not None:
+        e0 = kt.begin()
+    _check(lib().v2s_gemm_grouped(C.byref(a), n, pa, pb, pc, stream_ptr()), "v2s_gemm_grouped")
+    if kt is not None:
+        kind = "gemm_dma_grouped_kernel" if kt.by_symbol else "gemm_wgrad"
+        if kt.detail:
+            kind += f":{n}x{M}x{N}x{K}"
+        kt.end(kind, 2.0 * n * M * N * K, e0)
 
 
 def colsum(X: torch.Tensor, M: int, N: int, out: torch.Tensor, accumulate=True, ldx=None) -> None:
