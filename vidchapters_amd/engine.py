@@ -1035,6 +1035,7 @@ class Engine:
 
     def _begin_backward(self) -> None:
         """If the caller dropped the gradients (optimizer.zero_grad(set_to_none=True)) start from a zeroed arena."""
+        self._wgrad_groups = {}           # nothing collected by a backward that raised may leak into this one
         if self.arena.attach_grads():
             self.arena.grad.zero_()
 
