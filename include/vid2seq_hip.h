@@ -338,7 +338,7 @@ int v2s_argmax_step_seq(const float* logits, int64_t ld, int32_t rows, int32_t V
 int v2s_kv_append(const void* src, int64_t src_bs, void* cache, int64_t cache_bs, int64_t cache_rs,
                   int32_t B, int32_t width, int32_t pos, const int32_t* pos_dev, void* stream);
 /* beam search (HF 4.28 beam_search, call site vid2seq.py:150-162): per row the K best of log_softmax(logits) + beam_scores[row],
- * sorted descending (K in {2,4,8,16}); ban_token >= 0 is excluded from the candidates (not from the softmax) while
+ * sorted descending (K in {2,4,8,16,32}: specialised kernels; 33..512: K rounds over an LDS-resident row, for num_beams > 16); ban_token >= 0 is excluded from the candidates (not from the softmax) while
  * *pos_dev + 1 < min_length (HF's MinLengthLogitsProcessor on EOS, applied to log-probs; pos_dev = device step counter);
  * row_lse != NULL: use these row log-sum-exps instead of recomputing them (after v2s_repetition_penalty); and the beam reorder of the self-attention cache (modeling_t5.py:1771-1793):
  * dst[b, 0:len, :] = src[idx[b], 0:len, :] for [B][*][width] bf16 caches with batch stride bs and row stride rs */

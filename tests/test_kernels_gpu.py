@@ -846,7 +846,7 @@ def test_optimizer_kernels():
     assert relerr(emb, ref) < 1e-6 and torch.equal(embb, emb.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("K", [2, 8, 16])
+@pytest.mark.parametrize("K", [2, 8, 16, 40, 66])
 def test_topk_logprob_and_kv_gather(K):
     rows, V, ld = 12, 3211, 3216
     g = torch.Generator().manual_seed(K)
@@ -868,8 +868,8 @@ def test_topk_logprob_and_kv_gather(K):
     assert torch.equal(idx.cpu().long(), ri2) and (val.cpu().double() - rv2).abs().max() < 1e-5
     L.topk_logprob(logits.to(DEV), ld, rows, V, K, bs.to(DEV), val, idx, ban_token=ban, pos_dev=pos, min_length=3)
     assert torch.equal(idx.cpu().long(), ri)
-    if K <= 8:
-        # the 1024-thread threshold path (aligned rows of <= 32768 logits: candidates = elements >= the K-th largest thread maximum),
+    if K <= 8 or K > 32:
+        # (K > 32: the generic rounds kernel, same tie order)  the 1024-thread threshold path (aligned rows of <= 32768 logits: candidates = elements >= the K-th largest thread maximum),
         # with rows that overflow its 64-slot list (flat row, a wide plateau of equal maxima) falling back to the sorted-list path;
         # equal values: lower token first
         rows2, V2, ld2 = 9, 32200, 32256

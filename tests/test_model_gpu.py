@@ -224,10 +224,11 @@ def test_greedy_vs_reference_golden(golden_dir):
     assert isinstance(text, list) and len(text) == want.shape[0] and all(isinstance(t, str) for t in text)
 
 
-@pytest.mark.parametrize("nb", [2, 3, 5, 8, 12])
+@pytest.mark.parametrize("nb", [2, 3, 5, 8, 12, 20])
 def test_beam_search_other_widths(golden_dir, nb):
     """num_beams other than the default 4: 2 and 8 take the one-block-per-entry cross-attention (kv_group), 3, 5 and 12 one block per
-    beam row (12: the 32-candidate top-k); all of them the row-map instead of a cache reorder.  Reference = the fp32 oracle run here on the fixture's inputs; same bar as
+    beam row (12: the 32-candidate top-k; 20: more than 16 beams -- the generic K = 2*nb rounds top-k, one cross-attention block per
+    beam row; the reference forwards any num_beams, vid2seq.py:150-162); all of them the row-map instead of a cache reorder.  Reference = the fp32 oracle run here on the fixture's inputs; same bar as
     the golden test (valid hypotheses, >= 3/4 of the rows identical: bf16 logits can flip a near-tie)."""
     g = np.load(os.path.join(golden_dir, "small_beam.npz"))
     cfg = R.RefConfig.small()

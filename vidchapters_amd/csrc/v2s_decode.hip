@@ -1027,12 +1027,75 @@ extern "C" int v2s_kv_append(const void* src, int64_t src_bs, void* cache, int64
   return V2S_OK;
 }
 
+namespace {
+// Any K (wide beams: num_beams > 16 needs more than 32 candidates per row): the row's scores in LDS, K rounds of a block-wide argmax
+// (value descending, lower token first -- the order of the specialised kernels above).  ~1.5 us per round: for the rare wide-beam call.
+__global__ __launch_bounds__(1024) void topk_rounds_kernel(const float* __restrict__ logits, long ld, int V, int K, const float* __restrict__ beam_scores,
+                                                           float* __restrict__ out_val, int* __restrict__ out_idx, int ban_tok,
+                                                           const int* __restrict__ pos_dev, int min_length, const float* __restrict__ row_lse) {
+  extern __shared__ __attribute__((aligned(16))) float sv[];            // [V]
+  __shared__ float red_v[16], red_s[16];
+  __shared__ int red_i[16];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* z = logits + (long)row * ld;
+  const int ban = (ban_tok >= 0 && (pos_dev ? *pos_dev + 1 : 0) < min_length) ? ban_tok : -1;
+  float fm = -INFINITY;
+  for (int i = tid; i < V; i += 1024) { const float v = z[i]; sv[i] = i == ban ? -INFINITY : v; fm = fmaxf(fm, v); }
+  fm = wave_max(fm);
+  if (lane == 0) red_v[wave] = fm;
+  __syncthreads();
+  float M = red_v[0];
+  for (int w = 1; w < 16; ++w) M = fmaxf(M, red_v[w]);
+  float fs = 0.f;
+  for (int i = tid; i < V; i += 1024) fs += __expf(z[i] - M);            // normaliser over ALL tokens (the EOS ban comes after log_softmax)
+  fs = wave_sum(fs);
+  __syncthreads();
+  if (lane == 0) red_s[wave] = fs;
+  __syncthreads();
+  float S = 0.f;
+  for (int w = 0; w < 16; ++w) S += red_s[w];
+  const float lse = row_lse ? row_lse[row] : M + logf(S);
+  const float base = beam_scores ? beam_scores[row] : 0.f;
+  for (int r = 0; r < K; ++r) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 1024) { const float v = sv[i]; if (v > bv) { bv = v; bi = i; } }       // ascending i: the first maximum is the lowest token
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(bv, o, 64); const int i2 = __shfl_xor(bi, o, 64);
+      if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+    }
+    __syncthreads();
+    if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+    __syncthreads();
+    float gv = red_v[0]; int gi = red_i[0];
+    for (int w = 1; w < 16; ++w)
+      if (red_v[w] > gv || (red_v[w] == gv && red_i[w] < gi)) { gv = red_v[w]; gi = red_i[w]; }
+    if (tid == 0) {
+      const bool ok = gv > -INFINITY;
+      out_val[(long)row * K + r] = ok ? (gv - lse) + base : -INFINITY;
+      out_idx[(long)row * K + r] = ok ? gi : 0;
+      if (ok) sv[gi] = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
 extern "C" int v2s_topk_logprob(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const float* beam_scores,
                                 float* out_val, int32_t* out_idx, int32_t ban_token, const int32_t* pos_dev, int32_t min_length, const float* row_lse,
                                 void* stream) {
   V2S_CHECK(logits && out_val && out_idx && rows > 0 && V > 0, V2S_ERR_ARG, "v2s_topk_logprob: bad args");
-  V2S_CHECK(K == 2 || K == 4 || K == 8 || K == 16 || K == 32, V2S_ERR_ARG, "v2s_topk_logprob: K must be 2, 4, 8, 16 or 32 (got %d)", K);
+  V2S_CHECK(K == 2 || K == 4 || K == 8 || K == 16 || K == 32 || (K > 32 && K <= 512), V2S_ERR_ARG, "v2s_topk_logprob: K must be 2, 4, 8, 16, 32 or 33..512 (got %d)", K);
   hipStream_t s = (hipStream_t)stream;
+  if (K > 32) {                             // wide beams: generic K rounds over an LDS-resident row
+    V2S_CHECK((size_t)V * 4 <= 150 * 1024, V2S_ERR_SHAPE, "v2s_topk_logprob: K > 32 keeps the row in LDS: vocabulary %d too large", V);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)topk_rounds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    hipLaunchKernelGGL(topk_rounds_kernel, dim3(rows), dim3(1024), (size_t)V * 4, s, logits, (long)ld, V, K, beam_scores, out_val, out_idx, ban_token, pos_dev,
+                       min_length, row_lse);
+    V2S_LAUNCH_CHECK();
+    return V2S_OK;
+  }
   if (K == 2) hipLaunchKernelGGL((topk_logprob_kernel<2, 1024>), dim3(rows), dim3(1024), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
   else if (K == 4) hipLaunchKernelGGL((topk_logprob_kernel<4, 1024>), dim3(rows), dim3(1024), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);
   else if (K == 8) hipLaunchKernelGGL((topk_logprob_kernel<8, 1024>), dim3(rows), dim3(1024), 0, s, logits, (long)ld, V, beam_scores, out_val, out_idx, ban_token, pos_dev, min_length, row_lse);

@@ -1220,10 +1220,13 @@ class Engine:
         B, S, d = mem.shape
         nb = num_beams
         R = B * nb
-        if not 1 <= nb <= 16:
-            raise ValueError(f"num_beams must be in [1, 16] on the HIP path (got {nb})")
-        K = next(k for k in (2, 4, 8, 16, 32) if k >= 2 * nb)     # per-beam candidate lists are sorted: a longer list only adds entries
-                                                              # the merge never reaches, so any num_beams uses the next instantiated size
+        if not 1 <= nb <= 128:
+            raise ValueError(f"num_beams must be in [1, 128] on the HIP path (got {nb})")
+        if sample is not None and nb > 16:
+            raise ValueError(f"beam-sample keeps at most 64 warped candidates per beam row: num_beams <= 16 with sampling (got {nb})")
+        # per-beam candidate lists are sorted: a longer list only adds entries the merge never reaches, so any num_beams <= 16 uses the next
+        # instantiated size; wider beams (the reference forwards any num_beams, vid2seq.py:150-162) take the generic K = 2*nb rounds kernel
+        K = next((k for k in (2, 4, 8, 16, 32) if k >= 2 * nb), 2 * nb)
         inner, H, nl = self.inner, self.H, c.n_dec
         mem2 = mem.view(B * S, d)
         cross = []
