@@ -621,6 +621,25 @@ def test_skip_grad_memset_equals_zeroed_arena_and_survives_an_exception():
     assert model.engine()._fresh_grads is None
 
 
+def test_grouped_weight_gradients_equal_single_launches():
+    """Engine.group_wgrads: the decoder's / ViT's weight gradients of one projection across the layers are launched as ONE grouped GEMM
+    (v2s_gemm_grouped) -- same gradients as one launch per layer, in a two-pass step (second pass accumulates) and with a flush cadence
+    that does not divide the layer count."""
+    cfg = R.RefConfig.small(n_dec=3)
+    b = {k: v.to(DEV) for k, v in synth.make_batch(32, 10, 40, 12, cfg.vocab, 31, cfg.vit_dim, denoising=True).items()}     # 384 decoder rows, 320 ViT rows
+    res = {}
+    for grouped in (True, False):
+        model = build(cfg, 13).train()
+        eng = model.engine()
+        eng.group_wgrads, eng.group_flush_layers = grouped, 2
+        tr = Trainer(model, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=1.0)
+        tr.step(b)
+        res[grouped] = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()}
+    worst = min(cos(res[True][k], res[False][k]) for k in res[True] if res[False][k].abs().max() > 0)
+    print(f"grouped vs single weight-gradient launches: worst gradient cosine {worst:.7f}")
+    assert worst > 0.99999
+
+
 def test_beam_sample_rejects_top_k_outside_the_kept_list():
     """beam-sample keeps at most 64 warped candidates per beam row; sampling_top_k = 0 ("no filter") or > 64 would be truncated,
     i.e. a different distribution from HF's beam_sample -- generate() refuses it instead (greedy-loop sampling has no such limit)."""
