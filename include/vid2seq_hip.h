@@ -52,6 +52,13 @@ const char* v2s_last_error(void);
  *   "gemm_split"    1: split-K slice count from the rounds x length cost model (default), 0: fixed block-count target
  *   "gemm_p8"       8-phase ping-pong kernel (256-row tiles, counted vmcnt LDS-DMA ring): 1: where it measured faster (default),
  *                   0: never, 2: 256x256 tiles wherever legal, 3: 256x128 tiles wherever legal
+ *   "gemm_ps"       persistent 128x128 kernel with dedicated write-out waves (round-4 experiment, bit-identical, not faster): 0: never (default),
+ *                   2: wherever legal, 3: wherever legal with more tiles than block slots; "gemm_ps_nst" = its ring depth (2 | 3 | 4)
+ *   "gemm_w128"     4-wave 256x192 kernel with 128x96 wave tiles in AGPRs (round-4 experiment, NT only, bit-identical, not faster): 0: never
+ *                   (default), 2: wherever legal
+ *   "gemm_dbg"      profiling ablations of the tiled kernels (results invalid when non-zero): 1 = no global store, 2 = no epilogue, 3 = no hand-off
+ *   "fp32_io"       DEBUG: 1 = v2s_*norm_fwd/bwd, v2s_ce_bwd and v2s_attn_fwd/bwd take and return FP32 activations (attention: fp32-arithmetic
+ *                   reference kernels, dense layout only); parity work against fp32 references (<= 1e-4), never set by the product path
  *   "attn_bwd_part" 0: v2s_attn_bwd launches dQ and dK/dV kernels (default), 1: dQ only, 2: dK/dV only (per-kernel timing) */
 int v2s_set_option(const char* name, int value);
 int v2s_get_option(const char* name);
