@@ -335,6 +335,30 @@ typedef struct v2s_decode_attn_args {
   int32_t* row_map; int64_t row_map_ld;
 } v2s_decode_attn_args;
 int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream);
+/* Decode-step cross-attention against the encoder memory itself instead of per-layer K / V caches (d = 768, head width 64).
+ * The reference projects the memory to K and V in every decoder layer and keeps both (modeling_t5.py:484-525, past_key_value[2:4]);
+ * both come from the same rows, so with the folded query qp_h = Wk_h^T q_h and accn_h = sum_k p_k mem_k:
+ *   score_h[k] = qp_h . mem_k,  ctx_h = Wv_h accn_h   -- one pass over [S, d] per layer (half the bytes, one tensor for all layers).
+ * v2s_decode_qfold:   qp[rows][H][d] = per head ((rstd * x) Wq_h^T) Wk_h; x bf16 [rows][ldx]; wq bf16 [H*64][d] (RMSNorm weight
+ *                     folded into its columns when rms_eps > 0, else rstd = 1); wkT bf16 [d][H*64] = the K projection transposed.
+ * v2s_decode_memattn_plan (host only, no GPU work): cuts every entry's ceil(klen / 32) key tiles into pieces of at most tpb tiles, tpb the
+ *                     smallest value for which there are <= target_blocks pieces (one block per piece; one block per CU and launch), so
+ *                     that the blocks of a launch are equally long whatever the entries' lengths.  klen_host[e] >= 1 = the valid keys of
+ *                     entry e (a prefix of its memory rows).  Writes blk[4 * nblk] = (entry, first tile | end tile << 16, slot, klen) and
+ *                     slot_off[entries + 1] (the slots of entry e are slot_off[e] .. slot_off[e + 1], at most 64); both go to the device.
+ * v2s_decode_memattn: one block per blk entry: the R = beams * H consecutive rows of qp of its entry (R <= 48) against its key tiles of
+ *                     mem + entry * mem_es (bf16 [.][d]); writes the piece's normalised sums to part[slot][R16][d] (bf16) and (running
+ *                     max in the log2 domain, weight sum) to ml[slot][R16][2]; R16 = R rounded up to 16.
+ * v2s_decode_ctxfold: merges the pieces and applies the V projection: ctx[m][h*64 .. +64] = Wv_h accn[m][h] for the rows = entries * G
+ *                     query rows (row m = entry m / G, beam m % G); wv bf16 [H*64][d]; ctx bf16 with row stride ld_ctx. */
+int v2s_decode_qfold(const void* x, int64_t ldx, int32_t rows, const void* wq, const void* wkT, float rms_eps, void* qp, int32_t H,
+                     int32_t d, void* stream);
+int v2s_decode_memattn_plan(const int32_t* klen_host, int32_t entries, int32_t target_blocks, int32_t max_blocks, int32_t* blk,
+                            int32_t* slot_off, int32_t* nblk);
+int v2s_decode_memattn(const void* qp, const void* mem, int64_t mem_es, const int32_t* blk, int32_t nblk, int32_t R, float scale,
+                       void* part, float* ml, int32_t d, void* stream);
+int v2s_decode_ctxfold(const void* part, const float* ml, const int32_t* slot_off, int32_t rows, int32_t G, int32_t H, const void* wv,
+                       void* ctx, int64_t ld_ctx, int32_t d, void* stream);
 int v2s_argmax_step(const float* logits, int64_t ld, int32_t rows, int32_t V, int64_t* next_tok,
                     int32_t* unfinished, int32_t eos_id, int32_t pad_id, void* stream);
 /* same, and additionally stores the token at seq_out[row*seq_ld + *pos_dev + 1] (device-resident step counter) */

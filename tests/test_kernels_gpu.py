@@ -1169,3 +1169,57 @@ def test_decode_kernels():
     src = rnd(B, W, seed=6)
     L.kv_append(src, W, kc, 400 * W, W, B, W, 399)
     assert torch.equal(kc[:, 399], src)
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 4])
+def test_decode_cross_attention_on_the_shared_memory(G):
+    """v2s_decode_qfold + v2s_decode_memattn + v2s_decode_ctxfold (the decode step's cross-attention without per-layer K / V caches)
+    against the plain formulation: q = RMSNorm(x) Wq^T, K = mem Wk^T, V = mem Wv^T, softmax(q_h K_h^T) V_h over the valid key prefix
+    (modeling_t5.py:484-561; T5: no scaling, no position bias in cross-attention).  Key counts around the 32-key tile, one key, and
+    more splits than tiles."""
+    H, d, S = 12, 768, 700
+    klen_l = [700, 1, 31, 32, 33, 389]
+    E = len(klen_l)
+    rows = E * G
+    x = rnd(rows, d, seed=101)
+    lnw = 1.0 + 0.1 * rnd(d, seed=102, dtype=torch.float32)
+    wq = rnd(H * 64, d, seed=103, scale=0.25 * d ** -0.5)
+    wk = rnd(H * 64, d, seed=104, scale=d ** -0.5)
+    wv = rnd(H * 64, d, seed=105, scale=d ** -0.5)
+    mem = rnd(E, S, d, seed=106)
+    klen = torch.tensor(klen_l, dtype=torch.int32, device=DEV)
+    eps = 1e-6
+    wqf = torch.empty_like(wq)
+    L.scale_cols(wq, lnw, wqf, H * 64, d)
+    # reference (fp32 on the bf16 inputs; q rounded to bf16 like the K/V-cache path's projection output)
+    xf = x.float()
+    xn = xf * torch.rsqrt((xf * xf).mean(1, keepdim=True) + eps)
+    qr = (xn @ wqf.float().t()).bfloat16().float().view(E, G, H, 64)
+    K = (mem.float() @ wk.float().t()).view(E, S, H, 64)
+    V = (mem.float() @ wv.float().t()).view(E, S, H, 64)
+    sc = torch.einsum("eghd,ekhd->eghk", qr, K)
+    valid = torch.arange(S, device=DEV)[None, :] < klen[:, None]
+    sc = sc.masked_fill(~valid[:, None, None, :], float("-inf"))
+    ref = torch.einsum("eghk,ekhd->eghd", torch.softmax(sc, -1), V).reshape(rows, H * 64)
+    # folded queries alone
+    qp = torch.empty(rows, H, d, dtype=torch.bfloat16, device=DEV)
+    L.decode_qfold(x, rows, wqf, wk.t().contiguous(), eps, qp, H, d)
+    qp_ref = torch.einsum("rhj,hjc->rhc", qr.view(rows, H, 64), wk.float().view(H, 64, d))
+    assert relerr(qp, qp_ref) < 6e-3
+    memp = mem.clone()
+    for e, n in enumerate(klen_l):                    # rows past the valid prefix are never read into a result
+        memp[e, n:] = float("nan")
+    for blocks in (1, 24, 256, 10000):               # one piece per entry ... one tile per piece
+        plan = L.MemAttnPlan(klen_l, G * H, DEV, target_blocks=blocks)
+        assert plan.slot_off_host[-1] == plan.nblk and plan.nblk <= max(blocks, E) and (blocks > 1 or plan.nblk == E)
+        plan.part.fill_(float("nan")); plan.ml.fill_(float("nan"))
+        ctx = torch.empty(rows, H * 64, dtype=torch.bfloat16, device=DEV)
+        L.decode_memattn(qp, memp, S * d, plan, d)
+        L.decode_ctxfold(plan, rows, G, H, wv, ctx, d)
+        assert torch.isfinite(ctx.float()).all(), blocks
+        assert relerr(ctx, ref) < 1.5e-2, (blocks, relerr(ctx, ref))
+    with pytest.raises(RuntimeError):
+        L.MemAttnPlan([5, 0, 7], G * H, DEV)
+    plan.R = 49
+    with pytest.raises(RuntimeError):
+        L.decode_memattn(qp, memp, S * d, plan, d)

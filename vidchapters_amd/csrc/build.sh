@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # -munsafe-fp-atomics: hardware float atomics (global_atomic_add_f32 / ds_add_f32) instead of CAS loops; all our
 # atomics target ordinary (coarse-grained) device memory, where they are exact fp32 adds
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -munsafe-fp-atomics"
-SRCS="v2s_api v2s_gemm v2s_norm v2s_attn v2s_misc v2s_optim v2s_decode v2s_data"
+SRCS="v2s_api v2s_gemm v2s_norm v2s_attn v2s_misc v2s_optim v2s_decode v2s_memattn v2s_data"
 mkdir -p build
 pids=()
 for s in $SRCS; do

@@ -96,6 +96,10 @@ SYMBOLS = {
     "v2s_rowsumsq_range": (C.c_int, [_vp, _i32, _i32, _i64, _i64, _vp, _vp]),
     "v2s_timetoken_renorm_sq": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "v2s_decode_attn": (C.c_int, [C.POINTER(DecodeAttnArgs), _vp]),
+    "v2s_decode_qfold": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _f32, _vp, _i32, _i32, _vp]),
+    "v2s_decode_memattn_plan": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "v2s_decode_memattn": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _f32, _vp, _vp, _i32, _vp]),
+    "v2s_decode_ctxfold": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
     "v2s_argmax_step": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "v2s_argmax_step_seq": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "v2s_kv_append": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
@@ -517,6 +521,48 @@ def decode_attn(B, H, Nk, q, q_bs, k, v, kv_bs, kv_rs, o, o_bs, bias_row=None, b
     a.new_k, a.new_v, a.new_bs = ptr(new_k), ptr(new_v), new_bs
     a.row_map, a.row_map_ld = ptr(row_map), row_map_ld
     _check(lib().v2s_decode_attn(C.byref(a), stream_ptr()), "v2s_decode_attn")
+
+
+def decode_qfold(x, rows, wq, wkT, rms_eps, qp, H, d, ldx=None):
+    """Folded cross-attention queries of a decode step: qp[rows, H, d] = per head ((rstd * x) Wq_h^T) Wk_h (v2s_decode_qfold)."""
+    for t, n in ((x, "x"), (wq, "wq"), (wkT, "wkT"), (qp, "qp")):
+        _need(t, torch.bfloat16, "decode_qfold " + n)
+    _check(lib().v2s_decode_qfold(x.data_ptr(), ldx if ldx is not None else d, rows, wq.data_ptr(), wkT.data_ptr(), rms_eps, qp.data_ptr(),
+                                  H, d, stream_ptr()), "v2s_decode_qfold")
+
+
+class MemAttnPlan:
+    """Host plan of the decode step's memory cross-attention (v2s_decode_memattn_plan): which block takes which key tiles of which
+    entry, and where the pieces of an entry land.  Built once per generate() call from the entries' valid memory lengths; owns the
+    device copies of the tables and the partial-sum buffers."""
+
+    def __init__(self, klen, R, device, target_blocks=256):
+        import numpy as np
+        klen = np.ascontiguousarray(np.asarray(klen, dtype=np.int32))
+        E = int(klen.shape[0])
+        cap = max(E, target_blocks) + E
+        blk = np.zeros((cap, 4), dtype=np.int32); off = np.zeros(E + 1, dtype=np.int32); nb = C.c_int32(0)
+        _check(lib().v2s_decode_memattn_plan(klen.ctypes.data, E, target_blocks, cap, blk.ctypes.data, off.ctypes.data, C.byref(nb)),
+               "v2s_decode_memattn_plan")
+        self.entries, self.R, self.nblk = E, R, int(nb.value)
+        self.blk_host, self.slot_off_host = blk[:self.nblk].copy(), off
+        self.blk = torch.from_numpy(self.blk_host).to(device)
+        self.slot_off = torch.from_numpy(off).to(device)
+        qr = (R + 15) // 16 * 16
+        self.part = torch.empty(self.nblk * qr * 768, dtype=torch.bfloat16, device=device)
+        self.ml = torch.empty(self.nblk * qr * 2, dtype=torch.float32, device=device)
+
+
+def decode_memattn(qp, mem, mem_es, plan: MemAttnPlan, d, scale=1.0):
+    _need(qp, torch.bfloat16, "decode_memattn qp"); _need(mem, torch.bfloat16, "decode_memattn mem")
+    _check(lib().v2s_decode_memattn(qp.data_ptr(), mem.data_ptr(), mem_es, plan.blk.data_ptr(), plan.nblk, plan.R, scale,
+                                    plan.part.data_ptr(), plan.ml.data_ptr(), d, stream_ptr()), "v2s_decode_memattn")
+
+
+def decode_ctxfold(plan: MemAttnPlan, rows, G, H, wv, ctx, d, ld_ctx=None):
+    _need(wv, torch.bfloat16, "decode_ctxfold wv"); _need(ctx, torch.bfloat16, "decode_ctxfold ctx")
+    _check(lib().v2s_decode_ctxfold(plan.part.data_ptr(), plan.ml.data_ptr(), plan.slot_off.data_ptr(), rows, G, H, wv.data_ptr(),
+                                    ctx.data_ptr(), ld_ctx if ld_ctx is not None else H * 64, d, stream_ptr()), "v2s_decode_ctxfold")
 
 
 def argmax_step(logits, ld, rows, V, next_tok, unfinished, eos_id, pad_id):
