@@ -34,8 +34,9 @@ extern "C" {
 
 /* 3 (round 4): v2s_attn_bwd's `delta` became a [B][H][Nq][4] workspace it WRITES, v2s_topp_sample_step gained top_k, dact=RELU with
  * dropout expects z = the post-dropout activation (round 3 changes that a version-2 caller would corrupt memory with);
- * + v2s_rowsumsq_range / v2s_timetoken_renorm_sq, options gemm_ps / gemm_ps_nst / gemm_w128 */
-#define V2S_ABI_VERSION 3
+ * + v2s_rowsumsq_range / v2s_timetoken_renorm_sq, options gemm_ps / gemm_ps_nst / gemm_w128
+ * 4 (round 4): + v2s_decode_qfold / v2s_decode_memattn_plan / v2s_decode_memattn / v2s_decode_ctxfold (additions only) */
+#define V2S_ABI_VERSION 4
 
 int v2s_version(void);
 const char* v2s_last_error(void);
@@ -341,11 +342,12 @@ int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream);
  *   score_h[k] = qp_h . mem_k,  ctx_h = Wv_h accn_h   -- one pass over [S, d] per layer (half the bytes, one tensor for all layers).
  * v2s_decode_qfold:   qp[rows][H][d] = per head ((rstd * x) Wq_h^T) Wk_h; x bf16 [rows][ldx]; wq bf16 [H*64][d] (RMSNorm weight
  *                     folded into its columns when rms_eps > 0, else rstd = 1); wkT bf16 [d][H*64] = the K projection transposed.
- * v2s_decode_memattn_plan (host only, no GPU work): cuts every entry's ceil(klen / 32) key tiles into pieces of at most tpb tiles, tpb the
- *                     smallest value for which there are <= target_blocks pieces (one block per piece; one block per CU and launch), so
- *                     that the blocks of a launch are equally long whatever the entries' lengths.  klen_host[e] >= 1 = the valid keys of
- *                     entry e (a prefix of its memory rows).  Writes blk[4 * nblk] = (entry, first tile | end tile << 16, slot, klen) and
- *                     slot_off[entries + 1] (the slots of entry e are slot_off[e] .. slot_off[e + 1], at most 64); both go to the device.
+ * v2s_decode_memattn_plan (host only, no GPU work): cuts every entry's ceil(klen / 32) key tiles into ceil(tiles / tiles_per_piece) pieces
+ *                     of equal length (one block per piece).  The cut of an entry depends on its own length only, so a sequence decodes
+ *                     bit-identically in any batch; 8 tiles per piece fill 256 CUs with 64 entries of ~1000 keys.  klen_host[e] >= 1 =
+ *                     the valid keys of entry e (a prefix of its memory rows).  Writes blk[4 * nblk] = (entry, first tile | end tile
+ *                     << 16, slot, klen) and slot_off[entries + 1] (the slots of entry e are slot_off[e] .. slot_off[e + 1], at most
+ *                     64); both go to the device.
  * v2s_decode_memattn: one block per blk entry: the R = beams * H consecutive rows of qp of its entry (R <= 48) against its key tiles of
  *                     mem + entry * mem_es (bf16 [.][d]); writes the piece's normalised sums to part[slot][R16][d] (bf16) and (running
  *                     max in the log2 domain, weight sum) to ml[slot][R16][2]; R16 = R rounded up to 16.
@@ -353,7 +355,7 @@ int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream);
  *                     query rows (row m = entry m / G, beam m % G); wv bf16 [H*64][d]; ctx bf16 with row stride ld_ctx. */
 int v2s_decode_qfold(const void* x, int64_t ldx, int32_t rows, const void* wq, const void* wkT, float rms_eps, void* qp, int32_t H,
                      int32_t d, void* stream);
-int v2s_decode_memattn_plan(const int32_t* klen_host, int32_t entries, int32_t target_blocks, int32_t max_blocks, int32_t* blk,
+int v2s_decode_memattn_plan(const int32_t* klen_host, int32_t entries, int32_t tiles_per_piece, int32_t max_blocks, int32_t* blk,
                             int32_t* slot_off, int32_t* nblk);
 int v2s_decode_memattn(const void* qp, const void* mem, int64_t mem_es, const int32_t* blk, int32_t nblk, int32_t R, float scale,
                        void* part, float* ml, int32_t d, void* stream);

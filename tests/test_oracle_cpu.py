@@ -478,6 +478,38 @@ def test_c_abi_exports_every_declared_symbol():
     assert l.v2s_gemm(ctypes.byref(a), None) != 0 and b"v2s_gemm" in l.v2s_last_error()
 
 
+def test_decode_memattn_plan_is_per_entry_and_covers_every_tile():
+    """v2s_decode_memattn_plan (host logic of the decode step's memory cross-attention, no GPU work): every entry's key tiles are
+    covered exactly once by consecutive pieces of at most tiles_per_piece tiles, slots are consecutive, and an entry's cut depends
+    on its own length only -- the property that makes a sequence decode bit-identically in any batch."""
+    from vidchapters_amd import lib as L
+    l = L.lib()
+    rng = np.random.default_rng(3)
+
+    def plan(klen, tpp, cap=4096):
+        klen = np.ascontiguousarray(klen, dtype=np.int32)
+        blk = np.zeros((cap, 4), dtype=np.int32); off = np.zeros(len(klen) + 1, dtype=np.int32); nb = ctypes.c_int32(0)
+        rc = l.v2s_decode_memattn_plan(klen.ctypes.data, len(klen), tpp, cap, blk.ctypes.data, off.ctypes.data, ctypes.byref(nb))
+        return rc, blk[:nb.value], off
+
+    for tpp in (1, 3, 8, 1000):
+        klen = rng.integers(1, 2049, size=37)                  # <= 64 tiles: at most 64 pieces even at one tile per piece
+        rc, blk, off = plan(klen, tpp)
+        assert rc == 0 and off[0] == 0 and off[-1] == len(blk)
+        for e, n in enumerate(klen):
+            nt = -(-int(n) // 32)
+            mine = blk[off[e]:off[e + 1]]
+            assert len(mine) == -(-nt // tpp) and (mine[:, 0] == e).all() and (mine[:, 3] == n).all()
+            assert (mine[:, 2] == np.arange(off[e], off[e + 1])).all()
+            t0, t1 = mine[:, 1] & 0xffff, mine[:, 1] >> 16
+            assert t0[0] == 0 and t1[-1] == nt and (t0[1:] == t1[:-1]).all() and (t1 > t0).all() and (t1 - t0 <= tpp).all()
+            alone = plan([n], tpp)[1]                      # the same entry on its own: the same cut
+            assert (alone[:, 1] == mine[:, 1]).all()
+    assert plan([5, 0, 7], 8)[0] != 0 and b"klen" in l.v2s_last_error()
+    assert plan([100000], 1)[0] != 0                      # more than 64 pieces
+    assert plan([4000, 4000], 8, cap=20)[0] != 0          # table too small
+
+
 # ---------------------------------------------------------------------------------------------- evaluation metrics (§8f N4)
 def _eval_golden(golden_dir):
     import json

@@ -1,5 +1,6 @@
 """Interleaved A/B of library options on the cached greedy / beam decode loop (B = 64 videos, t5-base, 100 frames + 1000 ASR tokens).
 Usage: python tools/decode_ab.py [opt=value,opt=value ...]   e.g.  python tools/decode_ab.py gemm_skinny=2 gemm_skinny=1 gemm_skinny=3
+(engine attributes with the eng: prefix: eng:decode_mem_attn=0 eng:decode_mem_attn=1; env B, BEAMS, STEPS, ROUNDS)
 Each variant runs `rounds` times, interleaved; prints the per-variant median ms per decode step (whole greedy() call / steps, i.e. it
 includes the encoder prologue -- so the encoder-only time is measured too and subtracted)."""
 import os
@@ -21,7 +22,7 @@ def main():
     dev = torch.device("cuda")
     tok = SyntheticTokenizer(32100, 100)
     model = Vid2Seq("t5-base", tokenizer=tok, init_seed=1234, device=dev).eval()
-    b = synth.make_batch(64, 100, 1000, 8, len(tok), 4321, 768)
+    b = synth.make_batch(int(os.environ.get("B", "64")), 100, 1000, 8, len(tok), 4321, 768)
     ids = b["input_ids"].to(dev)
     vid = b["video"].to(dev).to(torch.bfloat16)
     eng = model.engine()
@@ -31,7 +32,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if beams > 1:
-            out = eng.beam_search(vid, inp, num_beams=beams, max_new_tokens=n)
+            out = eng.beam_search(vid, inp, num_beams=beams, max_new_tokens=n, min_length=n + 1)
         else:
             out = eng.greedy(vid, inp, max_new_tokens=n, stop_at_eos=False)
         torch.cuda.synchronize()
@@ -44,12 +45,19 @@ def main():
             saved = []
             for kv in v.split(","):
                 k, x = kv.split("=")
+                if k.startswith("eng:"):              # engine attribute, e.g. "eng:decode_mem_attn=0"
+                    saved.append((k, getattr(eng, k[4:])))
+                    setattr(eng, k[4:], int(x))
+                    continue
                 saved.append((k, L.get_option(k)))
                 L.set_option(k, int(x))
             t_short, _ = run(2)
             t_long, out = run(steps + 2)
             for k, x in saved:
-                L.set_option(k, x)
+                if k.startswith("eng:"):
+                    setattr(eng, k[4:], x)
+                else:
+                    L.set_option(k, x)
             if r:
                 res[v].append((t_long - t_short) / steps)
             toks[v] = out

@@ -13,246 +13,241 @@
 //   v2s_decode_ctxfold : merges the splits and applies Wv_h: ctx[m, h*64..] = Wv_h accn[m, h]
 // d = 768, head width 64 (t5-base); other widths keep the K/V-cache path (v2s_decode_attn).
 #include <math.h>
-#include <stdlib.h>
 #include "v2s_common.h"
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (a native vector: HIP's uint4 struct is copied by memcpy, which keeps arrays of it in scratch)
 constexpr int D = 768;            // model width = memory row
 constexpr int DH = 64;            // head width
-constexpr int CW = 24;            // 16-byte chunks per wave slice of a row (192 columns)
-constexpr int TK = 32;            // keys per tile
-constexpr int WTILE = TK * CW * 16;        // 12 KiB: one wave's [32 keys][192 columns] piece of a tile
-constexpr int STAGE = 4 * WTILE;           // 48 KiB
+constexpr int RC = D / 8;         // 16-byte chunks per row (96)
+constexpr int TK = 32;            // keys per plan tile (a block takes whole tiles; a wave works on 16 keys at a time)
+constexpr int QS_BYTES = 16 * D * 2;       // 24 KiB: the block's 16 folded query rows
+constexpr int TB_BYTES = 16 * D * 2;       // 24 KiB per wave: its current [16 keys][768] piece, staged for the transposing read
 
-__device__ __forceinline__ uint32_t ma_lds_addr(const void* p) {
-  return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
-}
-// LDS image of a wave's tile piece: row r (key), chunk c (0..23) at (r * 24 + swz(c, r)) * 16.  The swizzle keeps both fragment reads
-// conflict-free: the 16 rows of a score fragment (rows 8a + 4t + b) differ in (r0, r1, r3, r4) -> r0 flips bit 3 of the slot through
-// the 24-chunk row stride, (r1, r3, r4) go to chunk bits (1, 2, 0); the 4 rows x 2 chunks of a transposing read differ in r0, r1.
-__device__ __forceinline__ int ma_swz(int c, int r) {
-  const int f = (((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2) | ((r >> 4) & 1);
-  return c ^ f;                  // f < 8: stays inside the aligned group of 8 chunks
-}
+// LDS images, 16-byte chunk c (0..95) of row r at (r * 96 + swz(c, r)) * 16 (rows are 1536 B = 6 x 256 B apart: without a swizzle all
+// rows of a chunk column share their banks).  Query image: the 16 rows of one chunk column (one ds_read_b128 lane group) -> 16
+// slots.  Tile image: written by ds_write_b128 (8 consecutive lanes = 8 keys of one chunk column) and read by ds_read_b64_tr_b16 (a
+// 16-lane group = 4 keys x 2 chunks x 2 halves): key bits (0, 1) go to chunk bits (1, 2), key bit 2 to chunk bit 0 -- both conflict-free.
+__device__ __forceinline__ int q_swz(int c, int r) { return c ^ (r & 15); }
+__device__ __forceinline__ int t_swz(int c, int r) { return c ^ (((r & 3) << 2) | ((r >> 2) & 3)); }
 
 struct MemAttnP {
   const bf16_t* qp;                // [entries * R][D]
   const bf16_t* mem; long mem_es;  // [entries][S][D], entry stride in elements
   const int4* blk;                 // [gridDim.x]: (entry, first tile | end tile << 16, output slot, valid keys of the entry)
-  bf16_t* part;                    // [slots][QT*16][D]: per-piece normalised sums
-  float* ml;                       // [slots][QT*16][2]: running max (log2 domain), sum of weights
+  bf16_t* part;                    // [slots][qr][D]: per-piece normalised sums
+  float* ml;                       // [slots][qr][2]: running max (log2 domain), sum of weights
   int R, qr;                       // query rows per entry, padded to 16 (row stride of part / ml slots)
   float scale_log2;                // scale * log2(e)
-  int dbg;
 };
 
-// One block (4 waves, the only block of its CU: 152 KiB of LDS) per piece of an entry's key range (v2s_decode_memattn_plan).  Wave w owns columns [192 w, 192 w + 192) of the
-// memory rows for BOTH products: its share of the contraction of the scores, and its own output columns of the weighted sum -- so a
-// tile piece is fetched (LDS-DMA), waited for and read by one wave only; the four score partials are summed through LDS (two
-// barriers per tile).  Transposed formulation like decode_attn_mfma_kernel: S^T = tile . qp^T (fragment row q of key tile t stands
-// for key 8 (q >> 2) + 4 t + (q & 3), so lane (q, g) ends up with keys 8 g .. 8 g + 7 of query q: the layout the second product wants
-// its B operand in), acc^T = tile^T . P^T with the tile's transpose from ds_read_b64_tr_b16, P in bf16 (like the training kernels).
-__device__ __forceinline__ void ma_dma12(const uint32_t (&o)[12], const char* src, uint32_t dst) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %[keep], m0\n\t"
-      "s_mov_b32 m0, %[dst]\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %[o0], %[src]\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %[o1], %[src]\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %[o2], %[src]\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %[o3], %[src]\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %[o4], %[src]\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %[o5], %[src]\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %[o6], %[src]\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %[o7], %[src]\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %[o8], %[src]\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %[o9], %[src]\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %[o10], %[src]\n\t"
-      "s_add_u32 m0, m0, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %[o11], %[src]\n\t"
-      "s_mov_b32 m0, %[keep]"
-      : [keep] "=&s"(keep)
-      : [dst] "s"(dst), [src] "s"(src), [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3]), [o4] "v"(o[4]), [o5] "v"(o[5]),
-        [o6] "v"(o[6]), [o7] "v"(o[7]), [o8] "v"(o[8]), [o9] "v"(o[9]), [o10] "v"(o[10]), [o11] "v"(o[11])
-      : "memory", "scc");
-}
-
-template <int QT>
+// One block (4 waves, one per SIMD: 192 accumulator + ~230 other registers) per (piece of an entry's key range -- v2s_decode_memattn_plan --,
+// 16 query rows).  Every
+// wave is an independent flash-attention stream over its own 16-key groups of the piece (groups w, w + 4, ...) and ALL 768 columns:
+//   * its [16 keys][768] piece arrives straight in registers in the MFMA A layout (lane = (key, 8-column group)), the next piece is
+//     requested before this one is used: 24-48 KiB per wave in flight, no barrier and no LDS hand-off between waves in the loop;
+//   * S^T[16 keys x 16 queries] = piece . qp^T: 24 MFMAs (16x16x32) against the folded queries in LDS; lane (query, g) then holds
+//     the scores of keys 4 g .. 4 g + 3 -- which is the B layout of v_mfma_f32_16x16x16_bf16, so the weights go from the softmax
+//     registers into the second product as they are;
+//   * acc^T[768 x 16 queries] += piece^T . P^T: the piece's transpose comes from its LDS copy through ds_read_b64_tr_b16 (one read per
+//     MFMA), 48 column tiles;
+//   * the running maximum is lazy: the accumulators (192 registers in AGPRs) are rescaled only when the maximum grows by more than
+//     2^8 -- the first group, then almost never; weights stay <= 2^8.
+// The four streams are merged through LDS (round r: wave r publishes its accumulators, every wave adds its own 192 output columns)
+// and written as one normalised partial per piece; pieces are merged by ctxfold_kernel.
 __global__ __launch_bounds__(256, 1) void mem_attn_kernel(const MemAttnP p) {
-  constexpr int NST = 3;                         // tiles in the ring (LDS: 3 * 48 KiB + QT * 8 KiB of score partials)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s_part = reinterpret_cast<float*>(smem + NST * STAGE);          // [4 waves][QT][2 x f32x4][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane & 15, g = lane >> 4;
-  const int4 bk = p.blk[blockIdx.x];                          // (entry, first tile | end tile << 16, output slot, valid keys of the entry)
-  const int ent = bk.x, t0 = bk.y & 0xffff, n = (bk.y >> 16) - t0, klen = bk.w;      // n >= 1: the plan never emits an empty piece
-  const int qt0 = blockIdx.y * QT;                            // first query tile (of 16 rows) of this block
+  const int4 bk = p.blk[blockIdx.x];
+  const int ent = bk.x, t0 = bk.y & 0xffff, t1 = bk.y >> 16, klen = bk.w;
+  const int qt0 = blockIdx.y;                                 // which 16 of the entry's query rows
   const long orow = (long)bk.z * p.qr + qt0 * 16;
-  // LDS-DMA source offsets of the wave's 12 KiB piece (12 instructions of 64 x 16 B): position P = j * 64 + lane of the image
-  uint32_t doff[12];
-#pragma unroll
-  for (int j = 0; j < 12; ++j) {
-    const int P = j * 64 + lane, r = P / CW, cp = P % CW;
-    doff[j] = (uint32_t)(r * (D * 2) + (wave * CW + ma_swz(cp, r)) * 16);
-  }
+  const int kbase = t0 * TK, kend = min(klen, t1 * TK);      // kbase < kend: the plan never emits an empty piece
+  char* qs = smem;
+  char* tbw = smem + QS_BYTES + wave * TB_BYTES;
   const char* mbase = reinterpret_cast<const char*>(p.mem + (long)ent * p.mem_es);
-  const uint32_t lds0 = ma_lds_addr(smem) + wave * WTILE;
-  auto issue = [&](int i) {                       // tile i of this block -> ring stage i % NST
-    const int key0 = (t0 + i) * TK;
-    const char* src = mbase + (long)key0 * (D * 2);
-    const uint32_t dst = lds0 + (i % NST) * STAGE;
-    const int last = klen - 1 - key0;             // rows past the last valid key re-read it (scored -inf below)
-    if (last >= TK - 1) {
-      ma_dma12(doff, src, dst);
-    } else {
-      uint32_t o[12];
-#pragma unroll
-      for (int j = 0; j < 12; ++j) {
-        const int r = (j * 64 + lane) / CW;
-        o[j] = doff[j] - (uint32_t)((r > last ? r - last : 0) * (D * 2));
-      }
-      ma_dma12(o, src, dst);
-    }
-  };
-  // the first tiles are requested before anything else is loaded: their latency covers the query fragments'
-  issue(0);
-  if (n > 1) issue(1);
-  // folded queries as B operands: column = query row, 8 consecutive k per lane, this wave's 6 k-steps.  (These loads are younger
-  // than the DMAs above: the counted waits below only ever become stricter by them.)
-  bf16x8 qf[QT][6];
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int r = (qt0 + qt) * 16 + q;
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (r < p.R) v = *reinterpret_cast<const uint4*>(p.qp + ((long)ent * p.R + r) * D + wave * 192 + ks * 32 + g * 8);
-      qf[qt][ks] = __builtin_bit_cast(bf16x8, v);
-    }
+  // global -> registers: the 16 rows of a piece are one contiguous 24 KiB block; instruction i fetches its chunks 64 i .. 64 i + 63
+  // (1 KiB, whole cache lines -- fragment-shaped loads, 16 rows x 64 B per instruction, ran at half this rate).  Rows past the valid
+  // prefix re-read the entry's last row (their weight is 0 below).
+#define MA_LOAD(key0_)                                                                                                       \
+  {                                                                                                                          \
+    const int last_ = klen - 1 - (key0_);                                                                                    \
+    const char* src_ = mbase + (long)(key0_) * (D * 2);             /* wave-uniform */                                       \
+    if (last_ >= 15) {                                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < 24; ++i) t[i] = *reinterpret_cast<const u32x4*>(src_ + (uint32_t)(lane * 16 + i * 1024)); \
+    } else {                                                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < 24; ++i) {                                                                      \
+        /* row of chunk 64 i + lane: (64 i) / 96, one more from lane 96 - (64 i) % 96 on (compile-time threshold: a mask, no register) */ \
+        const int r_ = (i * 64) / RC + (lane >= RC - (i * 64) % RC ? 1 : 0);                                                 \
+        const int back_ = last_ < 0 ? r_ - last_ : (r_ > last_ ? r_ - last_ : 0);   /* rows to step back to the last valid one */ \
+        t[i] = *reinterpret_cast<const u32x4*>(src_ + (long)(lane * 16 + i * 1024 - back_ * (D * 2)));                      \
+      }                                                                                                                      \
+    }                                                                                                                        \
   }
-  float m[QT], l[QT];
-  f32x4 acc[QT][12];
+  // the block's folded queries (rows beyond R read as zero): requested first -- they are small and the barrier below waits for them
+  uint4 qv[6];
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    m[qt] = -INFINITY; l[qt] = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < 12; ++ct) acc[qt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 6; ++i) {
+    const int idx = tid + 256 * i, r = idx / RC, c = idx % RC;
+    const int gr = qt0 * 16 + r;
+    qv[i] = make_uint4(0, 0, 0, 0);
+    if (gr < p.R) qv[i] = *reinterpret_cast<const uint4*>(p.qp + ((long)ent * p.R + gr) * D + c * 8);
   }
-  for (int i = 0; i < n; ++i) {
-    // this wave's reads of the stage being refilled were consumed by MFMAs of the previous iteration: wave-private, no barrier
-    if (i + NST - 1 < n && p.dbg != 2) issue(i + NST - 1);
-    if (p.dbg == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (i + 2 < n) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (i + 1 < n) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (p.dbg == 1) continue;
-    const char* tile = smem + (p.dbg == 2 ? 0 : (i % NST)) * STAGE + wave * WTILE;
-    // ---- partial scores over this wave's 192 columns
-    f32x4 s[QT][2];
+  u32x4 t[24];                                                // the wave's current 16-key piece, 24 x 1 KiB (96 registers)
+  int j = wave;
+  bool have = kbase + 16 * j < kend;
+  MA_LOAD(kbase + 16 * j)
+  // (everything that does not depend on the loads goes before the barrier: it runs under their latency)
+  float mref = -INFINITY, l = 0.f;
+  f32x4 acc[48];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) { s[qt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[qt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int ct = 0; ct < 48; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // LDS addresses as (a few per-lane bases) + compile-time offsets (one address register per access would not fit).  Reads: the
+  // swizzles only touch the low 4 chunk bits, so chunk 16 a + b is base[b] + a * 256 bytes.  Writes: instruction i = 3 m + e puts chunk
+  // ce(lane) of row 2 m + re(lane); the swizzle term of that row is K(m) ^ (re << 2) with K(m) = ((m & 1) << 3) | (m >> 1) known at
+  // compile time, so the address is (w3[e] ^ (K(m) << 4)) + m * 3072.
+  uint32_t w3[3], ab[4], qb[4], rb[8];
+  {
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const int row = (q >> 2) * 8 + 4 * kt + (q & 3), c = ks * 4 + g;
-        const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tile + (row * CW + ma_swz(c, row)) * 16));
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[qt][ks], s[qt][kt], 0, 0, 0);
-      }
+    for (int e = 0; e < 3; ++e) {
+      const int P = e * 64 + lane, re = P / RC, ce = P % RC;
+      w3[e] = (uint32_t)((re * RC + (ce ^ (re << 2))) * 16);
     }
-    __syncthreads();                                      // every wave has read the previous tile's partials
+    const int r0 = 4 * g + (q >> 2), x = (q & 3) >> 1;
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
+    for (int e = 0; e < 4; ++e) {
+      ab[e] = (uint32_t)((q * RC + t_swz(e * 4 + g, q)) * 16);          // score A fragment: row = key q, chunk 16 a + 4 e + g
+      qb[e] = (uint32_t)((q * RC + q_swz(e * 4 + g, q)) * 16);
+    }
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-        *reinterpret_cast<f32x4*>(s_part + (((wave * QT + qt) * 2 + kt) * 64 + lane) * 4) = s[qt][kt];
-    __syncthreads();
-    const int kc = (t0 + i) * TK;
-    bf16x8 ph[QT];
+    for (int e = 0; e < 8; ++e) rb[e] = (uint32_t)((r0 * RC + t_swz(2 * e + x, r0)) * 16 + (q & 1) * 8);   // transposing read: chunk 16 a + 2 e + x
+  }
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  for (int i = 0; i < 6; ++i) {
+    const int idx = tid + 256 * i, r = idx / RC, c = idx % RC;
+    *reinterpret_cast<uint4*>(qs + (r * RC + q_swz(c, r)) * 16) = qv[i];
+  }
+  __syncthreads();
+  while (have) {
+    const int key0 = kbase + 16 * j;
+    asm volatile("" : "+v"(w3[0]), "+v"(w3[1]), "+v"(w3[2]));       // (opaque: keeps the 24 xor-ed addresses from being hoisted into registers)
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {                      // fixed order: the four waves compute identical sums
-        s0 += *reinterpret_cast<const f32x4*>(s_part + (((w * QT + qt) * 2 + 0) * 64 + lane) * 4);
-        s1 += *reinterpret_cast<const f32x4*>(s_part + (((w * QT + qt) * 2 + 1) * 64 + lane) * 4);
-      }
-      float sv[8];                                        // log2 domain: exp(x) = exp2(x log2 e)
+    for (int i = 0; i < 24; ++i) {
+      const int m = i / 3, K = ((m & 1) << 3) | (m >> 1);
+      *reinterpret_cast<u32x4*>(tbw + (w3[i % 3] ^ (uint32_t)(K << 4)) + m * 3072) = t[i];
+    }
+    // the staged copy doubles as register spill space: the piece's registers take the NEXT piece right away (in flight during this
+    // whole iteration), and the score product reads its A fragments back from LDS (each lane exactly what it wrote)
+    j += 4;
+    have = kbase + 16 * j < kend;
+    MA_LOAD(kbase + 16 * j)                     // (past the end: re-reads the entry's last row, never used)
+    f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sa;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) sv[e] = (e < 4 ? s0[e & 3] : s1[e & 3]) * p.scale_log2;
-      if (kc + TK > klen) {                               // only the last tile of an entry has keys past the valid prefix
+    for (int ks = 0; ks < 24; ks += 2) {
+      const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tbw + ab[ks & 3] + (ks >> 2) * 256));
+      const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tbw + ab[(ks + 1) & 3] + (ks >> 2) * 256));
+      const bf16x8 b0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qs + qb[ks & 3] + (ks >> 2) * 256));
+      const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qs + qb[(ks + 1) & 3] + (ks >> 2) * 256));
+      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, sa, 0, 0, 0);
+      sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, sb, 0, 0, 0);
+      if ((ks & 3) == 2) __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads from being hoisted wholesale (registers)
+    }
+    float sv[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sv[e] = kc + 8 * g + e < klen ? sv[e] : -INFINITY;
-      }
-      float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    for (int i = 0; i < 4; ++i) sv[i] = (sa[i] + sb[i]) * p.scale_log2;          // lane (query q, g): keys key0 + 4 g + i
+    if (key0 + 16 > klen) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sv[i] = key0 + 4 * g + i < klen ? sv[i] : -INFINITY;
+    }
+    // Reference of the exponentials: the maximum of the query's FIRST key group.  The accumulators (192 AGPRs) are never rescaled --
+    // a multiply would pull them through VGPRs --: weights may grow to 2^64 (fp32 / bf16 have the exponent range for it), and if a
+    // query's scores ever jump by more than that (44 nats) the wave raises that query's reference and redoes its stream from the
+    // first group (exact, and next to never taken).
+    const float mxl = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+    if (__builtin_amdgcn_ballot_w64(mxl > mref + 64.0f)) {                        // (-inf + 64 = -inf: always true for the first group)
+      float mx = fmaxf(mxl, __shfl_xor(mxl, 16, 64));                             // per query: over the four key groups
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m[qt], mx);                  // finite: a visited tile has a key < klen
-      float pr[8], ps = 0.f;
+      const bool jump = mx > mref + 64.0f;
+      const bool redo = __builtin_amdgcn_ballot_w64(jump && mref != -INFINITY) != 0;      // not the first group: sums exist
+      mref = jump ? mx : mref;
+      if (redo) {
+        l = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { pr[e] = __builtin_amdgcn_exp2f(sv[e] - mn); ps += pr[e]; }
-      if (__builtin_amdgcn_ballot_w64(mn != m[qt])) {     // the running maximum settles after a few tiles: no rescale then
-        const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);
-        l[qt] *= alpha;
-#pragma unroll
-        for (int ct = 0; ct < 12; ++ct) acc[qt][ct] *= alpha;
-        m[qt] = mn;
+        for (int ct = 0; ct < 48; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        j = wave;
+        have = true;
+        MA_LOAD(kbase + 16 * j)
+        continue;
       }
-      l[qt] += ps;
-      const uint4 uh = make_uint4(pack2bf(pr[0], pr[1]), pack2bf(pr[2], pr[3]), pack2bf(pr[4], pr[5]), pack2bf(pr[6], pr[7]));
-      ph[qt] = __builtin_bit_cast(bf16x8, uh);
     }
-    // ---- weighted sum of this wave's columns: A = tile^T (row = column 16 ct + q, 8 consecutive keys 8 g .. 8 g + 7)
+    float pr[4];
 #pragma unroll
-    for (int ct = 0; ct < 12; ++ct) {
-      const int r0 = g * 8 + (q >> 2), r1 = r0 + 4, c = 2 * ct + ((q & 3) >> 1), hb8 = (q & 1) * 8;
-      const s16x4 vlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((V2S_LDS s16x4*)(tile + (r0 * CW + ma_swz(c, r0)) * 16 + hb8));
-      const s16x4 vhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((V2S_LDS s16x4*)(tile + (r1 * CW + ma_swz(c, r1)) * 16 + hb8));
-      const s16x8 vv = {vlo[0], vlo[1], vlo[2], vlo[3], vhi[0], vhi[1], vhi[2], vhi[3]};
-      const bf16x8 a = __builtin_bit_cast(bf16x8, vv);
+    for (int i = 0; i < 4; ++i) pr[i] = __builtin_amdgcn_exp2f(sv[i] - mref);
+    l += (pr[0] + pr[1]) + (pr[2] + pr[3]);
+    const uint2 pu = make_uint2(pack2bf(pr[0], pr[1]), pack2bf(pr[2], pr[3]));
+    const s16x4 pb = __builtin_bit_cast(s16x4, pu);
+    // groups of 8 column tiles, the next group's transposing reads requested before this group's MFMAs (one wave per SIMD: nothing else
+    // hides the LDS latency)
+    s16x4 ta[2][8];
 #pragma unroll
-      for (int qt = 0; qt < QT; ++qt) acc[qt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ph[qt], acc[qt][ct], 0, 0, 0);
+    for (int e = 0; e < 8; ++e) ta[0][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((V2S_LDS s16x4*)(tbw + rb[e]));
+#pragma unroll
+    for (int gq = 0; gq < 6; ++gq) {
+      if (gq < 5) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          ta[(gq + 1) & 1][e] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((V2S_LDS s16x4*)(tbw + rb[e] + (gq + 1) * 256));
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[gq * 8 + e] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ta[gq & 1][e], pb, acc[gq * 8 + e], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // 8 DS reads (the next group) ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      // ... then 8 MFMAs (this group)
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // ---- write the split's partial: lane (query q, group g) holds columns 192 w + 16 ct + 4 g + 0..3
+  // ---- merge the four streams: every wave publishes its sums as bf16 (the exponent range of fp32: no normalisation needed) in its
+  // own staging buffer, then adds up its 192 output columns of all four with the streams' weights exp2(m_w - M) / L
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  __syncthreads();                                   // every wave is done with the query image
+  float* sm = reinterpret_cast<float*>(smem);        // [4 waves][16 queries][2]
+  if (g == 0) { sm[(wave * 16 + q) * 2] = mref; sm[(wave * 16 + q) * 2 + 1] = l; }
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    float ls = l[qt];
-    ls += __shfl_xor(ls, 16, 64);
-    ls += __shfl_xor(ls, 32, 64);
-    const float inv = 1.0f / ls;
-    const long row = orow + qt * 16 + q;
-    if (wave == 0 && g == 0) { p.ml[row * 2] = m[qt]; p.ml[row * 2 + 1] = ls; }
+  for (int ct = 0; ct < 48; ++ct)                    // [48 column tiles][64 lanes] x 4 bf16
+    *reinterpret_cast<uint2*>(tbw + (ct * 64 + lane) * 8) = make_uint2(pack2bf(acc[ct][0], acc[ct][1]), pack2bf(acc[ct][2], acc[ct][3]));
+  __syncthreads();
+  float M = -INFINITY;
 #pragma unroll
-    for (int ct = 0; ct < 12; ++ct) {
-      const uint2 o = make_uint2(pack2bf(acc[qt][ct][0] * inv, acc[qt][ct][1] * inv), pack2bf(acc[qt][ct][2] * inv, acc[qt][ct][3] * inv));
-      *reinterpret_cast<uint2*>(p.part + row * D + wave * 192 + ct * 16 + g * 4) = o;
+  for (int w = 0; w < 4; ++w) M = fmaxf(M, sm[(w * 16 + q) * 2]);
+  float sc[4], L = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float mw = sm[(w * 16 + q) * 2];
+    sc[w] = mw == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw - M);      // a wave without a key group has weight 0
+    L += sc[w] * sm[(w * 16 + q) * 2 + 1];
+  }
+  const float inv = 1.0f / L;
+  float fw[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) fw[w] = sc[w] * inv;
+  const long row = orow + q;
+  if (wave == 0 && g == 0) { p.ml[row * 2] = M; p.ml[row * 2 + 1] = L; }
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    f32x2 oe = f32x2{0.f, 0.f}, oo = oe;               // even / odd elements (packed fp32 FMAs)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint2 u = *reinterpret_cast<const uint2*>(smem + QS_BYTES + w * TB_BYTES + ((wave * 12 + c) * 64 + lane) * 8);
+      const f32x2 f = f32x2{fw[w], fw[w]};
+      oe += f * f32x2{__uint_as_float(u.x << 16), __uint_as_float(u.y << 16)};
+      oo += f * f32x2{__uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y & 0xffff0000u)};
     }
+    const float o[4] = {oe[0], oo[0], oe[1], oo[1]};
+    *reinterpret_cast<uint2*>(p.part + row * D + wave * 192 + c * 16 + g * 4) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
   }
 }
 
@@ -368,11 +363,13 @@ struct CtxFoldP {
 };
 
 // One block per (head, row tile of 16): ctx_h^T[64 x 16] = Wv_h accn_h^T with the pieces merged on the fly (weights
-// l_s exp2(m_s - max) / sum: per lane, its row's; kept in LDS).  The four waves split the contraction (192 columns each) and are
-// summed through LDS.  The piece loop is unrolled by four: 24 independent 16-byte loads in flight per lane.
+// l_s exp2(m_s - max) / sum: per lane, its row's).  The four waves split the contraction (192 columns each) and are summed through LDS.
+// Everything a wave needs from memory is requested before anything is computed: its Wv fragments, the first four pieces' sums, the
+// (max, weight sum) pairs -- the kernel is one round trip, not a chain of them.  Each wave derives the merge weights itself
+// (wave-private LDS rows, no barrier).
 __global__ __launch_bounds__(256) void ctxfold_kernel(const CtxFoldP p) {
   __shared__ __attribute__((aligned(16))) float red[4][4][64][4];
-  __shared__ float wsh[16][65];
+  __shared__ float wsh[4][16][65];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane & 15, g = lane >> 4;
   const int h = blockIdx.x, rt = blockIdx.y;
@@ -382,12 +379,19 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const CtxFoldP p) {
   const int s0 = p.slot_off[ent], ns = p.slot_off[ent + 1] - s0;         // 1 <= ns <= 64
   const long prow0 = (long)s0 * p.qr + r;                                 // + s * qr
   const bf16_t* wr = p.wv + ((long)h * DH + q) * D + wave * 192 + g * 8;
+  const bf16_t* pr = p.part + prow0 * D + wave * 192 + g * 8;
+  const long pstep = (long)p.qr * D;
   uint4 wf[6][4];
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
     for (int t = 0; t < 4; ++t) wf[ks][t] = *reinterpret_cast<const uint4*>(wr + (long)t * 16 * D + ks * 32);
-  if (wave == 0) {                                    // merge weights of the 16 rows: lanes (q, g) take pieces g, g + 4, ...
+  uint4 v0[4][6];                                     // the first four pieces (pieces past ns re-read the last one, weight 0)
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) v0[u][ks] = *reinterpret_cast<const uint4*>(pr + (u < ns ? u : ns - 1) * pstep + ks * 32);
+  {                                                   // merge weights of the 16 rows: lanes (q, g) take pieces g, g + 4, ...
     float mmax = -INFINITY;
     for (int s = g; s < ns; s += 4) mmax = fmaxf(mmax, p.ml[(prow0 + (long)s * p.qr) * 2]);
     mmax = fmaxf(mmax, __shfl_xor(mmax, 16, 64));
@@ -396,23 +400,32 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const CtxFoldP p) {
     for (int s = g; s < ns; s += 4) {
       const float* e = p.ml + (prow0 + (long)s * p.qr) * 2;
       const float w = e[1] * __builtin_amdgcn_exp2f(e[0] - mmax);
-      wsh[q][s] = w;
+      wsh[wave][q][s] = w;
       wsum += w;
     }
     wsum += __shfl_xor(wsum, 16, 64);
     wsum += __shfl_xor(wsum, 32, 64);
-    if (g == 0) wsh[q][64] = live ? 1.0f / wsum : 0.f;
+    if (g == 0) wsh[wave][q][64] = live ? 1.0f / wsum : 0.f;
   }
-  __syncthreads();
-  const float winv = wsh[q][64];
+  __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): this wave's weights are in LDS
+  const float winv = wsh[wave][q][64];
   float a8[6][8];
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
     for (int e = 0; e < 8; ++e) a8[ks][e] = 0.f;
-  const bf16_t* pr = p.part + prow0 * D + wave * 192 + g * 8;
-  const long pstep = (long)p.qr * D;
-  int s = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float w = u < ns ? wsh[wave][q][u] * winv : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+      float f[8];
+      unpack8(v0[u][ks], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a8[ks][e] += w * f[e];
+    }
+  }
+  int s = 4;
   for (; s + 4 <= ns; s += 4) {
     uint4 v[4][6];
 #pragma unroll
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const CtxFoldP p) {
       for (int ks = 0; ks < 6; ++ks) v[u][ks] = *reinterpret_cast<const uint4*>(pr + (s + u) * pstep + ks * 32);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float w = wsh[q][s + u] * winv;
+      const float w = wsh[wave][q][s + u] * winv;
 #pragma unroll
       for (int ks = 0; ks < 6; ++ks) {
         float f[8];
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const CtxFoldP p) {
     uint4 v[6];
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) v[ks] = *reinterpret_cast<const uint4*>(pr + s * pstep + ks * 32);
-    const float w = wsh[q][s] * winv;
+    const float w = wsh[wave][q][s] * winv;
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
       float f[8];
@@ -481,36 +494,18 @@ extern "C" int v2s_decode_qfold(const void* x, int64_t ldx, int32_t rows, const 
   return V2S_OK;
 }
 
-// Host-side plan of v2s_decode_memattn (no GPU work): cuts every entry's ceil(klen / 32) key tiles into pieces of at most `tpb` tiles,
-// tpb = the smallest value for which the pieces number <= target_blocks (one block per CU and launch: 152 KiB of LDS each), so that
-// all blocks of the launch are equally long whatever the entries' lengths.  blk[i] = (entry, first tile | end tile << 16, slot, klen);
-// slot_off[e] .. slot_off[e + 1] = the entry's slots.  Returns the number of blocks through *nblk (<= max_blocks, else an error).
-extern "C" int v2s_decode_memattn_plan(const int32_t* klen_host, int32_t entries, int32_t target_blocks, int32_t max_blocks, int32_t* blk,
+// Host-side plan of v2s_decode_memattn (no GPU work): cuts every entry's ceil(klen / 32) key tiles into ceil(tiles / tiles_per_piece)
+// pieces of equal length (+-1 tile).  The cut of an entry depends on ITS length only -- never on the batch it is decoded in -- so a
+// sequence's result is bit-identical whatever the batch composition (like the K/V-cache kernel's).  8 tiles per piece = 256 keys
+// = four 16-key groups per wave: 64 entries of ~1000 keys fill the 256 CUs once.  blk[i] = (entry, first tile | end tile << 16, slot,
+// klen); slot_off[e] .. slot_off[e + 1] = the entry's slots.  Returns the number of blocks through *nblk (<= max_blocks, else an error).
+extern "C" int v2s_decode_memattn_plan(const int32_t* klen_host, int32_t entries, int32_t tiles_per_piece, int32_t max_blocks, int32_t* blk,
                                        int32_t* slot_off, int32_t* nblk) {
-  V2S_CHECK(klen_host && blk && slot_off && nblk && entries > 0 && target_blocks > 0, V2S_ERR_ARG, "v2s_decode_memattn_plan: bad arguments");
-  long total = 0;
-  int ntmax = 0;
-  for (int e = 0; e < entries; ++e) {
-    V2S_CHECK(klen_host[e] >= 1 && klen_host[e] <= 32 * 65535, V2S_ERR_SHAPE, "v2s_decode_memattn_plan: klen[%d] = %d (needs >= 1)", e, klen_host[e]);
-    const int nt = (klen_host[e] + TK - 1) / TK;
-    total += nt;
-    ntmax = nt > ntmax ? nt : ntmax;
-  }
-  int tpb = (int)((total + target_blocks - 1) / target_blocks);
-  if (tpb < 1) tpb = 1;
-  for (;; ++tpb) {
-    long nb = 0;
-    bool ok = true;
-    for (int e = 0; e < entries; ++e) {
-      const int nt = (klen_host[e] + TK - 1) / TK, sp = (nt + tpb - 1) / tpb;
-      if (sp > 64) ok = false;
-      nb += sp;
-    }
-    if ((ok && nb <= (entries > target_blocks ? entries : target_blocks)) || tpb >= ntmax) break;
-  }
+  V2S_CHECK(klen_host && blk && slot_off && nblk && entries > 0 && tiles_per_piece > 0, V2S_ERR_ARG, "v2s_decode_memattn_plan: bad arguments");
   int b = 0;
   for (int e = 0; e < entries; ++e) {
-    const int nt = (klen_host[e] + TK - 1) / TK, sp = (nt + tpb - 1) / tpb;
+    V2S_CHECK(klen_host[e] >= 1 && klen_host[e] <= 32 * 65535, V2S_ERR_SHAPE, "v2s_decode_memattn_plan: klen[%d] = %d (needs >= 1)", e, klen_host[e]);
+    const int nt = (klen_host[e] + TK - 1) / TK, sp = (nt + tiles_per_piece - 1) / tiles_per_piece;
     V2S_CHECK(sp <= 64, V2S_ERR_SHAPE, "v2s_decode_memattn_plan: entry %d needs %d pieces (> 64)", e, sp);
     slot_off[e] = b;
     for (int s = 0; s < sp; ++s, ++b) {
@@ -532,28 +527,17 @@ extern "C" int v2s_decode_memattn(const void* qp, const void* mem, int64_t mem_e
   MemAttnP p;
   p.qp = (const bf16_t*)qp; p.mem = (const bf16_t*)mem; p.mem_es = mem_es; p.blk = (const int4*)blk; p.part = (bf16_t*)part; p.ml = ml;
   p.R = R; p.scale_log2 = scale * 1.4426950408889634f;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("V2S_MEMATTN_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
-  // query tiles of 16 rows per block: one (R <= 16), two (R <= 32), else one per block and a grid row per tile -- three tiles in
-  // one block (144 accumulators + 72 query-fragment registers) spill, and scratch traffic would break the counted DMA waits
-  const int QT = R <= 16 ? 1 : (R <= 32 ? 2 : 1);
   p.qr = (R + 15) / 16 * 16;
-  const size_t lds = (size_t)3 * STAGE + (size_t)4 * QT * 2 * 64 * 16;
-  const dim3 grid(nblk, (p.qr / 16 + QT - 1) / QT), block(256);
-  hipStream_t s = (hipStream_t)stream;
-#define V2S_MA(QTV)                                                                                                         \
-  {                                                                                                                         \
-    static bool attr_set = false;                                                                                           \
-    if (!attr_set) {                                                                                                        \
-      if (hipFuncSetAttribute((const void*)mem_attn_kernel<QTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
-        v2s_set_error("v2s_decode_memattn: cannot raise the dynamic LDS limit to %zu", lds);                                \
-        return V2S_ERR_LAUNCH;                                                                                              \
-      }                                                                                                                     \
-      attr_set = true;                                                                                                      \
-    }                                                                                                                       \
-    hipLaunchKernelGGL(mem_attn_kernel<QTV>, grid, block, lds, s, p);                                                       \
+  const size_t lds = (size_t)QS_BYTES + 4 * (size_t)TB_BYTES;           // 120 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)mem_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      v2s_set_error("v2s_decode_memattn: cannot raise the dynamic LDS limit to %zu", lds);
+      return V2S_ERR_LAUNCH;
+    }
+    attr_set = true;
   }
-  if (QT == 1) V2S_MA(1) else V2S_MA(2)
-#undef V2S_MA
+  hipLaunchKernelGGL(mem_attn_kernel, dim3(nblk, p.qr / 16), dim3(256), lds, (hipStream_t)stream, p);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

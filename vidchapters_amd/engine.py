@@ -90,6 +90,9 @@ class Engine:
         self.kstream = torch.cuda.Stream(device=device)   # cross-attention K|V projections of all decoder layers (forward) / the d(memory) chain (backward)
         self.overlap_kv = True    # see decoder_forward / _cross_attn_bwd
         self.group_wgrads = True  # decoder / ViT weight gradients of one projection across the layers as ONE grouped launch (_wgrad, flush_wgrads)
+        self.decode_mem_attn = 1      # generate(): cross-attention of a decode step on the encoder memory itself instead of per-layer K / V caches
+                                      # (_cross_on_memory): 0 = never, 1 = greedy / sampling (default; beams keep the grouped K/V kernel, which measured
+                                      # faster at 4 beams x 16 entries), 2 = beam search with <= 4 beams too
         self.group_flush_layers = 4  # ... every this many decoder layers (the launches then run beside the NEXT layers' under-filled 8192-row kernels)
         self._wgrad_groups: Dict = {}
         self.shadow_events = None # sharded optimizer: {"vit" | "enc" | "dec": event after which that group's bf16 shadow weights are whole}
@@ -1072,6 +1075,45 @@ class Engine:
         mask = torch.cat(masks, 1).contiguous() if len(masks) == 2 else masks[0]
         return mem, mask
 
+    def _cross_on_memory(self, mem: torch.Tensor, mem_mask: torch.Tensor, G: int):
+        """Decode-step cross-attention WITHOUT per-layer K / V caches (csrc/v2s_memattn.hip): scores and weighted sums are taken on the
+        encoder memory itself with the K projection folded into the query and the V projection applied to the result -- half the bytes
+        of a step's largest stream, one tensor for all layers, and no cross K / V projection of the memory at all.  Needs d_model 768
+        with 64-wide heads, at most 48 query rows per entry (G beams x H heads), and the usual memory mask (a prefix of valid rows
+        per entry, none empty); returns None otherwise and the K / V-cache path is used.  Returns ``attend(i, x, rows, ctx, folded)``."""
+        a, c = self.arena, self.cfg
+        B, S, d = mem.shape
+        H, inner = self.H, self.inner
+        if not self.decode_mem_attn or (G > 1 and self.decode_mem_attn < 2) or d != 768 or inner != H * 64 or G * H > 48:
+            return None
+        m = mem_mask.to(torch.bool)
+        ok = bool((m[:, 1:] <= m[:, :-1]).all().item()) if S > 1 else True
+        klen = m.sum(1).to(torch.int32)
+        klen_h = klen.tolist()
+        if not ok or min(klen_h) < 1:
+            return None
+        plan = L.MemAttnPlan(klen_h, G * H, self.device)
+        wkT, wv = [], []
+        for i in range(c.n_dec):
+            kvw = a.w(self._ca(i) + "k.weight", (2 * inner, d))
+            wkT.append(kvw[:inner].t().contiguous())
+            wv.append(kvw[inner:])
+        qp = self._bf(B * G * H, d)
+        nrm = [None]
+
+        def attend(i, x, rows, ctx, wq_folded, eps):
+            """ctx[rows, inner] = cross-attention of layer i for the residual rows x (RMSNorm inside: folded weights + eps, or applied here)"""
+            if wq_folded is not None:
+                L.decode_qfold(x, rows, wq_folded, wkT[i], eps, qp, H, d)
+            else:
+                if nrm[0] is None:
+                    nrm[0] = (self._bf(rows, d), self._f32(rows))
+                L.rmsnorm_fwd(x, a.f(self._ln("decoder", i, 1)), nrm[0][0], nrm[0][1], rows, d, eps)
+                L.decode_qfold(nrm[0][0], rows, a.w(self._ca(i) + "q.weight"), wkT[i], 0.0, qp, H, d)
+            L.decode_memattn(qp, mem, S * d, plan, d)
+            L.decode_ctxfold(plan, rows, G, H, wv[i], ctx, d)
+        return attend
+
     def _decode_weights(self):
         """Per generate() call: decoder projection weights with the preceding RMSNorm weight folded into their columns
         (W' = W * diag(w_ln)), so that the decode step runs norm + projection as ONE skinny GEMM with the row scale
@@ -1108,8 +1150,9 @@ class Engine:
         B, S, d = mem.shape
         inner, H, nl = self.inner, self.H, c.n_dec
         mem2 = mem.view(B * S, d)
+        on_mem = self._cross_on_memory(mem, mem_mask, 1)
         cross = []
-        for i in range(nl):
+        for i in range(nl if on_mem is None else 0):
             kv = self._bf(B * S, 2 * inner)
             L.gemm(mem2, a.w(self._ca(i) + "k.weight", (2 * inner, d)), kv, B * S, 2 * inner, d)
             cross.append(kv)
@@ -1149,9 +1192,12 @@ class Engine:
                               ctx, inner, bias_row=diag, bias_ld=2 * maxlen - 1, pos_dev=pos, bias_maxlen=maxlen,
                               new_k=qkv[:, inner:], new_v=qkv[:, 2 * inner:], new_bs=3 * inner)       # cache append fused
                 L.gemm(ctx, a.w(sa + "o.weight"), h2, B, d, inner, residual=h, decode=True)
-                proj(h2, B, "cq", i, ca + "q.weight", (inner, d), 1, q)
-                L.decode_attn(B, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
-                              key_mask=mem_mask, mask_ld=S)
+                if on_mem is not None:
+                    on_mem(i, h2, B, ctx, fw["cq"][i] if fw is not None else None, eps)
+                else:
+                    proj(h2, B, "cq", i, ca + "q.weight", (inner, d), 1, q)
+                    L.decode_attn(B, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
+                                  key_mask=mem_mask, mask_ld=S)
                 L.gemm(ctx, a.w(ca + "o.weight"), h, B, d, inner, residual=h2, decode=True)
                 proj(h, B, "wi", i, fp + "wi.weight", (self.ff, d), 2, u, act=L.ACT_RELU)
                 L.gemm(u, a.w(fp + "wo.weight"), h2, B, d, self.ff, residual=h, decode=True)
@@ -1229,8 +1275,9 @@ class Engine:
         K = next((k for k in (2, 4, 8, 16, 32) if k >= 2 * nb), 2 * nb)
         inner, H, nl = self.inner, self.H, c.n_dec
         mem2 = mem.view(B * S, d)
+        on_mem = self._cross_on_memory(mem, mem_mask, nb)
         cross = []
-        for i in range(nl):
+        for i in range(nl if on_mem is None else 0):
             kv = self._bf(B * S, 2 * inner)
             L.gemm(mem2, a.w(self._ca(i) + "k.weight", (2 * inner, d)), kv, B * S, 2 * inner, d)
             cross.append(kv)
@@ -1290,9 +1337,12 @@ class Engine:
                               new_k=qkv[:, inner:], new_v=qkv[:, 2 * inner:], new_bs=3 * inner,         # cache append fused
                               row_map=row_map, row_map_ld=maxlen)
                 L.gemm(ctx, a.w(sa + "o.weight"), h2, R, d, inner, residual=h, decode=True)
-                proj(h2, "cq", i, ca + "q.weight", (inner, d), 1, q)
-                L.decode_attn(R, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
-                              key_mask=mem_mask, mask_ld=S, kv_group=nb)
+                if on_mem is not None:
+                    on_mem(i, h2, R, ctx, fw["cq"][i] if fw is not None else None, eps)
+                else:
+                    proj(h2, "cq", i, ca + "q.weight", (inner, d), 1, q)
+                    L.decode_attn(R, H, S, q, inner, cross[i], cross[i][:, inner:], S * 2 * inner, 2 * inner, ctx, inner,
+                                  key_mask=mem_mask, mask_ld=S, kv_group=nb)
                 L.gemm(ctx, a.w(ca + "o.weight"), h, R, d, inner, residual=h2, decode=True)
                 proj(h, "wi", i, fp + "wi.weight", (self.ff, d), 2, u, act=L.ACT_RELU)
                 L.gemm(u, a.w(fp + "wo.weight"), h2, R, d, self.ff, residual=h, decode=True)

@@ -58,7 +58,7 @@ class DecodeAttnArgs(C.Structure):
                 ("kv_group", _i32), ("new_k", _vp), ("new_v", _vp), ("new_bs", _i64), ("row_map", _vp), ("row_map_ld", _i64)]
 
 
-ABI_VERSION = 3   # V2S_ABI_VERSION this binding was written against (include/vid2seq_hip.h)
+ABI_VERSION = 4   # V2S_ABI_VERSION this binding was written against (include/vid2seq_hip.h)
 
 #: every symbol include/vid2seq_hip.h declares (checked by tests/test_oracle_cpu.py::test_c_abi_exports_every_declared_symbol)
 SYMBOLS = {
@@ -534,15 +534,15 @@ def decode_qfold(x, rows, wq, wkT, rms_eps, qp, H, d, ldx=None):
 class MemAttnPlan:
     """Host plan of the decode step's memory cross-attention (v2s_decode_memattn_plan): which block takes which key tiles of which
     entry, and where the pieces of an entry land.  Built once per generate() call from the entries' valid memory lengths; owns the
-    device copies of the tables and the partial-sum buffers."""
+    device copies of the tables and the partial-sum buffers.  An entry's cut depends on its own length only (batch-independent results)."""
 
-    def __init__(self, klen, R, device, target_blocks=256):
+    def __init__(self, klen, R, device, tiles_per_piece=8):
         import numpy as np
         klen = np.ascontiguousarray(np.asarray(klen, dtype=np.int32))
         E = int(klen.shape[0])
-        cap = max(E, target_blocks) + E
+        cap = int(((np.maximum(klen, 1) + 31) // 32 + tiles_per_piece - 1).sum() // tiles_per_piece) + E
         blk = np.zeros((cap, 4), dtype=np.int32); off = np.zeros(E + 1, dtype=np.int32); nb = C.c_int32(0)
-        _check(lib().v2s_decode_memattn_plan(klen.ctypes.data, E, target_blocks, cap, blk.ctypes.data, off.ctypes.data, C.byref(nb)),
+        _check(lib().v2s_decode_memattn_plan(klen.ctypes.data, E, tiles_per_piece, cap, blk.ctypes.data, off.ctypes.data, C.byref(nb)),
                "v2s_decode_memattn_plan")
         self.entries, self.R, self.nblk = E, R, int(nb.value)
         self.blk_host, self.slot_off_host = blk[:self.nblk].copy(), off
