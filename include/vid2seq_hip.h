@@ -344,7 +344,7 @@ int v2s_decode_attn(const v2s_decode_attn_args* a, void* stream);
  *                     folded into its columns when rms_eps > 0, else rstd = 1); wkT bf16 [d][H*64] = the K projection transposed.
  * v2s_decode_memattn_plan (host only, no GPU work): cuts every entry's ceil(klen / 32) key tiles into ceil(tiles / tiles_per_piece) pieces
  *                     of equal length (one block per piece).  The cut of an entry depends on its own length only, so a sequence decodes
- *                     bit-identically in any batch; 8 tiles per piece fill 256 CUs with 64 entries of ~1000 keys.  klen_host[e] >= 1 =
+ *                     bit-identically in any batch; 9 tiles per piece = 4 pieces for 1100 keys: 64 such entries fill 256 CUs once.  klen_host[e] >= 1 =
  *                     the valid keys of entry e (a prefix of its memory rows).  Writes blk[4 * nblk] = (entry, first tile | end tile
  *                     << 16, slot, klen) and slot_off[entries + 1] (the slots of entry e are slot_off[e] .. slot_off[e + 1], at most
  *                     64); both go to the device.

@@ -42,7 +42,7 @@ def old():
 print(f"B={B} G={G} S={S}  valid keys {sum(klen_l)}  K|V bytes/layer {sum(klen_l) * 2 * W * 2 / 1e6:.1f} MB, memory bytes {sum(klen_l) * d * 2 / 1e6:.1f} MB")
 t = timeit(old)
 print(f"K/V cache kernel                 {t:7.2f} us/layer  ({sum(klen_l) * 2 * W * 2 / t / 1e6:.2f} TB/s of valid K|V)")
-for tpp in (16, 8, 4):
+for tpp in (18, 9, 5):
     plan = L.MemAttnPlan(klen_l, G * H, dev, tiles_per_piece=tpp)
     def qf():
         for i in range(NL):

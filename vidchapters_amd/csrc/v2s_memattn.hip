@@ -496,8 +496,9 @@ extern "C" int v2s_decode_qfold(const void* x, int64_t ldx, int32_t rows, const 
 
 // Host-side plan of v2s_decode_memattn (no GPU work): cuts every entry's ceil(klen / 32) key tiles into ceil(tiles / tiles_per_piece)
 // pieces of equal length (+-1 tile).  The cut of an entry depends on ITS length only -- never on the batch it is decoded in -- so a
-// sequence's result is bit-identical whatever the batch composition (like the K/V-cache kernel's).  8 tiles per piece = 256 keys
-// = four 16-key groups per wave: 64 entries of ~1000 keys fill the 256 CUs once.  blk[i] = (entry, first tile | end tile << 16, slot,
+// sequence's result is bit-identical whatever the batch composition (like the K/V-cache kernel's).  The engine uses 9 tiles (288
+// keys) per piece: the reference's longest memory (100 frames + 1000 tokens = 35 tiles) is 4 pieces, so 64 entries fill the 256 CUs
+// once (one block per CU: the kernel takes a whole CU's registers; a fifth piece per entry would mean a second, nearly empty round).  blk[i] = (entry, first tile | end tile << 16, slot,
 // klen); slot_off[e] .. slot_off[e + 1] = the entry's slots.  Returns the number of blocks through *nblk (<= max_blocks, else an error).
 extern "C" int v2s_decode_memattn_plan(const int32_t* klen_host, int32_t entries, int32_t tiles_per_piece, int32_t max_blocks, int32_t* blk,
                                        int32_t* slot_off, int32_t* nblk) {

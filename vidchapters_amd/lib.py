@@ -534,9 +534,10 @@ def decode_qfold(x, rows, wq, wkT, rms_eps, qp, H, d, ldx=None):
 class MemAttnPlan:
     """Host plan of the decode step's memory cross-attention (v2s_decode_memattn_plan): which block takes which key tiles of which
     entry, and where the pieces of an entry land.  Built once per generate() call from the entries' valid memory lengths; owns the
-    device copies of the tables and the partial-sum buffers.  An entry's cut depends on its own length only (batch-independent results)."""
+    device copies of the tables and the partial-sum buffers.  An entry's cut depends on its own length only (bit-identical results in
+    any batch); 9 tiles = 288 keys per piece: the reference's longest memory (100 frames + 1000 tokens) is 4 pieces, 64 entries = 256 blocks."""
 
-    def __init__(self, klen, R, device, tiles_per_piece=8):
+    def __init__(self, klen, R, device, tiles_per_piece=9):
         import numpy as np
         klen = np.ascontiguousarray(np.asarray(klen, dtype=np.int32))
         E = int(klen.shape[0])
