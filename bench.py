@@ -354,9 +354,22 @@ def generate_leg(model, tok, dev, Lx, B=64, new_tokens=256):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     steps = toks.shape[1] - 1
+    # same call on the per-layer cross K/V caches (Engine.decode_mem_attn = 0), back to back in this process: what the cross-attention
+    # on the shared encoder memory (csrc/v2s_memattn.hip, the default for greedy / sampling) buys
+    was = eng.decode_mem_attn
+    eng.decode_mem_attn = 0
+    eng.greedy(video, inp, max_new_tokens=8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.greedy(video, inp, max_new_tokens=new_tokens, stop_at_eos=False)
+    torch.cuda.synchronize()
+    dt_kv = time.perf_counter() - t0
+    eng.decode_mem_attn = was
     model.train()
     ms_step = dt / max(steps, 1) * 1e3
     return {"batch": B, "decode_steps": int(steps), "seconds": round(dt, 4), "sequences_per_s": round(B / dt, 2),
+            "cross_attention": "shared encoder memory (Engine.decode_mem_attn = 1)" if was else "per-layer K/V caches",
+            "kv_cache_path": {"seconds": round(dt_kv, 4), "sequences_per_s": round(B / dt_kv, 2), "ms_per_decode_step": round(dt_kv / max(steps, 1) * 1e3, 3)},
             "ms_per_decode_step": round(ms_step, 3), "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, ms_step, rows=B, valid_keys=100 * B + int((ids != 0).sum())),
             "note": "encode + 256 greedy decode steps (EOS stop disabled so that every run decodes the full length), static KV cache"}
 
