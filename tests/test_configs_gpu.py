@@ -233,20 +233,24 @@ def test_cfg4_greedy_vs_reference_cached_decoding(golden_dir):
     b = synth.make_batch(B, T, L, 8, 32200, seed, 768)
     video, ids = b["video"].to(DEV), b["input_ids"].to(DEV)
     inp = {"input_ids": ids, "attention_mask": ids != 0}
-    checked = 0
-    for tag, pen in (("", 1.0), ("_rp", float(g["penalty"]))):
-        want, mar = torch.from_numpy(g["tokens" + tag]), torch.from_numpy(g["margins" + tag])
-        got = model.engine().greedy(video, inp, max_new_tokens=max_new, stop_at_eos=False, repetition_penalty=pen).cpu()
-        assert got.shape == want.shape
-        for r in range(B):
-            diff = (got[r] != want[r]).nonzero()
-            n = int(diff[0]) if len(diff) else max_new + 1           # leading tokens identical to the reference's
-            # a divergence is only legitimate at a step the reference itself decided by less than the margin (token n comes from step n-1)
-            assert n == max_new + 1 or float(mar[r, n - 1]) < 0.02, (tag, r, n, float(mar[r, n - 1]), got[r].tolist(), want[r].tolist())
-            checked += n
-            print(f"cfg-4 vs reference{tag} row {r}: first {n} of {max_new + 1} tokens identical"
-                  + ("" if n == max_new + 1 else f" (reference margin at the diverging step: {float(mar[r, n - 1]):.4f})"))
-    assert checked >= 60            # measured: 25 + 25 + 20 + 25 of 4 x 25
+    eng = model.engine()
+    # both cross-attention paths of a decode step: on the shared encoder memory (the default, csrc/v2s_memattn.hip) and on per-layer K/V caches
+    for mode in (1, 0):
+        eng.decode_mem_attn = mode
+        checked = 0
+        for tag, pen in (("", 1.0), ("_rp", float(g["penalty"]))):
+            want, mar = torch.from_numpy(g["tokens" + tag]), torch.from_numpy(g["margins" + tag])
+            got = eng.greedy(video, inp, max_new_tokens=max_new, stop_at_eos=False, repetition_penalty=pen).cpu()
+            assert got.shape == want.shape
+            for r in range(B):
+                diff = (got[r] != want[r]).nonzero()
+                n = int(diff[0]) if len(diff) else max_new + 1           # leading tokens identical to the reference's
+                # a divergence is only legitimate at a step the reference itself decided by less than the margin (token n comes from step n-1)
+                assert n == max_new + 1 or float(mar[r, n - 1]) < 0.02, (mode, tag, r, n, float(mar[r, n - 1]), got[r].tolist(), want[r].tolist())
+                checked += n
+                print(f"cfg-4 vs reference{tag} (decode_mem_attn={mode}) row {r}: first {n} of {max_new + 1} tokens identical"
+                      + ("" if n == max_new + 1 else f" (reference margin at the diverging step: {float(mar[r, n - 1]):.4f})"))
+        assert checked >= 60            # measured: 25 + 25 + 20 + 25 of 4 x 25
 
 
 def test_cfg4_beam4_vs_reference_trajectory(golden_dir):
@@ -282,34 +286,38 @@ def test_cfg4_beam4_vs_reference_trajectory(golden_dir):
             seqs = seqs[src]
             seqs[:, t + 1] = nt[:, t].reshape(-1)
             teacher.append((nt[:, t].reshape(-1), ns[:, t].reshape(-1).astype(np.float32), src, seqs.copy()))
-        rec = model.engine().beam_search(video, inp, num_beams=nb, max_new_tokens=max_new, repetition_penalty=pen, teacher=teacher)
-        assert len(rec) == steps
-        worst, checked, order_checked = 0.0, 0, 0
-        for t in range(steps):
-            val, tok = rec[t]
-            for e in range(B):
-                if t > 0 and bool(done[e, t - 1]):
-                    continue
-                merged = sorted(((float(val[e * nb + r, k]), r, int(tok[e * nb + r, k])) for r in range(nb) for k in range(val.shape[1])
-                                 if np.isfinite(val[e * nb + r, k])), key=lambda x: -x[0])
-                for j in range(2 * nb):
-                    want = (int(cb[e, t, j]), int(ct[e, t, j]))
-                    hit = [i for i, (v, r, k) in enumerate(merged) if (r, k) == want]
-                    if not hit:      # a row's list holds K = 2*nb candidates: one that the reference ranks within 2*TOL of its (2*nb + 1)-th may drop out
-                        assert float(cs[e, t, j] - cs[e, t, 2 * nb]) < 2 * TOL, (tag, t, e, j, want, merged[:10], cs[e, t].tolist())
+        # the grouped K/V kernel (beam search's default), then the beams' 48 query rows per entry on the shared encoder memory
+        for mode in (1, 2):
+            model.engine().decode_mem_attn = mode
+            rec = model.engine().beam_search(video, inp, num_beams=nb, max_new_tokens=max_new, repetition_penalty=pen, teacher=teacher)
+            assert len(rec) == steps
+            worst, checked, order_checked = 0.0, 0, 0
+            for t in range(steps):
+                val, tok = rec[t]
+                for e in range(B):
+                    if t > 0 and bool(done[e, t - 1]):
                         continue
-                    diff = abs(merged[hit[0]][0] - float(cs[e, t, j]))
-                    worst = max(worst, diff)
-                    assert diff < TOL, (tag, t, e, j, merged[hit[0]], float(cs[e, t, j]))
-                    checked += 1
-                    gap_up = float(cs[e, t, j - 1] - cs[e, t, j]) if j else 1e9
-                    gap_dn = float(cs[e, t, j] - cs[e, t, j + 1])
-                    if min(gap_up, gap_dn) > 2 * TOL:
-                        assert hit[0] == j, (tag, t, e, j, hit[0], merged[:10], cs[e, t].tolist())
-                        order_checked += 1
-        print(f"cfg-4 beam-4{tag}: {checked} reference candidates over {steps} steps found with |score diff| <= {worst:.4f}; {order_checked} firm ranks identical")
-        assert checked >= (2 * nb - 1) * (steps if tag == '' else steps // 2) and order_checked >= 4
-        # free run
+                    merged = sorted(((float(val[e * nb + r, k]), r, int(tok[e * nb + r, k])) for r in range(nb) for k in range(val.shape[1])
+                                     if np.isfinite(val[e * nb + r, k])), key=lambda x: -x[0])
+                    for j in range(2 * nb):
+                        want = (int(cb[e, t, j]), int(ct[e, t, j]))
+                        hit = [i for i, (v, r, k) in enumerate(merged) if (r, k) == want]
+                        if not hit:      # a row's list holds K = 2*nb candidates: one that the reference ranks within 2*TOL of its (2*nb + 1)-th may drop out
+                            assert float(cs[e, t, j] - cs[e, t, 2 * nb]) < 2 * TOL, (tag, t, e, j, want, merged[:10], cs[e, t].tolist())
+                            continue
+                        diff = abs(merged[hit[0]][0] - float(cs[e, t, j]))
+                        worst = max(worst, diff)
+                        assert diff < TOL, (tag, t, e, j, merged[hit[0]], float(cs[e, t, j]))
+                        checked += 1
+                        gap_up = float(cs[e, t, j - 1] - cs[e, t, j]) if j else 1e9
+                        gap_dn = float(cs[e, t, j] - cs[e, t, j + 1])
+                        if min(gap_up, gap_dn) > 2 * TOL:
+                            assert hit[0] == j, (tag, t, e, j, hit[0], merged[:10], cs[e, t].tolist())
+                            order_checked += 1
+            print(f"cfg-4 beam-4{tag} (decode_mem_attn={mode}): {checked} reference candidates over {steps} steps found with |score diff| <= {worst:.4f}; {order_checked} firm ranks identical")
+            assert checked >= (2 * nb - 1) * (steps if tag == '' else steps // 2) and order_checked >= 4
+        # free run (default path)
+        model.engine().decode_mem_attn = 1
         want = torch.from_numpy(g["tokens" + tag])
         got = model.engine().beam_search(video, inp, num_beams=nb, max_new_tokens=max_new, repetition_penalty=pen).cpu()
         gp = torch.zeros_like(want); gp[:, :got.shape[1]] = got
