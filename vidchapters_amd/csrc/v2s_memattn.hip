@@ -27,9 +27,10 @@ constexpr int QS_BYTES = 16 * D * 2;       // 24 KiB: the block's 16 folded quer
 constexpr int TB_BYTES = 16 * D * 2;       // 24 KiB per wave: its current [16 keys][768] piece, staged for the transposing read
 
 // LDS images, 16-byte chunk c (0..95) of row r at (r * 96 + swz(c, r)) * 16 (rows are 1536 B = 6 x 256 B apart: without a swizzle all
-// rows of a chunk column share their banks).  Query image: the 16 rows of one chunk column (one ds_read_b128 lane group) -> 16
-// slots.  Tile image: written by ds_write_b128 (8 consecutive lanes = 8 keys of one chunk column) and read by ds_read_b64_tr_b16 (a
-// 16-lane group = 4 keys x 2 chunks x 2 halves): key bits (0, 1) go to chunk bits (1, 2), key bit 2 to chunk bit 0 -- both conflict-free.
+// rows of a chunk column share their banks).  Both swizzles permute the low 4 chunk bits by a bijection of the row's 4 bits, so the 16 rows
+// of one chunk column (a ds_read_b128 lane group: the score fragments of both images) land in 16 different 16-byte slots.  The tile
+// image additionally sends key bits (0, 1) to chunk bits (2, 3): the 4 keys x 2 chunks x 2 halves of a ds_read_b64_tr_b16 lane group are
+// conflict-free too, and so are its writes (8 consecutive lanes = 8 consecutive chunks of one row).
 __device__ __forceinline__ int q_swz(int c, int r) { return c ^ (r & 15); }
 __device__ __forceinline__ int t_swz(int c, int r) { return c ^ (((r & 3) << 2) | ((r >> 2) & 3)); }
 
@@ -43,20 +44,20 @@ struct MemAttnP {
   float scale_log2;                // scale * log2(e)
 };
 
-// One block (4 waves, one per SIMD: 192 accumulator + ~230 other registers) per (piece of an entry's key range -- v2s_decode_memattn_plan --,
-// 16 query rows).  Every
-// wave is an independent flash-attention stream over its own 16-key groups of the piece (groups w, w + 4, ...) and ALL 768 columns:
-//   * its [16 keys][768] piece arrives straight in registers in the MFMA A layout (lane = (key, 8-column group)), the next piece is
-//     requested before this one is used: 24-48 KiB per wave in flight, no barrier and no LDS hand-off between waves in the loop;
-//   * S^T[16 keys x 16 queries] = piece . qp^T: 24 MFMAs (16x16x32) against the folded queries in LDS; lane (query, g) then holds
-//     the scores of keys 4 g .. 4 g + 3 -- which is the B layout of v_mfma_f32_16x16x16_bf16, so the weights go from the softmax
+// One block (4 waves, one per SIMD: 192 accumulators in AGPRs + ~230 other registers) per (piece of an entry's key range --
+// v2s_decode_memattn_plan --, 16 query rows).  Every wave is an independent flash-attention stream over its own 16-key groups of the
+// piece (groups w, w + 4, ...) and ALL 768 columns; no barrier and no hand-off between waves inside the loop:
+//   * the group's 16 rows are one contiguous 24 KiB block: 24 coalesced 1 KiB loads into 96 registers, staged to a swizzled LDS copy as
+//     soon as they arrive; the copy doubles as register spill space -- the registers take the NEXT group right away (24 KiB per wave
+//     in flight during the whole iteration) and the products read their operands from LDS;
+//   * S^T[16 keys x 16 queries] = group . qp^T: 24 MFMAs (16x16x32) against the folded queries in LDS; lane (query, g) then holds the
+//     scores of keys 4 g .. 4 g + 3 -- which is the B layout of v_mfma_f32_16x16x16_bf16, so the weights go from the softmax
 //     registers into the second product as they are;
-//   * acc^T[768 x 16 queries] += piece^T . P^T: the piece's transpose comes from its LDS copy through ds_read_b64_tr_b16 (one read per
-//     MFMA), 48 column tiles;
-//   * the running maximum is lazy: the accumulators (192 registers in AGPRs) are rescaled only when the maximum grows by more than
-//     2^8 -- the first group, then almost never; weights stay <= 2^8.
-// The four streams are merged through LDS (round r: wave r publishes its accumulators, every wave adds its own 192 output columns)
-// and written as one normalised partial per piece; pieces are merged by ctxfold_kernel.
+//   * acc^T[768 x 16 queries] += group^T . P^T: the transpose comes from the LDS copy through ds_read_b64_tr_b16 (one read per MFMA),
+//     48 column tiles, the reads of the next eight tiles requested before the MFMAs of these eight;
+//   * the exponent reference of a stream is fixed (see below): the accumulators are never rescaled.
+// The four streams are merged through LDS (bf16: the cut of an entry into pieces and streams is a function of the entry alone, so
+// every rounding is too) and written as one normalised partial per piece; pieces are merged by ctxfold_kernel.
 __global__ __launch_bounds__(256, 1) void mem_attn_kernel(const MemAttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
