@@ -171,26 +171,33 @@ def test_cfg4_greedy_batch64_rows_equal_single_sequence_runs():
     b = synth.make_batch(B, 100, 1000, 8, 32200, 99, 768)
     video, ids = b["video"].to(DEV).to(torch.bfloat16), b["input_ids"].to(DEV)
     tok = lambda sl: {"input_ids": ids[sl], "attention_mask": ids[sl] != 0}  # noqa: E731
-    full = eng.greedy(video, tok(slice(0, B)), max_new_tokens=steps, stop_at_eos=False, repetition_penalty=1.3).cpu()
-    assert full.shape == (B, steps + 1) and full[:, 0].eq(0).all()
-    distinct = len(set(map(tuple, full.tolist())))
-    print(f"cfg-4: {distinct} distinct sequences among {B} rows; row 0: {full[0, :12].tolist()}")
-    assert full[:, 1:].max() < 32200 and distinct > B // 2        # rows differ: the inputs matter
-    first = []
-    for g0 in range(0, B, 8):                                    # all 64 rows against eight B=8 runs
-        part = eng.greedy(video[g0:g0 + 8], tok(slice(g0, g0 + 8)), max_new_tokens=steps, stop_at_eos=False, repetition_penalty=1.3).cpu()
-        for i in range(8):
-            same = part[i] == full[g0 + i]
+    # within EITHER cross-attention path (shared encoder memory / per-layer K/V caches, both forced here): a sequence's cut into pieces and
+    # every rounding depend on the sequence alone.  (In the default mode the B = 64 run takes the memory path and the small runs the K/V
+    # path: their rows then differ by bf16 rounding -- that is not asserted.)
+    for mode in (2, 0):
+        eng.decode_mem_attn = mode
+        full = eng.greedy(video, tok(slice(0, B)), max_new_tokens=steps, stop_at_eos=False, repetition_penalty=1.3).cpu()
+        assert full.shape == (B, steps + 1) and full[:, 0].eq(0).all()
+        distinct = len(set(map(tuple, full.tolist())))
+        print(f"cfg-4: {distinct} distinct sequences among {B} rows; row 0: {full[0, :12].tolist()}")
+        assert full[:, 1:].max() < 32200 and distinct > B // 2        # rows differ: the inputs matter
+        first = []
+        for g0 in range(0, B, 8):                                    # all 64 rows against eight B=8 runs
+            part = eng.greedy(video[g0:g0 + 8], tok(slice(g0, g0 + 8)), max_new_tokens=steps, stop_at_eos=False, repetition_penalty=1.3).cpu()
+            for i in range(8):
+                same = part[i] == full[g0 + i]
+                first.append(int((~same).nonzero()[0]) if (~same).any() else steps + 1)
+        for i in (0, 7, 31, 63):
+            one = eng.greedy(video[i:i + 1], tok(slice(i, i + 1)), max_new_tokens=steps, stop_at_eos=False, repetition_penalty=1.3).cpu()
+            same = one[0] == full[i]
             first.append(int((~same).nonzero()[0]) if (~same).any() else steps + 1)
-    for i in (0, 7, 31, 63):
-        one = eng.greedy(video[i:i + 1], tok(slice(i, i + 1)), max_new_tokens=steps, stop_at_eos=False, repetition_penalty=1.3).cpu()
-        same = one[0] == full[i]
-        first.append(int((~same).nonzero()[0]) if (~same).any() else steps + 1)
-    ident = sum(f == steps + 1 for f in first)
-    print(f"cfg-4 greedy B=64 x {steps} steps vs B=8 / B=1 runs: {ident} of {len(first)} rows identical over all {steps + 1} positions; "
-          f"first divergence of the others: {sorted(f for f in first if f <= steps)[:12]}")
-    # a flipped argmax (top-2 margin below bf16 noise) changes everything after it; with 256 steps x 64 rows a few rows may hit one
-    assert ident >= len(first) * 3 // 4 and sorted(first)[len(first) // 8] >= steps // 2
+        ident = sum(f == steps + 1 for f in first)
+        print(f"cfg-4 greedy B=64 x {steps} steps vs B=8 / B=1 runs (decode_mem_attn={mode}): {ident} of {len(first)} rows identical over all {steps + 1} positions; "
+              f"first divergence of the others: {sorted(f for f in first if f <= steps)[:12]}")
+        # a flipped argmax (top-2 margin below bf16 noise) changes everything after it; with 256 steps x 64 rows a few rows may hit one
+        assert ident >= len(first) * 3 // 4 and sorted(first)[len(first) // 8] >= steps // 2
+
+    eng.decode_mem_attn = 1
 
     # ---- stop-at-EOS at B=64: make a frequent token of the run above the EOS id and replay with the stopping rule on
     plain = eng.greedy(video, tok(slice(0, B)), max_new_tokens=64, stop_at_eos=False).cpu()
@@ -234,8 +241,9 @@ def test_cfg4_greedy_vs_reference_cached_decoding(golden_dir):
     video, ids = b["video"].to(DEV), b["input_ids"].to(DEV)
     inp = {"input_ids": ids, "attention_mask": ids != 0}
     eng = model.engine()
-    # both cross-attention paths of a decode step: on the shared encoder memory (the default, csrc/v2s_memattn.hip) and on per-layer K/V caches
-    for mode in (1, 0):
+    # both cross-attention paths of a decode step: on the shared encoder memory (csrc/v2s_memattn.hip: the default of large batches, forced
+    # here) and on per-layer K/V caches
+    for mode in (2, 0):
         eng.decode_mem_attn = mode
         checked = 0
         for tag, pen in (("", 1.0), ("_rp", float(g["penalty"]))):
@@ -286,8 +294,8 @@ def test_cfg4_beam4_vs_reference_trajectory(golden_dir):
             seqs = seqs[src]
             seqs[:, t + 1] = nt[:, t].reshape(-1)
             teacher.append((nt[:, t].reshape(-1), ns[:, t].reshape(-1).astype(np.float32), src, seqs.copy()))
-        # the grouped K/V kernel (beam search's default), then the beams' 48 query rows per entry on the shared encoder memory
-        for mode in (1, 2):
+        # the grouped K/V kernel (beam search's default), then the beams' 48 query rows per entry on the shared encoder memory (forced)
+        for mode in (1, 3):
             model.engine().decode_mem_attn = mode
             rec = model.engine().beam_search(video, inp, num_beams=nb, max_new_tokens=max_new, repetition_penalty=pen, teacher=teacher)
             assert len(rec) == steps

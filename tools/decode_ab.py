@@ -1,6 +1,6 @@
 """Interleaved A/B of library options on the cached greedy / beam decode loop (B = 64 videos, t5-base, 100 frames + 1000 ASR tokens).
 Usage: python tools/decode_ab.py [opt=value,opt=value ...]   e.g.  python tools/decode_ab.py gemm_skinny=2 gemm_skinny=1 gemm_skinny=3
-(engine attributes with the eng: prefix: eng:decode_mem_attn=0 eng:decode_mem_attn=1; env B, BEAMS, STEPS, ROUNDS)
+(engine attributes with the eng: prefix: eng:decode_mem_attn=0 eng:decode_mem_attn=2 (3 with BEAMS); env B, BEAMS, STEPS, ROUNDS)
 Each variant runs `rounds` times, interleaved; prints the per-variant median ms per decode step (whole greedy() call / steps, i.e. it
 includes the encoder prologue -- so the encoder-only time is measured too and subtracted)."""
 import os

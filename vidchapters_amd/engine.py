@@ -91,8 +91,9 @@ class Engine:
         self.overlap_kv = True    # see decoder_forward / _cross_attn_bwd
         self.group_wgrads = True  # decoder / ViT weight gradients of one projection across the layers as ONE grouped launch (_wgrad, flush_wgrads)
         self.decode_mem_attn = 1      # generate(): cross-attention of a decode step on the encoder memory itself instead of per-layer K / V caches
-                                      # (_cross_on_memory): 0 = never, 1 = greedy / sampling (default; beams keep the grouped K/V kernel, which measured
-                                      # faster at 4 beams x 16 entries), 2 = beam search with <= 4 beams too
+                                      # (_cross_on_memory): 0 = never; 1 = greedy / sampling when the step is bandwidth-bound (>= 48 000 valid memory
+                                      # keys in the batch: measured +5 % at 58 000 = B 64, -9 % at 28 000 = B 32; default); 2 = greedy / sampling
+                                      # always; 3 = beam search with <= 4 beams too (slower than the grouped K/V kernel at 16 entries x 4 beams)
         self.group_flush_layers = 4  # ... every this many decoder layers (the launches then run beside the NEXT layers' under-filled 8192-row kernels)
         self._wgrad_groups: Dict = {}
         self.shadow_events = None # sharded optimizer: {"vit" | "enc" | "dec": event after which that group's bf16 shadow weights are whole}
@@ -1080,17 +1081,21 @@ class Engine:
         encoder memory itself with the K projection folded into the query and the V projection applied to the result -- half the bytes
         of a step's largest stream, one tensor for all layers, and no cross K / V projection of the memory at all.  Needs d_model 768
         with 64-wide heads, at most 48 query rows per entry (G beams x H heads), and the usual memory mask (a prefix of valid rows
-        per entry, none empty); returns None otherwise and the K / V-cache path is used.  Returns ``attend(i, x, rows, ctx, folded)``."""
+        per entry, none empty) and, in the default mode, a batch large enough to be bandwidth-bound; returns None otherwise and the
+        K / V-cache path is used.  Either path gives a sequence the same result in any batch that takes that path; the two paths differ by
+        bf16 rounding.  Returns ``attend(i, x, rows, ctx, folded, eps)``."""
         a, c = self.arena, self.cfg
         B, S, d = mem.shape
         H, inner = self.H, self.inner
-        if not self.decode_mem_attn or (G > 1 and self.decode_mem_attn < 2) or d != 768 or inner != H * 64 or G * H > 48:
+        if not self.decode_mem_attn or (G > 1 and self.decode_mem_attn < 3) or d != 768 or inner != H * 64 or G * H > 48:
             return None
         m = mem_mask.to(torch.bool)
         ok = bool((m[:, 1:] <= m[:, :-1]).all().item()) if S > 1 else True
         klen = m.sum(1).to(torch.int32)
         klen_h = klen.tolist()
         if not ok or min(klen_h) < 1:
+            return None
+        if self.decode_mem_attn == 1 and sum(klen_h) < 48000:      # small batches: the K/V-cache kernels' shorter launch chain wins
             return None
         plan = L.MemAttnPlan(klen_h, G * H, self.device)
         wkT, wv = [], []
