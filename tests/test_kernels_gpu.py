@@ -1206,6 +1206,12 @@ def test_decode_cross_attention_on_the_shared_memory(G):
     L.decode_qfold(x, rows, wqf, wk.t().contiguous(), eps, qp, H, d)
     qp_ref = torch.einsum("rhj,hjc->rhc", qr.view(rows, H, 64), wk.float().view(H, 64, d))
     assert relerr(qp, qp_ref) < 6e-3
+    # the unfused form the engine uses beyond 64 rows: RMSNorm kernel first, then the fold without a row scale (rms_eps = 0)
+    nrm = torch.empty_like(x); rstd = torch.empty(rows, dtype=torch.float32, device=DEV)
+    L.rmsnorm_fwd(x, lnw, nrm, rstd, rows, d, eps)
+    qp_u = torch.empty_like(qp)
+    L.decode_qfold(nrm, rows, wq, wk.t().contiguous(), 0.0, qp_u, H, d)
+    assert relerr(qp_u, qp_ref) < 1e-2
     memp = mem.clone()
     for e, n in enumerate(klen_l):                    # rows past the valid prefix are never read into a result
         memp[e, n:] = float("nan")
