@@ -368,8 +368,9 @@ struct CtxFoldP {
 // Everything a wave needs from memory is requested before anything is computed: its Wv fragments, the first four pieces' sums, the
 // (max, weight sum) pairs -- the kernel is one round trip, not a chain of them.  Each wave derives the merge weights itself
 // (wave-private LDS rows, no barrier).
+template <int JT>          // 16-wide tiles of the head's 64 outputs per block (blockIdx.z walks the 4 / JT slices)
 __global__ __launch_bounds__(256) void ctxfold_kernel(const CtxFoldP p) {
-  __shared__ __attribute__((aligned(16))) float red[4][4][64][4];
+  __shared__ __attribute__((aligned(16))) float red[4][JT][64][4];
   __shared__ float wsh[4][16][65];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane & 15, g = lane >> 4;
@@ -379,14 +380,15 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const CtxFoldP p) {
   const int ent = live ? mrow / p.G : 0, r = live ? (mrow % p.G) * p.H + h : 0;
   const int s0 = p.slot_off[ent], ns = p.slot_off[ent + 1] - s0;         // 1 <= ns <= 64
   const long prow0 = (long)s0 * p.qr + r;                                 // + s * qr
-  const bf16_t* wr = p.wv + ((long)h * DH + q) * D + wave * 192 + g * 8;
+  const int j0 = blockIdx.z * (JT * 16);                                  // first of this block's outputs of the head
+  const bf16_t* wr = p.wv + ((long)h * DH + j0 + q) * D + wave * 192 + g * 8;
   const bf16_t* pr = p.part + prow0 * D + wave * 192 + g * 8;
   const long pstep = (long)p.qr * D;
-  uint4 wf[6][4];
+  uint4 wf[6][JT];
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wf[ks][t] = *reinterpret_cast<const uint4*>(wr + (long)t * 16 * D + ks * 32);
+    for (int t = 0; t < JT; ++t) wf[ks][t] = *reinterpret_cast<const uint4*>(wr + (long)t * 16 * D + ks * 32);
   uint4 v0[4][6];                                     // the first four pieces (pieces past ns re-read the last one, weight 0)
 #pragma unroll
   for (int u = 0; u < 4; ++u)
@@ -458,24 +460,26 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const CtxFoldP p) {
       for (int e = 0; e < 8; ++e) a8[ks][e] += w * f[e];
     }
   }
-  f32x4 acc[4];
+  f32x4 acc[JT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < JT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) {
     const uint4 bu = pack8(a8[ks]);
     const bf16x8 b = __builtin_bit_cast(bf16x8, bu);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][t]), b, acc[t], 0, 0, 0);
+    for (int t = 0; t < JT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][t]), b, acc[t], 0, 0, 0);
   }
 #pragma unroll
-  for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&red[wave][t][lane][0]) = acc[t];
+  for (int t = 0; t < JT; ++t) *reinterpret_cast<f32x4*>(&red[wave][t][lane][0]) = acc[t];
   __syncthreads();
-  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wave < JT) {                                    // wave t sums tile t of the four contraction quarters (fixed order)
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int w = 0; w < 4; ++w) o += *reinterpret_cast<const f32x4*>(&red[w][wave][lane][0]);
-  if (live)
-    *reinterpret_cast<uint2*>(p.ctx + (long)mrow * p.ld_ctx + h * DH + wave * 16 + 4 * g) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+    for (int w = 0; w < 4; ++w) o += *reinterpret_cast<const f32x4*>(&red[w][wave][lane][0]);
+    if (live)
+      *reinterpret_cast<uint2*>(p.ctx + (long)mrow * p.ld_ctx + h * DH + j0 + wave * 16 + 4 * g) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+  }
 }
 
 }  // namespace
@@ -552,7 +556,9 @@ extern "C" int v2s_decode_ctxfold(const void* part, const float* ml, const int32
   CtxFoldP p;
   p.part = (const bf16_t*)part; p.ml = ml; p.slot_off = slot_off; p.wv = (const bf16_t*)wv; p.ctx = (bf16_t*)ctx; p.ld_ctx = ld_ctx;
   p.rows = rows; p.G = G; p.H = H; p.qr = (G * H + 15) / 16 * 16;
-  hipLaunchKernelGGL(ctxfold_kernel, dim3(H, (rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, p);
+  // 16 of the head's 64 outputs per block: 4 x 12 x row-tile blocks (192 at 64 rows) that each pull ~125 KB, instead of 48 that pull ~200 KB --
+  // the kernel is bound by what one CU can load (8.8 -> 7.0 us at 64 rows; identical arithmetic either way)
+  hipLaunchKernelGGL(ctxfold_kernel<1>, dim3(H, (rows + 15) / 16, 4), dim3(256), 0, (hipStream_t)stream, p);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
