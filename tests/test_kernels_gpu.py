@@ -1226,10 +1226,12 @@ def test_decode_cross_attention_on_the_shared_memory(G):
         assert torch.isfinite(ctx.float()).all(), tpp
         assert relerr(ctx, ref) < 1.5e-2, (tpp, relerr(ctx, ref))
     # scores that jump by far more than the 44-nat headroom of the kernel's fixed exponent reference (late keys 40 x larger: hundreds
-    # of nats): the stream is redone with the raised reference.  Logits that large amplify any rounding of the queries, so the
+    # of nats, twice): the reference moves up and the sums of that query restart from zero (what was summed before weighs < 2^-54).
+    # Logits that large amplify any rounding of the queries, so the
     # reference here starts from the kernel's own folded queries: softmax(qp . mem) mem, then Wv per head.
     mem2 = mem.clone()
     mem2[:, 300:] *= 40.0
+    mem2[:, 500:] *= 8.0                              # a second, larger jump further on (references move more than once per stream)
     sc2 = torch.einsum("eghc,ekc->eghk", qp.float().view(E, G, H, d), mem2.float()).masked_fill(~valid[:, None, None, :], float("-inf"))
     assert float((sc2.amax(-1) - sc2[..., :16].amax(-1)).max()) > 60.0
     accn = torch.einsum("eghk,ekc->eghc", torch.softmax(sc2, -1), mem2.float()).bfloat16().float()
@@ -1254,6 +1256,27 @@ def test_decode_cross_attention_on_the_shared_memory(G):
     L.decode_memattn(qp_s, memp[sub].contiguous(), S * d, plan_s, d)
     L.decode_ctxfold(plan_s, len(sub) * G, G, H, wv, ctx_s, d)
     assert torch.equal(ctx_s, ctx_f[rows_s])
+    # scores that keep climbing (every 16-key group 3 x the previous over the last 20 groups: ~20 reference moves per stream): the cost of a
+    # jump must stay O(1) -- an earlier version redid the stream on every jump and took 4 x longer on a model trained for a few steps
+    if G == 1:
+        mem3 = mem.clone()
+        for k in range(20):
+            mem3[:, 380 + 16 * k:] *= 3.0
+        mem3 = mem3.clamp(-3e4, 3e4)
+        plan3 = L.MemAttnPlan(klen_l, G * H, DEV)
+        ctx3 = torch.empty(rows, H * 64, dtype=torch.bfloat16, device=DEV)
+        def timed(m):
+            L.decode_memattn(qp, m, S * d, plan3, d); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                L.decode_memattn(qp, m, S * d, plan3, d)
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+        t_plain, t_climb = timed(mem), timed(mem3)
+        L.decode_ctxfold(plan3, rows, G, H, wv, ctx3, d)
+        assert torch.isfinite(ctx3.float()).all()
+        assert t_climb < 2.0 * t_plain + 0.2, (t_plain, t_climb)
     with pytest.raises(RuntimeError):
         L.MemAttnPlan([5, 0, 7], G * H, DEV)
     plan.R = 49

@@ -29,6 +29,13 @@ if [ build/v2s_gemm.o -nt build/v2s_gemm.usage ] || [ ! -f build/v2s_gemm.usage 
   # value and memory: both have happened) -- say so loudly, the kernels stay correct but lose 10-30 %
   grep -E "Function Name|ScratchSize" build/v2s_gemm.usage.raw | paste - - | grep -vE "lane\]: 0 " | sed 's/.*Function Name: \([^ ]*\).*lane\]: \([0-9]*\).*/WARNING: \1 uses \2 bytes of scratch per lane/' >&2 || true
 fi
+# The decode memory-attention kernel keeps 192 accumulators in AGPRs and ~200 VGPRs: a spill puts scratch reloads (and their vmcnt(0)
+# waits) into every iteration of its loop -- measured 5 us per 16-key group instead of 0.7.  Say so loudly.
+if [ build/v2s_memattn.o -nt build/v2s_memattn.usage ] || [ ! -f build/v2s_memattn.usage ]; then
+  $HIPCC $FLAGS -c v2s_memattn.hip -o /dev/null -Rpass-analysis=kernel-resource-usage 2> build/v2s_memattn.usage.raw || true
+  grep -E "Function Name|ScratchSize" build/v2s_memattn.usage.raw | paste - - > build/v2s_memattn.usage || true
+  grep -vE "lane\]: 0 " build/v2s_memattn.usage | sed 's/.*Function Name: \([^ ]*\).*lane\]: \([0-9]*\).*/WARNING: \1 uses \2 bytes of scratch per lane/' >&2 || true
+fi
 OBJS=""; for s in $SRCS; do OBJS="$OBJS build/$s.o"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libvid2seq_hip.so $OBJS
 echo "built $(realpath ../libvid2seq_hip.so)"

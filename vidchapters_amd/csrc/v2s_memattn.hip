@@ -55,7 +55,7 @@ struct MemAttnP {
 //     registers into the second product as they are;
 //   * acc^T[768 x 16 queries] += group^T . P^T: the transpose comes from the LDS copy through ds_read_b64_tr_b16 (one read per MFMA),
 //     48 column tiles, the reads of the next eight tiles requested before the MFMAs of these eight;
-//   * the exponent reference of a stream is fixed (see below): the accumulators are never rescaled.
+//   * the exponent reference of a stream moves only on jumps of more than 2^64 (see below): the accumulators are never rescaled.
 // The four streams are merged through LDS (bf16: the cut of an entry into pieces and streams is a function of the entry alone, so
 // every rounding is too) and written as one normalised partial per piece; pieces are merged by ctxfold_kernel.
 __global__ __launch_bounds__(256, 1) void mem_attn_kernel(const MemAttnP p) {
@@ -165,24 +165,26 @@ __global__ __launch_bounds__(256, 1) void mem_attn_kernel(const MemAttnP p) {
       for (int i = 0; i < 4; ++i) sv[i] = key0 + 4 * g + i < klen ? sv[i] : -INFINITY;
     }
     // Reference of the exponentials: the maximum of the query's FIRST key group.  The accumulators (192 AGPRs) are never rescaled --
-    // a multiply would pull them through VGPRs --: weights may grow to 2^64 (fp32 / bf16 have the exponent range for it), and if a
-    // query's scores ever jump by more than that (44 nats) the wave raises that query's reference and redoes its stream from the
-    // first group (exact, and next to never taken).
+    // a multiply pulls them through VGPRs and the register allocator then keeps them there for the whole loop (256-956 B of scratch,
+    // reloaded in every iteration) --: weights may grow to 2^64 (fp32 and bf16 have the exponent range for it), and when a query's
+    // scores jump by more than that (44 nats) everything summed for it so far weighs < 1100 x 2^-64 of the new key, far below fp32
+    // resolution: its reference moves up and its sums restart from zero.  The zeroing is per lane (EXEC-masked v_accvgpr_write of the
+    // constant 0: no VGPR traffic); the asm barriers keep the compiler from turning the branch into selects, which spill again.
+    // (An earlier version redid the whole stream on a jump: with a trained model's logits that restarted again and again -- a 256-step
+    // generation went from 0.3 to 1.1 s.)
     const float mxl = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
     if (__builtin_amdgcn_ballot_w64(mxl > mref + 64.0f)) {                        // (-inf + 64 = -inf: always true for the first group)
       float mx = fmaxf(mxl, __shfl_xor(mxl, 16, 64));                             // per query: over the four key groups
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const bool jump = mx > mref + 64.0f;
-      const bool redo = __builtin_amdgcn_ballot_w64(jump && mref != -INFINITY) != 0;      // not the first group: sums exist
+      const bool had = mref != -INFINITY;
       mref = jump ? mx : mref;
-      if (redo) {
+      if (jump && had) {                      // divergent branch: only the lanes of the queries that jumped
+        asm volatile("" ::: "memory");
         l = 0.f;
 #pragma unroll
         for (int ct = 0; ct < 48; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        j = wave;
-        have = true;
-        MA_LOAD(kbase + 16 * j)
-        continue;
+        asm volatile("" ::: "memory");
       }
     }
     float pr[4];
