@@ -347,28 +347,33 @@ def generate_leg(model, tok, dev, Lx, B=64, new_tokens=256):
     ids = b["input_ids"].to(dev)
     inp = {"input_ids": ids, "attention_mask": ids != 0}
     eng = model.engine()
-    eng.greedy(video, inp, max_new_tokens=8)            # warm-up (allocations, LUTs)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    toks = eng.greedy(video, inp, max_new_tokens=new_tokens, stop_at_eos=False)      # fixed 256 decode steps
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    steps = toks.shape[1] - 1
-    # same call on the per-layer cross K/V caches (Engine.decode_mem_attn = 0), back to back in this process: what the cross-attention
-    # on the shared encoder memory (csrc/v2s_memattn.hip, the default for greedy / sampling) buys
+    # The default cross-attention path and, for comparison, the per-layer cross K/V caches (Engine.decode_mem_attn = 0), interleaved
+    # twice in this process, best of each: the first graph capture after the training legs releases the allocator's cache
+    # (torch.cuda.graph: synchronize + gc + empty_cache -- hundreds of ms, paid by whichever call comes first), so one run each
+    # measures the order of the calls, not the paths.
     was = eng.decode_mem_attn
-    eng.decode_mem_attn = 0
-    eng.greedy(video, inp, max_new_tokens=8)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.greedy(video, inp, max_new_tokens=new_tokens, stop_at_eos=False)
-    torch.cuda.synchronize()
-    dt_kv = time.perf_counter() - t0
+    best, runs = {}, []
+    toks = None
+    for rep in range(2):
+        for mode in (was, 0):
+            eng.decode_mem_attn = mode
+            eng.greedy(video, inp, max_new_tokens=8)            # warm-up (allocations, LUTs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out_toks = eng.greedy(video, inp, max_new_tokens=new_tokens, stop_at_eos=False)      # fixed 256 decode steps
+            torch.cuda.synchronize()
+            runs.append((int(mode), round(time.perf_counter() - t0, 4)))
+            best[mode] = min(best.get(mode, 1e9), runs[-1][1])
+            if mode == was:
+                toks = out_toks
     eng.decode_mem_attn = was
+    dt, dt_kv = best[was], best[0]
+    steps = toks.shape[1] - 1
     model.train()
     ms_step = dt / max(steps, 1) * 1e3
     return {"batch": B, "decode_steps": int(steps), "seconds": round(dt, 4), "sequences_per_s": round(B / dt, 2),
             "cross_attention": "shared encoder memory (Engine.decode_mem_attn = 1: the default takes it from 48 000 valid memory keys on)" if was else "per-layer K/V caches",
+            "runs_mode_seconds": runs,
             "kv_cache_path": {"seconds": round(dt_kv, 4), "sequences_per_s": round(B / dt_kv, 2), "ms_per_decode_step": round(dt_kv / max(steps, 1) * 1e3, 3)},
             "ms_per_decode_step": round(ms_step, 3), "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, ms_step, rows=B, valid_keys=100 * B + int((ids != 0).sum())),
             "note": "encode + 256 greedy decode steps (EOS stop disabled so that every run decodes the full length), static KV cache"}
@@ -403,11 +408,13 @@ def beam_leg(model, tok, dev, Lx, B=16, new_tokens=64, num_beams=4):
     inp = {"input_ids": ids, "attention_mask": ids != 0}
     eng = model.engine()
     eng.beam_search(video, inp, num_beams=num_beams, max_new_tokens=4)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    toks = eng.beam_search(video, inp, num_beams=num_beams, max_new_tokens=new_tokens, min_length=new_tokens + 1)   # EOS banned: full length
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = 1e9
+    for _ in range(2):                  # best of two (graph-capture housekeeping after other legs lands on whichever call comes first)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks = eng.beam_search(video, inp, num_beams=num_beams, max_new_tokens=new_tokens, min_length=new_tokens + 1)   # EOS banned: full length
+        torch.cuda.synchronize()
+        dt = min(dt, time.perf_counter() - t0)
     model.train()
     return {"batch": B, "num_beams": num_beams, "max_new_tokens": new_tokens, "returned_length": int(toks.shape[1]), "seconds": round(dt, 4),
             "sequences_per_s": round(B / dt, 2), "ms_per_decode_step": round(dt / new_tokens * 1e3, 3),
