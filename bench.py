@@ -375,19 +375,27 @@ def generate_leg(model, tok, dev, Lx, B=64, new_tokens=256):
             "cross_attention": "shared encoder memory (Engine.decode_mem_attn = 1: the default takes it from 48 000 valid memory keys on)" if was else "per-layer K/V caches",
             "runs_mode_seconds": runs,
             "kv_cache_path": {"seconds": round(dt_kv, 4), "sequences_per_s": round(B / dt_kv, 2), "ms_per_decode_step": round(dt_kv / max(steps, 1) * 1e3, 3)},
-            "ms_per_decode_step": round(ms_step, 3), "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, ms_step, rows=B, valid_keys=100 * B + int((ids != 0).sum())),
+            "ms_per_decode_step": round(ms_step, 3), "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, ms_step, rows=B, valid_keys=100 * B + int((ids != 0).sum()),
+                                        on_memory=bool(was) and (was >= 2 or 100 * B + int((ids != 0).sum()) >= 48000)),
             "note": "encode + 256 greedy decode steps (EOS stop disabled so that every run decodes the full length), static KV cache"}
 
 
-def decode_roofline(model, B, S, maxlen, ms_step, rows, valid_keys=None):
+def decode_roofline(model, B, S, maxlen, ms_step, rows, valid_keys=None, on_memory=False):
     """HBM roofline of one cached decode step (the step is bandwidth-bound: every byte below is read once per step and nothing is reused
-    across steps): cross-attention K/V of every layer for every VALID encoder position of every batch entry (`valid_keys` = their
-    count over the batch; padded positions are never fetched; shared by the beams of an entry), the self-attention cache
-    (average fill maxlen/2), the bf16 decoder weights incl. the tied LM head, and the fp32 logits written and read back.  `achieved`
-    includes the encoder pass amortised over the steps (ms_per_decode_step is end-to-end / steps)."""
+    across steps): the cross-attention stream of every layer over every VALID encoder position of every batch entry (`valid_keys` =
+    their count over the batch; padded positions are never fetched; shared by the beams of an entry) -- per-layer K and V ([., 2 * inner])
+    on the K/V-cache path, the d_model-wide memory row itself plus the folded-query / partial-sum buffers on the memory path
+    (`on_memory`, csrc/v2s_memattn.hip: half the bytes) --, the self-attention cache (average fill maxlen/2), the bf16 decoder weights
+    incl. the tied LM head (+ the transposed K projection the memory path reads), and the fp32 logits written and read back.
+    `achieved` includes the encoder pass amortised over the steps (ms_per_decode_step is end-to-end / steps)."""
     c = model.cfg
     d, inner, ff, nl, V = c.d_model, c.inner, c.d_ff, c.n_dec, c.vocab
-    cross = nl * (valid_keys if valid_keys is not None else B * S) * 2 * inner * 2
+    keys = valid_keys if valid_keys is not None else B * S
+    if on_memory:
+        pieces = 4 * B                                                         # <= 4 pieces of <= 288 keys per entry up to 1152 keys
+        cross = nl * (keys * d * 2 + 2 * rows * (inner // 64) * d * 2 + 2 * pieces * 16 * d * 2)      # memory rows; folded queries and partials written + read
+    else:
+        cross = nl * keys * 2 * inner * 2
     selfc = nl * rows * (maxlen / 2) * 2 * inner * 2
     weights = nl * (3 * inner * d + inner * d + inner * d + inner * d + 2 * d * ff) * 2 + V * d * 2
     logits = rows * V * 4 * 2
@@ -395,7 +403,8 @@ def decode_roofline(model, B, S, maxlen, ms_step, rows, valid_keys=None):
     ach = total / (ms_step / 1e3) / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
             "algorithmic_gb_per_step": round(total / 1e9, 3), "traffic": None,
-            "bytes": {"cross_kv": int(cross), "self_kv": int(selfc), "weights": int(weights), "logits": int(logits)}}
+            "cross_attention_path": "encoder memory" if on_memory else "per-layer K/V caches",
+            "bytes": {"cross": int(cross), "self_kv": int(selfc), "weights": int(weights), "logits": int(logits)}}
 
 
 def beam_leg(model, tok, dev, Lx, B=16, new_tokens=64, num_beams=4):
