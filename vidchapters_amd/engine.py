@@ -91,8 +91,8 @@ class Engine:
         self.overlap_kv = True    # see decoder_forward / _cross_attn_bwd
         self.group_wgrads = True  # decoder / ViT weight gradients of one projection across the layers as ONE grouped launch (_wgrad, flush_wgrads)
         self.decode_mem_attn = 1      # generate(): cross-attention of a decode step on the encoder memory itself instead of per-layer K / V caches
-                                      # (_cross_on_memory): 0 = never; 1 = greedy / sampling when the step is bandwidth-bound (>= 48 000 valid memory
-                                      # keys in the batch: measured +5 % at 58 000 = B 64, -9 % at 28 000 = B 32; default); 2 = greedy / sampling
+                                      # (_cross_on_memory): 0 = never; 1 = greedy / sampling when the step is bandwidth-bound (>= 40 000 valid memory
+                                      # keys in the batch: measured +10 % at B 128, +5 % at 58 000 = B 64, +2 % at 43 000 = B 48, -9 % at 28 000 = B 32; default); 2 = greedy / sampling
                                       # always; 3 = beam search with <= 4 beams too (slower than the grouped K/V kernel at 16 entries x 4 beams)
         self.group_flush_layers = 4  # ... every this many decoder layers (the launches then run beside the NEXT layers' under-filled 8192-row kernels)
         self._wgrad_groups: Dict = {}
@@ -1095,7 +1095,7 @@ class Engine:
         klen_h = klen.tolist()
         if not ok or min(klen_h) < 1:
             return None
-        if self.decode_mem_attn == 1 and sum(klen_h) < 48000:      # small batches: the K/V-cache kernels' shorter launch chain wins
+        if self.decode_mem_attn == 1 and sum(klen_h) < 40000:      # small batches: the K/V-cache kernels' shorter launch chain wins
             return None
         plan = L.MemAttnPlan(klen_h, G * H, self.device)
         wkT, wv = [], []
