@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn_kernel(const MemAttnP p) {
   u32x4 t[24];                                                // the wave's current 16-key piece, 24 x 1 KiB (96 registers)
   int j = wave;
   bool have = kbase + 16 * j < kend;
-  MA_LOAD(kbase + 16 * j)
+  if (have) MA_LOAD(kbase + 16 * j)
   // (everything that does not depend on the loads goes before the barrier: it runs under their latency)
   float mref = -INFINITY, l = 0.f;
   f32x4 acc[48];
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn_kernel(const MemAttnP p) {
     // whole iteration), and the score product reads its A fragments back from LDS (each lane exactly what it wrote)
     j += 4;
     have = kbase + 16 * j < kend;
-    MA_LOAD(kbase + 16 * j)                     // (past the end: re-reads the entry's last row, never used)
+    if (have) MA_LOAD(kbase + 16 * j)           // (an unconditional request past the end cost 24 KiB per wave and block: +25 % HBM traffic by PMC)
     f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sa;
 #pragma unroll
     for (int ks = 0; ks < 24; ks += 2) {
