@@ -401,8 +401,17 @@ def decode_roofline(model, B, S, maxlen, ms_step, rows, valid_keys=None, on_memo
     logits = rows * V * 4 * 2
     total = cross + selfc + weights + logits
     ach = total / (ms_step / 1e3) / 1e9
+    pmc = None                 # measured HBM bytes of the cross-attention kernel per layer (PMC, offline: B = 64 greedy shapes only)
+    try:
+        if rows == 64:
+            pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_traffic_decode_cross_attention.json")))
+            pmc = int(pj["kernels"]["mem_attn_kernel" if on_memory else "decode_attn_kernel"]["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        pmc = None
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
             "algorithmic_gb_per_step": round(total / 1e9, 3), "traffic": None,
+            "cross_attention_traffic_bytes_per_layer": pmc,
+            "cross_attention_traffic_note": "PMC, offline (profiles/r04_pmc_traffic_decode_cross_attention.json; 57 810 valid keys there)" if pmc else None,
             "cross_attention_path": "encoder memory" if on_memory else "per-layer K/V caches",
             "bytes": {"cross": int(cross), "self_kv": int(selfc), "weights": int(weights), "logits": int(logits)}}
 
