@@ -347,6 +347,8 @@ def generate_leg(model, tok, dev, Lx, B=64, new_tokens=256):
     ids = b["input_ids"].to(dev)
     inp = {"input_ids": ids, "attention_mask": ids != 0}
     eng = model.engine()
+    import gc
+    gc.collect(); torch.cuda.empty_cache(); torch.cuda.synchronize()      # the training legs' garbage and cached blocks: released here, not inside a timed call
     # The default cross-attention path and, for comparison, the per-layer cross K/V caches (Engine.decode_mem_attn = 0), interleaved
     # twice in this process, best of each: the first graph capture after the training legs releases the allocator's cache
     # (torch.cuda.graph: synchronize + gc + empty_cache -- hundreds of ms, paid by whichever call comes first), so one run each
