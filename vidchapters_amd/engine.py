@@ -94,6 +94,7 @@ class Engine:
                                       # (_cross_on_memory): 0 = never; 1 = greedy / sampling when the step is bandwidth-bound (>= 40 000 valid memory
                                       # keys in the batch: measured +10 % at B 128, +5 % at 58 000 = B 64, +2 % at 43 000 = B 48, -9 % at 28 000 = B 32; default); 2 = greedy / sampling
                                       # always; 3 = beam search with <= 4 beams too (slower than the grouped K/V kernel at 16 entries x 4 beams)
+        self.decode_mem_attn_min_keys = 40000     # mode 1: valid memory keys in the batch from which the memory path is taken
         self.group_flush_layers = 4  # ... every this many decoder layers (the launches then run beside the NEXT layers' under-filled 8192-row kernels)
         self._wgrad_groups: Dict = {}
         self.shadow_events = None # sharded optimizer: {"vit" | "enc" | "dec": event after which that group's bf16 shadow weights are whole}
@@ -1095,8 +1096,9 @@ class Engine:
         klen_h = klen.tolist()
         if not ok or min(klen_h) < 1:
             return None
-        if self.decode_mem_attn == 1 and sum(klen_h) < 40000:      # small batches: the K/V-cache kernels' shorter launch chain wins
+        if self.decode_mem_attn == 1 and sum(klen_h) < self.decode_mem_attn_min_keys:      # small batches: the K/V-cache kernels' shorter launch chain wins
             return None
+        assert mem.is_contiguous() and mem.dtype == torch.bfloat16
         plan = L.MemAttnPlan(klen_h, G * H, self.device)
         wkT, wv = [], []
         for i in range(c.n_dec):
