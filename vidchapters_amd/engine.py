@@ -1178,7 +1178,8 @@ class Engine:
         ha, hb = self._bf(B, d), self._bf(B, d)
         eos = c.eos_id if stop_at_eos else -1
 
-        fw = self._decode_weights() if (d % 128 == 0 and B <= 64) else None      # fused norm+projection: the M <= 64, K % 128 == 0 kernel
+        fw = self._decode_weights() if (d % 128 == 0 and B <= 512) else None     # fused norm + projection (v2s_gemm rms_eps: decode rows <= 512, K % 128 == 0)
+        fused_head = fw is not None and B <= 64                                  # the wide LM-head kernel stages 64 rows
         eps = c.eps
 
         def proj(x, rows, key, i, wname, shape, ln_idx, out, **kw):
@@ -1209,7 +1210,7 @@ class Engine:
                 proj(h, B, "wi", i, fp + "wi.weight", (self.ff, d), 2, u, act=L.ACT_RELU)
                 L.gemm(u, a.w(fp + "wo.weight"), h2, B, d, self.ff, residual=h, decode=True)
                 h, h2 = h2, h
-            if fw is not None:
+            if fused_head:
                 L.gemm(h, fw["head"], logits, B, self.V, d, ldc=self.ldv, alpha=d ** -0.5, rms_eps=eps, decode=True)
             else:
                 L.rmsnorm_fwd(h, a.f("t5_model.decoder.final_layer_norm.weight"), n, rstd, B, d, eps)
