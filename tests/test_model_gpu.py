@@ -574,6 +574,31 @@ def test_greedy_min_length_and_sampled_num_captions_vs_oracle():
     assert len(caps) == 12 and all(isinstance(t, str) for t in caps)
 
 
+def test_greedy_beyond_64_rows_vs_oracle():
+    """Greedy decoding at 72 rows: the projections stay on the fused RMSNorm + GEMM kernels (decode rows <= 512), the LM head leaves
+    the 64-row wide kernel for norm kernel + GEMM.  Against the oracle's greedy loop (bf16 may flip a near-tie: >= 90 % of the tokens),
+    and the rows of an 8-row run against the same rows inside the 72 (different head kernels: same bar)."""
+    cfg = R.RefConfig.small()
+    model = build(cfg, 41).eval()
+    P = synth.init_params(R.param_shapes(cfg), 41, cfg.d_model, cfg.inner, cfg.d_ff)
+    B = 72
+    b = synth.make_batch(B, cfg.num_features, 24, 12, cfg.vocab, 41, cfg.vit_dim)
+    Ew = P["t5_model.shared.weight"] * 6.0
+    P["t5_model.shared.weight"] = Ew
+    with torch.no_grad():
+        model.t5_model.shared.weight.copy_(Ew.to(DEV))
+    video, ids = b["video"].to(DEV), tok(b["input_ids"])
+    want = R.greedy_generate(P, cfg, b["video"], b["input_ids"], b["input_ids"] != 0, 10)
+    got = model.engine().greedy(video, ids, max_new_tokens=10).cpu()
+    n = min(got.shape[1], want.shape[1])
+    agree = (got[:, :n] == want[:, :n]).float().mean().item()
+    print(f"greedy at {B} rows vs oracle: {agree:.3f} of the tokens identical")
+    assert got.shape[0] == B and agree > 0.9
+    small = model.engine().greedy(video[:8], {k: v[:8] for k, v in ids.items()}, max_new_tokens=10).cpu()
+    m = min(small.shape[1], got.shape[1])
+    assert (small[:, :m] == got[:8, :m]).float().mean().item() > 0.9
+
+
 def test_fused_lm_head_equals_unfused():
     """Trainer path: LM head + label-smoothed CE + their backward run chunk by chunk inside the forward (Engine.fused_head; no
     [B*Lo, vocab] logits / d(logits) tensor).  Same kernels on row chunks: loss and every gradient must match the unfused head up to
