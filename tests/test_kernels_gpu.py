@@ -1279,6 +1279,8 @@ def test_decode_cross_attention_on_the_shared_memory(G):
         assert t_climb < 2.0 * t_plain + 0.2, (t_plain, t_climb)
     with pytest.raises(RuntimeError):
         L.MemAttnPlan([5, 0, 7], G * H, DEV)
-    plan.R = 49
+    with pytest.raises(ValueError):                   # a query buffer that does not match the plan
+        L.decode_memattn(qp[:-1], memp, S * d, plan, d)
+    plan.R = 49                                       # more than 48 query rows per entry: refused by the library
     with pytest.raises(RuntimeError):
-        L.decode_memattn(qp, memp, S * d, plan, d)
+        L.decode_memattn(torch.empty(E * 49 * d, dtype=torch.bfloat16, device=DEV), memp, S * d, plan, d)

@@ -556,12 +556,17 @@ class MemAttnPlan:
 
 def decode_memattn(qp, mem, mem_es, plan: MemAttnPlan, d, scale=1.0):
     _need(qp, torch.bfloat16, "decode_memattn qp"); _need(mem, torch.bfloat16, "decode_memattn mem")
+    if qp.numel() != plan.entries * plan.R * d or mem.numel() < (plan.entries - 1) * mem_es + d:
+        raise ValueError(f"decode_memattn: qp holds {qp.numel()} elements for {plan.entries} entries x {plan.R} rows x {d}, memory {mem.numel()} "
+                         f"elements for entry stride {mem_es}")
     _check(lib().v2s_decode_memattn(qp.data_ptr(), mem.data_ptr(), mem_es, plan.blk.data_ptr(), plan.nblk, plan.R, scale,
                                     plan.part.data_ptr(), plan.ml.data_ptr(), d, stream_ptr()), "v2s_decode_memattn")
 
 
 def decode_ctxfold(plan: MemAttnPlan, rows, G, H, wv, ctx, d, ld_ctx=None):
     _need(wv, torch.bfloat16, "decode_ctxfold wv"); _need(ctx, torch.bfloat16, "decode_ctxfold ctx")
+    if rows != plan.entries * G or G * H != plan.R:
+        raise ValueError(f"decode_ctxfold: {rows} rows / {G} beams x {H} heads do not match the plan ({plan.entries} entries, {plan.R} query rows each)")
     _check(lib().v2s_decode_ctxfold(plan.part.data_ptr(), plan.ml.data_ptr(), plan.slot_off.data_ptr(), rows, G, H, wv.data_ptr(),
                                     ctx.data_ptr(), ld_ctx if ld_ctx is not None else H * 64, d, stream_ptr()), "v2s_decode_ctxfold")
 
