@@ -35,7 +35,7 @@ extern "C" {
 /* 3 (round 4): v2s_attn_bwd's `delta` became a [B][H][Nq][4] workspace it WRITES, v2s_topp_sample_step gained top_k, dact=RELU with
  * dropout expects z = the post-dropout activation (round 3 changes that a version-2 caller would corrupt memory with);
  * + v2s_rowsumsq_range / v2s_timetoken_renorm_sq, options gemm_ps / gemm_ps_nst / gemm_w128
- * 4 (round 4): + v2s_decode_qfold / v2s_decode_memattn_plan / v2s_decode_memattn / v2s_decode_ctxfold (additions only) */
+ * 4 (round 4): + v2s_decode_qfold / v2s_decode_memattn_plan / v2s_decode_memattn / v2s_decode_ctxfold, v2s_beam_advance (additions only) */
 #define V2S_ABI_VERSION 4
 
 int v2s_version(void);
@@ -384,6 +384,21 @@ int v2s_topk_logprob(const float* logits, int64_t ld, int32_t rows, int32_t V, i
  * given the same row_lse */
 int v2s_repetition_penalty(float* scores, int64_t ld, int32_t rows, int32_t V, const int64_t* hist, int64_t hist_ld,
                            const int32_t* pos_dev, int32_t n_static, float penalty, float* row_lse, void* stream);
+/* Beam bookkeeping on the device (no host round trip per step): what transformers==4.28.0 BeamSearchScorer.process / BeamHypotheses.add do
+ * between two decoder steps for num_beams > 1, do_sample = False, early_stopping = False (call site vid2seq.py:150-162).  One block per batch
+ * entry merges the entry's nb x K per-beam candidates (v2s_topk_logprob output) into its 2 nb best, turns EOS candidates of rank < nb into
+ * finished hypotheses (the nb best per entry by sum_logprobs / len_pow[len] in double; len_pow [max_length + 1] device doubles =
+ * n^length_penalty as the host computes it, so that scores and their ties are bit-identical to the Python scorer), the first nb others into the next beams
+ * (next_tok / beam_scores / src_rows), marks the entry done when its heap is full and cannot be beaten (done[e], *ndone counts them), and
+ * applies the beam permutation in place to the entry's rows of hist ([rows][max_length] int64 decoder ids so far; column *pos_dev + 1 gets
+ * the new tokens) and of row_map (v2s_decode_attn; may be NULL).  *pos_dev = step index t (sequences hold t + 1 tokens).  State (caller
+ * allocates, zero-initialised except heap_worst = 1e9): hyp_tok [B][nb][max_length], hyp_len / hyp_score / hyp_order [B][nb], heap_n /
+ * heap_worst / heap_added / done [B], ndone [1].  num_beams <= 16, 2 <= K <= 32. */
+int v2s_beam_advance(const float* cand_val, const int32_t* cand_tok, int32_t K, int32_t B, int32_t nb, int32_t eos_id, int32_t pad_id,
+                     const double* len_pow, const int32_t* pos_dev, int64_t* hist, int64_t hist_ld, int32_t max_length,
+                     int32_t* row_map, int64_t row_map_ld, int64_t* next_tok, float* beam_scores, int32_t* src_rows,
+                     int32_t* hyp_tok, int32_t* hyp_len, double* hyp_score, int32_t* hyp_order, int32_t* heap_n,
+                     double* heap_worst, int32_t* heap_added, int32_t* done, int32_t* ndone, void* stream);
 int v2s_kv_gather(const void* src, void* dst, const int32_t* idx, int64_t bs, int64_t rs, int32_t B, int32_t len,
                   int32_t width, void* stream);
 /* HF 4.28 MinLengthLogitsProcessor for greedy_search (generate(min_length=...), vid2seq.py:155): scores[r][token] = -inf for every row

@@ -1284,3 +1284,66 @@ def test_decode_cross_attention_on_the_shared_memory(G):
     plan.R = 49                                       # more than 48 query rows per entry: refused by the library
     with pytest.raises(RuntimeError):
         L.decode_memattn(torch.empty(E * 49 * d, dtype=torch.bfloat16, device=DEV), memp, S * d, plan, d)
+
+
+@pytest.mark.parametrize("nb,K,lp", [(4, 8, 1.0), (2, 4, 0.6), (3, 8, 1.0), (8, 16, 2.0), (16, 32, 1.0), (1, 2, 1.0)])
+def test_beam_advance_on_device_equals_the_host_scorer(nb, K, lp):
+    """v2s_beam_advance (BeamSearchScorer.process + BeamHypotheses.add on the device) against vidchapters_amd/beam.py, the host
+    restatement of transformers 4.28's scorer: random per-beam sorted candidate lists with many EOS candidates and many ties, several
+    entries, until every entry is done or the length runs out -- next tokens, scores, source rows, token history, row map, done flags,
+    every step; the finished hypotheses (in insertion order) and the finalized sequences at the end."""
+    from vidchapters_amd.beam import BeamScorer
+    rng = np.random.default_rng(nb * 100 + K)
+    B, maxlen, eos, pad, start, V = 5, 24, 1, 0, 0, 40
+    R = B * nb
+    sc = BeamScorer(B, nb, lp, eos, pad, start, maxlen + 1)
+    st = L.BeamState(B, nb, maxlen + 1, DEV, lp)
+    hist = torch.from_numpy(sc.seqs.copy()).to(DEV)
+    row_map = torch.zeros(R, maxlen, dtype=torch.int32, device=DEV)
+    host_map = np.zeros((R, maxlen), dtype=np.int32)
+    nxt = torch.zeros(R, dtype=torch.long, device=DEV)
+    bscore = torch.from_numpy(sc.scores.reshape(-1).copy()).to(DEV)
+    src = torch.zeros(R, dtype=torch.int32, device=DEV)
+    pos = torch.zeros(1, dtype=torch.int32, device=DEV)
+    steps = 0
+    for t in range(maxlen):
+        # per-row candidates: running score + sorted steps on a coarse grid (ties across beams), EOS with probability ~ 1/4 from step 2
+        base = sc.scores.reshape(-1).astype(np.float32)
+        inc = np.sort(rng.integers(1, 12, size=(R, K)), axis=1).astype(np.float32) * np.float32(-0.25)
+        val = (np.maximum(base, np.float32(-50.0))[:, None] + inc).astype(np.float32)
+        tok = np.stack([rng.permutation(np.arange(2, V))[:K] for _ in range(R)]).astype(np.int32)
+        if t >= 2:
+            put = rng.random(R) < 0.3
+            tok[put, rng.integers(0, min(K, 3))] = eos
+        host_map[:, t] = np.arange(R)
+        row_map[:, t] = torch.arange(R, dtype=torch.int32, device=DEV)
+        was_done = sc.done.copy()
+        ntok, nsrc, fin = sc.advance(val.copy(), tok.copy())
+        L.beam_advance(torch.from_numpy(val).to(DEV), torch.from_numpy(tok).to(DEV), K, st, eos, pad, pos, hist, row_map, nxt, bscore, src)
+        L.counter_add(pos, 1)
+        steps += 1
+        live = np.repeat(~was_done, nb)              # finished entries: pad tokens, rows nobody reads any more
+        assert np.array_equal(nxt.cpu().numpy(), ntok)
+        assert np.array_equal(bscore.cpu().numpy()[live], sc.scores.reshape(-1)[live])
+        assert np.array_equal(src.cpu().numpy()[live], nsrc[live])
+        host_map[live] = host_map[nsrc][live]
+        assert np.array_equal(hist.cpu().numpy()[live], sc.seqs[live]), t
+        assert np.array_equal(row_map.cpu().numpy()[live][:, :t + 1], host_map[live][:, :t + 1])
+        assert np.array_equal(st.done.cpu().numpy().astype(bool), sc.done)
+        assert int(st.ndone.item()) == int(sc.done.sum())
+        if fin:
+            break
+    assert sum(len(h.items) for h in sc.heaps) >= B and steps > 3          # (finished hypotheses everywhere; most parametrisations also finish entries)
+    hn, ht, hl = st.heap_n.cpu().numpy(), st.hyp_tok.cpu().numpy(), st.hyp_len.cpu().numpy()
+    hs, ho = st.hyp_score.cpu().numpy(), st.hyp_order.cpu().numpy()
+    for b in range(B):
+        slots = sorted(range(int(hn[b])), key=lambda i: int(ho[b, i]))
+        assert len(slots) == len(sc.heaps[b].items)
+        for i, (score, toks) in zip(slots, sc.heaps[b].items):
+            assert hs[b, i] == score
+            assert np.array_equal(ht[b, i, :hl[b, i]], toks)
+        assert st.heap_worst.cpu().numpy()[b] == sc.heaps[b].worst
+    with pytest.raises(RuntimeError):
+        L.beam_advance(torch.zeros(17 * 64, device=DEV), torch.zeros(17 * 64, dtype=torch.int32, device=DEV), 64, L.BeamState(1, 17, 8, DEV),
+                       eos, pad, pos, torch.zeros(17, 8, dtype=torch.long, device=DEV), None, torch.zeros(17, dtype=torch.long, device=DEV),
+                       torch.zeros(17, device=DEV), torch.zeros(17, dtype=torch.int32, device=DEV))

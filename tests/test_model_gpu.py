@@ -309,6 +309,34 @@ def test_beam_search_vs_golden(golden_dir):
     assert len(text2) == 2 * out.shape[0] and text2[0::2] == text
 
 
+@pytest.mark.parametrize("nb,kw", [(4, {}), (4, {"length_penalty": 0.6}), (4, {"repetition_penalty": 1.3}), (4, {"min_length": 7, "num_return": 3}),
+                                   (2, {}), (3, {"num_return": 2}), (8, {}), (12, {"length_penalty": 2.0})])
+def test_beam_search_device_scorer_equals_host_scorer(golden_dir, nb, kw):
+    """The beam bookkeeping on the device (v2s_beam_advance inside the replayed graph, no host round trip per step) returns the very
+    tokens of the host scorer (vidchapters_amd/beam.py, the restatement of transformers 4.28's BeamSearchScorer that the golden and
+    oracle tests pin): same kernels before it, so the comparison is exact -- EOS-heavy fixture (entries finish at different steps),
+    length / repetition penalties, min_length, several returned sequences, widths with and without the grouped cross-attention."""
+    g = np.load(os.path.join(golden_dir, "small_beam.npz"))
+    cfg = R.RefConfig.small()
+    max_new = int(g["max_new"])
+    for i in range(min(3, len(g["seed"]))):
+        model = build(cfg, int(g["seed"][i])).eval()
+        with torch.no_grad():
+            E = model.t5_model.shared.weight
+            E.mul_(6.0)
+            E[1] = E[int(g["fav"][i])] * float(g["fac"][i])
+        video, ids = torch.from_numpy(g["video"][i]).to(DEV), torch.from_numpy(g["input_ids"][i])
+        eng = model.engine()
+        outs = {}
+        for dev in (True, False):
+            eng.beam_on_device = dev
+            outs[dev] = eng.beam_search(video, tok(ids), num_beams=nb, max_new_tokens=max_new, **kw).cpu()
+        eng.beam_on_device = True
+        assert torch.equal(outs[True], outs[False]), (nb, kw, i, outs[True].tolist(), outs[False].tolist())
+        eager = eng.beam_search(video, tok(ids), num_beams=nb, max_new_tokens=max_new, use_graph=False, **kw).cpu()
+        assert torch.equal(eager, outs[True])
+
+
 
 def test_checkpoint_load_after_engine_build_takes_effect():
     """load_state_dict (dvc.py:354-361) into a model whose arena / bf16 shadow already exist: the next forward must see the

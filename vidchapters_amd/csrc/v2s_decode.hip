@@ -1105,6 +1105,138 @@ extern "C" int v2s_topk_logprob(const float* logits, int64_t ld, int32_t rows, i
   return V2S_OK;
 }
 
+// ---- beam bookkeeping on the device: what transformers==4.28.0 BeamSearchScorer.process / BeamHypotheses.add do between two decoder
+// steps (call site model/vid2seq.py:150-162, num_beams > 1, do_sample = False, early_stopping = False), restated after
+// vidchapters_amd/beam.py (the host scorer, which stays the reference and serves sampling / teacher forcing).  One block per batch
+// entry: merges the entry's nb x K per-beam candidates into its 2 nb best (stable: value descending, flat index ascending), walks
+// them like process() (EOS candidates of rank < nb become finished hypotheses, the first nb others the next beams), keeps the nb best
+// hypotheses per entry (score = sum_logprobs / len^length_penalty in double, evicting the lowest (score, insertion order)), marks the
+// entry done when the heap is full and cannot be beaten, then applies the beam permutation IN PLACE to the entry's rows of the token
+// history and of the self-attention row map (column by column: a thread reads the nb values of its column, then writes them) and
+// appends the new tokens.  With it a beam step needs no host round trip: the decode graph replays back to back.
+struct BeamAdvP {
+  const float* cand_val; const int* cand_tok; int K;          // [rows][K], sorted per row
+  int B, nb, eos, pad;
+  const double* len_pow;                                      // [max_length + 1]: n^length_penalty as the host computes it (bit-identical scores)
+  const int* pos_dev;                                         // step index t: the sequences hold t + 1 tokens
+  long* hist; long hist_ld; int max_length;                   // [rows][max_length] decoder ids so far
+  int* row_map; long row_map_ld;                              // [rows][maxlen] or NULL
+  long* next_tok; float* beam_scores; int* src_rows;          // [rows]: outputs for the next step
+  int* hyp_tok; int* hyp_len; double* hyp_score; int* hyp_order;   // [B][nb][max_length] / [B][nb]
+  int* heap_n; double* heap_worst; int* heap_added; int* done; int* ndone;   // [B], [1]
+};
+
+__global__ __launch_bounds__(256) void beam_advance_kernel(const BeamAdvP p) {
+  __shared__ float s_val[512];
+  __shared__ int s_tok[512];
+  __shared__ float sel_val[32];
+  __shared__ int sel_tok[32], sel_src[32];
+  __shared__ int new_tok[16], new_src[16], push_src[16], push_slot[16], n_push;
+  __shared__ float new_sc[16];
+  const int ent = blockIdx.x, tid = threadIdx.x, nb = p.nb, K = p.K, n = nb * K;
+  const int cur_len = *p.pos_dev + 1;
+  const int row0 = ent * nb;
+  if (p.done[ent]) {                         // a finished entry keeps its rows; its beams emit pad (BeamSearchScorer.process)
+    if (tid < nb) { p.next_tok[row0 + tid] = p.pad; p.beam_scores[row0 + tid] = 0.f; p.src_rows[row0 + tid] = row0 + tid; }
+    return;
+  }
+  for (int i = tid; i < n; i += 256) { s_val[i] = p.cand_val[(long)row0 * K + i]; s_tok[i] = p.cand_tok[(long)row0 * K + i]; }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {       // rank of candidate i among the entry's n (stable descending)
+    const float v = s_val[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (s_val[j] > v || (s_val[j] == v && j < i)) ? 1 : 0;
+    if (rank < 2 * nb) { sel_val[rank] = v; sel_tok[rank] = s_tok[i]; sel_src[rank] = i / K; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int k = 0, np = 0;
+    int hn = p.heap_n[ent], added = p.heap_added[ent];
+    double worst = p.heap_worst[ent];
+    const double denom = p.len_pow[cur_len];
+    for (int rank = 0; rank < 2 * nb; ++rank) {
+      const int t = sel_tok[rank];
+      if (t == p.eos) {
+        if (rank < nb) {                     // BeamHypotheses.add
+          const double score = (double)sel_val[rank] / denom;
+          if (hn < nb || score > worst) {
+            int slot;
+            if (hn < nb) {
+              slot = hn++;
+              worst = score < worst ? score : worst;
+            } else {                         // evict the lowest (score, insertion order); the new one is strictly better than it
+              slot = 0;
+              for (int i = 1; i < nb; ++i) {
+                const double a = p.hyp_score[ent * nb + i], b = p.hyp_score[ent * nb + slot];
+                if (a < b || (a == b && p.hyp_order[ent * nb + i] < p.hyp_order[ent * nb + slot])) slot = i;
+              }
+            }
+            p.hyp_score[ent * nb + slot] = score; p.hyp_order[ent * nb + slot] = added++; p.hyp_len[ent * nb + slot] = cur_len;
+            if (hn >= nb) {
+              worst = p.hyp_score[ent * nb];
+              for (int i = 1; i < nb; ++i) worst = p.hyp_score[ent * nb + i] < worst ? p.hyp_score[ent * nb + i] : worst;
+            }
+            push_src[np] = sel_src[rank]; push_slot[np] = slot; ++np;
+          }
+        }
+        continue;
+      }
+      new_tok[k] = t; new_src[k] = sel_src[rank]; new_sc[k] = sel_val[rank];
+      if (++k == nb) break;
+    }
+    for (; k < nb; ++k) { new_tok[k] = p.pad; new_src[k] = k; new_sc[k] = 0.f; }     // (cannot happen with 2 nb candidates and one EOS id)
+    p.heap_n[ent] = hn; p.heap_added[ent] = added; p.heap_worst[ent] = worst;
+    n_push = np;
+    if (hn >= nb && worst >= (double)sel_val[0] / denom) { p.done[ent] = 1; atomicAdd(p.ndone, 1); }
+  }
+  __syncthreads();
+  for (int i = 0; i < n_push; ++i) {         // finished hypotheses: the sequence of the source beam BEFORE this step's permutation
+    const long* src = p.hist + (long)(row0 + push_src[i]) * p.hist_ld;
+    int* dst = p.hyp_tok + ((long)ent * nb + push_slot[i]) * p.max_length;
+    for (int c = tid; c < cur_len; c += 256) dst[c] = (int)src[c];
+    __syncthreads();                         // (a later push of this step may reuse the slot)
+  }
+  // the permutation, column by column in place; then the new tokens
+  for (int c = tid; c < cur_len; c += 256) {
+    long v[16];
+    for (int j = 0; j < nb; ++j) v[j] = p.hist[(long)(row0 + new_src[j]) * p.hist_ld + c];
+    for (int j = 0; j < nb; ++j) p.hist[(long)(row0 + j) * p.hist_ld + c] = v[j];
+  }
+  if (p.row_map) {
+    for (int c = tid; c < cur_len; c += 256) {           // keys 0 .. t were written by this step's attention kernels
+      int v[16];
+      for (int j = 0; j < nb; ++j) v[j] = p.row_map[(long)(row0 + new_src[j]) * p.row_map_ld + c];
+      for (int j = 0; j < nb; ++j) p.row_map[(long)(row0 + j) * p.row_map_ld + c] = v[j];
+    }
+  }
+  if (tid < nb) {
+    if (cur_len < p.max_length) p.hist[(long)(row0 + tid) * p.hist_ld + cur_len] = new_tok[tid];
+    p.next_tok[row0 + tid] = new_tok[tid];
+    p.beam_scores[row0 + tid] = new_sc[tid];
+    p.src_rows[row0 + tid] = row0 + new_src[tid];
+  }
+}
+
+extern "C" int v2s_beam_advance(const float* cand_val, const int32_t* cand_tok, int32_t K, int32_t B, int32_t nb, int32_t eos_id, int32_t pad_id,
+                                const double* len_pow, const int32_t* pos_dev, int64_t* hist, int64_t hist_ld, int32_t max_length,
+                                int32_t* row_map, int64_t row_map_ld, int64_t* next_tok, float* beam_scores, int32_t* src_rows,
+                                int32_t* hyp_tok, int32_t* hyp_len, double* hyp_score, int32_t* hyp_order, int32_t* heap_n,
+                                double* heap_worst, int32_t* heap_added, int32_t* done, int32_t* ndone, void* stream) {
+  V2S_CHECK(cand_val && cand_tok && len_pow && pos_dev && hist && next_tok && beam_scores && src_rows && hyp_tok && hyp_len && hyp_score && hyp_order &&
+            heap_n && heap_worst && heap_added && done && ndone, V2S_ERR_ARG, "v2s_beam_advance: null pointer");
+  V2S_CHECK(B > 0 && nb >= 1 && nb <= 16 && K >= 2 && K <= 32 && nb * K <= 512 && K * nb >= 2 * nb && max_length > 1, V2S_ERR_SHAPE,
+            "v2s_beam_advance: needs 1 <= num_beams <= 16, 2 <= K <= 32 (nb=%d K=%d)", nb, K);
+  BeamAdvP p;
+  p.cand_val = cand_val; p.cand_tok = cand_tok; p.K = K; p.B = B; p.nb = nb; p.eos = eos_id; p.pad = pad_id; p.len_pow = len_pow;
+  p.pos_dev = pos_dev; p.hist = (long*)hist; p.hist_ld = hist_ld; p.max_length = max_length; p.row_map = row_map; p.row_map_ld = row_map_ld;
+  p.next_tok = (long*)next_tok; p.beam_scores = beam_scores; p.src_rows = src_rows; p.hyp_tok = hyp_tok; p.hyp_len = hyp_len;
+  p.hyp_score = hyp_score; p.hyp_order = hyp_order; p.heap_n = heap_n; p.heap_worst = heap_worst; p.heap_added = heap_added; p.done = done;
+  p.ndone = ndone;
+  hipLaunchKernelGGL(beam_advance_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
 extern "C" int v2s_kv_gather(const void* src, void* dst, const int32_t* idx, int64_t bs, int64_t rs, int32_t B, int32_t len,
                              int32_t width, void* stream) {
   V2S_CHECK(src && dst && idx && B > 0 && len > 0 && width > 0 && (width % 8) == 0 && ((bs | rs) % 8) == 0 && src != dst, V2S_ERR_ARG,

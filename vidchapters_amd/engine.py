@@ -95,6 +95,7 @@ class Engine:
                                       # keys in the batch: measured +10 % at B 128, +5 % at 58 000 = B 64, +2 % at 43 000 = B 48, -9 % at 28 000 = B 32; default); 2 = greedy / sampling
                                       # always; 3 = beam search with <= 4 beams too (slower than the grouped K/V kernel at 16 entries x 4 beams)
         self.decode_mem_attn_min_keys = 40000     # mode 1: valid memory keys in the batch from which the memory path is taken
+        self.beam_on_device = True    # beam search (no sampling, <= 16 beams): hypothesis bookkeeping on the device (v2s_beam_advance): no host round trip per step
         self.group_flush_layers = 4  # ... every this many decoder layers (the launches then run beside the NEXT layers' under-filled 8192-row kernels)
         self._wgrad_groups: Dict = {}
         self.shadow_events = None # sharded optimizer: {"vit" | "enc" | "dec": event after which that group's bf16 shadow weights are whole}
@@ -1260,8 +1261,9 @@ class Engine:
         candidates of a row come from ``v2s_beam_sample_cand`` (warped scores + Gumbel keys) instead of ``v2s_topk_logprob``.
         The encoder memory is NOT replicated per beam: cross K/V are projected once per batch entry and the nb beams of an
         entry read the same rows (``kv_group``).  A step = decoder forward for B*nb rows -> ``v2s_topk_logprob`` (log-softmax +
-        running beam score + per-beam top 2*nb), captured as a hipGraph; the host merges the candidates (beam.BeamScorer) and
-        sends back next tokens, scores and source rows.  The self-attention cache is never moved: a [rows][maxlen] ``row_map`` says
+        running beam score + per-beam top 2*nb) -> ``v2s_beam_advance`` (BeamSearchScorer.process on the device: next tokens, scores,
+        source rows, finished hypotheses, the beam permutation), captured as a hipGraph and replayed back to back; with sampling or
+        a teacher the host merges the candidates instead (beam.BeamScorer) and sends back next tokens, scores and source rows.  The self-attention cache is never moved: a [rows][maxlen] ``row_map`` says
         which cache row holds each (beam, position) key, and a beam reorder permutes the rows of that table (v2s_decode_attn
         row_map) -- HF copies every cached K/V row (modeling_t5.py:1771-1793), 12 layers x rows x len x 3 KB per step.
         ``teacher`` (parity tests at real shapes, tests/test_configs_gpu.py): a list of per-step decisions (tokens int64 [rows],
@@ -1320,8 +1322,10 @@ class Engine:
         ha, hb = self._bf(R, d), self._bf(R, d)
         cbs = maxlen * 2 * inner
         rp = repetition_penalty != 1.0
-        hist = torch.zeros(R, maxlen + 1, dtype=torch.long, device=self.device) if rp else None     # decoder ids so far, per beam
+        dev_scorer = self.beam_on_device and sample is None and teacher is None and nb <= 16 and K <= 32
+        hist = torch.zeros(R, maxlen + 1, dtype=torch.long, device=self.device) if (rp or dev_scorer) else None     # decoder ids so far, per beam
         row_lse = self._f32(R) if rp else None
+        bstate = L.BeamState(B, nb, maxlen + 1, self.device, length_penalty) if dev_scorer else None
 
         fw = self._decode_weights() if (d % 128 == 0 and R <= 512) else None     # fused norm + projection (v2s_gemm rms_eps)
         fused_head = fw is not None and R <= 64
@@ -1368,10 +1372,12 @@ class Engine:
             else:
                 L.topk_logprob(logits, self.ldv, R, self.V, K, bscore, cand_val, cand_tok, ban_token=c.eos_id, pos_dev=pos,
                                min_length=min_length, row_lse=row_lse if rp else None)
+            if dev_scorer:      # BeamSearchScorer.process on the device: next tokens / scores / source rows, finished hypotheses, the beam
+                L.beam_advance(cand_val, cand_tok, K, bstate, c.eos_id, c.pad_id, pos, hist, row_map, nxt, bscore, src_dev)      # permutation of hist and row_map
             L.counter_add(pos, 1)
 
         scorer = BeamScorer(B, nb, length_penalty, c.eos_id, c.pad_id, c.dec_start_id, max_new_tokens + 1, sample=sample is not None)
-        if rp:
+        if hist is not None:
             hist.copy_(torch.from_numpy(scorer.seqs))
         bscore.copy_(torch.from_numpy(scorer.scores.reshape(-1)))
         identity = np.arange(R, dtype=np.int32)
@@ -1389,6 +1395,10 @@ class Engine:
                         step()
                     pos.copy_(pos_keep)            # capture does not execute, but keep the counter explicit
                 graph.replay()
+            if dev_scorer:          # the graph replays back to back; the all-entries-done test of HF is evaluated every 8 steps
+                if t % 8 == 7 and int(bstate.ndone.item()) == B:
+                    break
+                continue
             cand_host.copy_(cand, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             if teacher is not None:
@@ -1417,6 +1427,17 @@ class Engine:
             return recorded
         if not 1 <= num_return <= nb:
             raise ValueError(f"num_captions must be in [1, num_beams] (got {num_return})")
+        if dev_scorer:              # hand the device state to the host scorer's finalize (BeamSearchScorer.finalize)
+            scorer.seqs = hist.cpu().numpy()
+            scorer.scores = bscore.cpu().numpy().reshape(B, nb).copy()
+            scorer.cur_len = int(pos.item()) + 1
+            scorer.done = bstate.done.cpu().numpy().astype(bool)
+            hn, ht, hl = bstate.heap_n.cpu().numpy(), bstate.hyp_tok.cpu().numpy(), bstate.hyp_len.cpu().numpy()
+            hs, ho, hw = bstate.hyp_score.cpu().numpy(), bstate.hyp_order.cpu().numpy(), bstate.heap_worst.cpu().numpy()
+            for b in range(B):      # in insertion order: ties between equal scores resolve like on the host
+                slots = sorted(range(int(hn[b])), key=lambda i: int(ho[b, i]))
+                scorer.heaps[b].items = [(float(hs[b, i]), ht[b, i, :int(hl[b, i])].astype(np.int64)) for i in slots]
+                scorer.heaps[b].worst = float(hw[b])
         return torch.from_numpy(scorer.finalize(num_return)).to(self.device)
 
 

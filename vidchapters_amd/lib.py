@@ -113,6 +113,8 @@ SYMBOLS = {
     "v2s_beam_sample_cand": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _f32, _f32, _i32, _u32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "v2s_repetition_penalty": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _f32, _vp, _vp]),
     "v2s_kv_gather": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "v2s_beam_advance": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "v2s_ban_token": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
 }
 
@@ -593,6 +595,33 @@ def counter_add(ctr, delta):
 def topk_logprob(logits, ld, rows, V, K, beam_scores, out_val, out_idx, ban_token=-1, pos_dev=None, min_length=0, row_lse=None):
     _check(lib().v2s_topk_logprob(logits.data_ptr(), ld, rows, V, K, ptr(beam_scores), out_val.data_ptr(), out_idx.data_ptr(),
                                   ban_token, ptr(pos_dev), min_length, ptr(row_lse), stream_ptr()), "v2s_topk_logprob")
+
+
+class BeamState:
+    """Device-resident hypothesis bookkeeping of a beam search (v2s_beam_advance): the state BeamSearchScorer keeps on the host."""
+
+    def __init__(self, B, nb, max_length, device, length_penalty=1.0):
+        i32 = dict(dtype=torch.int32, device=device)
+        self.B, self.nb, self.max_length = B, nb, max_length
+        # n ** length_penalty as Python computes it (BeamHypotheses.add: sum_logprobs / (hyp.shape[-1] ** length_penalty)): scores bit-identical
+        self.len_pow = torch.tensor([float(n) ** float(length_penalty) for n in range(max_length + 1)], dtype=torch.float64).to(device)
+        self.hyp_tok = torch.zeros(B, nb, max_length, **i32)
+        self.hyp_len = torch.zeros(B, nb, **i32); self.hyp_order = torch.zeros(B, nb, **i32)
+        self.hyp_score = torch.zeros(B, nb, dtype=torch.float64, device=device)
+        self.heap_n = torch.zeros(B, **i32); self.heap_added = torch.zeros(B, **i32)
+        self.heap_worst = torch.full((B,), 1e9, dtype=torch.float64, device=device)
+        self.done = torch.zeros(B, **i32); self.ndone = torch.zeros(1, **i32)
+
+
+def beam_advance(cand_val, cand_tok, K, st: BeamState, eos_id, pad_id, pos_dev, hist, row_map, next_tok, beam_scores, src_rows):
+    _need(cand_val, torch.float32, "beam_advance cand_val"); _need(cand_tok, torch.int32, "beam_advance cand_tok")
+    _need(hist, torch.int64, "beam_advance hist"); _need(next_tok, torch.int64, "beam_advance next_tok")
+    _need(beam_scores, torch.float32, "beam_advance beam_scores"); _need(src_rows, torch.int32, "beam_advance src_rows")
+    _check(lib().v2s_beam_advance(cand_val.data_ptr(), cand_tok.data_ptr(), K, st.B, st.nb, eos_id, pad_id, st.len_pow.data_ptr(), pos_dev.data_ptr(),
+                                  hist.data_ptr(), hist.stride(0), st.max_length, ptr(row_map), row_map.stride(0) if row_map is not None else 0,
+                                  next_tok.data_ptr(), beam_scores.data_ptr(), src_rows.data_ptr(), st.hyp_tok.data_ptr(), st.hyp_len.data_ptr(),
+                                  st.hyp_score.data_ptr(), st.hyp_order.data_ptr(), st.heap_n.data_ptr(), st.heap_worst.data_ptr(),
+                                  st.heap_added.data_ptr(), st.done.data_ptr(), st.ndone.data_ptr(), stream_ptr()), "v2s_beam_advance")
 
 
 def repetition_penalty(scores, ld, rows, V, hist, penalty, pos_dev=None, n_static=0, row_lse=None):
