@@ -435,8 +435,22 @@ def beam_leg(model, tok, dev, Lx, B=16, new_tokens=64, num_beams=4):
         toks = eng.beam_search(video, inp, num_beams=num_beams, max_new_tokens=new_tokens, min_length=new_tokens + 1)   # EOS banned: full length
         torch.cuda.synchronize()
         dt = min(dt, time.perf_counter() - t0)
+    dt_host = 1e9                       # the same search with the hypothesis bookkeeping on the host (one round trip per step), for comparison
+    was = eng.beam_on_device
+    eng.beam_on_device = False
+    try:
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            toks_host = eng.beam_search(video, inp, num_beams=num_beams, max_new_tokens=new_tokens, min_length=new_tokens + 1)
+            torch.cuda.synchronize()
+            dt_host = min(dt_host, time.perf_counter() - t0)
+    finally:
+        eng.beam_on_device = was
     model.train()
-    return {"batch": B, "num_beams": num_beams, "max_new_tokens": new_tokens, "returned_length": int(toks.shape[1]), "seconds": round(dt, 4),
+    return {"batch": B, "num_beams": num_beams, "scorer": "device (v2s_beam_advance inside the replayed graph)" if was else "host",
+            "host_scorer": {"seconds": round(dt_host, 4), "sequences_per_s": round(B / dt_host, 2),
+                            "tokens_identical": bool(toks.shape == toks_host.shape and (toks == toks_host).all())}, "max_new_tokens": new_tokens, "returned_length": int(toks.shape[1]), "seconds": round(dt, 4),
             "sequences_per_s": round(B / dt, 2), "ms_per_decode_step": round(dt / new_tokens * 1e3, 3),
             "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, dt / new_tokens * 1e3, rows=B * num_beams,
                                         valid_keys=100 * B + int((ids != 0).sum())),
