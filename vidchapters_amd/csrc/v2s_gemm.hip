@@ -1741,6 +1741,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
     int m = m0 + i * 16 + r; m = m < p.M ? m : p.M - 1;
     ap[i] = p.A + (long)m * p.lda + kbeg + kc;
   }
+  // a thread owns at most one 8-wide output chunk: its residual operand is requested NOW, so that the epilogue's one dependent global
+  // load (an L2 round trip on the critical path of a launch that is all latency) hides behind the weight stream
+  static_assert(MT * 16 * NT * 2 <= WAVES * 64, "one output chunk per thread");
+  const bool res_ahead = p.residual != nullptr && p.dact == V2S_ACT_NONE && p.dbg != 4;      // (gemm_dbg = 4: A/B switch, same results)
+  uint4 res_chunk = uint4{0, 0, 0, 0};
+  if (res_ahead && tid < MT * 16 * NT * 2) {
+    const int rm = m0 + tid / (NT * 2), rn = n0 + (tid % (NT * 2)) * 8;
+    if (rm < p.M && rn < p.N) res_chunk = *reinterpret_cast<const uint4*>(p.residual + (long)rm * p.ldr + rn);
+  }
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -1816,7 +1825,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= rstd;
       }
-      epilogue_chunk(p, v, m, gn, 0);
+      if (res_ahead) epilogue_chunk<true>(p, v, m, gn, 0, res_chunk);
+      else epilogue_chunk<false>(p, v, m, gn, 0);
     }
   }
 }
