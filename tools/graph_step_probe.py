@@ -1,5 +1,6 @@
 """Captured training step (Trainer.step_graph) with and without the three-stream overlap inside the capture, against the eager step.
-usage: python tools/graph_step_probe.py"""
+usage: python tools/graph_step_probe.py     (PROBE=captured | eager: only the overlapped captured / eager step -- for sweeps of the runtime's
+graph knobs, e.g. DEBUG_HIP_FORCE_GRAPH_QUEUES=8 PROBE=captured python tools/graph_step_probe.py)"""
 import os
 import sys
 import time
@@ -38,6 +39,11 @@ def measure(overlap, graph):
     return sorted(ts)[1]
 
 
+only = os.environ.get("PROBE", "")
+if only:
+    knobs = {k: v for k, v in os.environ.items() if k.startswith(("DEBUG_HIP_", "DEBUG_CLR_", "GPU_MAX_HW"))}
+    print(f"overlap True  {only:8s}: {measure(True, only == 'captured'):7.2f} ms/step   {knobs}")
+    sys.exit(0)
 for overlap in (True, False):
     for graph in (False, True):
         print(f"overlap {overlap!s:5s} {'captured' if graph else 'eager   '}: {measure(overlap, graph):7.2f} ms/step")
