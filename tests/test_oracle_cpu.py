@@ -478,6 +478,29 @@ def test_c_abi_exports_every_declared_symbol():
     assert l.v2s_gemm(ctypes.byref(a), None) != 0 and b"v2s_gemm" in l.v2s_last_error()
 
 
+def test_integration_doc_stubs_match_the_binding():
+    """The ctypes stubs printed in INTEGRATION.md (what a maintainer of another host copies) declare the same number and kind of arguments as
+    the package's own binding for every entry point they bind, the header's parameter lists agree with both, and the document names the
+    ABI version the library reports (tools/check_integration_stubs.py executes the same blocks on the GPU)."""
+    from vidchapters_amd import lib as L
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    header = open(os.path.join(ROOT, "include", "vid2seq_hip.h")).read()
+    ns = {"C": ctypes, "VP": ctypes.c_void_p, "I32": ctypes.c_int32, "I64": ctypes.c_int64, "F32": ctypes.c_float, "GemmArgs": L.GemmArgs}
+    found = re.findall(r"^lib\.(v2s_[a-z0-9_]+)\.argtypes(?:, lib\.\1\.restype)? = (\[.*?\](?: \+ \[VP\] \* \d+)?)", doc, flags=re.M)
+    assert len(found) >= 6, found
+    for name, expr in found:
+        types = eval(expr, ns)
+        want = L.SYMBOLS[name][1]
+        if name == "v2s_gemm":              # the doc's stub declares its own GemmArgs structure
+            assert len(types) == len(want) == 2
+            continue
+        assert [ctypes.sizeof(t) for t in types] == [ctypes.sizeof(t) for t in want], (name, len(types), len(want))
+        assert [t is ctypes.c_float for t in types] == [t is ctypes.c_float for t in want], name
+        decl = re.search(r"^[A-Za-z_0-9\* ]+?[ \*]" + name + r"\s*\(([^;]*?)\)\s*;", header, flags=re.S | re.M).group(1)
+        assert len([a for a in decl.split(",") if a.strip()]) == len(want), (name, decl)
+    assert f"written against ({L.ABI_VERSION})" in doc
+
+
 def test_decode_memattn_plan_is_per_entry_and_covers_every_tile():
     """v2s_decode_memattn_plan (host logic of the decode step's memory cross-attention, no GPU work): every entry's key tiles are
     covered exactly once by consecutive pieces of at most tiles_per_piece tiles, slots are consecutive, and an entry's cut depends
