@@ -1,0 +1,400 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled K-loop of gemm_a4_kernel (v2s_gemm_a4.inc is its output; build.sh runs it).
+
+Why a generator: the kernel keeps ONE wave per SIMD (4 waves, 256 x 256 block tile, 128 x 128 wave tile = 256 fp32 accumulators in
+AGPRs, v_mfma_f32_32x32x16_bf16), so nothing hides a stall: every ds_read / LDS-DMA / scalar instruction has to sit in the shadow of
+an MFMA and every wait has to be a COUNTED s_waitcnt.  hipcc does not schedule that (its one-wave loops stop at
+1.0-1.1 PF with 48 % issue stalls), so the whole K loop is one inline-asm statement with literal registers, and this script is the
+scheduler: it places the filler instructions in the MFMA gaps and derives every s_waitcnt count from a scoreboard of the wave's
+outstanding LDS / vector-memory operations instead of by hand.
+
+Replaces the main loop of every nn.Linear forward / dgrad GEMM with M, N >= 256 (reference: model/modeling_t5.py:304-311,528-536,581;
+model/vit.py:41,53,17,20).
+
+Structure (per wave; "stage" = 32 k of the block tile = 16 KiB of A rows + 16 KiB of B rows in LDS, ring of 4 stages = 128 KiB;
+"step" = 16 k = one v_mfma_32x32x16 per accumulator block = 16 MFMAs):
+  step 2s   (even): MFMAs on fragment set F0 | ds_reads of (stage s, k-half 1) -> F1 | LDS-DMA of stage s+3 into the slot of stage s-1
+  step 2s+1 (odd) : MFMAs on F1 | after the 2nd MFMA: s_waitcnt vmcnt(stage s+1 landed) lgkmcnt(0); s_barrier | ds_reads of
+                    (stage s+1, k-half 0) -> F0
+  The barrier in step 2s+1 publishes stage s+1 (RAW) and proves every wave is done reading stage s (WAR for the DMA of stage s+4,
+  issued in step 2s+2).  The DMA stream never stops: past the last stage it re-requests the last stage, so every count is a constant.
+
+LDS images (the DMA writes 1 KiB per wave-instruction at M0 + 16 * lane, so any swizzle is applied to the per-lane SOURCE address):
+  K-contiguous operand ([rows][32 k], 64 B per row): 16-byte slot g of row r is stored at slot g ^ ((r >> 2) & 3); read with ds_read_b128
+  by lane (h = lane >> 5, r = lane & 31): conflict-free for the b128 lane groups.
+  [k][n] operand (dgrad's W; TB): [32 k][256 n], 512 B per k-row, 32-byte granule g of k-row k stored at granule g ^ 2 (k & 3); read with
+  ds_read_b64_tr_b16 (two per fragment).
+Accumulator orientation: mfma(srcA = W rows (n), srcB = X rows (m)): lane (h, m) of block (bi, bj) holds output row m and sixteen
+columns; the W rows of a fragment are read in the permuted order n = 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3) (i = MFMA row index), which
+makes those sixteen columns CONSECUTIVE: n = 32 bj + 16 h + r for accumulator register r.
+"""
+import sys
+
+# ---- literal register map (one wave) -----------------------------------------------------------------------------------------
+F = [0, 32]                  # fragment sets: BF[bj] = v[F + 4 bj .. +3], AF[bi] = v[F + 16 + 4 bi .. +3]
+V_OA, V_OB = 64, 68          # per-lane DMA source offsets (4 + 4)
+V_DA = 72                    # ds_read addresses of the A operand: [k-half 0, k-half 1, k-half 0 + 64 KiB, k-half 1 + 64 KiB]
+V_DB = 76                    # NT: same four for the B operand; TB: eight: [bj] and [bj] + 64 KiB
+V_T = 84                     # temporaries v84..v99
+S_PA, S_PB = 36, 38          # running source bases (64-bit)
+S_LDSW = 40                  # LDS base + wave * 4096
+S_IT = 41                    # loop counter
+S_STA, S_STB = 42, 43        # bytes per stage
+S_ADV = 44                   # stages the pointers may still advance
+S_T = 46                     # temporaries s46..s55
+NV_CLOBBER = 100             # v0..v99
+STAGE = 32768
+A_PART, B_PART = 0, 16384
+
+
+class Gen:
+    def __init__(self, tb):
+        self.tb = tb
+        self.lines = []
+        self.lgkm = []       # outstanding LDS operations, oldest first: tags
+        self.vm = []         # outstanding vector-memory operations: tags
+        self.nmfma = 0
+
+    def e(self, s):
+        self.lines.append(s)
+
+    # ---- scoreboard
+    def lds_op(self, tag, text):
+        assert len(self.lgkm) < 15, "lgkmcnt is a 4-bit counter"
+        self.lgkm.append(tag)
+        self.e(text)
+
+    def need(self, tags):
+        """every LDS operation whose tag is in `tags` must have returned"""
+        idx = max((i for i, t in enumerate(self.lgkm) if t in tags), default=-1)
+        if idx >= 0:
+            self.e(f"s_waitcnt lgkmcnt({len(self.lgkm) - idx - 1})")
+            self.lgkm = self.lgkm[idx + 1:]
+
+    def vm_op(self, tag, text):
+        assert len(self.vm) < 63
+        self.vm.append(tag)
+        self.e(text)
+
+    def vm_need(self, tag, also_lgkm0=False):
+        idx = max(i for i, t in enumerate(self.vm) if t == tag)
+        n = len(self.vm) - idx - 1
+        self.vm = self.vm[idx + 1:]
+        if also_lgkm0:
+            self.e(f"s_waitcnt vmcnt({n}) lgkmcnt(0)")
+            self.lgkm = []
+        else:
+            self.e(f"s_waitcnt vmcnt({n})")
+
+    # ---- pieces
+    def frag_reads(self, slot, kh, fs):
+        """ds_reads of (ring slot, k-half kh) into fragment set fs, in the order the MFMAs want them: BF0 AF0 BF1 BF2 BF3 AF1 AF2 AF3.
+        Returns a list of (tag, text) groups (one group = the reads of one fragment)."""
+        hi = slot >> 1
+        base = (slot & 1) * STAGE
+        out = []
+
+        def a_frag(bi):
+            reg = F[fs] + 16 + 4 * bi
+            addr = V_DA + kh + 2 * hi
+            return [(f"F{fs}A{bi}", f"ds_read_b128 v[{reg}:{reg + 3}], v{addr} offset:{base + A_PART + bi * 2048}")]
+
+        def b_frag(bj):
+            reg = F[fs] + 4 * bj
+            if not self.tb:
+                addr = V_DB + kh + 2 * hi
+                return [(f"F{fs}B{bj}", f"ds_read_b128 v[{reg}:{reg + 3}], v{addr} offset:{base + B_PART + bj * 2048}")]
+            addr = V_DB + bj + 4 * hi
+            off = base + B_PART + kh * 8192
+            return [(f"F{fs}B{bj}", f"ds_read_b64_tr_b16 v[{reg}:{reg + 1}], v{addr} offset:{off}"),
+                    (f"F{fs}B{bj}", f"ds_read_b64_tr_b16 v[{reg + 2}:{reg + 3}], v{addr} offset:{off + 2048}")]
+
+        for kind, i in (("b", 0), ("a", 0), ("b", 1), ("b", 2), ("b", 3), ("a", 1), ("a", 2), ("a", 3)):
+            out.append(a_frag(i) if kind == "a" else b_frag(i))
+        return out
+
+    def dma_pairs(self, slot, tag):
+        """the 8 LDS-DMA requests of one stage: (m0 setup, request)"""
+        out = []
+        for part, voff, sp in ((A_PART, V_OA, S_PA), (B_PART, V_OB, S_PB)):
+            for i in range(4):
+                imm = slot * STAGE + part + i * 1024
+                out.append((f"s_add_u32 m0, s{S_LDSW}, 0x{imm:x}", (tag, f"global_load_lds_dwordx4 v{voff + i}, s[{sp}:{sp + 1}]")))
+        return out
+
+    def advance(self):
+        t = S_T
+        return [f"s_cmp_lg_u32 s{S_ADV}, 0",
+                f"s_cselect_b32 s{t}, s{S_STA}, 0",
+                f"s_cselect_b32 s{t + 1}, s{S_STB}, 0",
+                f"s_cselect_b32 s{t + 2}, 1, 0",
+                f"s_add_u32 s{S_PA}, s{S_PA}, s{t}",
+                f"s_addc_u32 s{S_PA + 1}, s{S_PA + 1}, 0",
+                f"s_add_u32 s{S_PB}, s{S_PB}, s{t + 1}",
+                f"s_addc_u32 s{S_PB + 1}, s{S_PB + 1}, 0",
+                f"s_sub_u32 s{S_ADV}, s{S_ADV}, s{t + 2}"]
+
+    def mfma(self, fs, bi, bj, first=False):
+        acc = 16 * (4 * bi + bj)
+        bf, af = F[fs] + 4 * bj, F[fs] + 16 + 4 * bi
+        self.need({f"F{fs}B{bj}", f"F{fs}A{bi}"})
+        c = "0" if first else f"a[{acc}:{acc + 15}]"
+        self.e(f"v_mfma_f32_32x32x16_bf16 a[{acc}:{acc + 15}], v[{bf}:{bf + 3}], v[{af}:{af + 3}], {c}")
+        self.nmfma += 1
+
+    def step(self, fs, gaps, first=False):
+        """16 MFMAs on fragment set fs; gaps[j] = list of callables run after MFMA j"""
+        j = 0
+        for bi in range(4):
+            for bj in range(4):
+                self.mfma(fs, bi, bj, first)
+                for f in gaps.get(j, []):
+                    f()
+                j += 1
+
+    # ---- the statement
+    def setup(self):
+        e = self.e
+        T, S = V_T, S_T
+        e("s_nop 4")
+        e(f"v_and_b32 v{T}, 63, %[tid]")                    # lane
+        e(f"v_lshrrev_b32 v{T + 1}, 6, %[tid]")             # wave
+        e("s_nop 1")
+        e(f"v_readfirstlane_b32 s{S}, v{T + 1}")            # w
+        e(f"s_mov_b32 s{S_PA}, %[pa0]"); e(f"s_mov_b32 s{S_PA + 1}, %[pa1]")
+        e(f"s_mov_b32 s{S_PB}, %[pb0]"); e(f"s_mov_b32 s{S_PB + 1}, %[pb1]")
+        e(f"s_lshr_b32 s{S + 1}, s{S}, 1")                  # wm
+        e(f"s_and_b32 s{S + 2}, s{S}, 1")                   # wn
+        e(f"s_lshl_b32 s{S + 3}, s{S}, 12")
+        e(f"s_add_u32 s{S_LDSW}, %[lds], s{S + 3}")
+        e(f"s_mov_b32 s{S_IT}, %[niter]")
+        e(f"s_lshl_b32 s{S_ADV}, %[niter], 2")
+        e(f"s_sub_u32 s{S_ADV}, s{S_ADV}, 1")               # nst - 1 pointer advances
+        e(f"s_mov_b32 s{S_STA}, 64")
+        # --- DMA source offsets of the A operand (and of a K-contiguous B operand): chunk = 16 rows x 64 B; lane -> row (lane >> 2), stored
+        #     slot (lane & 3) holds logical slot (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3)
+        e(f"v_lshrrev_b32 v{T + 2}, 2, v{T}")               # lane >> 2
+        e(f"v_lshrrev_b32 v{T + 3}, 4, v{T}")
+        e(f"v_and_b32 v{T + 3}, 3, v{T + 3}")
+        e(f"v_and_b32 v{T + 4}, 3, v{T}")
+        e(f"v_xor_b32 v{T + 4}, v{T + 4}, v{T + 3}")
+        e(f"v_lshlrev_b32 v{T + 4}, 4, v{T + 4}")           # g * 16 bytes
+        e(f"s_lshl_b32 s{S + 4}, s{S}, 6")                  # w * 64 rows
+
+        def rows(voff, r0, rmax, ld):
+            e(f"s_add_u32 s{S + 5}, {r0}, s{S + 4}")
+            e(f"v_add_u32 v{T + 5}, s{S + 5}, v{T + 2}")
+            for i in range(4):
+                e(f"v_add_u32 v{T + 6}, {16 * i}, v{T + 5}")
+                e(f"v_min_u32 v{T + 6}, {rmax}, v{T + 6}")
+                e(f"v_mul_lo_u32 v{T + 6}, v{T + 6}, {ld}")
+                e(f"v_add_u32 v{voff + i}, v{T + 6}, v{T + 4}")
+
+        rows(V_OA, "%[m0]", "%[mmax]", "%[lda]")
+        if not self.tb:
+            e(f"s_mov_b32 s{S_STB}, 64")
+            rows(V_OB, "%[n0]", "%[nmax]", "%[ldb]")
+        else:
+            # [k][n] operand: chunk c = wave * 4 + i holds k-rows 2c, 2c+1; lane -> k = 2c + (lane >> 5), stored 16-byte slot p = lane & 31
+            # = granule p >> 1 (holds logical granule (p >> 1) ^ 2 (k & 3)), half p & 1; k & 3 = 2 (i & 1) + (lane >> 5)
+            e(f"s_lshl_b32 s{S_STB}, %[ldb], 5")            # 32 k-rows per stage
+            e(f"v_lshrrev_b32 v{T + 5}, 5, v{T}")           # lane >> 5
+            e(f"v_and_b32 v{T + 6}, 31, v{T}")              # p
+            e(f"v_lshrrev_b32 v{T + 7}, 1, v{T + 6}")       # stored granule
+            e(f"v_and_b32 v{T + 8}, 1, v{T + 6}")           # half
+            e(f"s_lshl_b32 s{S + 5}, s{S}, 3")              # w * 8
+            e(f"v_add_u32 v{T + 9}, s{S + 5}, v{T + 5}")    # w * 8 + (lane >> 5)
+            for i in range(4):
+                e(f"v_add_u32 v{T + 10}, {2 * (i & 1)}, v{T + 5}")       # k & 3
+                e(f"v_lshlrev_b32 v{T + 10}, 1, v{T + 10}")
+                e(f"v_xor_b32 v{T + 10}, v{T + 7}, v{T + 10}")          # logical granule
+                e(f"v_lshlrev_b32 v{T + 10}, 4, v{T + 10}")             # * 16 columns
+                e(f"v_lshl_add_u32 v{T + 10}, v{T + 8}, 3, v{T + 10}")  # + half * 8
+                e(f"v_add_u32 v{T + 10}, %[n0], v{T + 10}")
+                e(f"v_min_u32 v{T + 10}, %[nmax], v{T + 10}")
+                e(f"v_lshlrev_b32 v{T + 10}, 1, v{T + 10}")             # bytes
+                e(f"v_add_u32 v{T + 11}, {2 * i}, v{T + 9}")            # k
+                e(f"v_mul_lo_u32 v{T + 11}, v{T + 11}, %[ldb]")
+                e(f"v_add_u32 v{V_OB + i}, v{T + 11}, v{T + 10}")
+        # --- ds_read addresses.  A operand (X rows, MFMA srcB): lane (h, r): row wm * 128 + r, slot (2 kh + h) ^ ((r >> 2) & 3)
+        e(f"v_and_b32 v{T + 5}, 31, v{T}")                  # r = i
+        e(f"v_lshrrev_b32 v{T + 6}, 5, v{T}")               # h
+        e(f"v_lshrrev_b32 v{T + 7}, 2, v{T + 5}")
+        e(f"v_and_b32 v{T + 7}, 3, v{T + 7}")               # (r >> 2) & 3
+        e(f"v_xor_b32 v{T + 7}, v{T + 6}, v{T + 7}")        # h ^ f
+        e(f"v_lshlrev_b32 v{T + 7}, 4, v{T + 7}")
+        e(f"s_lshl_b32 s{S + 5}, s{S + 1}, 13")             # wm * 128 rows * 64 B
+        e(f"v_lshl_add_u32 v{T + 8}, v{T + 5}, 6, s{S + 5}")
+        e(f"v_add_u32 v{T + 8}, %[lds], v{T + 8}")
+        e(f"v_add_u32 v{V_DA}, v{T + 8}, v{T + 7}")
+        e(f"v_xor_b32 v{V_DA + 1}, 32, v{V_DA}")            # k-half 1: slot ^ 2 (the LDS base is a multiple of 64)
+        e(f"v_add_u32 v{V_DA + 2}, 0x10000, v{V_DA}")
+        e(f"v_add_u32 v{V_DA + 3}, 0x10000, v{V_DA + 1}")
+        if not self.tb:
+            # B operand (W rows, MFMA srcA), permuted: MFMA row i reads tile row wn * 128 + 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3);
+            # (row >> 2) & 3 = i >> 3
+            e(f"v_lshrrev_b32 v{T + 7}, 2, v{T + 5}")
+            e(f"v_and_b32 v{T + 7}, 1, v{T + 7}")
+            e(f"v_lshlrev_b32 v{T + 7}, 4, v{T + 7}")       # 16 ((i >> 2) & 1)
+            e(f"v_lshrrev_b32 v{T + 8}, 3, v{T + 5}")       # i >> 3 (= f)
+            e(f"v_lshl_add_u32 v{T + 7}, v{T + 8}, 2, v{T + 7}")
+            e(f"v_and_b32 v{T + 9}, 3, v{T + 5}")
+            e(f"v_add_u32 v{T + 7}, v{T + 7}, v{T + 9}")    # perm(i)
+            e(f"v_xor_b32 v{T + 8}, v{T + 6}, v{T + 8}")    # h ^ f
+            e(f"v_lshlrev_b32 v{T + 8}, 4, v{T + 8}")
+            e(f"s_lshl_b32 s{S + 5}, s{S + 2}, 13")         # wn * 128 * 64
+            e(f"v_lshl_add_u32 v{T + 7}, v{T + 7}, 6, s{S + 5}")
+            e(f"v_add_u32 v{T + 7}, %[lds], v{T + 7}")
+            e(f"v_add_u32 v{V_DB}, v{T + 7}, v{T + 8}")
+            e(f"v_xor_b32 v{V_DB + 1}, 32, v{V_DB}")
+            e(f"v_add_u32 v{V_DB + 2}, 0x10000, v{V_DB}")
+            e(f"v_add_u32 v{V_DB + 3}, 0x10000, v{V_DB + 1}")
+        else:
+            # [k][n] operand through ds_read_b64_tr_b16: 16-lane group grp = lane >> 4 (k-half hh = grp >> 1, column half nh = grp & 1);
+            # lane j of a group supplies the address of 4 columns of k-row hh * 8 + (j >> 2) and receives column j of the 4 x 16 block the
+            # group's addresses describe.  Run cq = j & 3 of the block must be the MFMA rows 16 nh + 4 cq .. +3 = columns
+            # 16 (cq & 1) + 8 nh + 4 (cq >> 1) .. +3 of the 32-column fragment bj (the permutation above): granule
+            # (wn * 8 + 2 bj + (j & 1)) ^ 2 q  (q = j >> 2 = k & 3)  =  wn * 8 + (j & 1) + 2 (bj ^ q), byte (16 nh + 8 ((j >> 1) & 1)) inside it
+            e(f"v_and_b32 v{T + 7}, 15, v{T}")              # j
+            e(f"v_lshrrev_b32 v{T + 8}, 4, v{T}")           # grp
+            e(f"v_and_b32 v{T + 9}, 1, v{T + 8}")           # nh
+            e(f"v_lshrrev_b32 v{T + 10}, 1, v{T + 8}")      # hh
+            e(f"v_lshrrev_b32 v{T + 11}, 2, v{T + 7}")      # q
+            e(f"v_lshl_add_u32 v{T + 12}, v{T + 10}, 3, v{T + 11}")     # k-row hh * 8 + q
+            e(f"v_lshlrev_b32 v{T + 12}, 9, v{T + 12}")     # * 512 B
+            e(f"v_and_b32 v{T + 13}, 1, v{T + 7}")          # j & 1
+            e(f"s_lshl_b32 s{S + 5}, s{S + 2}, 3")          # wn * 8
+            e(f"v_add_u32 v{T + 13}, s{S + 5}, v{T + 13}")
+            e(f"v_lshl_add_u32 v{T + 12}, v{T + 13}, 5, v{T + 12}")     # + granule base * 32
+            e(f"v_lshl_add_u32 v{T + 12}, v{T + 9}, 4, v{T + 12}")      # + 16 nh
+            e(f"v_lshrrev_b32 v{T + 13}, 1, v{T + 7}")
+            e(f"v_and_b32 v{T + 13}, 1, v{T + 13}")
+            e(f"v_lshl_add_u32 v{T + 12}, v{T + 13}, 3, v{T + 12}")     # + 8 ((j >> 1) & 1)
+            e(f"v_add_u32 v{T + 12}, %[lds], v{T + 12}")
+            for bj in range(4):
+                e(f"v_xor_b32 v{T + 13}, {bj}, v{T + 11}")              # bj ^ q
+                e(f"v_lshl_add_u32 v{V_DB + bj}, v{T + 13}, 6, v{T + 12}")
+                e(f"v_add_u32 v{V_DB + 4 + bj}, 0x10000, v{V_DB + bj}")
+        e("s_nop 4")                                        # VALU-written VGPRs / SALU-written SGPRs -> vector memory
+
+    def issue_stage_now(self, slot, tag):
+        for m0set, (t, req) in self.dma_pairs(slot, tag):
+            self.e(m0set)
+            self.e("s_nop 0")
+            self.vm_op(t, req)
+        for s in self.advance():
+            self.e(s)
+
+    def body(self, first_iter_c0):
+        """4 stages = 8 steps; first_iter_c0: the MFMAs of stage 0 / k-half 0 start from C = 0 (peeled first iteration)"""
+        for st in range(4):
+            # ---- even step: F0 <- already read; reads of (slot st, k-half 1) -> F1; DMA of stage + 3 into slot (st + 3) & 3
+            gaps = {}
+            reads = self.frag_reads(st, 1, 1)
+            for gi, grp in enumerate(reads):
+                gaps.setdefault(gi, []).extend((lambda tg=tg, tx=tx: self.lds_op(tg, tx)) for tg, tx in grp)
+            tag = f"stage{self.stage_ctr + 3}"
+            pairs = self.dma_pairs((st + 3) & 3, tag)
+            # m0 setup in gap g, the request one MFMA later (the MFMA in between is the wait state the M0 write needs)
+            for k, (m0set, (t, req)) in enumerate(pairs):
+                g = 7 + k
+                gaps.setdefault(g, []).append(lambda m0set=m0set: self.e(m0set))
+                gaps.setdefault(g + 1, []).insert(0, (lambda t=t, req=req: self.vm_op(t, req)))
+            # (gap 15's request lands after the last MFMA of this step: the first MFMA of the odd step follows it)
+            self.step(0, gaps, first=(first_iter_c0 and st == 0))
+            # pointer bookkeeping: in the first gaps of the odd step
+            adv = self.advance()
+            # ---- odd step
+            gaps = {0: [(lambda s=s: self.e(s)) for s in adv[:4]], 1: [(lambda s=s: self.e(s)) for s in adv[4:]]}
+
+            def sync():
+                self.vm_need(f"stage{self.stage_ctr + 1}", also_lgkm0=True)
+                self.e("s_barrier")
+            gaps[1].append(sync)
+            reads = self.frag_reads((st + 1) & 3, 0, 0)
+            for gi, grp in enumerate(reads):
+                gaps.setdefault(2 + gi, []).extend((lambda tg=tg, tx=tx: self.lds_op(tg, tx)) for tg, tx in grp)
+            self.step(1, gaps)
+            self.stage_ctr += 1
+
+    def main(self):
+        e = self.e
+        self.setup()
+        # prologue: stages 0, 1, 2
+        self.stage_ctr = 0
+        for s in range(3):
+            self.issue_stage_now(s, f"stage{s}")
+        self.vm_need("stage0")
+        e("s_barrier")
+        for grp in self.frag_reads(0, 0, 0):
+            for tg, tx in grp:
+                self.lds_op(tg, tx)
+        # first iteration peeled (C = 0 in its first step), then the loop
+        entry = (list(self.lgkm), len(self.vm))
+        self.body(True)
+        assert (list(self.lgkm), len(self.vm)) == entry, (self.lgkm, self.vm, entry)
+        e(f"s_sub_u32 s{S_IT}, s{S_IT}, 1")
+        e(f"s_cmp_eq_u32 s{S_IT}, 0")
+        e("s_cbranch_scc1 L_a4_done_%=")
+        e("L_a4_loop_%=:")
+        self.vm = [f"stage{self.stage_ctr + 1}"] * 8 + [f"stage{self.stage_ctr + 2}"] * 8      # rename: same queue shape
+        self.body(False)
+        assert (list(self.lgkm), len(self.vm)) == entry
+        e(f"s_sub_u32 s{S_IT}, s{S_IT}, 1")
+        e(f"s_cmp_lg_u32 s{S_IT}, 0")
+        e("s_cbranch_scc1 L_a4_loop_%=")
+        e("L_a4_done_%=:")
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        e("s_barrier")
+        return self.lines
+
+
+def dump_lines(bi):
+    """accumulator blocks (bi, 0..3) -> fp32 staging: lane (h, m): row wm * 32 + m of the pass, columns wn * 128 + 32 bj + 16 h + r;
+    %[sa] = this lane's staging byte address (row * 1040 + (wn * 128 + 16 h) * 4)"""
+    out = []
+    for bj in range(4):
+        for q in range(4):
+            acc = 16 * (4 * bi + bj) + 4 * q
+            out.append(f"ds_write_b128 %[sa], a[{acc}:{acc + 3}] offset:{bj * 128 + q * 16}")
+    out.append("s_waitcnt lgkmcnt(0)")
+    return out
+
+
+def clobbers():
+    c = ['"memory"', '"scc"', '"vcc"']
+    c += [f'"v{i}"' for i in range(NV_CLOBBER)]
+    c += [f'"a{i}"' for i in range(256)]
+    c += [f'"s{i}"' for i in range(36, 56)]
+    return ", ".join(c)
+
+
+def as_c_string(lines):
+    return "\n".join('  "' + ln + '\\n\\t"' for ln in lines)
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else "v2s_gemm_a4.inc"
+    parts = ["// GENERATED by gen_gemm_a4.py -- do not edit.  The hand-scheduled K loop of gemm_a4_kernel (see the generator's header).",
+             "// clang-format off"]
+    stats = {}
+    for tb in (False, True):
+        g = Gen(tb)
+        lines = g.main()
+        stats[tb] = (len(lines), g.nmfma)
+        parts.append(f"#define A4_MAIN_{'NN' if tb else 'NT'} \\")
+        parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in lines))
+        parts.append("")
+    for bi in range(4):
+        parts.append(f"#define A4_DUMP_{bi} \\")
+        parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in dump_lines(bi)))
+        parts.append("")
+    parts.append(f"#define A4_CLOBBERS {clobbers()}")
+    parts.append("// clang-format on")
+    with open(out, "w") as f:
+        f.write("\n".join(parts) + "\n")
+    print(f"wrote {out}: NT {stats[False][0]} lines / {stats[False][1]} MFMAs, NN {stats[True][0]} lines / {stats[True][1]} MFMAs")
+
+
+if __name__ == "__main__":
+    main()

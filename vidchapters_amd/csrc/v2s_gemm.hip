@@ -1981,6 +1981,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   }
 }
 
+#include "v2s_gemm_a4.h"
+
 }  // namespace
 
 static int num_cus() {
@@ -2029,6 +2031,12 @@ static bool ps_auto(const v2s_gemm_args* a, long t128, int slots, int p8, bool p
 // Shapes the 128 x 128-wave-tile kernel takes by default (gemm_w128 = 1).
 static bool w128_auto(const v2s_gemm_args* a) {
   (void)a;
+  return false;
+}
+
+// Shapes the 4-wave asm-scheduled 256 x 256 kernel takes by default (gemm_a4 = 1).  Rules from tools/gemm_a4_ab.py (profiles/r05_gemm_a4_ab.txt).
+static bool a4_auto(const v2s_gemm_args* a, long t256) {
+  (void)a; (void)t256;
   return false;
 }
 
@@ -2264,6 +2272,18 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     }
     if (ps) { bm = BM; bn = BN; p8 = 0; p8d = false; w4 = false; }
   }
+  // 4-wave asm-scheduled 256 x 256 kernel (gemm_a4_kernel): forward / dgrad shapes, any epilogue, never split-K
+  bool a4 = false;
+  {
+    const int amode = v2s_opt_gemm_a4();
+    const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+    const bool a_ok = amode != 0 && p8_force != 0 && tr && !a->transA && (a->K % 128) == 0 && a->M >= 256 && a->N >= 256 && (a->N % 8) == 0 &&
+                      !(plain_split && t256 < 512) && (long)a->M * a->lda < (1L << 30) &&
+                      (a->transB ? 32 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 30);
+    if (a_ok && (amode == 2 || (amode == 1 && v2s_opt_gemm_p8() == 1 && a4_auto(a, t256)))) {
+      a4 = true; bm = 256; bn = 256; p8 = 0; p8d = false; w4 = false; w128 = false; ps = false;
+    }
+  }
   p.tilesM = (a->M + bm - 1) / bm; p.tilesN = (a->N + bn - 1) / bn;
   // split-K: weight-gradient GEMMs have few output tiles (768x768 -> 36) but a huge contraction (all tokens);
   // slice K so that the chip is filled.  Only for fp32 outputs with a plain epilogue; partials go to the workspace.
@@ -2296,7 +2316,18 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     }
   }
   const unsigned nblocks = (unsigned)(p.tilesM * p.tilesN * p.splitk);
-  if (w128 && p.splitk == 1) {
+  if (a4 && p.splitk == 1) {
+    static bool attr_a4 = false;
+    if (!attr_a4) {
+      (void)hipFuncSetAttribute((const void*)gemm_a4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_a4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS);
+      attr_a4 = true;
+    }
+    const dim3 grid(nblocks), block(256);
+    g_last_gemm = a->transB ? "gemm_a4_kernel<true>" : "gemm_a4_kernel<false>";
+    if (a->transB) hipLaunchKernelGGL((gemm_a4_kernel<true>), grid, block, A4_LDS, s, p);
+    else hipLaunchKernelGGL((gemm_a4_kernel<false>), grid, block, A4_LDS, s, p);
+  } else if (w128 && p.splitk == 1) {
     static bool attr_w = false;
     if (!attr_w) {
       (void)hipFuncSetAttribute((const void*)gemm_wt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WT<4>::LDS);
