@@ -1,0 +1,65 @@
+"""CPU tests of the GENERATED K loop of gemm_a4_kernel (vidchapters_amd/csrc/gen_gemm_a4.py -> v2s_gemm_a4.inc): the generated
+instruction text is executed on the functional model of tools/a4_emu.py (4 waves x 64 lanes, LDS, LDS-DMA, ds_read_b128 /
+ds_read_b64_tr_b16, v_mfma_f32_32x32x16_bf16, scalar loop control) and must reproduce X . W^T for both operand layouts under every
+combination of lazy / eager completion of LDS reads and DMA writes and several wave interleavings -- which is what checks the counted
+s_waitcnt values and the barrier protocol, not just the address arithmetic.  (The -m gpu counterpart is
+tests/test_kernels_gpu.py::test_gemm_a4_kernel.)"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import a4_emu as E  # noqa: E402
+
+GEN = os.path.join(ROOT, "vidchapters_amd", "csrc", "gen_gemm_a4.py")
+MODES = ((False, False, "fwd"), (True, True, "random"), (True, False, "random"), (False, True, "rev"), (True, True, "fwd"))
+
+
+@pytest.fixture(scope="module")
+def inc(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("a4") / "v2s_gemm_a4.inc")
+    subprocess.run([sys.executable, GEN, out], check=True)
+    return out
+
+
+def test_committed_inc_is_what_the_generator_emits(inc):
+    committed = os.path.join(ROOT, "vidchapters_amd", "csrc", "v2s_gemm_a4.inc")
+    assert open(committed).read() == open(inc).read(), "v2s_gemm_a4.inc is stale: run gen_gemm_a4.py"
+
+
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (600, 512, 384)])
+def test_generated_loop_computes_the_product(inc, tb, M, N, K):
+    tile = ((M - 1) // 256, (N - 1) // 256)          # the ragged last tile row
+    for lazy_ds, lazy_dma, sched in MODES:
+        err = E.check(inc, tb, M, N, K, tile=tile, lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched)
+        assert err < 2e-5, (tb, M, N, K, lazy_ds, lazy_dma, sched, err)
+
+
+def test_the_model_catches_a_wrong_wait_a_missing_barrier_and_a_wrong_slot(inc, tmp_path):
+    """the emulator is only worth something if it rejects broken schedules: three mutations of the generated text"""
+    src = open(inc).read()
+
+    def nth(s, pat, rep, n):
+        idx = [m.start() for m in re.finditer(re.escape(pat), s)]
+        return s[:idx[n]] + rep + s[idx[n] + len(pat):]
+
+    muts = {"vmcnt": nth(src, "s_waitcnt vmcnt(16) lgkmcnt(0)", "s_waitcnt vmcnt(24) lgkmcnt(0)", 2),
+            "barrier": nth(src, "s_barrier", "s_nop 0", 3),
+            "lgkm": nth(src, "s_waitcnt lgkmcnt(6)", "s_waitcnt lgkmcnt(7)", 10),
+            "slot": nth(src, "s_add_u32 m0, s40, 0x18000", "s_add_u32 m0, s40, 0x10000", 1)}
+    for name, text in muts.items():
+        p = str(tmp_path / f"{name}.inc")
+        open(p, "w").write(text)
+        caught = False
+        for lazy_ds, lazy_dma, sched in MODES:
+            try:
+                err = E.check(p, False, 256, 256, 256, lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched)
+                caught |= not (err < 1e-3)           # NaN (poisoned register read) or a wrong product
+            except (AssertionError, RuntimeError):
+                caught = True
+        assert caught, name
