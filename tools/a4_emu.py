@@ -79,6 +79,13 @@ class Block:
                 return arr[addr - base: addr - base + n]
         raise RuntimeError(f"global read out of bounds: 0x{addr:x} (+{n})")
 
+    def gwrite(self, addr, data):
+        for base, arr in self.gmem:
+            if base <= addr and addr + len(data) <= base + len(arr):
+                arr[addr - base: addr - base + len(data)] = data
+                return
+        raise RuntimeError(f"global write out of bounds: 0x{addr:x} (+{len(data)})")
+
     # ---- operand decoding
     def src(self, w, tok, vec=True):
         """value of a source operand: scalar -> np.uint32, vector -> np.uint32[64]"""
@@ -150,6 +157,12 @@ class Block:
             else:
                 r = a - b; w.scc = int(b > a)
             self.sets(w, ops[0], r & 0xFFFFFFFF); return
+        if op in ("s_mul_i32", "s_mul_hi_u32", "s_min_u32", "s_max_u32"):
+            a, b = int(S(ops[1])), int(S(ops[2]))
+            r = {"s_mul_i32": (a * b) & 0xFFFFFFFF, "s_mul_hi_u32": (a * b) >> 32, "s_min_u32": min(a, b), "s_max_u32": max(a, b)}[op]
+            if op in ("s_min_u32", "s_max_u32"):
+                w.scc = int(r == a)
+            self.sets(w, ops[0], r); return
         if op in ("s_lshl_b32", "s_lshr_b32", "s_and_b32", "s_or_b32"):
             a, b = int(S(ops[1])), int(S(ops[2]))
             r = {"s_lshl_b32": (a << (b & 31)), "s_lshr_b32": a >> (b & 31), "s_and_b32": a & b, "s_or_b32": a | b}[op] & 0xFFFFFFFF
@@ -225,11 +238,18 @@ class Block:
             addr = V(ops[1]).astype(np.int64) + offset
             arr = w.v if kd == "v" else w.a
             arr[d0:d0 + dn] = POISON
+            tr = op != "ds_read_b128"
+            box = {}
 
-            def complete(addr=addr.copy(), d0=d0, dn=dn, arr=arr, tr=(op != "ds_read_b128")):
+            def sample(addr=addr.copy(), dn=dn, tr=tr, box=box):
+                """read LDS (once): at the latest moment the ordering rules allow -- retirement, or just before a later LDS write of the SAME
+                wave (a wave's LDS operations execute in order)"""
+                if "d" in box:
+                    return
+                out = np.zeros((dn, 64), np.uint32)
                 if not tr:
                     for l in range(64):
-                        arr[d0:d0 + 4, l] = self.lds[addr[l]:addr[l] + 16].view(np.uint32)
+                        out[:, l] = self.lds[addr[l]:addr[l] + 16].view(np.uint32)
                 else:
                     # 16-lane groups: lane j supplies the address of 4 bf16 (k-row j >> 2 of the block, columns 4 (j & 3) ..); lane i receives
                     # column i: for kk = 0..3 the element (i & 3) of the run supplied by lane 4 kk + (i >> 2)
@@ -240,8 +260,14 @@ class Block:
                                 srcl = g * 16 + 4 * kk + (i >> 2)
                                 a_ = addr[srcl] + 2 * (i & 3)
                                 vals.append(int(self.lds[a_]) | (int(self.lds[a_ + 1]) << 8))
-                            arr[d0, g * 16 + i] = vals[0] | (vals[1] << 16)
-                            arr[d0 + 1, g * 16 + i] = vals[2] | (vals[3] << 16)
+                            out[0, g * 16 + i] = vals[0] | (vals[1] << 16)
+                            out[1, g * 16 + i] = vals[2] | (vals[3] << 16)
+                box["d"] = out
+
+            def complete(d0=d0, dn=dn, arr=arr, box=box, sample=sample):
+                sample()
+                arr[d0:d0 + dn] = box["d"]
+            complete.sample = sample
             if self.lazy_ds:
                 assert len(w.lgkm) < 15
                 w.lgkm.append(complete)
@@ -253,9 +279,12 @@ class Block:
             addr = V(ops[0]).astype(np.int64) + offset
             arr = w.v if kd == "v" else w.a
             data = arr[d0:d0 + 4].copy()
+            for f in w.lgkm:                                 # older reads of this wave execute first
+                if hasattr(f, "sample"):
+                    f.sample()
             for l in range(64):
                 self.lds[addr[l]:addr[l] + 16] = np.ascontiguousarray(data[:, l]).view(np.uint8)
-            w.lgkm.append(lambda: None)
+            w.lgkm.append(lambda: None)               # (a dump statement issues 16 writes before its lgkmcnt(0): the hardware stalls at 15)
             return
         if op == "global_load_lds_dwordx4":
             voff = V(ops[0]).astype(np.int64)
@@ -271,6 +300,22 @@ class Block:
                 w.vm.append(complete)
             else:
                 complete(); w.vm.append(lambda: None)
+            assert len(w.vm) <= 63
+            return
+        if op == "buffer_store_dwordx4":
+            # buffer_store_dwordx4 vdata[4], voffset, srd[4], soffset offen   (raw buffer: out of range when voffset + 16 > num_records)
+            assert ops[3].endswith("offen"), ins
+            kd, d0, dn = self.rng(ops[0]); assert dn == 4
+            voff = V(ops[1]).astype(np.int64)
+            k, sb, n = self.rng(ops[2]); assert n == 4
+            base = int(w.s[sb]) | ((int(w.s[sb + 1]) & 0xFFFF) << 32)
+            nrec = int(w.s[sb + 2])
+            soff = int(S(ops[3].replace("offen", "").strip()))
+            data = (w.v if kd == "v" else w.a)[d0:d0 + 4].copy()
+            for l in range(64):
+                if int(voff[l]) + 16 <= nrec:
+                    self.gwrite(base + soff + int(voff[l]), np.ascontiguousarray(data[:, l]).view(np.uint8))
+            w.vm.append(lambda: None)
             assert len(w.vm) <= 63
             return
         raise RuntimeError(f"unhandled instruction: {ins}")
@@ -391,6 +436,59 @@ def check(inc, tb, M, N, K, tile=(0, 0), seed=1, lazy_ds=True, lazy_dma=True, sc
     return err
 
 
+SUB_P = dict(tid="v250", pa0="s8", pa1="s9", pb0="s10", pb1="s11", lda="s12", ldb="s13", pc0="s14", pc1="s15", ldc="s16", cbytes="s17",
+             niter="s18", lds="s19", bid="s20", grid="s21", q="s22", r="s23", magic="s24", tilesn="s25", nmy="s26")
+
+
+def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="random", verbose=False):
+    """the persistent deferred-write-out kernel: `grid` blocks walk the (M / 256) x (N / 256) tiles; returns the max abs error of the bf16
+    output against the fp64 product rounded to bf16 inputs"""
+    macros = parse_inc(inc)
+    rs = np.random.RandomState(seed)
+    X = (rs.randn(M, K) * 0.5).astype(np.float32)
+    W = (rs.randn(N, K) * 0.5).astype(np.float32)
+    to_bf = lambda f: ((f.view(np.uint32) + 0x7FFF + ((f.view(np.uint32) >> 16) & 1)) >> 16).astype(np.uint16)
+    Xb, Wb = to_bf(X), to_bf(W)
+    ref = bf16_to_f32(Xb).astype(np.float64) @ bf16_to_f32(Wb).astype(np.float64).T
+    lda = K
+    if tb:
+        Bmem, ldb = np.ascontiguousarray(Wb.T), N
+    else:
+        Bmem, ldb = Wb, K
+    ldc = N
+    Cmem = np.full(M * ldc, 0x7FC0, np.uint16)            # NaN-filled output
+    PA, PB, PC = 0x10000000, 0x30000000, 0x50000000
+    gmem = [(PA, Xb.view(np.uint8).reshape(-1)), (PB, Bmem.view(np.uint8).reshape(-1)), (PC, Cmem.view(np.uint8))]
+    tilesM, tilesN = M // 256, N // 256
+    ntiles = tilesM * tilesN
+    prog = render(macros["A4P_MAIN_NN" if tb else "A4P_MAIN_NT"], SUB_P)
+    for bid in range(grid):
+        blk = Block(prog, gmem, lazy_ds, lazy_dma)
+        for w in blk.waves:
+            w.a[:] = np.float32(np.nan).view(np.uint32)   # garbage accumulators at kernel start
+            w.v[250] = np.arange(64, dtype=np.uint32) + 64 * w.wid
+            w.s[8], w.s[9] = PA & 0xFFFFFFFF, PA >> 32
+            w.s[10], w.s[11] = PB & 0xFFFFFFFF, PB >> 32
+            w.s[12], w.s[13] = lda * 2, ldb * 2
+            w.s[14], w.s[15] = PC & 0xFFFFFFFF, PC >> 32
+            w.s[16], w.s[17] = ldc * 2, M * ldc * 2
+            w.s[18], w.s[19] = K // 128, 0
+            w.s[20], w.s[21] = bid, grid
+            w.s[22], w.s[23] = ntiles >> 3, ntiles & 7
+            w.s[24], w.s[25] = ((1 << 32) + tilesN - 1) // tilesN, tilesN
+            w.s[26] = (ntiles - bid + grid - 1) // grid
+        blk.run(sched=sched, seed=seed + bid)
+        assert all(not w.vm and not w.lgkm for w in blk.waves)
+    got = bf16_to_f32(Cmem).reshape(M, ldc).astype(np.float64)
+    refb = bf16_to_f32(to_bf(ref.astype(np.float32))).astype(np.float64)
+    err = np.abs(got - refb)
+    bad = ~(err <= 0.0079 * np.abs(refb) + 1e-6)          # one bf16 ulp: the fp32 sums differ from fp64 in the last bits
+    if verbose:
+        print(f"persistent tb={tb} M={M} N={N} K={K} grid={grid} lazy_ds={lazy_ds} lazy_dma={lazy_dma} sched={sched}: "
+              f"{int(bad.sum())} wrong of {bad.size}, NaN {int(np.isnan(got).sum())}, max abs err {np.nanmax(err):.3e}")
+    return int(bad.sum())
+
+
 if __name__ == "__main__":
     import os
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
@@ -400,6 +498,13 @@ if __name__ == "__main__":
         if a.startswith("--inc="):
             inc = a[6:]
     M, N, K = (int(x) for x in args[:3]) if len(args) >= 3 else (256, 256, 128)
+    if "--persistent" in sys.argv:
+        grid = int(args[3]) if len(args) > 3 else 2
+        nbad = 0
+        for lazy_ds, lazy_dma, sched in ((False, False, "fwd"), (True, True, "random"), (True, False, "random"), (False, True, "rev"), (True, True, "fwd")):
+            nbad += check_p(inc, tb, M, N, K, grid, lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched, verbose=True)
+        print("OK" if nbad == 0 else "FAILED")
+        sys.exit(0 if nbad == 0 else 1)
     worst = 0.0
     for lazy_ds, lazy_dma, sched in ((False, False, "fwd"), (True, True, "random"), (True, False, "random"), (False, True, "rev"), (True, True, "fwd")):
         worst = max(worst, check(inc, tb, M, N, K, tile=((M - 1) // 256, (N - 1) // 256), lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched, verbose=True))

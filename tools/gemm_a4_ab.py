@@ -25,7 +25,8 @@ if "--large" in sys.argv:
               ("NT", 64000, 1024, 4096, "enc wo fwd"), ("NN", 64000, 1024, 3072, "enc QKV dgrad"), ("NN", 64000, 4096, 1024, "enc wo dgrad")]
 if "--quick" in sys.argv:
     SHAPES = SHAPES[:4] + SHAPES[5:7] + SHAPES[-1:]
-VARIANTS = [("default", dict()), ("a4", dict(gemm_a4=2)), ("a4-nostore", dict(gemm_a4=2, gemm_dbg=1)), ("a4-mainloop", dict(gemm_a4=2, gemm_dbg=2))]
+VARIANTS = [("default", dict()), ("a4", dict(gemm_a4=2)), ("a4-nostore", dict(gemm_a4=2, gemm_dbg=1)), ("a4v1", dict(gemm_a4=3)), ("a4v1-mainloop", dict(gemm_a4=3, gemm_dbg=2))]
+# gemm_a4 = 2: the persistent deferred-write-out kernel where it is legal (plain bf16 epilogue, whole tiles), else the one-tile kernel; 3: one-tile kernel only
 DEF = dict(gemm_a4=0, gemm_dbg=0)
 
 
@@ -42,7 +43,8 @@ def check():
     """a4 against fp32 torch on bf16-rounded inputs, plain and fused epilogues, ragged edges, both operand layouts"""
     cases = [("NT", 256, 256, 128, ""), ("NT", 512, 512, 256, ""), ("NT", 1000, 520, 384, ""), ("NT", 2000, 768, 768, "res"), ("NT", 1300, 1544, 384, "act"),
              ("NT", 600, 520, 256, "f32"), ("NT", 3200, 768, 2048, "bias"), ("NN", 256, 256, 128, ""), ("NN", 777, 392, 256, "dact"), ("NN", 2048, 768, 2304, ""),
-             ("NN", 1000, 520, 384, "res"), ("NT", 32000, 2304, 768, ""), ("NN", 32000, 768, 2304, ""), ("NT", 35200, 1536, 768, "")]
+             ("NN", 1000, 520, 384, "res"), ("NT", 32000, 2304, 768, ""), ("NN", 32000, 768, 2304, ""), ("NT", 35200, 1536, 768, ""),
+             ("NT", 512, 512, 384, ""), ("NN", 768, 512, 512, ""), ("NT", 8192, 768, 768, ""), ("NN", 32000, 3072, 768, ""), ("NT", 66048, 256, 384, ""), ("NT", 256, 66048, 384, "")]
     bad = 0
     for kind, M, N, K, ep in cases:
         g = torch.Generator(device=dev); g.manual_seed(M * 7 + N * 3 + K)
@@ -60,18 +62,19 @@ def check():
         if ep == "dact":
             z = torch.relu(rn(M, N)); kw.update(dact=L.ACT_RELU, z=z); ref = ref * (z.float() > 0)
         outs = {}
-        for name, o in (("default", {}), ("a4", dict(gemm_a4=2))):
+        for name, o in (("default", {}), ("a4", dict(gemm_a4=2)), ("a4v1", dict(gemm_a4=3))):
             setopts(o)
             C = torch.full((M, N), float("nan"), dtype=torch.float32 if ep == "f32" else torch.bfloat16, device=dev)
             L.gemm(A, B, C, M, N, K, **kw)
             torch.cuda.synchronize()
             outs[name] = (C, L.lib().v2s_last_gemm_kernel().decode())
         setopts({})
-        e_a4, e_def = relerr(outs["a4"][0], ref), relerr(outs["default"][0], ref)
+        e_a4, e_v1, e_def = relerr(outs["a4"][0], ref), relerr(outs["a4v1"][0], ref), relerr(outs["default"][0], ref)
         tol = 2e-5 if ep == "f32" else 3e-3
-        ok = "gemm_a4" in outs["a4"][1] and e_a4 < tol and bool(torch.isfinite(outs["a4"][0]).all())
+        ok = all("gemm_a4" in outs[n][1] and relerr(outs[n][0], ref) < tol and bool(torch.isfinite(outs[n][0]).all()) for n in ("a4", "a4v1"))
+        ok = ok and bool(torch.equal(outs["a4"][0], outs["a4v1"][0]))       # same K order, same single rounding: the two forms agree bit for bit
         bad += 0 if ok else 1
-        print(f"check {kind} {M}x{N}x{K} {ep or 'plain':5s}: a4 rel err {e_a4:.2e} (default {e_def:.2e})  [{outs['a4'][1]}] {'ok' if ok else 'FAILED'}", flush=True)
+        print(f"check {kind} {M}x{N}x{K} {ep or 'plain':5s}: a4 rel err {e_a4:.2e} / one-tile {e_v1:.2e} (default {e_def:.2e})  [{outs['a4'][1]} | {outs['a4v1'][1]}] {'ok' if ok else 'FAILED'}", flush=True)
     return bad
 
 

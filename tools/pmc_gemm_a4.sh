@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/pmc_r5
 i=0
-for spec in "32000 2304 768 0 0 1|gemm_a4=2,gemm_dbg=2" "32000 2304 768 0 0 1|gemm_a4=2" "32000 2304 768 0 0 1|" "32000 768 2304 0 1 1|gemm_a4=2" "32000 768 2304 0 1 1|" "8192 8192 8192 0 0 1|gemm_a4=2,gemm_dbg=2" "8192 8192 8192 0 0 1|gemm_a4=2"; do
+for spec in "32000 2304 768 0 0 1|gemm_a4=3,gemm_dbg=2" "32000 2304 768 0 0 1|gemm_a4=2" "32000 2304 768 0 0 1|gemm_a4=2,gemm_dbg=1" "32000 2304 768 0 0 1|" "32000 768 2304 0 1 1|gemm_a4=2" "8192 8192 8192 0 0 1|gemm_a4=2"; do
   cfg=${spec%%|*}; opts=${spec##*|}
   i=$((i+1))
   tag=$(echo $cfg | awk '{print $1"_"$2"_"$3}')_v$i

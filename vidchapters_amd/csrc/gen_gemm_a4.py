@@ -60,7 +60,10 @@ class Gen:
 
     # ---- scoreboard
     def lds_op(self, tag, text):
-        assert len(self.lgkm) < 15, "lgkmcnt is a 4-bit counter"
+        if len(self.lgkm) >= 15:                # lgkmcnt is a 4-bit counter: retire the older half (long done) to make room
+            keep = 7
+            self.e(f"s_waitcnt lgkmcnt({keep})")
+            self.lgkm = self.lgkm[len(self.lgkm) - keep:]
         self.lgkm.append(tag)
         self.e(text)
 
@@ -142,14 +145,20 @@ class Gen:
         self.e(f"v_mfma_f32_32x32x16_bf16 a[{acc}:{acc + 15}], v[{bf}:{bf + 3}], v[{af}:{af + 3}], {c}")
         self.nmfma += 1
 
-    def step(self, fs, gaps, first=False):
-        """16 MFMAs on fragment set fs; gaps[j] = list of callables run after MFMA j"""
+    def step(self, fs, gaps, first=False, pre=None):
+        """16 MFMAs on fragment set fs; gaps[j] = list of callables run after MFMA j, pre[j] = before it; after the gap's own fillers
+        up to self.bg_rate entries of the background stream self.bg (deferred write-out work) are emitted"""
         j = 0
         for bi in range(4):
             for bj in range(4):
+                for f in (pre or {}).get(j, []):
+                    f()
                 self.mfma(fs, bi, bj, first)
                 for f in gaps.get(j, []):
                     f()
+                for _ in range(getattr(self, "bg_rate", 0)):
+                    if getattr(self, "bg", None):
+                        self.bg.pop(0)()
                 j += 1
 
     # ---- the statement
@@ -349,6 +358,375 @@ class Gen:
         return self.lines
 
 
+# =====================================================================================================================================
+# Persistent form with a DEFERRED write-out ("a4p"): one block per CU walks its tiles; the bf16 output of tile t leaves the chip during
+# the main loop of tile t+1.  Plain bf16 epilogue (alpha = 1), M and N multiples of 256, K >= 384.
+#   * step 0 of a tile: before the first MFMA of accumulator block b (which starts from C = 0) the block's sixteen values of the PREVIOUS
+#     tile are read out of the AGPRs and rounded to bf16 pairs (v_cvt_pk_bf16_f32) into eight "held" VGPRs (128 in all);
+#   * steps 1..8: a background stream of write-out work, one instruction per MFMA gap: per 32-row block row c of the wave's 128 x 128
+#     sub-tile  W_c: 8 ds_write_b128 held -> a wave-private 8 KiB staging block (rows of 256 B, 16-byte chunks XOR-swizzled with
+#     row & 7),  R_c: 8 ds_read_b128 back as whole rows (4 rows x 256 B per instruction, into the same held registers),  S_c: 8
+#     buffer_store_dwordx4 (each lane 16 B, 16 lanes = one 256-byte row segment: full cache lines).  No barrier: the staging block is
+#     private to the wave and LDS executes a wave's operations in order;
+#   * the DMA stream does not stop at a tile edge: the last three stages' requests of a tile already fetch the next tile (scalar bases
+#     switched by a uniform branch in the last loop iteration); past the block's last tile the same tile is requested again (harmless)
+#     so that every counted wait keeps its constant;
+#   * the stores ride the wave's in-order vmcnt queue between the DMA requests: the scoreboard counts them like any other operation.
+#     The first tile of a block has nothing held: its stores go through a buffer descriptor with num_records = 0 (dropped).
+#   * after the block's last tile: convert + write out without a main loop beside it (drain).
+V_HELD = 100                 # v100..v227
+V_STW = 228                  # staging write addresses: 4 variants q = 2 (bj & 1) + half
+V_STR = 232                  # staging read addresses: row-group parity 0 / 1
+V_STO = 234                  # store offset: (lane >> 4) * ldc_bytes + (lane & 15) * 16
+NV_CLOBBER_P = 240
+S_K, S_NMY = 44, 45          # tile ordinal of this block, its tile count
+S_SRD = 56                   # s56..s59 buffer descriptor of C
+S_ST_PREV, S_ST_CUR, S_ST_NEXT = 60, 61, 62   # store offsets (bytes): running one of the held tile, base of the current / next tile
+S_ST_WAVE = 63               # (wm * 128) * ldc_bytes + wn * 256
+S_ST_STEP = 64               # 4 rows: 4 * ldc_bytes
+S_X = 68                     # temporaries s68..s79 (tile coordinates)
+RING = 4 * STAGE
+
+
+class GenP(Gen):
+    def __init__(self, tb):
+        super().__init__(tb)
+        self.bg = []
+        self.bg_rate = 1
+
+    # ---- lane constants (tile-independent)
+    def setup_p(self):
+        e = self.e
+        T, S = V_T, S_T
+        e("s_nop 4")
+        e(f"v_and_b32 v{T}, 63, %[tid]")                    # lane
+        e(f"v_lshrrev_b32 v{T + 1}, 6, %[tid]")             # wave
+        e("s_nop 1")
+        e(f"v_readfirstlane_b32 s{S}, v{T + 1}")            # w
+        e(f"s_lshr_b32 s{S + 1}, s{S}, 1")                  # wm
+        e(f"s_and_b32 s{S + 2}, s{S}, 1")                   # wn
+        e(f"s_lshl_b32 s{S + 3}, s{S}, 12")
+        e(f"s_add_u32 s{S_LDSW}, %[lds], s{S + 3}")
+        e(f"s_mov_b32 s{S_STA}, 64")
+        # DMA source offsets relative to the TILE's first row: chunk = 16 rows x 64 B; (row >> 2) & 3 = (lane >> 4) & 3
+        e(f"v_lshrrev_b32 v{T + 2}, 2, v{T}")
+        e(f"v_lshrrev_b32 v{T + 3}, 4, v{T}")
+        e(f"v_and_b32 v{T + 3}, 3, v{T + 3}")
+        e(f"v_and_b32 v{T + 4}, 3, v{T}")
+        e(f"v_xor_b32 v{T + 4}, v{T + 4}, v{T + 3}")
+        e(f"v_lshlrev_b32 v{T + 4}, 4, v{T + 4}")           # g * 16 bytes
+        e(f"s_lshl_b32 s{S + 4}, s{S}, 6")                  # w * 64 rows
+        e(f"v_add_u32 v{T + 5}, s{S + 4}, v{T + 2}")        # tile row w * 64 + (lane >> 2)
+
+        def rows(voff, ld):
+            for i in range(4):
+                e(f"v_add_u32 v{T + 6}, {16 * i}, v{T + 5}")
+                e(f"v_mul_lo_u32 v{T + 6}, v{T + 6}, {ld}")
+                e(f"v_add_u32 v{voff + i}, v{T + 6}, v{T + 4}")
+
+        rows(V_OA, "%[lda]")
+        if not self.tb:
+            e(f"s_mov_b32 s{S_STB}, 64")
+            rows(V_OB, "%[ldb]")
+        else:
+            e(f"s_lshl_b32 s{S_STB}, %[ldb], 5")
+            e(f"v_lshrrev_b32 v{T + 5}, 5, v{T}")
+            e(f"v_and_b32 v{T + 6}, 31, v{T}")
+            e(f"v_lshrrev_b32 v{T + 7}, 1, v{T + 6}")
+            e(f"v_and_b32 v{T + 8}, 1, v{T + 6}")
+            e(f"s_lshl_b32 s{S + 5}, s{S}, 3")
+            e(f"v_add_u32 v{T + 9}, s{S + 5}, v{T + 5}")
+            for i in range(4):
+                e(f"v_add_u32 v{T + 10}, {2 * (i & 1)}, v{T + 5}")
+                e(f"v_lshlrev_b32 v{T + 10}, 1, v{T + 10}")
+                e(f"v_xor_b32 v{T + 10}, v{T + 7}, v{T + 10}")
+                e(f"v_lshlrev_b32 v{T + 10}, 4, v{T + 10}")
+                e(f"v_lshl_add_u32 v{T + 10}, v{T + 8}, 3, v{T + 10}")  # column inside the tile
+                e(f"v_lshlrev_b32 v{T + 10}, 1, v{T + 10}")
+                e(f"v_add_u32 v{T + 11}, {2 * i}, v{T + 9}")
+                e(f"v_mul_lo_u32 v{T + 11}, v{T + 11}, %[ldb]")
+                e(f"v_add_u32 v{V_OB + i}, v{T + 11}, v{T + 10}")
+        # ds_read addresses: identical to the one-tile kernel
+        e(f"v_and_b32 v{T + 5}, 31, v{T}")
+        e(f"v_lshrrev_b32 v{T + 6}, 5, v{T}")
+        e(f"v_lshrrev_b32 v{T + 7}, 2, v{T + 5}")
+        e(f"v_and_b32 v{T + 7}, 3, v{T + 7}")
+        e(f"v_xor_b32 v{T + 7}, v{T + 6}, v{T + 7}")
+        e(f"v_lshlrev_b32 v{T + 7}, 4, v{T + 7}")
+        e(f"s_lshl_b32 s{S + 5}, s{S + 1}, 13")
+        e(f"v_lshl_add_u32 v{T + 8}, v{T + 5}, 6, s{S + 5}")
+        e(f"v_add_u32 v{T + 8}, %[lds], v{T + 8}")
+        e(f"v_add_u32 v{V_DA}, v{T + 8}, v{T + 7}")
+        e(f"v_xor_b32 v{V_DA + 1}, 32, v{V_DA}")
+        e(f"v_add_u32 v{V_DA + 2}, 0x10000, v{V_DA}")
+        e(f"v_add_u32 v{V_DA + 3}, 0x10000, v{V_DA + 1}")
+        if not self.tb:
+            e(f"v_lshrrev_b32 v{T + 7}, 2, v{T + 5}")
+            e(f"v_and_b32 v{T + 7}, 1, v{T + 7}")
+            e(f"v_lshlrev_b32 v{T + 7}, 4, v{T + 7}")
+            e(f"v_lshrrev_b32 v{T + 8}, 3, v{T + 5}")
+            e(f"v_lshl_add_u32 v{T + 7}, v{T + 8}, 2, v{T + 7}")
+            e(f"v_and_b32 v{T + 9}, 3, v{T + 5}")
+            e(f"v_add_u32 v{T + 7}, v{T + 7}, v{T + 9}")
+            e(f"v_xor_b32 v{T + 8}, v{T + 6}, v{T + 8}")
+            e(f"v_lshlrev_b32 v{T + 8}, 4, v{T + 8}")
+            e(f"s_lshl_b32 s{S + 5}, s{S + 2}, 13")
+            e(f"v_lshl_add_u32 v{T + 7}, v{T + 7}, 6, s{S + 5}")
+            e(f"v_add_u32 v{T + 7}, %[lds], v{T + 7}")
+            e(f"v_add_u32 v{V_DB}, v{T + 7}, v{T + 8}")
+            e(f"v_xor_b32 v{V_DB + 1}, 32, v{V_DB}")
+            e(f"v_add_u32 v{V_DB + 2}, 0x10000, v{V_DB}")
+            e(f"v_add_u32 v{V_DB + 3}, 0x10000, v{V_DB + 1}")
+        else:
+            e(f"v_and_b32 v{T + 7}, 15, v{T}")
+            e(f"v_lshrrev_b32 v{T + 8}, 4, v{T}")
+            e(f"v_and_b32 v{T + 9}, 1, v{T + 8}")
+            e(f"v_lshrrev_b32 v{T + 10}, 1, v{T + 8}")
+            e(f"v_lshrrev_b32 v{T + 11}, 2, v{T + 7}")
+            e(f"v_lshl_add_u32 v{T + 12}, v{T + 10}, 3, v{T + 11}")
+            e(f"v_lshlrev_b32 v{T + 12}, 9, v{T + 12}")
+            e(f"v_and_b32 v{T + 13}, 1, v{T + 7}")
+            e(f"s_lshl_b32 s{S + 5}, s{S + 2}, 3")
+            e(f"v_add_u32 v{T + 13}, s{S + 5}, v{T + 13}")
+            e(f"v_lshl_add_u32 v{T + 12}, v{T + 13}, 5, v{T + 12}")
+            e(f"v_lshl_add_u32 v{T + 12}, v{T + 9}, 4, v{T + 12}")
+            e(f"v_lshrrev_b32 v{T + 13}, 1, v{T + 7}")
+            e(f"v_and_b32 v{T + 13}, 1, v{T + 13}")
+            e(f"v_lshl_add_u32 v{T + 12}, v{T + 13}, 3, v{T + 12}")
+            e(f"v_add_u32 v{T + 12}, %[lds], v{T + 12}")
+            for bj in range(4):
+                e(f"v_xor_b32 v{T + 13}, {bj}, v{T + 11}")
+                e(f"v_lshl_add_u32 v{V_DB + bj}, v{T + 13}, 6, v{T + 12}")
+                e(f"v_add_u32 v{V_DB + 4 + bj}, 0x10000, v{V_DB + bj}")
+        # ---- write-out constants.  Staging block of this wave: LDS + ring + wave * 8 KiB, 32 rows x 256 B.
+        # lane (h, m) holds row m, 16-byte chunks 4 bj + 2 h + half of the row; chunk c of row m is stored at chunk c ^ (m & 7)
+        e(f"s_lshl_b32 s{S + 5}, s{S}, 13")
+        e(f"s_add_u32 s{S + 5}, s{S + 5}, 0x{RING:x}")
+        e(f"s_add_u32 s{S + 5}, s{S + 5}, %[lds]")          # staging base
+        e(f"v_and_b32 v{T + 5}, 31, v{T}")                  # m
+        e(f"v_lshrrev_b32 v{T + 6}, 5, v{T}")               # h
+        e(f"v_and_b32 v{T + 7}, 7, v{T + 5}")               # m & 7
+        e(f"v_lshl_add_u32 v{T + 8}, v{T + 5}, 8, s{S + 5}")            # base + m * 256
+        for q in range(4):
+            e(f"v_lshl_add_u32 v{T + 9}, v{T + 6}, 1, {((q >> 1) << 2) | (q & 1)}")      # ((q >> 1) << 2) | (h << 1) | (q & 1)
+            e(f"v_xor_b32 v{T + 9}, v{T + 9}, v{T + 7}")
+            e(f"v_lshl_add_u32 v{V_STW + q}, v{T + 9}, 4, v{T + 8}")
+        # read-back: lane l: row 4 i + (l >> 4), chunk l & 15, stored at (l & 15) ^ ((4 (i & 1) + (l >> 4)) & 7)
+        e(f"v_lshrrev_b32 v{T + 5}, 4, v{T}")               # l >> 4
+        e(f"v_and_b32 v{T + 6}, 15, v{T}")                  # l & 15
+        e(f"v_lshl_add_u32 v{T + 8}, v{T + 5}, 8, s{S + 5}")            # base + (l >> 4) * 256
+        for par in range(2):
+            e(f"v_add_u32 v{T + 9}, {4 * par}, v{T + 5}")
+            e(f"v_xor_b32 v{T + 9}, v{T + 6}, v{T + 9}")
+            e(f"v_lshl_add_u32 v{V_STR + par}, v{T + 9}, 4, v{T + 8}")
+        # store offset of the lane inside a 4-row group
+        e(f"v_mul_lo_u32 v{T + 9}, v{T + 5}, %[ldc]")
+        e(f"v_lshl_add_u32 v{V_STO}, v{T + 6}, 4, v{T + 9}")
+        e(f"s_lshl_b32 s{S + 6}, s{S + 1}, 7")              # wm * 128 rows
+        e(f"s_mul_i32 s{S_ST_WAVE}, s{S + 6}, %[ldc]")
+        e(f"s_lshl_b32 s{S + 6}, s{S + 2}, 8")              # wn * 128 columns * 2 B
+        e(f"s_add_u32 s{S_ST_WAVE}, s{S_ST_WAVE}, s{S + 6}")
+        e(f"s_lshl_b32 s{S_ST_STEP}, %[ldc], 2")
+        # buffer descriptor of C: base, stride 0, num_records = 0 (nothing held yet), flags
+        e(f"s_mov_b32 s{S_SRD}, %[pc0]")
+        e(f"s_and_b32 s{S_SRD + 1}, %[pc1], 0xffff")
+        e(f"s_mov_b32 s{S_SRD + 2}, 0")
+        e(f"s_mov_b32 s{S_SRD + 3}, 0x00020000")
+        e(f"s_mov_b32 s{S_K}, 0")
+        e(f"s_mov_b32 s{S_NMY}, %[nmy]")
+
+    def tile_setup(self, sk, store_dst):
+        """scalar only: tile ordinal in s{sk} -> running source bases (s36..s39) and the tile's store offset base in s{store_dst}"""
+        e = self.e
+        X = S_X
+        e(f"s_mul_i32 s{X}, s{sk}, %[grid]")
+        e(f"s_add_u32 s{X}, s{X}, %[bid]")                  # id = bid + k * grid
+        e(f"s_and_b32 s{X + 1}, s{X}, 7")                   # XCD-aware bijective remap (xcd_remap): consecutive tiles stay on one XCD
+        e(f"s_lshr_b32 s{X + 2}, s{X}, 3")
+        e(f"s_mul_i32 s{X + 3}, s{X + 1}, %[q]")
+        e(f"s_min_u32 s{X + 4}, s{X + 1}, %[r]")
+        e(f"s_add_u32 s{X + 3}, s{X + 3}, s{X + 4}")
+        e(f"s_add_u32 s{X + 3}, s{X + 3}, s{X + 2}")        # logical tile
+        e(f"s_mul_hi_u32 s{X + 5}, s{X + 3}, %[magic]")     # tm = tile / tilesN
+        e(f"s_mul_i32 s{X + 6}, s{X + 5}, %[tilesn]")
+        e(f"s_sub_u32 s{X + 6}, s{X + 3}, s{X + 6}")        # tn
+        e(f"s_lshl_b32 s{X + 5}, s{X + 5}, 8")              # m0
+        e(f"s_lshl_b32 s{X + 6}, s{X + 6}, 8")              # n0
+        e(f"s_mul_i32 s{X + 7}, s{X + 5}, %[lda]")
+        e(f"s_mul_hi_u32 s{X + 8}, s{X + 5}, %[lda]")
+        e(f"s_add_u32 s{S_PA}, %[pa0], s{X + 7}")
+        e(f"s_addc_u32 s{S_PA + 1}, %[pa1], s{X + 8}")
+        if not self.tb:
+            e(f"s_mul_i32 s{X + 7}, s{X + 6}, %[ldb]")
+            e(f"s_mul_hi_u32 s{X + 8}, s{X + 6}, %[ldb]")
+            e(f"s_add_u32 s{S_PB}, %[pb0], s{X + 7}")
+            e(f"s_addc_u32 s{S_PB + 1}, %[pb1], s{X + 8}")
+        else:
+            e(f"s_lshl_b32 s{X + 7}, s{X + 6}, 1")
+            e(f"s_add_u32 s{S_PB}, %[pb0], s{X + 7}")
+            e(f"s_addc_u32 s{S_PB + 1}, %[pb1], 0")
+        e(f"s_mul_i32 s{X + 7}, s{X + 5}, %[ldc]")
+        e(f"s_lshl_b32 s{X + 8}, s{X + 6}, 1")
+        e(f"s_add_u32 s{X + 7}, s{X + 7}, s{X + 8}")
+        e(f"s_add_u32 s{store_dst}, s{X + 7}, s{S_ST_WAVE}")
+
+    def advance_p(self):
+        return [f"s_add_u32 s{S_PA}, s{S_PA}, s{S_STA}", f"s_addc_u32 s{S_PA + 1}, s{S_PA + 1}, 0",
+                f"s_add_u32 s{S_PB}, s{S_PB}, s{S_STB}", f"s_addc_u32 s{S_PB + 1}, s{S_PB + 1}, 0"]
+
+    # ---- write-out pieces
+    def conv(self, b):
+        for i in range(8):
+            self.e(f"v_accvgpr_read_b32 v{V_T + 2 * i}, a{16 * b + 2 * i}")
+            self.e(f"v_accvgpr_read_b32 v{V_T + 2 * i + 1}, a{16 * b + 2 * i + 1}")
+        for i in range(8):
+            self.e(f"v_cvt_pk_bf16_f32 v{V_HELD + 8 * b + i}, v{V_T + 2 * i}, v{V_T + 2 * i + 1}")
+
+    def wops(self, c):
+        out = []
+        for j in range(8):
+            bj, half = j >> 1, j & 1
+            q = (bj & 1) * 2 + half
+            reg = V_HELD + (c * 4 + bj) * 8 + half * 4
+            out.append(lambda reg=reg, q=q, bj=bj, c=c: self.lds_op(f"W{c}", f"ds_write_b128 v{V_STW + q}, v[{reg}:{reg + 3}] offset:{(bj >> 1) * 128}"))
+        return out
+
+    def rops(self, c):
+        out = []
+        for i in range(8):
+            reg = V_HELD + c * 32 + 4 * i
+            out.append(lambda reg=reg, i=i, c=c: self.lds_op(f"R{c}_{i}", f"ds_read_b128 v[{reg}:{reg + 3}], v{V_STR + (i & 1)} offset:{i * 1024}"))
+        return out
+
+    def sops(self, c):
+        out = []
+        for i in range(8):
+            reg = V_HELD + c * 32 + 4 * i
+
+            def st(reg=reg, i=i, c=c):
+                self.need({f"R{c}_{i}"})
+                self.vm_op("st", f"buffer_store_dwordx4 v[{reg}:{reg + 3}], v{V_STO}, s[{S_SRD}:{S_SRD + 3}], s{S_ST_PREV} offen")
+            out.append(st)
+            out.append(lambda: self.e(f"s_add_u32 s{S_ST_PREV}, s{S_ST_PREV}, s{S_ST_STEP}"))
+        return out
+
+    def writeout_stream(self):
+        nop = lambda: None
+        seq = self.wops(0) + self.rops(0) + self.wops(1) + self.sops(0) + self.rops(1) + self.wops(2) + self.sops(1) + self.rops(2) + \
+            self.wops(3) + self.sops(2) + self.rops(3) + [nop] * 6 + self.sops(3)
+        return seq
+
+    def body_p(self, kind):
+        """4 stages; kind: 'T' = first iteration of a tile (conversion of the previous tile in step 0, write-out stream starts),
+        'S' = second (the stream runs out), 'P' = any later one (with the tile switch of the DMA stream when it is the tile's last)"""
+        for st in range(4):
+            gaps, pre = {}, {}
+            reads = self.frag_reads(st, 1, 1)
+            for gi, grp in enumerate(reads):
+                gaps.setdefault(gi, []).extend((lambda tg=tg, tx=tx: self.lds_op(tg, tx)) for tg, tx in grp)
+            tag = f"stage{self.stage_ctr + 3}"
+            pairs = self.dma_pairs((st + 3) & 3, tag)
+            for k, (m0set, (t, req)) in enumerate(pairs):
+                g = 7 + k
+                gaps.setdefault(g, []).append(lambda m0set=m0set: self.e(m0set))
+                gaps.setdefault(g + 1, []).insert(0, (lambda t=t, req=req: self.vm_op(t, req)))
+            first = kind == "T" and st == 0
+            if first:
+                for b in range(16):
+                    pre[b] = [lambda b=b: self.conv(b)]
+            rate = self.bg_rate
+            if first:
+                self.bg_rate = 0                             # the stream starts after the conversion step
+            self.step(0, gaps, first=first, pre=pre)
+            self.bg_rate = rate
+            if first:
+                self.bg = self.writeout_stream()
+            adv = self.advance_p()
+            gaps = {0: [(lambda s=s: self.e(s)) for s in adv]}
+
+            def sync():
+                self.vm_need(f"stage{self.stage_ctr + 1}", also_lgkm0=True)
+                self.e("s_barrier")
+            gaps[1] = [sync]
+            if kind == "P" and st == 0:
+                gaps[1].append(self.tile_switch)
+            reads = self.frag_reads((st + 1) & 3, 0, 0)
+            for gi, grp in enumerate(reads):
+                gaps.setdefault(2 + gi, []).extend((lambda tg=tg, tx=tx: self.lds_op(tg, tx)) for tg, tx in grp)
+            self.step(1, gaps)
+            self.stage_ctr += 1
+        assert not self.bg or kind == "T", "write-out stream did not finish in two iterations"
+
+    def tile_switch(self):
+        """in the LAST iteration of a tile, after the tile's last stage has been requested: point the DMA stream at the block's next tile
+        (or at the same tile again when there is none)"""
+        e = self.e
+        e(f"s_cmp_lg_u32 s{S_IT}, 1")
+        e("s_cbranch_scc1 L_a4p_nosw_%=")
+        e(f"s_add_u32 s{S_X + 9}, s{S_K}, 1")
+        e(f"s_sub_u32 s{S_X + 10}, s{S_NMY}, 1")
+        e(f"s_min_u32 s{S_X + 9}, s{S_X + 9}, s{S_X + 10}")
+        self.tile_setup(S_X + 9, S_ST_NEXT)
+        e("L_a4p_nosw_%=:")
+
+    def main_p(self):
+        e = self.e
+        self.setup_p()
+        self.tile_setup(S_K, S_ST_CUR)
+        e(f"s_mov_b32 s{S_ST_PREV}, s{S_ST_CUR}")
+        e("s_nop 4")
+        self.stage_ctr = 0
+        for s in range(3):
+            for m0set, (t, req) in self.dma_pairs(s, f"stage{s}"):
+                e(m0set); e("s_nop 0"); self.vm_op(t, req)
+            for x in self.advance_p():
+                e(x)
+        self.vm_need("stage0")
+        e("s_barrier")
+        for grp in self.frag_reads(0, 0, 0):
+            for tg, tx in grp:
+                self.lds_op(tg, tx)
+        entry = (list(self.lgkm), list(self.vm))
+        shape = lambda: (list(self.lgkm), ["st" if t == "st" else "d" for t in self.vm])
+        entry_shape = shape()
+        e("L_a4p_tile_%=:")
+        self.body_p("T")
+        self.body_p("S")
+        assert shape() == entry_shape, (shape(), entry_shape)
+        e(f"s_sub_u32 s{S_IT}, %[niter], 2")
+        e("L_a4p_loop_%=:")
+        self.vm = [f"stage{self.stage_ctr + 1}"] * 8 + [f"stage{self.stage_ctr + 2}"] * 8
+        self.body_p("P")
+        assert shape() == entry_shape
+        e(f"s_sub_u32 s{S_IT}, s{S_IT}, 1")
+        e(f"s_cmp_lg_u32 s{S_IT}, 0")
+        e("s_cbranch_scc1 L_a4p_loop_%=")
+        # tile boundary
+        e(f"s_mov_b32 s{S_ST_PREV}, s{S_ST_CUR}")
+        e(f"s_mov_b32 s{S_ST_CUR}, s{S_ST_NEXT}")
+        e(f"s_mov_b32 s{S_SRD + 2}, %[cbytes]")
+        e(f"s_add_u32 s{S_K}, s{S_K}, 1")
+        e(f"s_cmp_lt_u32 s{S_K}, s{S_NMY}")
+        e("s_cbranch_scc1 L_a4p_tile_%=")
+        # drain: the block's last tile is still in the accumulators
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        self.vm, self.lgkm = [], []
+        for b in range(16):
+            self.conv(b)
+        for f in self.writeout_stream():
+            f()
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        return self.lines
+
+
+def clobbers_p():
+    c = ['"memory"', '"scc"', '"vcc"']
+    c += [f'"v{i}"' for i in range(NV_CLOBBER_P)]
+    c += [f'"a{i}"' for i in range(256)]
+    c += [f'"s{i}"' for i in range(36, 80)]
+    return ", ".join(c)
+
+
 def dump_lines(bi):
     """accumulator blocks (bi, 0..3) -> fp32 staging: lane (h, m): row wm * 32 + m of the pass, columns wn * 128 + 32 bj + 16 h + r;
     %[sa] = this lane's staging byte address (row * 1040 + (wn * 128 + 16 h) * 4)"""
@@ -385,6 +763,14 @@ def main():
         parts.append(f"#define A4_MAIN_{'NN' if tb else 'NT'} \\")
         parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in lines))
         parts.append("")
+    for tb in (False, True):
+        g = GenP(tb)
+        lines = g.main_p()
+        stats[("p", tb)] = (len(lines), g.nmfma)
+        parts.append(f"#define A4P_MAIN_{'NN' if tb else 'NT'} \\")
+        parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in lines))
+        parts.append("")
+    parts.append(f"#define A4P_CLOBBERS {clobbers_p()}")
     for bi in range(4):
         parts.append(f"#define A4_DUMP_{bi} \\")
         parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in dump_lines(bi)))
@@ -393,7 +779,8 @@ def main():
     parts.append("// clang-format on")
     with open(out, "w") as f:
         f.write("\n".join(parts) + "\n")
-    print(f"wrote {out}: NT {stats[False][0]} lines / {stats[False][1]} MFMAs, NN {stats[True][0]} lines / {stats[True][1]} MFMAs")
+    print(f"wrote {out}: NT {stats[False][0]} lines / {stats[False][1]} MFMAs, NN {stats[True][0]} lines / {stats[True][1]} MFMAs; "
+          f"persistent NT {stats[('p', False)][0]} lines, NN {stats[('p', True)][0]} lines")
 
 
 if __name__ == "__main__":

@@ -2273,15 +2273,19 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     if (ps) { bm = BM; bn = BN; p8 = 0; p8d = false; w4 = false; }
   }
   // 4-wave asm-scheduled 256 x 256 kernel (gemm_a4_kernel): forward / dgrad shapes, any epilogue, never split-K
-  bool a4 = false;
+  bool a4 = false, a4p = false;
   {
     const int amode = v2s_opt_gemm_a4();
     const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
     const bool a_ok = amode != 0 && p8_force != 0 && tr && !a->transA && (a->K % 128) == 0 && a->M >= 256 && a->N >= 256 && (a->N % 8) == 0 &&
                       !(plain_split && t256 < 512) && (long)a->M * a->lda < (1L << 30) &&
                       (a->transB ? 32 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 30);
-    if (a_ok && (amode == 2 || (amode == 1 && v2s_opt_gemm_p8() == 1 && a4_auto(a, t256)))) {
+    if (a_ok && (amode >= 2 || (amode == 1 && v2s_opt_gemm_p8() == 1 && a4_auto(a, t256)))) {
       a4 = true; bm = 256; bn = 256; p8 = 0; p8d = false; w4 = false; w128 = false; ps = false;
+      // persistent form with the deferred write-out: plain bf16 epilogue, whole tiles (gemm_a4 = 3: never)
+      a4p = amode != 3 && a->c_dtype == V2S_BF16 && !a->accumulate && !a->bias && !a->pre && !a->residual && a->dact == V2S_ACT_NONE &&
+            a->act == V2S_ACT_NONE && a->dropout_p == 0.f && a->alpha == 1.0f && (a->M % 256) == 0 && (a->N % 256) == 0 && a->K >= 384 &&
+            !plain_split && (long)a->M * a->ldc * 2 < (1L << 31) && t256 < 65536;
     }
   }
   p.tilesM = (a->M + bm - 1) / bm; p.tilesN = (a->N + bn - 1) / bn;
@@ -2316,7 +2320,20 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     }
   }
   const unsigned nblocks = (unsigned)(p.tilesM * p.tilesN * p.splitk);
-  if (a4 && p.splitk == 1) {
+  if (a4p && p.splitk == 1) {
+    static bool attr_a4p = false;
+    if (!attr_a4p) {
+      (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
+      attr_a4p = true;
+    }
+    const int ncu = num_cus();
+    const int nt = p.tilesM * p.tilesN;
+    const dim3 grid((unsigned)(nt < ncu ? nt : ncu)), block(256);
+    g_last_gemm = a->transB ? "gemm_a4p_kernel<true>" : "gemm_a4p_kernel<false>";
+    if (a->transB) hipLaunchKernelGGL((gemm_a4p_kernel<true>), grid, block, A4P_LDS, s, p);
+    else hipLaunchKernelGGL((gemm_a4p_kernel<false>), grid, block, A4P_LDS, s, p);
+  } else if (a4 && p.splitk == 1) {
     static bool attr_a4 = false;
     if (!attr_a4) {
       (void)hipFuncSetAttribute((const void*)gemm_a4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS);

@@ -121,3 +121,44 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmP p) {
     if (ps + 1 < 4) __syncthreads();
   }
 }
+
+// =====================================================================================================================================
+// gemm_a4p_kernel: the PERSISTENT form with a deferred write-out (generator: class GenP).  One block per CU walks its tiles (ids
+// blockIdx.x + k * gridDim.x through the XCD-aware remap); the bf16 output of a tile is rounded out of the AGPRs at the first step of the
+// next tile and leaves through a wave-private LDS transposition as full 256-byte row segments while that tile's MFMAs run; the DMA
+// stream never stops at a tile edge.  Plain bf16 epilogue, M and N multiples of 256, K a multiple of 128 and >= 384.  The whole kernel
+// body is the asm statement.
+constexpr int A4P_LDS = 4 * 32768 + 4 * 8192;      // ring + one 8 KiB staging block per wave = all 160 KiB
+
+template <bool TB>
+__global__ __launch_bounds__(256, 1) void gemm_a4p_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const uint32_t lds = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const uint32_t pa0 = (uint32_t)(uintptr_t)p.A, pa1 = (uint32_t)((uintptr_t)p.A >> 32);
+  const uint32_t pb0 = (uint32_t)(uintptr_t)p.B, pb1 = (uint32_t)((uintptr_t)p.B >> 32);
+  const uint32_t pc0 = (uint32_t)(uintptr_t)p.C, pc1 = (uint32_t)((uintptr_t)p.C >> 32);
+  const uint32_t lda = (uint32_t)(p.lda * 2), ldb = (uint32_t)(p.ldb * 2), ldc = (uint32_t)(p.ldc * 2);
+  const uint32_t cbytes = p.dbg == 1 ? 0u : (uint32_t)((long)p.M * p.ldc * 2);      // gemm_dbg = 1: every store out of range (ablation)
+  const uint32_t niter = (uint32_t)(p.K / 128);
+  const uint32_t ntiles = (uint32_t)(p.tilesM * p.tilesN), tilesn = (uint32_t)p.tilesN;
+  const uint32_t bid = blockIdx.x, grid = gridDim.x;
+  const uint32_t q = ntiles >> 3, r = ntiles & 7;
+  const uint32_t magic = (uint32_t)(((1ull << 32) + tilesn - 1) / tilesn);
+  const uint32_t nmy = (ntiles - bid + grid - 1) / grid;
+  if constexpr (TB) {
+    asm volatile(A4P_MAIN_NN
+                 :
+                 : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb),
+                   [pc0] "s"(pc0), [pc1] "s"(pc1), [ldc] "s"(ldc), [cbytes] "s"(cbytes), [niter] "s"(niter), [lds] "s"(lds),
+                   [bid] "s"(bid), [grid] "s"(grid), [q] "s"(q), [r] "s"(r), [magic] "s"(magic), [tilesn] "s"(tilesn), [nmy] "s"(nmy)
+                 : A4P_CLOBBERS);
+  } else {
+    asm volatile(A4P_MAIN_NT
+                 :
+                 : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb),
+                   [pc0] "s"(pc0), [pc1] "s"(pc1), [ldc] "s"(ldc), [cbytes] "s"(cbytes), [niter] "s"(niter), [lds] "s"(lds),
+                   [bid] "s"(bid), [grid] "s"(grid), [q] "s"(q), [r] "s"(r), [magic] "s"(magic), [tilesn] "s"(tilesn), [nmy] "s"(nmy)
+                 : A4P_CLOBBERS);
+  }
+}
