@@ -44,7 +44,7 @@ def check():
     cases = [("NT", 256, 256, 128, ""), ("NT", 512, 512, 256, ""), ("NT", 1000, 520, 384, ""), ("NT", 2000, 768, 768, "res"), ("NT", 1300, 1544, 384, "act"),
              ("NT", 600, 520, 256, "f32"), ("NT", 3200, 768, 2048, "bias"), ("NN", 256, 256, 128, ""), ("NN", 777, 392, 256, "dact"), ("NN", 2048, 768, 2304, ""),
              ("NN", 1000, 520, 384, "res"), ("NT", 32000, 2304, 768, ""), ("NN", 32000, 768, 2304, ""), ("NT", 35200, 1536, 768, ""),
-             ("NT", 512, 512, 384, ""), ("NN", 768, 512, 512, ""), ("NT", 8192, 768, 768, ""), ("NN", 32000, 3072, 768, ""), ("NT", 66048, 256, 384, ""), ("NT", 256, 66048, 384, "")]
+             ("NT", 512, 512, 384, ""), ("NN", 768, 512, 512, ""), ("NT", 8192, 768, 768, ""), ("NN", 32000, 3072, 768, ""), ("NT", 66048, 512, 384, ""), ("NT", 512, 66048, 384, ""), ("NT", 66048, 256, 384, "")]
     bad = 0
     for kind, M, N, K, ep in cases:
         g = torch.Generator(device=dev); g.manual_seed(M * 7 + N * 3 + K)

@@ -2284,7 +2284,7 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
       a4 = true; bm = 256; bn = 256; p8 = 0; p8d = false; w4 = false; w128 = false; ps = false;
       // persistent form with the deferred write-out: plain bf16 epilogue, whole tiles (gemm_a4 = 3: never)
       a4p = amode != 3 && a->c_dtype == V2S_BF16 && !a->accumulate && !a->bias && !a->pre && !a->residual && a->dact == V2S_ACT_NONE &&
-            a->act == V2S_ACT_NONE && a->dropout_p == 0.f && a->alpha == 1.0f && (a->M % 256) == 0 && (a->N % 256) == 0 && a->K >= 384 &&
+            a->act == V2S_ACT_NONE && a->dropout_p == 0.f && a->alpha == 1.0f && (a->M % 256) == 0 && (a->N % 256) == 0 && a->N >= 512 && a->K >= 384 &&
             !plain_split && (long)a->M * a->ldc * 2 < (1L << 31) && t256 < 65536;
     }
   }
