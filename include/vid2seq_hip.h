@@ -57,6 +57,9 @@ const char* v2s_last_error(void);
  *                   2: wherever legal, 3: wherever legal with more tiles than block slots; "gemm_ps_nst" = its ring depth (2 | 3 | 4)
  *   "gemm_w128"     4-wave 256x192 kernel with 128x96 wave tiles in AGPRs (round-4 experiment, NT only, bit-identical, not faster): 0: never
  *                   (default), 2: wherever legal
+ *   "gemm_a4"       4-wave 256x256 kernels with a generated, hand-scheduled asm K loop (128x128 wave tiles in AGPRs, v_mfma 32x32x16, counted
+ *                   waits; round 5): 1: where they measured faster (default: the persistent deferred-write-out form on plain bf16 GEMMs with
+ *                   >= 256 whole tiles), 0: never, 2: wherever legal, 3: the one-tile form wherever legal
  *   "gemm_dbg"      profiling ablations of the tiled kernels (results invalid when non-zero): 1 = no global store, 2 = no epilogue, 3 = no hand-off
  *   "fp32_io"       DEBUG: 1 = v2s_*norm_fwd/bwd, v2s_ce_bwd and v2s_attn_fwd/bwd take and return FP32 activations (attention: fp32-arithmetic
  *                   reference kernels, dense layout only); parity work against fp32 references (<= 1e-4), never set by the product path

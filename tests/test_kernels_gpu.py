@@ -517,6 +517,42 @@ def test_experimental_gemm_kernels_are_bit_identical(opt, val, tag):
         assert torch.equal(outs[0][0], outs[val][0]), (kind, M, N, K, ep)
 
 
+@pytest.mark.parametrize("kind,M,N,K,ep", [
+    ("NT", 512, 512, 384, ""), ("NN", 768, 512, 512, ""), ("NT", 2048, 768, 768, ""), ("NN", 1024, 1536, 640, ""),      # persistent form (plain, whole tiles)
+    ("NT", 1000, 520, 384, ""), ("NT", 2000, 768, 768, "res"), ("NT", 1300, 1544, 384, "act"), ("NT", 600, 520, 256, "f32"),
+    ("NN", 777, 392, 256, "dact"), ("NT", 768, 768, 2048, "bias")])
+def test_gemm_a4_kernel(kind, M, N, K, ep):
+    """gemm_a4_kernel / gemm_a4p_kernel (generated asm K loop, 4 waves, 128 x 128 wave tiles in AGPRs, v_mfma 32x32x16): against fp32 torch on
+    the bf16 inputs, plain and fused epilogues, ragged edges, both weight layouts; where the persistent deferred-write-out form is legal it
+    must agree BIT FOR BIT with the one-tile form (same K order, one rounding).  CPU counterpart on the generated text: test_gemm_a4_emu.py."""
+    A = rnd(M, K, seed=M + 1, scale=0.5)
+    B = rnd(*((K, N) if kind == "NN" else (N, K)), seed=N + 2, scale=0.5)
+    kw = dict(transB=(kind == "NN"), ldb=N if kind == "NN" else K)
+    ref = A.float() @ (B.float() if kind == "NN" else B.float().t())
+    if ep == "res":
+        r = rnd(M, N, seed=7); kw.update(residual=r); ref = ref + r.float()
+    if ep == "act":
+        kw.update(act=L.ACT_RELU); ref = torch.relu(ref)
+    if ep == "bias":
+        b = rnd(N, seed=9, dtype=torch.float32); kw.update(bias=b, act=L.ACT_GELU); ref = torch.nn.functional.gelu(ref + b)
+    if ep == "dact":
+        z = torch.relu(rnd(M, N, seed=9)); kw.update(dact=L.ACT_RELU, z=z); ref = ref * (z.float() > 0)
+    outs = {}
+    try:
+        for mode in (2, 3):
+            L.set_option("gemm_a4", mode)
+            C_ = torch.full((M, N), float("nan"), dtype=torch.float32 if ep == "f32" else torch.bfloat16, device=DEV)
+            L.gemm(A, B, C_, M, N, K, **kw)
+            outs[mode] = (C_, L.lib().v2s_last_gemm_kernel().decode())
+    finally:
+        L.set_option("gemm_a4", 1)
+    whole = ep == "" and M % 256 == 0 and N % 256 == 0 and N >= 512 and K >= 384
+    assert ("gemm_a4p_kernel" in outs[2][1]) == whole and "gemm_a4_kernel" in outs[3][1], (outs[2][1], outs[3][1])
+    for mode in (2, 3):
+        assert relerr(outs[mode][0], ref) < (2e-5 if ep == "f32" else 3e-3), (mode, kind, M, N, K, ep)
+    assert torch.equal(outs[2][0], outs[3][0])
+
+
 def test_fp32_io_debug_mode_norm_ce_attention():
     """SURVEY 8c "tolerances to state": with fp32 activations in and out (library option fp32_io) the norm, cross-entropy and
     attention entry points must agree with fp32 torch to <= 1e-4 -- the debug mode that separates a kernel bug from bf16 rounding.

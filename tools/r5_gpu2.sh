@@ -1,0 +1,5 @@
+# round 5: a4 in the step -- GPU tests of the GEMM family, step A/B, bench line
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm" 2>&1 | tail -5
+timeout 900 python tools/step_ab.py "gemm_a4=0" "gemm_a4=1" --steps 8 --block 4 2>&1 | tail -3 | tee gpurun_out/r05_step_ab_a4.txt

@@ -2034,10 +2034,17 @@ static bool w128_auto(const v2s_gemm_args* a) {
   return false;
 }
 
-// Shapes the 4-wave asm-scheduled 256 x 256 kernel takes by default (gemm_a4 = 1).  Rules from tools/gemm_a4_ab.py (profiles/r05_gemm_a4_ab.txt).
+// Shapes the 4-wave asm-scheduled 256 x 256 kernels take by default (gemm_a4 = 1).  Measured with tools/gemm_a4_ab.py, variants interleaved in
+// one process (profiles/r05_b_gemm_a4p_ab.txt; us default / persistent a4p / vendor): 32000x2304x768 139 / 108 / 108, 32000x768x768 52 / 44 / 47,
+// 32000x3072x768 168 / 135 / 134, 32000x768x3072 150 / 139 / 125, dgrads 32000x768x2304 122 / 104 / 103, 32000x3072x768 172 / 127 / 154,
+// 32000x768x3072 154 / 133 / 163, 8192x2304x768 45 / 42, 8192x3072x768 52 / 45; with fewer tiles than CUs the 128 x 128 kernels win
+// (8192x768x768 18.8 / 20.2, 8192x768x3072 47 / 59).  The one-tile form (synchronous epilogue, any epilogue) loses to the default dispatch
+// everywhere (1 block per CU: nothing runs beside its epilogue) and is only taken when forced.
 static bool a4_auto(const v2s_gemm_args* a, long t256) {
-  (void)a; (void)t256;
-  return false;
+  const bool persistent_ok = a->c_dtype == V2S_BF16 && !a->accumulate && !a->bias && !a->pre && !a->residual && a->dact == V2S_ACT_NONE &&
+                             a->act == V2S_ACT_NONE && a->dropout_p == 0.f && a->alpha == 1.0f && (a->M % 256) == 0 && (a->N % 256) == 0 &&
+                             a->N >= 512 && a->K >= 384;
+  return persistent_ok && t256 >= 256;
 }
 
 // Which form of the 8-phase kernel runs this problem: p8 = tile width (0 = none), p8d = deferred-epilogue persistent form.
