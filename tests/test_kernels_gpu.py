@@ -549,7 +549,7 @@ def test_gemm_a4_kernel(kind, M, N, K, ep):
     whole = ep == "" and M % 256 == 0 and N % 256 == 0 and N >= 512 and K >= 384
     assert ("gemm_a4p_kernel" in outs[2][1]) == whole and "gemm_a4_kernel" in outs[3][1], (outs[2][1], outs[3][1])
     for mode in (2, 3):
-        assert relerr(outs[mode][0], ref) < (2e-5 if ep == "f32" else 3e-3), (mode, kind, M, N, K, ep)
+        assert relerr(outs[mode][0], ref) < (2e-5 if ep == "f32" else 5e-3), (mode, kind, M, N, K, ep)      # bf16 half-ulp of the largest element: up to 2^-8
     assert torch.equal(outs[2][0], outs[3][0])
 
 
