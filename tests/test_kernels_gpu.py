@@ -553,6 +553,26 @@ def test_gemm_a4_kernel(kind, M, N, K, ep):
     assert torch.equal(outs[2][0], outs[3][0])
 
 
+@pytest.mark.parametrize("M,N,K,split", [(768, 512, 1024, False), (520, 776, 384, False), (768, 768, 4096, True), (1536, 768, 2304, True)])
+def test_gemm_a4_weight_gradient(M, N, K, split):
+    """the TN form of gemm_a4_kernel (dY^T X: both operands [k][rows], tr-read fragments), fp32 accumulate into C, with and without the
+    split-K workspace (slices of whole 128-wide iterations + the deterministic reduce)"""
+    A = rnd(K, M, seed=M + 3, scale=0.5)
+    B = rnd(K, N, seed=N + 4, scale=0.5)
+    C0 = rnd(M, N, seed=5, dtype=torch.float32)
+    ref = A.float().t() @ B.float() + C0
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV) if split else None
+    try:
+        L.set_option("gemm_a4", 2)
+        C_ = C0.clone()
+        L.gemm(A, B, C_, M, N, K, transA=True, transB=True, accumulate=True, workspace=ws)
+        kern = L.lib().v2s_last_gemm_kernel().decode()
+    finally:
+        L.set_option("gemm_a4", 1)
+    assert kern == "gemm_a4_kernel<true, true>", kern
+    assert relerr(C_, ref) < 2e-5
+
+
 def test_fp32_io_debug_mode_norm_ce_attention():
     """SURVEY 8c "tolerances to state": with fp32 activations in and out (library option fp32_io) the norm, cross-entropy and
     attention entry points must agree with fp32 torch to <= 1e-4 -- the debug mode that separates a kernel bug from bf16 rounding.

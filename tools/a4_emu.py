@@ -379,7 +379,7 @@ SUB = dict(tid="v120", pa0="s8", pa1="s9", pb0="s10", pb1="s11", lda="s12", ldb=
            niter="s18", lds="s19", sa="v121")
 
 
-def check(inc, tb, M, N, K, tile=(0, 0), seed=1, lazy_ds=True, lazy_dma=True, sched="random", verbose=False):
+def check(inc, tb, M, N, K, tile=(0, 0), seed=1, lazy_ds=True, lazy_dma=True, sched="random", verbose=False, ta=False):
     """run one 256 x 256 tile of C = X . W^T (W given as [N][K], or as [K][N] when tb) through the generated main loop + dumps; returns max
     abs error against the fp64 product of the bf16 inputs"""
     macros = parse_inc(inc)
@@ -390,14 +390,18 @@ def check(inc, tb, M, N, K, tile=(0, 0), seed=1, lazy_ds=True, lazy_dma=True, sc
     Xb, Wb = to_bf(X), to_bf(W)
     Xf, Wf = bf16_to_f32(Xb).astype(np.float64), bf16_to_f32(Wb).astype(np.float64)
     ref = Xf @ Wf.T
-    lda = K
+    if ta:
+        Amem, lda = np.ascontiguousarray(Xb.T), M            # [K][M] (weight gradients: dY^T)
+        assert tb
+    else:
+        Amem, lda = Xb, K
     if tb:
         Bmem, ldb = np.ascontiguousarray(Wb.T), N            # [K][N]
     else:
         Bmem, ldb = Wb, K
     PA, PB = 0x10000000, 0x30000000
-    gmem = [(PA, Xb.view(np.uint8).reshape(-1)), (PB, Bmem.view(np.uint8).reshape(-1))]
-    blk = Block(render(macros["A4_MAIN_NN" if tb else "A4_MAIN_NT"], SUB), gmem, lazy_ds, lazy_dma)
+    gmem = [(PA, Amem.view(np.uint8).reshape(-1)), (PB, Bmem.view(np.uint8).reshape(-1))]
+    blk = Block(render(macros["A4_MAIN_TN" if ta else ("A4_MAIN_NN" if tb else "A4_MAIN_NT")], SUB), gmem, lazy_ds, lazy_dma)
     tm, tn = tile
     m0, n0 = tm * 256, tn * 256
     for w in blk.waves:
@@ -406,7 +410,7 @@ def check(inc, tb, M, N, K, tile=(0, 0), seed=1, lazy_ds=True, lazy_dma=True, sc
         w.s[10], w.s[11] = PB & 0xFFFFFFFF, PB >> 32
         w.s[12], w.s[13] = lda * 2, ldb * 2
         w.s[14], w.s[15] = m0, n0
-        w.s[16] = M - 1
+        w.s[16] = (((M + 7) & ~7) - 8) if ta else M - 1
         w.s[17] = (((N + 7) & ~7) - 8) if tb else N - 1
         w.s[18] = K // 128
         w.s[19] = 0
@@ -432,7 +436,7 @@ def check(inc, tb, M, N, K, tile=(0, 0), seed=1, lazy_ds=True, lazy_dma=True, sc
     mm, nn = min(256, M - m0), min(256, N - n0)
     err = np.abs(got[:mm, :nn].astype(np.float64) - ref[m0:m0 + mm, n0:n0 + nn]).max()
     if verbose:
-        print(f"tb={tb} M={M} N={N} K={K} tile={tile} lazy_ds={lazy_ds} lazy_dma={lazy_dma} sched={sched}: max abs err {err:.3e}")
+        print(f"ta={ta} tb={tb} M={M} N={N} K={K} tile={tile} lazy_ds={lazy_ds} lazy_dma={lazy_dma} sched={sched}: max abs err {err:.3e}")
     return err
 
 
@@ -492,7 +496,8 @@ def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="
 if __name__ == "__main__":
     import os
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    tb = "--nn" in sys.argv
+    ta = "--tn" in sys.argv
+    tb = "--nn" in sys.argv or ta
     inc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "vidchapters_amd", "csrc", "v2s_gemm_a4.inc")
     for a in sys.argv[1:]:
         if a.startswith("--inc="):
@@ -507,5 +512,5 @@ if __name__ == "__main__":
         sys.exit(0 if nbad == 0 else 1)
     worst = 0.0
     for lazy_ds, lazy_dma, sched in ((False, False, "fwd"), (True, True, "random"), (True, False, "random"), (False, True, "rev"), (True, True, "fwd")):
-        worst = max(worst, check(inc, tb, M, N, K, tile=((M - 1) // 256, (N - 1) // 256), lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched, verbose=True))
+        worst = max(worst, check(inc, tb, M, N, K, tile=((M - 1) // 256, (N - 1) // 256), lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched, verbose=True, ta=ta))
     print("OK" if worst < 1e-3 * (K ** 0.5) else "FAILED")

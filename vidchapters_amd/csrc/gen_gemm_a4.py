@@ -33,16 +33,16 @@ import sys
 # ---- literal register map (one wave) -----------------------------------------------------------------------------------------
 F = [0, 32]                  # fragment sets: BF[bj] = v[F + 4 bj .. +3], AF[bi] = v[F + 16 + 4 bi .. +3]
 V_OA, V_OB = 64, 68          # per-lane DMA source offsets (4 + 4)
-V_DA = 72                    # ds_read addresses of the A operand: [k-half 0, k-half 1, k-half 0 + 64 KiB, k-half 1 + 64 KiB]
-V_DB = 76                    # NT: same four for the B operand; TB: eight: [bj] and [bj] + 64 KiB
-V_T = 84                     # temporaries v84..v99
+V_DA = 72                    # ds_read addresses of the A operand, 8 registers.  K-contiguous operand: [k-half 0, k-half 1, k-half 0 + 64 KiB,
+V_DB = 80                    # k-half 1 + 64 KiB]; [k][rows] operand (tr reads): [block 0..3] and [block 0..3] + 64 KiB.  Same for B.
+V_T = 88                     # temporaries v88..v103
 S_PA, S_PB = 36, 38          # running source bases (64-bit)
 S_LDSW = 40                  # LDS base + wave * 4096
 S_IT = 41                    # loop counter
 S_STA, S_STB = 42, 43        # bytes per stage
 S_ADV = 44                   # stages the pointers may still advance
 S_T = 46                     # temporaries s46..s55
-NV_CLOBBER = 100             # v0..v99
+NV_CLOBBER = 104             # v0..v103
 STAGE = 32768
 A_PART, B_PART = 0, 16384
 
@@ -59,8 +59,8 @@ ODD_REQ = [4, 7, 10, 14]
 
 
 class Gen:
-    def __init__(self, tb):
-        self.tb = tb
+    def __init__(self, tb, ta=False):
+        self.tb, self.ta = tb, ta
         self.lines = []
         self.lgkm = []       # outstanding LDS operations, oldest first: tags
         self.vm = []         # outstanding vector-memory operations: tags
@@ -106,26 +106,19 @@ class Gen:
         Returns a list of (tag, text) groups (one group = the reads of one fragment)."""
         hi = slot >> 1
         base = (slot & 1) * STAGE
-        out = []
 
-        def a_frag(bi):
-            reg = F[fs] + 16 + 4 * bi
-            addr = V_DA + kh + 2 * hi
-            return [(f"F{fs}A{bi}", f"ds_read_b128 v[{reg}:{reg + 3}], v{addr} offset:{base + A_PART + bi * 2048}")]
+        def frag(which, blk):
+            tr = self.ta if which == "A" else self.tb
+            reg = F[fs] + (16 if which == "A" else 0) + 4 * blk
+            vd, part = (V_DA, A_PART) if which == "A" else (V_DB, B_PART)
+            tag = f"F{fs}{which}{blk}"
+            if not tr:
+                return [(tag, f"ds_read_b128 v[{reg}:{reg + 3}], v{vd + kh + 2 * hi} offset:{base + part + blk * 2048}")]
+            off = base + part + kh * 8192
+            return [(tag, f"ds_read_b64_tr_b16 v[{reg}:{reg + 1}], v{vd + blk + 4 * hi} offset:{off}"),
+                    (tag, f"ds_read_b64_tr_b16 v[{reg + 2}:{reg + 3}], v{vd + blk + 4 * hi} offset:{off + 2048}")]
 
-        def b_frag(bj):
-            reg = F[fs] + 4 * bj
-            if not self.tb:
-                addr = V_DB + kh + 2 * hi
-                return [(f"F{fs}B{bj}", f"ds_read_b128 v[{reg}:{reg + 3}], v{addr} offset:{base + B_PART + bj * 2048}")]
-            addr = V_DB + bj + 4 * hi
-            off = base + B_PART + kh * 8192
-            return [(f"F{fs}B{bj}", f"ds_read_b64_tr_b16 v[{reg}:{reg + 1}], v{addr} offset:{off}"),
-                    (f"F{fs}B{bj}", f"ds_read_b64_tr_b16 v[{reg + 2}:{reg + 3}], v{addr} offset:{off + 2048}")]
-
-        for kind, i in (("b", 0), ("a", 0), ("b", 1), ("b", 2), ("b", 3), ("a", 1), ("a", 2), ("a", 3)):
-            out.append(a_frag(i) if kind == "a" else b_frag(i))
-        return out
+        return [frag(w, i) for w, i in (("B", 0), ("A", 0), ("B", 1), ("B", 2), ("B", 3), ("A", 1), ("A", 2), ("A", 3))]
 
     def dma_pairs(self, slot, tag):
         """the 8 LDS-DMA requests of one stage: (m0 setup, request)"""
@@ -172,8 +165,8 @@ class Gen:
                         self.bg.pop(0)()
                 j += 1
 
-    # ---- the statement
-    def setup(self):
+    # ---- address arithmetic shared by the one-tile and the persistent kernel.  v{V_T} = lane, s{S_T} = wave, s{S_T+1} = wm, s{S_T+2} = wn.
+    def setup_common(self):
         e = self.e
         T, S = V_T, S_T
         e("s_nop 4")
@@ -181,120 +174,149 @@ class Gen:
         e(f"v_lshrrev_b32 v{T + 1}, 6, %[tid]")             # wave
         e("s_nop 1")
         e(f"v_readfirstlane_b32 s{S}, v{T + 1}")            # w
-        e(f"s_mov_b32 s{S_PA}, %[pa0]"); e(f"s_mov_b32 s{S_PA + 1}, %[pa1]")
-        e(f"s_mov_b32 s{S_PB}, %[pb0]"); e(f"s_mov_b32 s{S_PB + 1}, %[pb1]")
         e(f"s_lshr_b32 s{S + 1}, s{S}, 1")                  # wm
         e(f"s_and_b32 s{S + 2}, s{S}, 1")                   # wn
         e(f"s_lshl_b32 s{S + 3}, s{S}, 12")
         e(f"s_add_u32 s{S_LDSW}, %[lds], s{S + 3}")
-        e(f"s_mov_b32 s{S_IT}, %[niter]")
-        e(f"s_lshl_b32 s{S_ADV}, %[niter], 2")
-        e(f"s_sub_u32 s{S_ADV}, s{S_ADV}, 1")               # nst - 1 pointer advances
-        e(f"s_mov_b32 s{S_STA}, 64")
-        # --- DMA source offsets of the A operand (and of a K-contiguous B operand): chunk = 16 rows x 64 B; lane -> row (lane >> 2), stored
-        #     slot (lane & 3) holds logical slot (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3)
-        e(f"v_lshrrev_b32 v{T + 2}, 2, v{T}")               # lane >> 2
+
+    def setup_dma_rows(self, voff, ld, r0=None, rmax=None):
+        """K-contiguous operand ([rows][32 k] image): chunk c = wave * 4 + i = 16 rows x 64 B; lane -> row (lane >> 2), stored slot lane & 3
+        holds logical slot (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3).  Offsets relative to row r0 (clamped to rmax) or,
+        when r0 is None, to the tile's first row (no clamp: whole tiles)."""
+        e = self.e
+        T, S = V_T, S_T
+        e(f"v_lshrrev_b32 v{T + 2}, 2, v{T}")
         e(f"v_lshrrev_b32 v{T + 3}, 4, v{T}")
         e(f"v_and_b32 v{T + 3}, 3, v{T + 3}")
         e(f"v_and_b32 v{T + 4}, 3, v{T}")
         e(f"v_xor_b32 v{T + 4}, v{T + 4}, v{T + 3}")
-        e(f"v_lshlrev_b32 v{T + 4}, 4, v{T + 4}")           # g * 16 bytes
+        e(f"v_lshlrev_b32 v{T + 4}, 4, v{T + 4}")           # logical slot * 16 bytes
         e(f"s_lshl_b32 s{S + 4}, s{S}, 6")                  # w * 64 rows
-
-        def rows(voff, r0, rmax, ld):
-            e(f"s_add_u32 s{S + 5}, {r0}, s{S + 4}")
-            e(f"v_add_u32 v{T + 5}, s{S + 5}, v{T + 2}")
-            for i in range(4):
-                e(f"v_add_u32 v{T + 6}, {16 * i}, v{T + 5}")
+        if r0 is not None:
+            e(f"s_add_u32 s{S + 4}, {r0}, s{S + 4}")
+        e(f"v_add_u32 v{T + 5}, s{S + 4}, v{T + 2}")
+        for i in range(4):
+            e(f"v_add_u32 v{T + 6}, {16 * i}, v{T + 5}")
+            if rmax is not None:
                 e(f"v_min_u32 v{T + 6}, {rmax}, v{T + 6}")
-                e(f"v_mul_lo_u32 v{T + 6}, v{T + 6}, {ld}")
-                e(f"v_add_u32 v{voff + i}, v{T + 6}, v{T + 4}")
+            e(f"v_mul_lo_u32 v{T + 6}, v{T + 6}, {ld}")
+            e(f"v_add_u32 v{voff + i}, v{T + 6}, v{T + 4}")
 
-        rows(V_OA, "%[m0]", "%[mmax]", "%[lda]")
-        if not self.tb:
-            e(f"s_mov_b32 s{S_STB}, 64")
-            rows(V_OB, "%[n0]", "%[nmax]", "%[ldb]")
-        else:
-            # [k][n] operand: chunk c = wave * 4 + i holds k-rows 2c, 2c+1; lane -> k = 2c + (lane >> 5), stored 16-byte slot p = lane & 31
-            # = granule p >> 1 (holds logical granule (p >> 1) ^ 2 (k & 3)), half p & 1; k & 3 = 2 (i & 1) + (lane >> 5)
-            e(f"s_lshl_b32 s{S_STB}, %[ldb], 5")            # 32 k-rows per stage
-            e(f"v_lshrrev_b32 v{T + 5}, 5, v{T}")           # lane >> 5
-            e(f"v_and_b32 v{T + 6}, 31, v{T}")              # p
-            e(f"v_lshrrev_b32 v{T + 7}, 1, v{T + 6}")       # stored granule
-            e(f"v_and_b32 v{T + 8}, 1, v{T + 6}")           # half
-            e(f"s_lshl_b32 s{S + 5}, s{S}, 3")              # w * 8
-            e(f"v_add_u32 v{T + 9}, s{S + 5}, v{T + 5}")    # w * 8 + (lane >> 5)
-            for i in range(4):
-                e(f"v_add_u32 v{T + 10}, {2 * (i & 1)}, v{T + 5}")       # k & 3
-                e(f"v_lshlrev_b32 v{T + 10}, 1, v{T + 10}")
-                e(f"v_xor_b32 v{T + 10}, v{T + 7}, v{T + 10}")          # logical granule
-                e(f"v_lshlrev_b32 v{T + 10}, 4, v{T + 10}")             # * 16 columns
-                e(f"v_lshl_add_u32 v{T + 10}, v{T + 8}, 3, v{T + 10}")  # + half * 8
-                e(f"v_add_u32 v{T + 10}, %[n0], v{T + 10}")
-                e(f"v_min_u32 v{T + 10}, %[nmax], v{T + 10}")
-                e(f"v_lshlrev_b32 v{T + 10}, 1, v{T + 10}")             # bytes
-                e(f"v_add_u32 v{T + 11}, {2 * i}, v{T + 9}")            # k
-                e(f"v_mul_lo_u32 v{T + 11}, v{T + 11}, %[ldb]")
-                e(f"v_add_u32 v{V_OB + i}, v{T + 11}, v{T + 10}")
-        # --- ds_read addresses.  A operand (X rows, MFMA srcB): lane (h, r): row wm * 128 + r, slot (2 kh + h) ^ ((r >> 2) & 3)
-        e(f"v_and_b32 v{T + 5}, 31, v{T}")                  # r = i
+    def setup_dma_tr(self, voff, ld, c0=None, cmax=None):
+        """[k][rows] operand ([32 k][256 rows] image, 512 B per k-row): chunk c = wave * 4 + i holds k-rows 2c, 2c+1; lane -> k = 2c + (lane >> 5),
+        stored 16-byte slot p = lane & 31 = granule p >> 1 (holds logical granule (p >> 1) ^ 2 (k & 3)), half p & 1; k & 3 = 2 (i & 1) + (lane >> 5)"""
+        e = self.e
+        T, S = V_T, S_T
+        e(f"v_lshrrev_b32 v{T + 5}, 5, v{T}")               # lane >> 5
+        e(f"v_and_b32 v{T + 6}, 31, v{T}")                  # p
+        e(f"v_lshrrev_b32 v{T + 7}, 1, v{T + 6}")           # stored granule
+        e(f"v_and_b32 v{T + 8}, 1, v{T + 6}")               # half
+        e(f"s_lshl_b32 s{S + 5}, s{S}, 3")                  # w * 8
+        e(f"v_add_u32 v{T + 9}, s{S + 5}, v{T + 5}")        # w * 8 + (lane >> 5)
+        for i in range(4):
+            e(f"v_add_u32 v{T + 10}, {2 * (i & 1)}, v{T + 5}")           # k & 3
+            e(f"v_lshlrev_b32 v{T + 10}, 1, v{T + 10}")
+            e(f"v_xor_b32 v{T + 10}, v{T + 7}, v{T + 10}")              # logical granule
+            e(f"v_lshlrev_b32 v{T + 10}, 4, v{T + 10}")                 # * 16 columns
+            e(f"v_lshl_add_u32 v{T + 10}, v{T + 8}, 3, v{T + 10}")      # + half * 8
+            if c0 is not None:
+                e(f"v_add_u32 v{T + 10}, {c0}, v{T + 10}")
+                e(f"v_min_u32 v{T + 10}, {cmax}, v{T + 10}")
+            e(f"v_lshlrev_b32 v{T + 10}, 1, v{T + 10}")                 # bytes
+            e(f"v_add_u32 v{T + 11}, {2 * i}, v{T + 9}")                # k
+            e(f"v_mul_lo_u32 v{T + 11}, v{T + 11}, {ld}")
+            e(f"v_add_u32 v{voff + i}, v{T + 11}, v{T + 10}")
+
+    def setup_ds_rows(self, vd, swh, perm):
+        """ds_read_b128 addresses of a K-contiguous operand: lane (h, i): tile row wh * 128 + perm(i), slot (2 kh + h) ^ ((row >> 2) & 3).
+        perm(i) = 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3) (the W rows: makes a lane's sixteen accumulator columns consecutive), (row >> 2) & 3 = i >> 3"""
+        e = self.e
+        T = V_T
+        e(f"v_and_b32 v{T + 5}, 31, v{T}")                  # i
         e(f"v_lshrrev_b32 v{T + 6}, 5, v{T}")               # h
-        e(f"v_lshrrev_b32 v{T + 7}, 2, v{T + 5}")
-        e(f"v_and_b32 v{T + 7}, 3, v{T + 7}")               # (r >> 2) & 3
-        e(f"v_xor_b32 v{T + 7}, v{T + 6}, v{T + 7}")        # h ^ f
-        e(f"v_lshlrev_b32 v{T + 7}, 4, v{T + 7}")
-        e(f"s_lshl_b32 s{S + 5}, s{S + 1}, 13")             # wm * 128 rows * 64 B
-        e(f"v_lshl_add_u32 v{T + 8}, v{T + 5}, 6, s{S + 5}")
-        e(f"v_add_u32 v{T + 8}, %[lds], v{T + 8}")
-        e(f"v_add_u32 v{V_DA}, v{T + 8}, v{T + 7}")
-        e(f"v_xor_b32 v{V_DA + 1}, 32, v{V_DA}")            # k-half 1: slot ^ 2 (the LDS base is a multiple of 64)
-        e(f"v_add_u32 v{V_DA + 2}, 0x10000, v{V_DA}")
-        e(f"v_add_u32 v{V_DA + 3}, 0x10000, v{V_DA + 1}")
-        if not self.tb:
-            # B operand (W rows, MFMA srcA), permuted: MFMA row i reads tile row wn * 128 + 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3);
-            # (row >> 2) & 3 = i >> 3
+        if perm:
             e(f"v_lshrrev_b32 v{T + 7}, 2, v{T + 5}")
             e(f"v_and_b32 v{T + 7}, 1, v{T + 7}")
-            e(f"v_lshlrev_b32 v{T + 7}, 4, v{T + 7}")       # 16 ((i >> 2) & 1)
+            e(f"v_lshlrev_b32 v{T + 7}, 4, v{T + 7}")
             e(f"v_lshrrev_b32 v{T + 8}, 3, v{T + 5}")       # i >> 3 (= f)
             e(f"v_lshl_add_u32 v{T + 7}, v{T + 8}, 2, v{T + 7}")
             e(f"v_and_b32 v{T + 9}, 3, v{T + 5}")
-            e(f"v_add_u32 v{T + 7}, v{T + 7}, v{T + 9}")    # perm(i)
-            e(f"v_xor_b32 v{T + 8}, v{T + 6}, v{T + 8}")    # h ^ f
-            e(f"v_lshlrev_b32 v{T + 8}, 4, v{T + 8}")
-            e(f"s_lshl_b32 s{S + 5}, s{S + 2}, 13")         # wn * 128 * 64
-            e(f"v_lshl_add_u32 v{T + 7}, v{T + 7}, 6, s{S + 5}")
-            e(f"v_add_u32 v{T + 7}, %[lds], v{T + 7}")
-            e(f"v_add_u32 v{V_DB}, v{T + 7}, v{T + 8}")
-            e(f"v_xor_b32 v{V_DB + 1}, 32, v{V_DB}")
-            e(f"v_add_u32 v{V_DB + 2}, 0x10000, v{V_DB}")
-            e(f"v_add_u32 v{V_DB + 3}, 0x10000, v{V_DB + 1}")
+            e(f"v_add_u32 v{T + 7}, v{T + 7}, v{T + 9}")    # row = perm(i)
         else:
-            # [k][n] operand through ds_read_b64_tr_b16: 16-lane group grp = lane >> 4 (k-half hh = grp >> 1, column half nh = grp & 1);
-            # lane j of a group supplies the address of 4 columns of k-row hh * 8 + (j >> 2) and receives column j of the 4 x 16 block the
-            # group's addresses describe.  Run cq = j & 3 of the block must be the MFMA rows 16 nh + 4 cq .. +3 = columns
-            # 16 (cq & 1) + 8 nh + 4 (cq >> 1) .. +3 of the 32-column fragment bj (the permutation above): granule
-            # (wn * 8 + 2 bj + (j & 1)) ^ 2 q  (q = j >> 2 = k & 3)  =  wn * 8 + (j & 1) + 2 (bj ^ q), byte (16 nh + 8 ((j >> 1) & 1)) inside it
-            e(f"v_and_b32 v{T + 7}, 15, v{T}")              # j
-            e(f"v_lshrrev_b32 v{T + 8}, 4, v{T}")           # grp
-            e(f"v_and_b32 v{T + 9}, 1, v{T + 8}")           # nh
-            e(f"v_lshrrev_b32 v{T + 10}, 1, v{T + 8}")      # hh
-            e(f"v_lshrrev_b32 v{T + 11}, 2, v{T + 7}")      # q
-            e(f"v_lshl_add_u32 v{T + 12}, v{T + 10}, 3, v{T + 11}")     # k-row hh * 8 + q
-            e(f"v_lshlrev_b32 v{T + 12}, 9, v{T + 12}")     # * 512 B
-            e(f"v_and_b32 v{T + 13}, 1, v{T + 7}")          # j & 1
-            e(f"s_lshl_b32 s{S + 5}, s{S + 2}, 3")          # wn * 8
-            e(f"v_add_u32 v{T + 13}, s{S + 5}, v{T + 13}")
+            e(f"v_mov_b32 v{T + 7}, v{T + 5}")              # row = i
+            e(f"v_lshrrev_b32 v{T + 8}, 2, v{T + 5}")
+            e(f"v_and_b32 v{T + 8}, 3, v{T + 8}")           # f
+        e(f"v_xor_b32 v{T + 8}, v{T + 6}, v{T + 8}")        # h ^ f
+        e(f"v_lshlrev_b32 v{T + 8}, 4, v{T + 8}")
+        e(f"s_lshl_b32 s{S_T + 5}, s{swh}, 13")             # wh * 128 rows * 64 B
+        e(f"v_lshl_add_u32 v{T + 7}, v{T + 7}, 6, s{S_T + 5}")
+        e(f"v_add_u32 v{T + 7}, %[lds], v{T + 7}")
+        e(f"v_add_u32 v{vd}, v{T + 7}, v{T + 8}")
+        e(f"v_xor_b32 v{vd + 1}, 32, v{vd}")                # k-half 1: slot ^ 2 (the LDS base is a multiple of 64)
+        e(f"v_add_u32 v{vd + 2}, 0x10000, v{vd}")
+        e(f"v_add_u32 v{vd + 3}, 0x10000, v{vd + 1}")
+
+    def setup_ds_tr(self, vd, swh, perm):
+        """ds_read_b64_tr_b16 addresses of a [k][rows] operand: 16-lane group grp = lane >> 4 (k-half hh = grp >> 1, row half nh = grp & 1); lane j
+        of a group supplies the address of 4 rows of k-row hh * 8 + (j >> 2) and receives row j of the 4 x 16 block the group's addresses
+        describe.  Run cq = j & 3 of the block must be the MFMA indices 16 nh + 4 cq .. +3 of the 32-row fragment blk:
+          natural order: rows 16 nh + 4 cq ..: granule (wh * 8 + 2 blk + nh) ^ 2 q = wh * 8 + nh + 2 (blk ^ q), byte 8 cq inside it   (q = j >> 2 = k & 3)
+          permuted (W) : rows 16 (cq & 1) + 8 nh + 4 (cq >> 1) ..: granule wh * 8 + (cq & 1) + 2 (blk ^ q), byte 16 nh + 8 (cq >> 1)"""
+        e = self.e
+        T = V_T
+        e(f"v_and_b32 v{T + 7}, 15, v{T}")                  # j
+        e(f"v_lshrrev_b32 v{T + 8}, 4, v{T}")               # grp
+        e(f"v_and_b32 v{T + 9}, 1, v{T + 8}")               # nh
+        e(f"v_lshrrev_b32 v{T + 10}, 1, v{T + 8}")          # hh
+        e(f"v_lshrrev_b32 v{T + 11}, 2, v{T + 7}")          # q
+        e(f"v_lshl_add_u32 v{T + 12}, v{T + 10}, 3, v{T + 11}")         # k-row hh * 8 + q
+        e(f"v_lshlrev_b32 v{T + 12}, 9, v{T + 12}")         # * 512 B
+        e(f"s_lshl_b32 s{S_T + 5}, s{swh}, 3")              # wh * 8
+        if perm:
+            e(f"v_and_b32 v{T + 13}, 1, v{T + 7}")          # cq & 1
+            e(f"v_add_u32 v{T + 13}, s{S_T + 5}, v{T + 13}")
             e(f"v_lshl_add_u32 v{T + 12}, v{T + 13}, 5, v{T + 12}")     # + granule base * 32
             e(f"v_lshl_add_u32 v{T + 12}, v{T + 9}, 4, v{T + 12}")      # + 16 nh
             e(f"v_lshrrev_b32 v{T + 13}, 1, v{T + 7}")
             e(f"v_and_b32 v{T + 13}, 1, v{T + 13}")
-            e(f"v_lshl_add_u32 v{T + 12}, v{T + 13}, 3, v{T + 12}")     # + 8 ((j >> 1) & 1)
-            e(f"v_add_u32 v{T + 12}, %[lds], v{T + 12}")
-            for bj in range(4):
-                e(f"v_xor_b32 v{T + 13}, {bj}, v{T + 11}")              # bj ^ q
-                e(f"v_lshl_add_u32 v{V_DB + bj}, v{T + 13}, 6, v{T + 12}")
-                e(f"v_add_u32 v{V_DB + 4 + bj}, 0x10000, v{V_DB + bj}")
+            e(f"v_lshl_add_u32 v{T + 12}, v{T + 13}, 3, v{T + 12}")     # + 8 (cq >> 1)
+        else:
+            e(f"v_add_u32 v{T + 13}, s{S_T + 5}, v{T + 9}")             # wh * 8 + nh
+            e(f"v_lshl_add_u32 v{T + 12}, v{T + 13}, 5, v{T + 12}")
+            e(f"v_and_b32 v{T + 13}, 3, v{T + 7}")                      # cq
+            e(f"v_lshl_add_u32 v{T + 12}, v{T + 13}, 3, v{T + 12}")     # + 8 cq
+        e(f"v_add_u32 v{T + 12}, %[lds], v{T + 12}")
+        for blk in range(4):
+            e(f"v_xor_b32 v{T + 13}, {blk}, v{T + 11}")                 # blk ^ q
+            e(f"v_lshl_add_u32 v{vd + blk}, v{T + 13}, 6, v{T + 12}")
+            e(f"v_add_u32 v{vd + 4 + blk}, 0x10000, v{vd + blk}")
+
+    # ---- the statement
+    def setup(self):
+        e = self.e
+        S = S_T
+        self.setup_common()
+        e(f"s_mov_b32 s{S_PA}, %[pa0]"); e(f"s_mov_b32 s{S_PA + 1}, %[pa1]")
+        e(f"s_mov_b32 s{S_PB}, %[pb0]"); e(f"s_mov_b32 s{S_PB + 1}, %[pb1]")
+        e(f"s_mov_b32 s{S_IT}, %[niter]")
+        e(f"s_lshl_b32 s{S_ADV}, %[niter], 2")
+        e(f"s_sub_u32 s{S_ADV}, s{S_ADV}, 1")               # nst - 1 pointer advances
+        if not self.ta:
+            e(f"s_mov_b32 s{S_STA}, 64")
+            self.setup_dma_rows(V_OA, "%[lda]", "%[m0]", "%[mmax]")
+            self.setup_ds_rows(V_DA, S + 1, perm=False)
+        else:
+            e(f"s_lshl_b32 s{S_STA}, %[lda], 5")            # 32 k-rows per stage
+            self.setup_dma_tr(V_OA, "%[lda]", "%[m0]", "%[mmax]")
+            self.setup_ds_tr(V_DA, S + 1, perm=False)
+        if not self.tb:
+            e(f"s_mov_b32 s{S_STB}, 64")
+            self.setup_dma_rows(V_OB, "%[ldb]", "%[n0]", "%[nmax]")
+            self.setup_ds_rows(V_DB, S + 2, perm=True)
+        else:
+            e(f"s_lshl_b32 s{S_STB}, %[ldb], 5")
+            self.setup_dma_tr(V_OB, "%[ldb]", "%[n0]", "%[nmax]")
+            self.setup_ds_tr(V_DB, S + 2, perm=True)
         e("s_nop 4")                                        # VALU-written VGPRs / SALU-written SGPRs -> vector memory
 
     def issue_stage_now(self, slot, tag):
@@ -403,10 +425,10 @@ class Gen:
 #   * the stores ride the wave's in-order vmcnt queue between the DMA requests: the scoreboard counts them like any other operation.
 #     The first tile of a block has nothing held: its stores go through a buffer descriptor with num_records = 0 (dropped).
 #   * after the block's last tile: convert + write out without a main loop beside it (drain).
-V_HELD = 100                 # v100..v227
-V_STW = 228                  # staging write addresses: 4 variants q = 2 (bj & 1) + half
-V_STR = 232                  # staging read addresses: row-group parity 0 / 1
-V_STO = 234                  # store offset: (lane >> 4) * ldc_bytes + (lane & 15) * 16
+V_HELD = 104                 # v104..v231
+V_STW = 232                  # staging write addresses: 4 variants q = 2 (bj & 1) + half
+V_STR = 236                  # staging read addresses: row-group parity 0 / 1
+V_STO = 238                  # store offset: (lane >> 4) * ldc_bytes + (lane & 15) * 16
 NV_CLOBBER_P = 240
 S_K, S_NMY = 44, 45          # tile ordinal of this block, its tile count
 S_SRD = 56                   # s56..s59 buffer descriptor of C
@@ -427,106 +449,18 @@ class GenP(Gen):
     def setup_p(self):
         e = self.e
         T, S = V_T, S_T
-        e("s_nop 4")
-        e(f"v_and_b32 v{T}, 63, %[tid]")                    # lane
-        e(f"v_lshrrev_b32 v{T + 1}, 6, %[tid]")             # wave
-        e("s_nop 1")
-        e(f"v_readfirstlane_b32 s{S}, v{T + 1}")            # w
-        e(f"s_lshr_b32 s{S + 1}, s{S}, 1")                  # wm
-        e(f"s_and_b32 s{S + 2}, s{S}, 1")                   # wn
-        e(f"s_lshl_b32 s{S + 3}, s{S}, 12")
-        e(f"s_add_u32 s{S_LDSW}, %[lds], s{S + 3}")
+        self.setup_common()
         e(f"s_mov_b32 s{S_STA}, 64")
-        # DMA source offsets relative to the TILE's first row: chunk = 16 rows x 64 B; (row >> 2) & 3 = (lane >> 4) & 3
-        e(f"v_lshrrev_b32 v{T + 2}, 2, v{T}")
-        e(f"v_lshrrev_b32 v{T + 3}, 4, v{T}")
-        e(f"v_and_b32 v{T + 3}, 3, v{T + 3}")
-        e(f"v_and_b32 v{T + 4}, 3, v{T}")
-        e(f"v_xor_b32 v{T + 4}, v{T + 4}, v{T + 3}")
-        e(f"v_lshlrev_b32 v{T + 4}, 4, v{T + 4}")           # g * 16 bytes
-        e(f"s_lshl_b32 s{S + 4}, s{S}, 6")                  # w * 64 rows
-        e(f"v_add_u32 v{T + 5}, s{S + 4}, v{T + 2}")        # tile row w * 64 + (lane >> 2)
-
-        def rows(voff, ld):
-            for i in range(4):
-                e(f"v_add_u32 v{T + 6}, {16 * i}, v{T + 5}")
-                e(f"v_mul_lo_u32 v{T + 6}, v{T + 6}, {ld}")
-                e(f"v_add_u32 v{voff + i}, v{T + 6}, v{T + 4}")
-
-        rows(V_OA, "%[lda]")
+        self.setup_dma_rows(V_OA, "%[lda]")
+        self.setup_ds_rows(V_DA, S + 1, perm=False)
         if not self.tb:
             e(f"s_mov_b32 s{S_STB}, 64")
-            rows(V_OB, "%[ldb]")
+            self.setup_dma_rows(V_OB, "%[ldb]")
+            self.setup_ds_rows(V_DB, S + 2, perm=True)
         else:
             e(f"s_lshl_b32 s{S_STB}, %[ldb], 5")
-            e(f"v_lshrrev_b32 v{T + 5}, 5, v{T}")
-            e(f"v_and_b32 v{T + 6}, 31, v{T}")
-            e(f"v_lshrrev_b32 v{T + 7}, 1, v{T + 6}")
-            e(f"v_and_b32 v{T + 8}, 1, v{T + 6}")
-            e(f"s_lshl_b32 s{S + 5}, s{S}, 3")
-            e(f"v_add_u32 v{T + 9}, s{S + 5}, v{T + 5}")
-            for i in range(4):
-                e(f"v_add_u32 v{T + 10}, {2 * (i & 1)}, v{T + 5}")
-                e(f"v_lshlrev_b32 v{T + 10}, 1, v{T + 10}")
-                e(f"v_xor_b32 v{T + 10}, v{T + 7}, v{T + 10}")
-                e(f"v_lshlrev_b32 v{T + 10}, 4, v{T + 10}")
-                e(f"v_lshl_add_u32 v{T + 10}, v{T + 8}, 3, v{T + 10}")  # column inside the tile
-                e(f"v_lshlrev_b32 v{T + 10}, 1, v{T + 10}")
-                e(f"v_add_u32 v{T + 11}, {2 * i}, v{T + 9}")
-                e(f"v_mul_lo_u32 v{T + 11}, v{T + 11}, %[ldb]")
-                e(f"v_add_u32 v{V_OB + i}, v{T + 11}, v{T + 10}")
-        # ds_read addresses: identical to the one-tile kernel
-        e(f"v_and_b32 v{T + 5}, 31, v{T}")
-        e(f"v_lshrrev_b32 v{T + 6}, 5, v{T}")
-        e(f"v_lshrrev_b32 v{T + 7}, 2, v{T + 5}")
-        e(f"v_and_b32 v{T + 7}, 3, v{T + 7}")
-        e(f"v_xor_b32 v{T + 7}, v{T + 6}, v{T + 7}")
-        e(f"v_lshlrev_b32 v{T + 7}, 4, v{T + 7}")
-        e(f"s_lshl_b32 s{S + 5}, s{S + 1}, 13")
-        e(f"v_lshl_add_u32 v{T + 8}, v{T + 5}, 6, s{S + 5}")
-        e(f"v_add_u32 v{T + 8}, %[lds], v{T + 8}")
-        e(f"v_add_u32 v{V_DA}, v{T + 8}, v{T + 7}")
-        e(f"v_xor_b32 v{V_DA + 1}, 32, v{V_DA}")
-        e(f"v_add_u32 v{V_DA + 2}, 0x10000, v{V_DA}")
-        e(f"v_add_u32 v{V_DA + 3}, 0x10000, v{V_DA + 1}")
-        if not self.tb:
-            e(f"v_lshrrev_b32 v{T + 7}, 2, v{T + 5}")
-            e(f"v_and_b32 v{T + 7}, 1, v{T + 7}")
-            e(f"v_lshlrev_b32 v{T + 7}, 4, v{T + 7}")
-            e(f"v_lshrrev_b32 v{T + 8}, 3, v{T + 5}")
-            e(f"v_lshl_add_u32 v{T + 7}, v{T + 8}, 2, v{T + 7}")
-            e(f"v_and_b32 v{T + 9}, 3, v{T + 5}")
-            e(f"v_add_u32 v{T + 7}, v{T + 7}, v{T + 9}")
-            e(f"v_xor_b32 v{T + 8}, v{T + 6}, v{T + 8}")
-            e(f"v_lshlrev_b32 v{T + 8}, 4, v{T + 8}")
-            e(f"s_lshl_b32 s{S + 5}, s{S + 2}, 13")
-            e(f"v_lshl_add_u32 v{T + 7}, v{T + 7}, 6, s{S + 5}")
-            e(f"v_add_u32 v{T + 7}, %[lds], v{T + 7}")
-            e(f"v_add_u32 v{V_DB}, v{T + 7}, v{T + 8}")
-            e(f"v_xor_b32 v{V_DB + 1}, 32, v{V_DB}")
-            e(f"v_add_u32 v{V_DB + 2}, 0x10000, v{V_DB}")
-            e(f"v_add_u32 v{V_DB + 3}, 0x10000, v{V_DB + 1}")
-        else:
-            e(f"v_and_b32 v{T + 7}, 15, v{T}")
-            e(f"v_lshrrev_b32 v{T + 8}, 4, v{T}")
-            e(f"v_and_b32 v{T + 9}, 1, v{T + 8}")
-            e(f"v_lshrrev_b32 v{T + 10}, 1, v{T + 8}")
-            e(f"v_lshrrev_b32 v{T + 11}, 2, v{T + 7}")
-            e(f"v_lshl_add_u32 v{T + 12}, v{T + 10}, 3, v{T + 11}")
-            e(f"v_lshlrev_b32 v{T + 12}, 9, v{T + 12}")
-            e(f"v_and_b32 v{T + 13}, 1, v{T + 7}")
-            e(f"s_lshl_b32 s{S + 5}, s{S + 2}, 3")
-            e(f"v_add_u32 v{T + 13}, s{S + 5}, v{T + 13}")
-            e(f"v_lshl_add_u32 v{T + 12}, v{T + 13}, 5, v{T + 12}")
-            e(f"v_lshl_add_u32 v{T + 12}, v{T + 9}, 4, v{T + 12}")
-            e(f"v_lshrrev_b32 v{T + 13}, 1, v{T + 7}")
-            e(f"v_and_b32 v{T + 13}, 1, v{T + 13}")
-            e(f"v_lshl_add_u32 v{T + 12}, v{T + 13}, 3, v{T + 12}")
-            e(f"v_add_u32 v{T + 12}, %[lds], v{T + 12}")
-            for bj in range(4):
-                e(f"v_xor_b32 v{T + 13}, {bj}, v{T + 11}")
-                e(f"v_lshl_add_u32 v{V_DB + bj}, v{T + 13}, 6, v{T + 12}")
-                e(f"v_add_u32 v{V_DB + 4 + bj}, 0x10000, v{V_DB + bj}")
+            self.setup_dma_tr(V_OB, "%[ldb]")
+            self.setup_ds_tr(V_DB, S + 2, perm=True)
         # ---- write-out constants.  Staging block of this wave: LDS + ring + wave * 8 KiB, 32 rows x 256 B.
         # lane (h, m) holds row m, 16-byte chunks 4 bj + 2 h + half of the row; chunk c of row m is stored at chunk c ^ (m & 7)
         e(f"s_lshl_b32 s{S + 5}, s{S}, 13")
@@ -757,11 +691,11 @@ def main():
     parts = ["// GENERATED by gen_gemm_a4.py -- do not edit.  The hand-scheduled K loop of gemm_a4_kernel (see the generator's header).",
              "// clang-format off"]
     stats = {}
-    for tb in (False, True):
-        g = Gen(tb)
+    for tb, ta in ((False, False), (True, False), (True, True)):
+        g = Gen(tb, ta)
         lines = g.main()
         stats[tb] = (len(lines), g.nmfma)
-        parts.append(f"#define A4_MAIN_{'NN' if tb else 'NT'} \\")
+        parts.append(f"#define A4_MAIN_{'TN' if ta else ('NN' if tb else 'NT')} \\")
         parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in lines))
         parts.append("")
     for tb in (False, True):

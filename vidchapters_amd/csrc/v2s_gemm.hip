@@ -2044,7 +2044,9 @@ static bool a4_auto(const v2s_gemm_args* a, long t256) {
   const bool persistent_ok = a->c_dtype == V2S_BF16 && !a->accumulate && !a->bias && !a->pre && !a->residual && a->dact == V2S_ACT_NONE &&
                              a->act == V2S_ACT_NONE && a->dropout_p == 0.f && a->alpha == 1.0f && (a->M % 256) == 0 && (a->N % 256) == 0 &&
                              a->N >= 512 && a->K >= 384;
-  return persistent_ok && t256 >= 256;
+  if (a->transA)      // split-K weight gradients with a long contraction (tools/gemm_wgrad_ab.py, profiles/r05_c_gemm_a4_wgrad_ab.txt)
+    return a->workspace != nullptr && a->c_dtype == V2S_F32 && a->K >= 16384 && t256 >= 9;
+  return !a->transA && persistent_ok && t256 >= 256;
 }
 
 // Which form of the 8-phase kernel runs this problem: p8 = tile width (0 = none), p8d = deferred-epilogue persistent form.
@@ -2284,13 +2286,14 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
   {
     const int amode = v2s_opt_gemm_a4();
     const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
-    const bool a_ok = amode != 0 && p8_force != 0 && tr && !a->transA && (a->K % 128) == 0 && a->M >= 256 && a->N >= 256 && (a->N % 8) == 0 &&
-                      !(plain_split && t256 < 512) && (long)a->M * a->lda < (1L << 30) &&
+    const bool a_ok = amode != 0 && p8_force != 0 && tr && (a->K % 128) == 0 && a->M >= 256 && a->N >= 256 && (a->N % 8) == 0 &&
+                      (a->transA ? (a->M % 8) == 0 : !(plain_split && t256 < 512)) &&
+                      (a->transA ? 32 * a->lda + a->M : (long)a->M * a->lda) < (1L << 30) &&
                       (a->transB ? 32 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 30);
     if (a_ok && (amode >= 2 || (amode == 1 && v2s_opt_gemm_p8() == 1 && a4_auto(a, t256)))) {
       a4 = true; bm = 256; bn = 256; p8 = 0; p8d = false; w4 = false; w128 = false; ps = false;
       // persistent form with the deferred write-out: plain bf16 epilogue, whole tiles (gemm_a4 = 3: never)
-      a4p = amode != 3 && a->c_dtype == V2S_BF16 && !a->accumulate && !a->bias && !a->pre && !a->residual && a->dact == V2S_ACT_NONE &&
+      a4p = amode != 3 && !a->transA && a->c_dtype == V2S_BF16 && !a->accumulate && !a->bias && !a->pre && !a->residual && a->dact == V2S_ACT_NONE &&
             a->act == V2S_ACT_NONE && a->dropout_p == 0.f && a->alpha == 1.0f && (a->M % 256) == 0 && (a->N % 256) == 0 && a->N >= 512 && a->K >= 384 &&
             !plain_split && (long)a->M * a->ldc * 2 < (1L << 31) && t256 < 65536;
     }
@@ -2320,7 +2323,8 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     const long per_slice = (long)a->M * a->N * 4;
     if ((long)sp * per_slice > a->workspace_bytes) sp = (int)(a->workspace_bytes / per_slice);
     if (sp > 1) {
-      int kper = ((a->K + sp - 1) / sp + BK - 1) / BK * BK;
+      const int kq = a4 ? 128 : BK;                     // the a4 loop walks K in iterations of 128
+      int kper = ((a->K + sp - 1) / sp + kq - 1) / kq * kq;
       p.kper = kper;
       p.splitk = (a->K + kper - 1) / kper;
       p.alpha = 1.0f;           // alpha and the accumulate are applied by the reduction
@@ -2340,17 +2344,19 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     g_last_gemm = a->transB ? "gemm_a4p_kernel<true>" : "gemm_a4p_kernel<false>";
     if (a->transB) hipLaunchKernelGGL((gemm_a4p_kernel<true>), grid, block, A4P_LDS, s, p);
     else hipLaunchKernelGGL((gemm_a4p_kernel<false>), grid, block, A4P_LDS, s, p);
-  } else if (a4 && p.splitk == 1) {
+  } else if (a4) {
     static bool attr_a4 = false;
     if (!attr_a4) {
-      (void)hipFuncSetAttribute((const void*)gemm_a4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_a4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_a4_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_a4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_a4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4_LDS);
       attr_a4 = true;
     }
     const dim3 grid(nblocks), block(256);
-    g_last_gemm = a->transB ? "gemm_a4_kernel<true>" : "gemm_a4_kernel<false>";
-    if (a->transB) hipLaunchKernelGGL((gemm_a4_kernel<true>), grid, block, A4_LDS, s, p);
-    else hipLaunchKernelGGL((gemm_a4_kernel<false>), grid, block, A4_LDS, s, p);
+    g_last_gemm = a->transA ? "gemm_a4_kernel<true, true>" : (a->transB ? "gemm_a4_kernel<false, true>" : "gemm_a4_kernel<false, false>");
+    if (a->transA) hipLaunchKernelGGL((gemm_a4_kernel<true, true>), grid, block, A4_LDS, s, p);
+    else if (a->transB) hipLaunchKernelGGL((gemm_a4_kernel<false, true>), grid, block, A4_LDS, s, p);
+    else hipLaunchKernelGGL((gemm_a4_kernel<false, false>), grid, block, A4_LDS, s, p);
   } else if (w128 && p.splitk == 1) {
     static bool attr_w = false;
     if (!attr_w) {

@@ -20,8 +20,9 @@
 constexpr int A4_LDS = 4 * 32768;                 // ring of 4 stages; the epilogue's 64 x 260 fp32 staging block (66 560 B) lives in it
 constexpr int A4_PB = 260;                        // staging pitch in floats (1040 B: eight consecutive rows of a ds_write_b128 pass cover all banks)
 
-template <bool TB>
+template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmP p) {
+  static_assert(!TA || TB, "(transA, !transB) is not generated");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int nwg = p.tilesM * p.tilesN * p.splitk;
@@ -30,15 +31,21 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmP p) {
   const int m0 = tm * 256, n0 = tn * 256;
   const int kbeg = slice * p.kper, kend = min(p.K, kbeg + p.kper);
   const uint32_t lds = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-  const char* pa = reinterpret_cast<const char*>(p.A) + (long)kbeg * 2;
+  const char* pa = reinterpret_cast<const char*>(p.A) + (TA ? (long)kbeg * p.lda * 2 : (long)kbeg * 2);
   const char* pb = reinterpret_cast<const char*>(p.B) + (TB ? (long)kbeg * p.ldb * 2 : (long)kbeg * 2);
   const uint32_t pa0 = (uint32_t)(uintptr_t)pa, pa1 = (uint32_t)((uintptr_t)pa >> 32);
   const uint32_t pb0 = (uint32_t)(uintptr_t)pb, pb1 = (uint32_t)((uintptr_t)pb >> 32);
   const uint32_t lda = (uint32_t)(p.lda * 2), ldb = (uint32_t)(p.ldb * 2);
-  const uint32_t mmax = (uint32_t)(p.M - 1);
+  const uint32_t mmax = TA ? (uint32_t)(((p.M + 7) & ~7) - 8) : (uint32_t)(p.M - 1);
   const uint32_t nmax = TB ? (uint32_t)(((p.N + 7) & ~7) - 8) : (uint32_t)(p.N - 1);
   const uint32_t niter = (uint32_t)((kend - kbeg) / 128);
-  if constexpr (TB) {
+  if constexpr (TA) {
+    asm volatile(A4_MAIN_TN
+                 :
+                 : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb),
+                   [m0] "s"(m0), [n0] "s"(n0), [mmax] "s"(mmax), [nmax] "s"(nmax), [niter] "s"(niter), [lds] "s"(lds)
+                 : A4_CLOBBERS);
+  } else if constexpr (TB) {
     asm volatile(A4_MAIN_NN
                  :
                  : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb),
