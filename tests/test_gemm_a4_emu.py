@@ -46,7 +46,7 @@ def test_weight_gradient_form(inc):
         assert E.check(inc, True, 520, 304, 256, tile=(2, 1), lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched, ta=True) < 2e-5
 
 
-@pytest.mark.parametrize("tb,M,N,K,grid", [(False, 512, 768, 512, 2), (True, 768, 512, 384, 1)])
+@pytest.mark.parametrize("tb,M,N,K,grid", [(False, 512, 768, 512, 2), (True, 768, 512, 384, 1), (False, 600, 520, 384, 2)])
 def test_persistent_deferred_writeout(inc, tb, M, N, K, grid):
     """gemm_a4p: `grid` blocks walk all tiles; conversion at the first step of the next tile, wave-private LDS transposition, buffer stores
     (the first tile's through a zero-length descriptor), DMA stream across tile edges, drain after the last tile: every bf16 output exact"""
@@ -65,7 +65,7 @@ def test_the_model_catches_a_wrong_wait_a_missing_barrier_and_a_wrong_slot(inc, 
     muts = {"vmcnt": nth(src, "s_waitcnt vmcnt(16) lgkmcnt(0)", "s_waitcnt vmcnt(28) lgkmcnt(0)", 2),
             "barrier": nth(src, "s_barrier", "s_nop 0", 3),
             "lgkm": nth(src, "s_waitcnt lgkmcnt(6)", "s_waitcnt lgkmcnt(7)", 10),
-            "slot": nth(src, "s_add_u32 m0, s40, 0x19000", "s_add_u32 m0, s40, 0x11000", 1)}
+            "slot": nth(src, "s_add_u32 m0, s40, 0x1c400", "s_add_u32 m0, s40, 0x14400", 1)}
     for name, text in muts.items():
         p = str(tmp_path / f"{name}.inc")
         open(p, "w").write(text)

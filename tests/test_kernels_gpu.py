@@ -546,7 +546,7 @@ def test_gemm_a4_kernel(kind, M, N, K, ep):
             outs[mode] = (C_, L.lib().v2s_last_gemm_kernel().decode())
     finally:
         L.set_option("gemm_a4", 1)
-    whole = ep == "" and M % 256 == 0 and N % 256 == 0 and N >= 512 and K >= 384
+    whole = ep == "" and N >= 512 and K >= 384           # the persistent form: plain bf16 epilogue (ragged edges: the last tile row / column overlaps)
     assert ("gemm_a4p_kernel" in outs[2][1]) == whole and "gemm_a4_kernel" in outs[3][1], (outs[2][1], outs[3][1])
     for mode in (2, 3):
         assert relerr(outs[mode][0], ref) < (2e-5 if ep == "f32" else 5e-3), (mode, kind, M, N, K, ep)      # bf16 half-ulp of the largest element: up to 2^-8
@@ -563,7 +563,7 @@ def test_gemm_a4_weight_gradient(M, N, K, split):
     ref = A.float().t() @ B.float() + C0
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV) if split else None
     try:
-        L.set_option("gemm_a4", 2)
+        L.set_option("gemm_a4", 2)                      # (default dispatch keeps weight gradients on the two-blocks-per-CU kernels: they share CUs with the main chain)
         C_ = C0.clone()
         L.gemm(A, B, C_, M, N, K, transA=True, transB=True, accumulate=True, workspace=ws)
         kern = L.lib().v2s_last_gemm_kernel().decode()

@@ -441,7 +441,7 @@ def check(inc, tb, M, N, K, tile=(0, 0), seed=1, lazy_ds=True, lazy_dma=True, sc
 
 
 SUB_P = dict(tid="v250", pa0="s8", pa1="s9", pb0="s10", pb1="s11", lda="s12", ldb="s13", pc0="s14", pc1="s15", ldc="s16", cbytes="s17",
-             niter="s18", lds="s19", bid="s20", grid="s21", q="s22", r="s23", magic="s24", tilesn="s25", nmy="s26")
+             niter="s18", lds="s19", bid="s20", grid="s21", q="s22", r="s23", magic="s24", tilesn="s25", nmy="s26", mlast="s27", nlast="s28")
 
 
 def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="random", verbose=False):
@@ -463,7 +463,7 @@ def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="
     Cmem = np.full(M * ldc, 0x7FC0, np.uint16)            # NaN-filled output
     PA, PB, PC = 0x10000000, 0x30000000, 0x50000000
     gmem = [(PA, Xb.view(np.uint8).reshape(-1)), (PB, Bmem.view(np.uint8).reshape(-1)), (PC, Cmem.view(np.uint8))]
-    tilesM, tilesN = M // 256, N // 256
+    tilesM, tilesN = (M + 255) // 256, (N + 255) // 256
     ntiles = tilesM * tilesN
     prog = render(macros["A4P_MAIN_NN" if tb else "A4P_MAIN_NT"], SUB_P)
     for bid in range(grid):
@@ -481,6 +481,7 @@ def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="
             w.s[22], w.s[23] = ntiles >> 3, ntiles & 7
             w.s[24], w.s[25] = ((1 << 32) + tilesN - 1) // tilesN, tilesN
             w.s[26] = (ntiles - bid + grid - 1) // grid
+            w.s[27], w.s[28] = M - 256, N - 256
         blk.run(sched=sched, seed=seed + bid)
         assert all(not w.vm and not w.lgkm for w in blk.waves)
     got = bf16_to_f32(Cmem).reshape(M, ldc).astype(np.float64)

@@ -411,7 +411,7 @@ class Gen:
 
 # =====================================================================================================================================
 # Persistent form with a DEFERRED write-out ("a4p"): one block per CU walks its tiles; the bf16 output of tile t leaves the chip during
-# the main loop of tile t+1.  Plain bf16 epilogue (alpha = 1), M and N multiples of 256, K >= 384.
+# the main loop of tile t+1.  Plain bf16 epilogue (alpha = 1), M >= 256, N >= 512 (multiples of 8), K >= 384.
 #   * step 0 of a tile: before the first MFMA of accumulator block b (which starts from C = 0) the block's sixteen values of the PREVIOUS
 #     tile are read out of the AGPRs and rounded to bf16 pairs (v_cvt_pk_bf16_f32) into eight "held" VGPRs (128 in all);
 #   * steps 1..8: a background stream of write-out work, one instruction per MFMA gap: per 32-row block row c of the wave's 128 x 128
@@ -515,6 +515,10 @@ class GenP(Gen):
         e(f"s_sub_u32 s{X + 6}, s{X + 3}, s{X + 6}")        # tn
         e(f"s_lshl_b32 s{X + 5}, s{X + 5}, 8")              # m0
         e(f"s_lshl_b32 s{X + 6}, s{X + 6}, 8")              # n0
+        # ragged M / N (>= 256): the last tile row / column is shifted up to END at the edge; it overlaps its neighbour, whose rows it
+        # recomputes and rewrites with identical values (plain epilogue: no operand is read back)
+        e(f"s_min_u32 s{X + 5}, s{X + 5}, %[mlast]")
+        e(f"s_min_u32 s{X + 6}, s{X + 6}, %[nlast]")
         e(f"s_mul_i32 s{X + 7}, s{X + 5}, %[lda]")
         e(f"s_mul_hi_u32 s{X + 8}, s{X + 5}, %[lda]")
         e(f"s_add_u32 s{S_PA}, %[pa0], s{X + 7}")

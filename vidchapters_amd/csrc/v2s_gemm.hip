@@ -2042,10 +2042,10 @@ static bool w128_auto(const v2s_gemm_args* a) {
 // everywhere (1 block per CU: nothing runs beside its epilogue) and is only taken when forced.
 static bool a4_auto(const v2s_gemm_args* a, long t256) {
   const bool persistent_ok = a->c_dtype == V2S_BF16 && !a->accumulate && !a->bias && !a->pre && !a->residual && a->dact == V2S_ACT_NONE &&
-                             a->act == V2S_ACT_NONE && a->dropout_p == 0.f && a->alpha == 1.0f && (a->M % 256) == 0 && (a->N % 256) == 0 &&
-                             a->N >= 512 && a->K >= 384;
-  if (a->transA)      // split-K weight gradients with a long contraction (tools/gemm_wgrad_ab.py, profiles/r05_c_gemm_a4_wgrad_ab.txt)
-    return a->workspace != nullptr && a->c_dtype == V2S_F32 && a->K >= 16384 && t256 >= 9;
+                             a->act == V2S_ACT_NONE && a->dropout_p == 0.f && a->alpha == 1.0f && a->N >= 512 && a->K >= 384;
+  if (a->transA)      // split-K weight gradients with a long contraction (tools/gemm_wgrad_ab.py, profiles/r05_c_gemm_a4_wgrad_ab.txt; us before / a4):
+                      // 2304x768x32000 134 / 112, 3072x768x32000 159 / 144, 768x3072x32000 157 / 145, 1536x768x35200 91 / 86; 768x768x32000 (9 tiles) 54 / 56
+    return v2s_opt_gemm_a4() == 4 && a->workspace != nullptr && a->c_dtype == V2S_F32 && a->K >= 16384 && t256 >= 18;
   return !a->transA && persistent_ok && t256 >= 256;
 }
 
@@ -2290,11 +2290,11 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
                       (a->transA ? (a->M % 8) == 0 : !(plain_split && t256 < 512)) &&
                       (a->transA ? 32 * a->lda + a->M : (long)a->M * a->lda) < (1L << 30) &&
                       (a->transB ? 32 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 30);
-    if (a_ok && (amode >= 2 || (amode == 1 && v2s_opt_gemm_p8() == 1 && a4_auto(a, t256)))) {
+    if (a_ok && (amode == 2 || amode == 3 || ((amode == 1 || amode == 4) && v2s_opt_gemm_p8() == 1 && a4_auto(a, t256)))) {
       a4 = true; bm = 256; bn = 256; p8 = 0; p8d = false; w4 = false; w128 = false; ps = false;
       // persistent form with the deferred write-out: plain bf16 epilogue, whole tiles (gemm_a4 = 3: never)
       a4p = amode != 3 && !a->transA && a->c_dtype == V2S_BF16 && !a->accumulate && !a->bias && !a->pre && !a->residual && a->dact == V2S_ACT_NONE &&
-            a->act == V2S_ACT_NONE && a->dropout_p == 0.f && a->alpha == 1.0f && (a->M % 256) == 0 && (a->N % 256) == 0 && a->N >= 512 && a->K >= 384 &&
+            a->act == V2S_ACT_NONE && a->dropout_p == 0.f && a->alpha == 1.0f && a->N >= 512 && a->K >= 384 &&
             !plain_split && (long)a->M * a->ldc * 2 < (1L << 31) && t256 < 65536;
     }
   }

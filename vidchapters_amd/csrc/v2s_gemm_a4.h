@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmP p) {
 // gemm_a4p_kernel: the PERSISTENT form with a deferred write-out (generator: class GenP).  One block per CU walks its tiles (ids
 // blockIdx.x + k * gridDim.x through the XCD-aware remap); the bf16 output of a tile is rounded out of the AGPRs at the first step of the
 // next tile and leaves through a wave-private LDS transposition as full 256-byte row segments while that tile's MFMAs run; the DMA
-// stream never stops at a tile edge.  Plain bf16 epilogue, M and N multiples of 256, K a multiple of 128 and >= 384.  The whole kernel
+// stream never stops at a tile edge.  Plain bf16 epilogue, M >= 256, N >= 512 (a ragged last tile row / column is shifted up to end at the
+// edge and overlaps its neighbour), K a multiple of 128 and >= 384.  The whole kernel
 // body is the asm statement.
 constexpr int A4P_LDS = 4 * 32768 + 4 * 8192;      // ring + one 8 KiB staging block per wave = all 160 KiB
 
@@ -153,19 +154,22 @@ __global__ __launch_bounds__(256, 1) void gemm_a4p_kernel(const GemmP p) {
   const uint32_t q = ntiles >> 3, r = ntiles & 7;
   const uint32_t magic = (uint32_t)(((1ull << 32) + tilesn - 1) / tilesn);
   const uint32_t nmy = (ntiles - bid + grid - 1) / grid;
+  const uint32_t mlast = (uint32_t)(p.M - 256), nlast = (uint32_t)(p.N - 256);
   if constexpr (TB) {
     asm volatile(A4P_MAIN_NN
                  :
                  : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb),
                    [pc0] "s"(pc0), [pc1] "s"(pc1), [ldc] "s"(ldc), [cbytes] "s"(cbytes), [niter] "s"(niter), [lds] "s"(lds),
-                   [bid] "s"(bid), [grid] "s"(grid), [q] "s"(q), [r] "s"(r), [magic] "s"(magic), [tilesn] "s"(tilesn), [nmy] "s"(nmy)
+                   [bid] "s"(bid), [grid] "s"(grid), [q] "s"(q), [r] "s"(r), [magic] "s"(magic), [tilesn] "s"(tilesn), [nmy] "s"(nmy),
+                   [mlast] "s"(mlast), [nlast] "s"(nlast)
                  : A4P_CLOBBERS);
   } else {
     asm volatile(A4P_MAIN_NT
                  :
                  : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb),
                    [pc0] "s"(pc0), [pc1] "s"(pc1), [ldc] "s"(ldc), [cbytes] "s"(cbytes), [niter] "s"(niter), [lds] "s"(lds),
-                   [bid] "s"(bid), [grid] "s"(grid), [q] "s"(q), [r] "s"(r), [magic] "s"(magic), [tilesn] "s"(tilesn), [nmy] "s"(nmy)
+                   [bid] "s"(bid), [grid] "s"(grid), [q] "s"(q), [r] "s"(r), [magic] "s"(magic), [tilesn] "s"(tilesn), [nmy] "s"(nmy),
+                   [mlast] "s"(mlast), [nlast] "s"(nlast)
                  : A4P_CLOBBERS);
   }
 }
