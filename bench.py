@@ -71,8 +71,8 @@ def rccl_choices(path: str) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60, help="timed steps (default 60 = a 3 s region: box-to-box noise of +-3 %% needs more than a second of signal)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--asr-tokens", type=int, default=1000)
     ap.add_argument("--target-tokens", type=int, default=256)
@@ -91,8 +91,9 @@ def main():
     ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the data-parallel gradient all-reduce")
     ap.add_argument("--bucket-mib", type=int, default=48, help="wire bytes per gradient all-reduce (MiB)")
     ap.add_argument("--shard-optimizer", action="store_true", help="data parallel: reduce-scatter the gradient buckets, Adam on the local 1/N "
-                    "stripes, all-gather the bf16 shadow weights under the next forward (train.GradSync shard=True): the DEFAULT for N > 1")
-    ap.add_argument("--replicated-optimizer", action="store_true", help="data parallel: all-reduce + full Adam on every rank instead")
+                    "stripes, all-gather the bf16 shadow weights under the next forward (train.GradSync shard=True).  OPT-IN: its RCCL path has "
+                    "never run on a real multi-GPU node, and it needs Trainer.prepare_checkpoint() before a state_dict()")
+    ap.add_argument("--replicated-optimizer", action="store_true", help="data parallel: all-reduce + full Adam on every rank (the default)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,7 +106,7 @@ def main():
         import torch.distributed as dist
         # which algorithm / protocol RCCL picks for the step's collectives (ring vs tree, LL / LL128 / Simple) decides what the per-link
         # xGMI bandwidth buys: ask the library to log its choices (TUNING subsystem) and summarise them in the JSON line
-        if "NCCL_DEBUG" not in os.environ:
+        if "NCCL_DEBUG" not in os.environ and os.environ.get("V2S_RCCL_LOG", "0") == "1":      # opt-in: logging changes the timed run
             os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING", NCCL_DEBUG_FILE=f"/tmp/v2s_rccl_{os.getpid()}_rank{rank}.log")
         backend = os.environ.get("V2S_DIST_BACKEND", "nccl")   # "nccl" == RCCL on ROCm; "gloo" lets two ranks share one GPU to
         if backend == "nccl":                                  # exercise the multi-rank control flow where only one GPU exists
@@ -124,7 +125,7 @@ def main():
     log(f"model built: {sum(p.numel() for p in model.parameters()) / 1e6:.1f} M parameters")
     model.engine().overlap = not a.no_overlap
     trainer = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=a.denoising, grad_comm_dtype=a.grad_comm_dtype,
-                      bucket_bytes=a.bucket_mib << 20, shard_optimizer=(False if a.replicated_optimizer else (True if a.shard_optimizer else None)))
+                      bucket_bytes=a.bucket_mib << 20, shard_optimizer=bool(a.shard_optimizer) and not a.replicated_optimizer)
     batch = {k: v.to(dev) for k, v in synth.make_batch(B, T, Lx, Lo, len(tok), 1234 + rank, 768, denoising=a.denoising > 0).items()}
     batch["video"] = batch["video"].to(torch.bfloat16)       # features resident in HBM as bf16 (documented in DESIGN.md)
     batch["input_lens"] = (batch["input_ids"] != 0).sum(1).tolist()      # host-side lengths, as a data loader knows them
@@ -327,6 +328,17 @@ def main():
         out["generate_beam4"] = beam_leg(model, tok, dev, Lx)
         out["input_pipeline"] = input_leg(dev, B, Lx, Lo)
 
+    if rank == 0 and "roofline" in out and "generate_greedy" in out:
+        # the decode legs' summary inside `roofline` (the driver keeps that object whole): cached decode is HBM-bound, fractions of 8 TB/s
+        def dsum(leg):
+            r = leg["roofline"]
+            return {"ms_per_step": leg["ms_per_decode_step"], "sequences_per_s": leg["sequences_per_s"], "bound": "hbm", "achieved": r["achieved"],
+                    "peak": r["peak"], "unit": r["unit"], "frac": r["frac"], "algorithmic_gb_per_step": r["algorithmic_gb_per_step"],
+                    "launches": leg.get("launches_per_decode_step")}
+        out["roofline"]["decode"] = {"greedy": dsum(out["generate_greedy"]), "beam4": dsum(out["generate_beam4"]),
+                                     "note": "cfg-4: greedy B = 64 x 256 steps; the callers' default beam search: 16 entries x 4 beams x 64 steps; "
+                                             "launches = library launches of one captured decode step (vidchapters_amd.lib.launch_count)"}
+
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline (oracle on host cores) ...")
         out["cpu_baseline"] = cpu_baseline(model, tok, Lx, Lo, all_cores=a.cpu_all_cores)
@@ -368,6 +380,7 @@ def generate_leg(model, tok, dev, Lx, B=64, new_tokens=256):
             best[mode] = min(best.get(mode, 1e9), runs[-1][1])
             if mode == was:
                 toks = out_toks
+                n_launch = int(getattr(eng, "last_decode_launches", 0))
     eng.decode_mem_attn = was
     dt, dt_kv = best[was], best[0]
     steps = toks.shape[1] - 1
@@ -377,8 +390,9 @@ def generate_leg(model, tok, dev, Lx, B=64, new_tokens=256):
             "cross_attention": "shared encoder memory (Engine.decode_mem_attn = 1: the default takes it from 40 000 valid memory keys on)" if was else "per-layer K/V caches",
             "runs_mode_seconds": runs,
             "kv_cache_path": {"seconds": round(dt_kv, 4), "sequences_per_s": round(B / dt_kv, 2), "ms_per_decode_step": round(dt_kv / max(steps, 1) * 1e3, 3)},
+            "launches_per_decode_step": n_launch,
             "ms_per_decode_step": round(ms_step, 3), "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, ms_step, rows=B, valid_keys=100 * B + int((ids != 0).sum()),
-                                        on_memory=bool(was) and (was >= 2 or 100 * B + int((ids != 0).sum()) >= 40000)),
+                                        on_memory=getattr(eng, 'last_cross_path', '') == 'memory' if was else False),
             "note": "encode + 256 greedy decode steps (EOS stop disabled so that every run decodes the full length), static KV cache"}
 
 
@@ -435,6 +449,7 @@ def beam_leg(model, tok, dev, Lx, B=16, new_tokens=64, num_beams=4):
         toks = eng.beam_search(video, inp, num_beams=num_beams, max_new_tokens=new_tokens, min_length=new_tokens + 1)   # EOS banned: full length
         torch.cuda.synchronize()
         dt = min(dt, time.perf_counter() - t0)
+    launches = int(getattr(eng, "last_decode_launches", 0))
     dt_host = 1e9                       # the same search with the hypothesis bookkeeping on the host (one round trip per step), for comparison
     was = eng.beam_on_device
     eng.beam_on_device = False
@@ -451,7 +466,7 @@ def beam_leg(model, tok, dev, Lx, B=16, new_tokens=64, num_beams=4):
     return {"batch": B, "num_beams": num_beams, "scorer": "device (v2s_beam_advance inside the replayed graph)" if was else "host",
             "host_scorer": {"seconds": round(dt_host, 4), "sequences_per_s": round(B / dt_host, 2),
                             "tokens_identical": bool(toks.shape == toks_host.shape and (toks == toks_host).all())}, "max_new_tokens": new_tokens, "returned_length": int(toks.shape[1]), "seconds": round(dt, 4),
-            "sequences_per_s": round(B / dt, 2), "ms_per_decode_step": round(dt / new_tokens * 1e3, 3),
+            "sequences_per_s": round(B / dt, 2), "ms_per_decode_step": round(dt / new_tokens * 1e3, 3), "launches_per_decode_step": launches,
             "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, dt / new_tokens * 1e3, rows=B * num_beams,
                                         valid_keys=100 * B + int((ids != 0).sum())),
             "note": "encode + beam search, min_length = max length so that every run decodes all steps"}

@@ -94,7 +94,7 @@ class Engine:
                                       # (_cross_on_memory): 0 = never; 1 = greedy / sampling when the step is bandwidth-bound (>= 40 000 valid memory
                                       # keys in the batch: measured +10 % at B 128, +5 % at 58 000 = B 64, +2 % at 43 000 = B 48, -9 % at 28 000 = B 32; default); 2 = greedy / sampling
                                       # always; 3 = beam search with <= 4 beams too (slower than the grouped K/V kernel at 16 entries x 4 beams)
-        self.decode_mem_attn_min_keys = 40000     # mode 1: valid memory keys in the batch from which the memory path is taken
+        self.decode_mem_attn_min_keys = 40000     # mode 1: memory positions of the call (B x S: shape, not content) from which the memory path is taken
         self.beam_on_device = True    # beam search (no sampling, <= 16 beams): hypothesis bookkeeping on the device (v2s_beam_advance): no host round trip per step
         self.group_flush_layers = 4  # ... every this many decoder layers (the launches then run beside the NEXT layers' under-filled 8192-row kernels)
         self._wgrad_groups: Dict = {}
@@ -1097,7 +1097,10 @@ class Engine:
         klen_h = klen.tolist()
         if not ok or min(klen_h) < 1:
             return None
-        if self.decode_mem_attn == 1 and sum(klen_h) < self.decode_mem_attn_min_keys:      # small batches: the K/V-cache kernels' shorter launch chain wins
+        # small batches: the K/V-cache kernels' shorter launch chain wins.  The choice is made from the call's SHAPE (B x S memory positions),
+        # never from the batch's content, so that which path a sequence takes -- the two differ by bf16 rounding -- does not depend on its
+        # neighbours' lengths; Engine.last_cross_path records it
+        if self.decode_mem_attn == 1 and B * S < self.decode_mem_attn_min_keys:
             return None
         assert mem.is_contiguous() and mem.dtype == torch.bfloat16
         plan = L.MemAttnPlan(klen_h, G * H, self.device)
@@ -1159,6 +1162,7 @@ class Engine:
         inner, H, nl = self.inner, self.H, c.n_dec
         mem2 = mem.view(B * S, d)
         on_mem = self._cross_on_memory(mem, mem_mask, 1)
+        self.last_cross_path = "memory" if on_mem is not None else "kv-cache"
         cross = []
         for i in range(nl if on_mem is None else 0):
             kv = self._bf(B * S, 2 * inner)
@@ -1228,7 +1232,9 @@ class Engine:
                 L.argmax_step_seq(logits, self.ldv, B, self.V, nxt, unfinished, eos, c.pad_id, seq, maxlen + 1, pos)
             L.counter_add(pos, 1)
 
+        c0 = L.launch_count
         step()                                   # step 0 eagerly (also warms every code path before capture)
+        self.last_decode_launches = L.launch_count - c0          # library launches of one decode step (bench.py reports it)
         done_steps = 1
         graph = None
         if use_graph and maxlen > 1:
@@ -1385,7 +1391,9 @@ class Engine:
         recorded = []
         for t in range(maxlen if teacher is None else min(maxlen, len(teacher) + 1)):
             if t == 0 or not use_graph:
+                c0 = L.launch_count
                 step()
+                self.last_decode_launches = L.launch_count - c0
             else:
                 if graph is None:
                     torch.cuda.synchronize()

@@ -154,7 +154,12 @@ def lib() -> C.CDLL:
     return _LIB
 
 
+launch_count = 0      # successful library calls so far (one kernel launch each on the decode path): Engine.last_decode_launches, bench.py
+
+
 def _check(rc: int, what: str) -> None:
+    global launch_count
+    launch_count += 1
     if rc != 0:
         raise RuntimeError(f"{what} failed (rc={rc}): {lib().v2s_last_error().decode()}")
 

@@ -265,9 +265,11 @@ class Trainer:
                  clip_max_norm: float = 1.0, generative: float = 1.0, denoising: float = 1.0, schedule: str = "",
                  fraction_warmup_steps: float = 0.1, num_training_steps: int = 1, group=None, bucket_bytes: int = 48 << 20,
                  grad_comm_dtype: str = "fp32", force_collectives: bool = False, shard_optimizer: Optional[bool] = None):
-        """``shard_optimizer``: None (default) = sharded whenever the group has more than one rank (reduce-scatter + Adam on the owned
-        1/N stripes + overlapped bf16 all-gather: less wire traffic and 1/N of the optimizer's HBM traffic per rank), True / False force it.
-        With a sharded optimizer call :meth:`prepare_checkpoint` (a collective) before ``model.state_dict()`` / ``Trainer.state_dict()``."""
+        """``shard_optimizer``: False / None (default) = replicated optimizer (all-reduce + full Adam on every rank: a reference-style
+        `if is_main_process(): save(model.state_dict())` loop, dvc.py:310-330, works unchanged).  True = sharded (reduce-scatter + Adam on
+        the owned 1/N stripes + overlapped bf16 all-gather: less wire traffic and 1/N of the optimizer's HBM traffic per rank) -- OPT-IN
+        until its RCCL path has run on a real multi-GPU node: it then needs :meth:`prepare_checkpoint` (a collective, every rank) before
+        ``model.state_dict()`` / ``Trainer.state_dict()``.  :meth:`close` detaches the guards it installs on the model."""
         self.model = model
         self.eng = model.engine()
         a = self.eng.arena
@@ -281,8 +283,7 @@ class Trainer:
         self.high_priority = False       # experiment (see step): faster step by step, slower in a pipelined loop -> off
         self.overlap_gather = True       # sharded optimizer: all-gather the bf16 shadow on the communication stream under the next forward
         self._hi_stream = None
-        if shard_optimizer is None:
-            shard_optimizer = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        shard_optimizer = bool(shard_optimizer)
         self.sync = GradSync(a, group, bucket_bytes=bucket_bytes, comm_dtype=grad_comm_dtype, force=force_collectives, shard=shard_optimizer)
         self.world = self.sync.world
         self._sq_ws = torch.empty(1024, dtype=torch.float32, device=dev)
@@ -293,8 +294,15 @@ class Trainer:
             # stale-master guards (sharded optimizer): a re-cast of the bf16 shadow from the masters (an in-place torch update of a
             # Parameter, mark_dirty, load_state_dict) or a state_dict() of the module would silently use the (world-1)/world stale
             # matrices -- fail loudly instead; gather_master() (a collective: every rank) makes them current
-            a.stale_guard = self._stale_guard
-            model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self._stale_guard("model.state_dict()"))
+            import weakref
+            me = weakref.ref(self)             # the guards must not keep a discarded Trainer alive (or raise for it forever): weak reference + close()
+
+            def guard(what, me=me):
+                t = me()
+                if t is not None:
+                    t._stale_guard(what)
+            a.stale_guard = guard
+            self._sd_hook = model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: guard("model.state_dict()"))
         # arena ranges (engine._arena_order): decoder matrices | encoder matrices | ViT matrices + pos_embed | the small fp32-consumed
         # parameters | the tied embedding, whose last rows (time tokens + the zero tail) every rank keeps whole (renorm reads them)
         names = a.names
@@ -310,6 +318,22 @@ class Trainer:
         tt0 = sh0 + ((self.eng.V - model.num_bins) * self.eng.d) // 64 * 64 if model.num_bins else sh1
         self._r_shared, self._r_timetok = (sh0, tt0), (tt0, sh1)
         assert self._r_dec[1] == self._r_enc[0] and self._r_enc[1] == self._r_vis[0] and self._r_vis[1] == self._r_small[0] and self._r_small[1] == sh0
+
+    def close(self) -> None:
+        """Detach this Trainer from the model: removes the stale-master guards (sharded optimizer) so that a replaced / discarded Trainer
+        neither stays alive nor makes ``model.state_dict()`` raise.  Call :meth:`gather_master` first if its masters are still needed."""
+        h = getattr(self, "_sd_hook", None)
+        if h is not None:
+            h.remove()
+            self._sd_hook = None
+        if getattr(self.eng.arena, "stale_guard", None) is not None and self.sync.shard:
+            self.eng.arena.stale_guard = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _stale_guard(self, what: str) -> None:
         if self.sync.masters_stale:
@@ -607,6 +631,11 @@ class Trainer:
     def gather_master(self) -> None:
         """Sharded optimizer only: make every rank's fp32 master weights (= the nn.Module's parameters) current.  Call before
         ``model.state_dict()`` / evaluation through the module; a no-op otherwise."""
+        ev = self.eng.shadow_events            # an asynchronous shadow all-gather may still be writing the bf16 copies mark_dirty re-casts
+        if ev:
+            for e in ev.values():
+                torch.cuda.current_stream().wait_event(e)
+            self.eng.shadow_events = None
         self.sync.gather_master()
         self.eng.mark_dirty()
 
@@ -638,6 +667,7 @@ class Trainer:
             raise ValueError("optimizer state was saved for a different parameter layout")
         self.step_count = int(sd["step_count"])
         self.m.copy_(sd["exp_avg"]); self.v.copy_(sd["exp_avg_sq"])
+        self.sync.moments_stale = False        # whole moments were just loaded on this rank
         self.eng.set_rng_state(sd["dropout_rng"])
 
     def grad_norm(self) -> torch.Tensor:
