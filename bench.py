@@ -381,18 +381,19 @@ def generate_leg(model, tok, dev, Lx, B=64, new_tokens=256):
             if mode == was:
                 toks = out_toks
                 n_launch = int(getattr(eng, "last_decode_launches", 0))
+                path_was = getattr(eng, "last_cross_path", "")
     eng.decode_mem_attn = was
     dt, dt_kv = best[was], best[0]
     steps = toks.shape[1] - 1
     model.train()
     ms_step = dt / max(steps, 1) * 1e3
     return {"batch": B, "decode_steps": int(steps), "seconds": round(dt, 4), "sequences_per_s": round(B / dt, 2),
-            "cross_attention": "shared encoder memory (Engine.decode_mem_attn = 1: the default takes it from 40 000 valid memory keys on)" if was else "per-layer K/V caches",
+            "cross_attention": "shared encoder memory (Engine.decode_mem_attn = 1: taken from 40 000 memory positions B x S on)" if path_was == "memory" else "per-layer K/V caches",
             "runs_mode_seconds": runs,
             "kv_cache_path": {"seconds": round(dt_kv, 4), "sequences_per_s": round(B / dt_kv, 2), "ms_per_decode_step": round(dt_kv / max(steps, 1) * 1e3, 3)},
             "launches_per_decode_step": n_launch,
             "ms_per_decode_step": round(ms_step, 3), "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, ms_step, rows=B, valid_keys=100 * B + int((ids != 0).sum()),
-                                        on_memory=getattr(eng, 'last_cross_path', '') == 'memory' if was else False),
+                                        on_memory=(path_was == 'memory')),
             "note": "encode + 256 greedy decode steps (EOS stop disabled so that every run decodes the full length), static KV cache"}
 
 

@@ -829,6 +829,31 @@ def case_shape(v2s, tag, cfg, B, T, L, Lo, seed, check_oracle=True):
     npz(f"{tag}_scalars.npz", **arrs)
 
 
+def case_shape_bf16(tag, cfg, B, T, L, Lo, seed):
+    """The same inputs and weights as case_shape, run through the ORACLE in its bf16 mode (oracle/vid2seq_ref.py: a round-to-bf16 wherever
+    the HIP engine stores a bf16 tensor, forward and backward; fp32 accumulation): loss, per-tensor gradient norms and the same strided
+    gradient samples -> <tag>_bf16mode.npz.  Needs no reference import (the mode is pinned against the fp32 golden of the reference by
+    tests/test_oracle_cpu.py within the bf16 noise measured in profiles/r02_bf16_noise_cfg2_shape.txt)."""
+    print(f"[{tag} / bf16 mode] d_model={cfg.d_model} layers={cfg.n_enc}+{cfg.n_dec} B={B} T={T} L={L} Lo={Lo}  (oracle, fp32 accumulate, bf16 stores)")
+    P = oracle_params(cfg, seed, grad=True)
+    batch = synth.make_batch(B, T, L, Lo, cfg.vocab, seed, cfg.vit_dim)
+    with R.bf16_mode():
+        out, vd = R.vid2seq_forward(P, cfg, batch["video"], batch["input_ids"], batch["input_ids"] != 0, batch["output_ids"], batch["output_ids"] != 0)
+        out["loss"].backward()
+    arrs = {"seed": seed, "B": B, "T": T, "L": L, "Lo": Lo, "loss": out["loss"].detach(),
+            "memory_slice": vd["video"][:, ::max(1, T // 8), :32].detach()}
+    keys, vals, tot = [], [], 0.0
+    for k in P:
+        g = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        keys.append(k); vals.append(float(g.norm())); tot += vals[-1] ** 2
+        if wants_slice(k, cfg.n_enc):
+            arrs["gs:" + k] = grad_sample(k, g)
+    arrs["grad_norm"] = tot ** 0.5
+    arrs["grad_norm_keys"], arrs["grad_norm_vals"] = np.array(keys), np.array(vals)
+    print(f"  loss = {float(out['loss']):.7f}; total grad norm = {tot ** 0.5:.6f}")
+    npz(f"{tag}_bf16mode.npz", **arrs)
+
+
 def ref_greedy_margins(m, batch, max_new, penalty=1.0):
     """ref_greedy without the EOS stop, returning the tokens and the top-1 / top-2 logit margin of every step (a bf16 engine can
     only be held to the steps whose margin exceeds its logit noise).  penalty != 1: HF-4.28 RepetitionPenaltyLogitsProcessor on the
@@ -972,6 +997,7 @@ def case_beam_full(v2s, B=2, T=100, L=1000, nb=4, max_new=16, seed=2027):
 
 def case_shapes(v2s):
     case_shape(v2s, "full_cfg2", R.RefConfig(), B=2, T=100, L=1000, Lo=256, seed=2024)
+    case_shape_bf16("full_cfg2", R.RefConfig(), B=2, T=100, L=1000, Lo=256, seed=2024)
     large = R.RefConfig(d_model=1024, d_kv=64, heads=16, d_ff=4096, n_enc=24, n_dec=24, num_features=200)
     case_shape(v2s, "large_cfg5", large, B=1, T=200, L=2000, Lo=256, seed=2025)
     case_greedy_full(v2s)
@@ -984,10 +1010,16 @@ def main():
     ap.add_argument("--only-eval", action="store_true", help="regenerate tests/golden/eval_metrics.json only")
     ap.add_argument("--only-shapes", action="store_true", help="regenerate the big-shape goldens (cfg-2 shape, t5-large / cfg-5 shape) only")
     ap.add_argument("--only-beam-full", action="store_true", help="regenerate tests/golden/full_cfg4_beam4.npz only")
+    ap.add_argument("--only-bf16-mode", action="store_true", help="regenerate tests/golden/full_cfg2_bf16mode.npz only (oracle in bf16 mode; no reference import)")
     a = ap.parse_args()
     if a.only_eval:
         case_schedule()
         case_eval()
+        return
+    if a.only_bf16_mode:
+        torch.manual_seed(0)
+        torch.set_num_threads(os.cpu_count())
+        case_shape_bf16("full_cfg2", R.RefConfig(), B=2, T=100, L=1000, Lo=256, seed=2024)
         return
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
