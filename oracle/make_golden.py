@@ -851,6 +851,26 @@ def case_shape_bf16(tag, cfg, B, T, L, Lo, seed):
     arrs["grad_norm"] = tot ** 0.5
     arrs["grad_norm_keys"], arrs["grad_norm_vals"] = np.array(keys), np.array(vals)
     print(f"  loss = {float(out['loss']):.7f}; total grad norm = {tot ** 0.5:.6f}")
+    # SELF-NOISE FLOOR: the same computation with another fp32 summation order (3 BLAS threads instead of all).  At this depth bf16
+    # arithmetic is chaotic -- a different rounding of a handful of elements flips ReLU masks and shifts softmax rows downstream -- so two
+    # correct implementations of the SAME rounding points decorrelate; the per-tensor cosine between the two runs is what a third correct
+    # implementation (the HIP engine) can be expected to reach against either, and what the GPU test holds it to.
+    nt = torch.get_num_threads()
+    torch.set_num_threads(3)
+    P2 = oracle_params(cfg, seed, grad=True)
+    with R.bf16_mode():
+        out2, _ = R.vid2seq_forward(P2, cfg, batch["video"], batch["input_ids"], batch["input_ids"] != 0, batch["output_ids"], batch["output_ids"] != 0)
+        out2["loss"].backward()
+    torch.set_num_threads(nt)
+    worst = (1.0, "")
+    for k in P:
+        if wants_slice(k, cfg.n_enc):
+            a_, b_ = grad_sample(k, P[k].grad).double().flatten(), grad_sample(k, P2[k].grad).double().flatten()
+            c_ = float(a_ @ b_ / (a_.norm() * b_.norm() + 1e-30))
+            arrs["sc:" + k] = np.float32(c_)
+            worst = min(worst, (c_, k))
+    arrs["self_loss"] = out2["loss"].detach()
+    print(f"  self-noise (another summation order): loss {float(out2['loss']):.7f}, worst per-tensor cosine {worst[0]:.4f} ({worst[1]})")
     npz(f"{tag}_bf16mode.npz", **arrs)
 
 

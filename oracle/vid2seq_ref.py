@@ -76,6 +76,42 @@ def _rb(x):      # rounded going backward only: d(scores), d(logits)
     return _Round.apply(x, False, True) if BF16_MODE else x
 
 
+def _bf(x):
+    return x.bfloat16().float()
+
+
+class _AttnCoreBf16(torch.autograd.Function):
+    """softmax(scale * q k^T + bias) v as the engine's flash kernels compute it (csrc/v2s_attn.hip), bf16 mode only: probabilities rounded to
+    bf16 as MFMA operands, the context stored in bf16; backward: dO in bf16, delta = rowsum(dO * O) from the STORED (rounded) context -- not
+    sum_k P dP --, dP = dO v^T in fp32, dS = P (dP - delta) rounded to bf16 for the dQ / dK products, dV = P_bf16^T dO; the bias gradient sums
+    the fp32 dS."""
+    @staticmethod
+    def forward(ctx, q, k, v, bias, scale):
+        s = (q @ k.transpose(-1, -2)) * scale + bias
+        p = torch.softmax(s.float(), dim=-1)
+        o = _bf(_bf(p) @ v)
+        ctx.save_for_backward(q, k, v, p, o)
+        ctx.scale, ctx.bias_shape = scale, bias.shape
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, p, o = ctx.saved_tensors
+        do = _bf(do)
+        delta = (do * o).sum(-1, keepdim=True)
+        dp = do @ v.transpose(-1, -2)
+        ds = p * (dp - delta)
+        dsb = _bf(ds)
+        dq = (dsb @ k) * ctx.scale
+        dk = (dsb.transpose(-1, -2) @ q) * ctx.scale
+        dv = _bf(p).transpose(-1, -2) @ do
+        db = ds
+        for d_, n in enumerate(ctx.bias_shape):            # reduce to the (broadcast) bias shape
+            if n == 1 and db.shape[d_] != 1:
+                db = db.sum(d_, keepdim=True)
+        return dq, dk, dv, db, None
+
+
 @dataclass
 class RefConfig:
     """Shapes of the path.  Defaults = t5-base + args.py:107-329 defaults."""
@@ -224,9 +260,12 @@ def t5_attention(P: Params, prefix: str, cfg: RefConfig, x: torch.Tensor, bias: 
         if past is not None:                                   # :515 growing self cache
             k = torch.cat([past[0], k], dim=2)
             v = torch.cat([past[1], v], dim=2)
-    scores = _rb(q @ k.transpose(-1, -2)) + bias
-    w = torch.softmax(scores.float(), dim=-1)
-    o = _ra((_rf(w) @ v).transpose(1, 2).reshape(x.shape[0], x.shape[1], cfg.inner))
+    if BF16_MODE:
+        o = _AttnCoreBf16.apply(q, k, v, bias, 1.0).transpose(1, 2).reshape(x.shape[0], x.shape[1], cfg.inner)
+    else:
+        scores = q @ k.transpose(-1, -2) + bias
+        w = torch.softmax(scores.float(), dim=-1)
+        o = (w @ v).transpose(1, 2).reshape(x.shape[0], x.shape[1], cfg.inner)
     return o @ _rf(P[prefix + "o.weight"]).T, (k, v)          # (bf16 mode: the caller rounds h + this, like the GEMM epilogue does)
 
 
@@ -340,8 +379,11 @@ def vit_forward(P: Params, cfg: RefConfig, x: torch.Tensor) -> torch.Tensor:
         p = f"visual_encoder.blocks.{i}."
         n = _ra(F.layer_norm(x, (C,), P[p + "norm1.weight"], P[p + "norm1.bias"], cfg.ln_eps))
         qkv = _ra(n @ _rf(P[p + "attn.qkv.weight"]).T + P[p + "attn.qkv.bias"]).reshape(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
-        att = torch.softmax(_rb(qkv[0] @ qkv[1].transpose(-1, -2)) * scale, dim=-1)
-        o = _ra((_rf(att) @ qkv[2]).transpose(1, 2).reshape(B, N, C))
+        if BF16_MODE:
+            o = _AttnCoreBf16.apply(qkv[0], qkv[1], qkv[2], torch.zeros(1, 1, 1, 1), scale).transpose(1, 2).reshape(B, N, C)
+        else:
+            att = torch.softmax((qkv[0] @ qkv[1].transpose(-1, -2)) * scale, dim=-1)
+            o = (att @ qkv[2]).transpose(1, 2).reshape(B, N, C)
         x = _ra(x + (o @ _rf(P[p + "attn.proj.weight"]).T + P[p + "attn.proj.bias"]))
         n = _ra(F.layer_norm(x, (C,), P[p + "norm2.weight"], P[p + "norm2.bias"], cfg.ln_eps))
         hdn = _ra(F.gelu(n @ _rf(P[p + "mlp.fc1.weight"]).T + P[p + "mlp.fc1.bias"]))

@@ -125,13 +125,24 @@ def test_cfg2_shape_vs_bf16_mode_oracle(golden_dir):
     tot = float(torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values())))
     print(f"  {len(cs)} sampled gradient tensors: worst cosines {[(round(c_, 5), n_) for c_, n_ in cs[:4]]}; mean {sum(c_ for c_, _ in cs) / len(cs):.5f}")
     print(f"  total grad norm hip={tot:.5f} oracle={float(g['grad_norm']):.5f}")
-    assert rel <= A_BF16MODE_LOSS_REL and c > 0.99995
-    assert cs[0][0] > A_BF16MODE_MIN_COS, cs[:4]
-    assert abs(tot - float(g["grad_norm"])) <= 5e-3 * float(g["grad_norm"])
+    # per tensor: no further from the oracle than the oracle is from ITSELF under another fp32 summation order (fixture keys "sc:")
+    below = sorted((c_ - float(g["sc:" + n_]), round(c_, 5), round(float(g["sc:" + n_]), 5), n_) for c_, n_ in cs)
+    print(f"  engine cosine minus the oracle's self-noise cosine, per tensor: min {below[0][0]:+.4f} ({below[0][3]}), "
+          f"median {below[len(below) // 2][0]:+.4f}, max {below[-1][0]:+.4f}")
+    assert rel <= A_BF16MODE_LOSS_REL and c > 0.9999
+    assert cs[0][0] > A_BF16MODE_MIN_COS and sum(c_ for c_, _ in cs) / len(cs) > A_BF16MODE_MEAN_COS, cs[:4]
+    assert below[0][0] > -A_BF16MODE_BELOW_SELF, below[:4]
+    assert abs(tot - float(g["grad_norm"])) <= 1e-2 * float(g["grad_norm"])
 
 
-# measured (profiles/r05_bf16mode_parity.txt): see the numbers printed by the test
-A_BF16MODE_LOSS_REL, A_BF16MODE_MIN_COS = 1e-3, 0.97
+# Thresholds (measured, profiles/r05_bf16mode_parity.txt): loss rel 3.8e-6 (2.7e-5 against the fp32 reference); per-tensor cosine worst 0.986 /
+# mean 0.9915 (0.975 / 0.989 against fp32).  0.999 on every tensor is not attainable by ANY implementation: bf16 arithmetic at this depth is
+# chaotic -- the oracle in bf16 mode against ITSELF with another fp32 summation order (3 BLAS threads instead of 8) scores worst 0.9866 / mean
+# 0.9937, with a 1e-6 relative jitter on the video input worst 0.9896 / mean 0.9934 (tests/tools/bf16_mode_self_noise.py) -- and the weakest
+# tensors are the same ones at the same level (decoder block 11 wi: self 0.9903, engine 0.9901).  The fixture therefore carries that
+# self-noise cosine per tensor, and the engine must stay within A_BF16MODE_BELOW_SELF of it on EVERY sampled tensor: a kernel bug that
+# moves one tensor beyond its own rounding noise fails, which the 0.972 bound against fp32 could not see.
+A_BF16MODE_LOSS_REL, A_BF16MODE_MIN_COS, A_BF16MODE_MEAN_COS, A_BF16MODE_BELOW_SELF = 1e-4, 0.98, 0.988, 0.012      # measured: min -0.0080 (encoder block 0 norms: 0.986 vs 0.994), median -0.002
 
 
 def test_t5_large_cfg5_shape_vs_reference_golden(golden_dir):
