@@ -59,18 +59,26 @@ ODD_REQ = [4, 7, 10, 14]
 
 
 class Gen:
-    def __init__(self, tb, ta=False):
+    def __init__(self, tb, ta=False, abl=""):
         self.tb, self.ta = tb, ta
+        self.abl = abl           # profiling ablations of the main loop (results invalid): "nodma" = no LDS-DMA requests, "noread" = no fragment
+                                 # reads, "none" = neither (MFMAs + barriers only), "nobar" = no s_barrier
         self.lines = []
         self.lgkm = []       # outstanding LDS operations, oldest first: tags
         self.vm = []         # outstanding vector-memory operations: tags
         self.nmfma = 0
 
     def e(self, s):
+        if self.abl == "nobar" and s == "s_barrier":
+            return
+        if self.abl in ("nodma", "none") and s.startswith("s_add_u32 m0,"):
+            return
         self.lines.append(s)
 
     # ---- scoreboard
     def lds_op(self, tag, text):
+        if self.abl in ("noread", "none") and tag.startswith("F"):
+            return
         if len(self.lgkm) >= 15:                # lgkmcnt is a 4-bit counter: retire the older half (long done) to make room
             keep = 7
             self.e(f"s_waitcnt lgkmcnt({keep})")
@@ -88,6 +96,8 @@ class Gen:
     def vm_op(self, tag, text):
         assert len(self.vm) < 63
         self.vm.append(tag)
+        if self.abl in ("nodma", "none") and tag.startswith("stage"):
+            return               # (the scoreboard still counts it: waits become vmcnt(N) on an emptier queue, i.e. free)
         self.e(text)
 
     def vm_need(self, tag, also_lgkm0=False):
@@ -702,6 +712,13 @@ def main():
         parts.append(f"#define A4_MAIN_{'TN' if ta else ('NN' if tb else 'NT')} \\")
         parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in lines))
         parts.append("")
+    parts.append("#ifdef V2S_A4_ABLATIONS")
+    for abl in ("nodma", "noread", "none", "nobar"):
+        g = Gen(False, False, abl)
+        parts.append(f"#define A4_MAIN_NT_{abl.upper()} \\")
+        parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in g.main()))
+        parts.append("")
+    parts.append("#endif")
     for tb in (False, True):
         g = GenP(tb)
         lines = g.main_p()

@@ -52,6 +52,14 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmP p) {
                    [m0] "s"(m0), [n0] "s"(n0), [mmax] "s"(mmax), [nmax] "s"(nmax), [niter] "s"(niter), [lds] "s"(lds)
                  : A4_CLOBBERS);
   } else {
+#ifdef V2S_A4_ABLATIONS      // profiling build only (tools/build_a4_ablations.sh): gemm_dbg = 11..14 selects an ablated main loop (results invalid)
+#define A4_ABL_ARGS : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb), \
+                   [m0] "s"(m0), [n0] "s"(n0), [mmax] "s"(mmax), [nmax] "s"(nmax), [niter] "s"(niter), [lds] "s"(lds) : A4_CLOBBERS
+    if (p.dbg == 11) { asm volatile(A4_MAIN_NT_NODMA : A4_ABL_ARGS); return; }
+    if (p.dbg == 12) { asm volatile(A4_MAIN_NT_NOREAD : A4_ABL_ARGS); return; }
+    if (p.dbg == 13) { asm volatile(A4_MAIN_NT_NONE : A4_ABL_ARGS); return; }
+    if (p.dbg == 14) { asm volatile(A4_MAIN_NT_NOBAR : A4_ABL_ARGS); return; }
+#endif
     asm volatile(A4_MAIN_NT
                  :
                  : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb),

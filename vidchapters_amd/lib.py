@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvid2seq_hip.so")
+LIB_PATH = os.environ.get("V2S_LIB") or os.path.join(_HERE, "libvid2seq_hip.so")      # V2S_LIB: developer override (profiling builds)
 
 V2S_BF16, V2S_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
