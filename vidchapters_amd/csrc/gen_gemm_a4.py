@@ -52,10 +52,18 @@ A_PART, B_PART = 0, 16384
 # (MI355X_MICROARCH.md, per-instruction constants), and the MFMA behind it only hides 32.  A stage's 8 requests therefore go out one
 # per ~4 MFMAs over 30 gaps: requests 0-3 of stage s+4 in the odd step of stage s (after its barrier), requests 4-7 in the even step
 # of stage s+1; the M0 write sits one gap ahead of its request (the MFMA between them is the wait state it needs).
-EVEN_READS = [0, 1, 3, 5, 7, 9, 11, 13]
-EVEN_REQ = [2, 6, 10, 14]
-ODD_READS = [2, 3, 5, 6, 8, 9, 11, 12]
-ODD_REQ = [4, 7, 10, 14]
+import os
+_PLAN = os.environ.get("A4_PLAN", "spread")
+if _PLAN == "early":         # fragment reads as early as the step allows (complete long before the next wait), requests in the remaining gaps
+    EVEN_READS = [0, 1, 2, 3, 4, 5, 6, 7]
+    EVEN_REQ = [9, 11, 13, 15]
+    ODD_READS = [2, 3, 4, 5, 6, 7, 8, 9]
+    ODD_REQ = [11, 12, 14, 15]
+else:
+    EVEN_READS = [0, 1, 3, 5, 7, 9, 11, 13]
+    EVEN_REQ = [2, 6, 10, 14]
+    ODD_READS = [2, 3, 5, 6, 8, 9, 11, 12]
+    ODD_REQ = [4, 7, 10, 14]
 
 
 class Gen:
@@ -105,7 +113,7 @@ class Gen:
         n = len(self.vm) - idx - 1
         self.vm = self.vm[idx + 1:]
         if also_lgkm0:
-            self.e(f"s_waitcnt vmcnt({n}) lgkmcnt(0)")
+            self.e("s_waitcnt lgkmcnt(0)" if self.abl == "nowait" else f"s_waitcnt vmcnt({n}) lgkmcnt(0)")
             self.lgkm = []
         else:
             self.e(f"s_waitcnt vmcnt({n})")
@@ -713,7 +721,7 @@ def main():
         parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in lines))
         parts.append("")
     parts.append("#ifdef V2S_A4_ABLATIONS")
-    for abl in ("nodma", "noread", "none", "nobar"):
+    for abl in ("nodma", "noread", "none", "nobar", "nowait"):
         g = Gen(False, False, abl)
         parts.append(f"#define A4_MAIN_NT_{abl.upper()} \\")
         parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in g.main()))

@@ -15,7 +15,10 @@
 // idle) ring, and the library's ordinary 8-wide row-chunk epilogue (epilogue_chunk: bias / activation / mask / dropout / residual / fp32
 // or bf16 store / split-K slice) runs on it.  The compiler never sees the accumulators; build.sh fails the build if it ever emits a
 // v_accvgpr_* or scratch access of its own in this kernel (it could only be a spill into our registers).
-#include "v2s_gemm_a4.inc"
+#ifndef A4_INC
+#define A4_INC "v2s_gemm_a4.inc"      // (tools/build_a4_ablations.sh substitutes experimental schedules)
+#endif
+#include A4_INC
 
 constexpr int A4_LDS = 4 * 32768;                 // ring of 4 stages; the epilogue's 64 x 260 fp32 staging block (66 560 B) lives in it
 constexpr int A4_PB = 260;                        // staging pitch in floats (1040 B: eight consecutive rows of a ds_write_b128 pass cover all banks)
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmP p) {
     if (p.dbg == 12) { asm volatile(A4_MAIN_NT_NOREAD : A4_ABL_ARGS); return; }
     if (p.dbg == 13) { asm volatile(A4_MAIN_NT_NONE : A4_ABL_ARGS); return; }
     if (p.dbg == 14) { asm volatile(A4_MAIN_NT_NOBAR : A4_ABL_ARGS); return; }
+    if (p.dbg == 15) { asm volatile(A4_MAIN_NT_NOWAIT : A4_ABL_ARGS); return; }
 #endif
     asm volatile(A4_MAIN_NT
                  :
