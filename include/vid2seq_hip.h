@@ -257,6 +257,10 @@ int v2s_embed_bwd(const int64_t* ids, const void* dy, float* dtable, int64_t n, 
 int v2s_add_bcast(const void* x, const void* add, void* y, int64_t n, int64_t add_n, void* stream);
 int v2s_dropout(const void* x, void* y, int64_t n, float p, uint32_t seed, void* stream);
 int v2s_add(const void* a, const void* b, void* y, int64_t n, void* stream);
+/* y[n] = sum_{p < nparts} parts[p * stride + .] (bf16 terms summed in fp32, one rounding; n, stride multiples of 8).  Round 5: the twelve
+ * decoder layers' cross-attention memory gradients are written by plain GEMMs and summed once (modeling_t5.py:528-536 backward) instead of
+ * a chain of residual epilogues. */
+int v2s_sum_n(const void* parts, int64_t stride, int32_t nparts, void* y, int64_t n, void* stream);
 /* out_f32[i mod add_n] += sum over broadcast copies of dy (pos_embed gradient) */
 int v2s_bcast_grad(const void* dy, float* out, int64_t n, int64_t add_n, void* stream);
 

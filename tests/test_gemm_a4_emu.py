@@ -54,6 +54,13 @@ def test_persistent_deferred_writeout(inc, tb, M, N, K, grid):
         assert E.check_p(inc, tb, M, N, K, grid, lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched) == 0
 
 
+def test_persistent_relu_mask_epilogue(inc):
+    """gemm_a4p with dact = RELU: the z tile prefetched into the held registers during the tile's third iteration, masked + scaled at the
+    conversion (z > 0 incl. -0 and negative z; scale 1 / 0.9); K = 512 is the shortest contraction it takes (T, S, Z and one loop iteration)"""
+    for (M, N, K, grid), (lazy_ds, lazy_dma, sched) in zip(((512, 768, 640, 2), (600, 520, 512, 1)), (MODES[1], MODES[3])):
+        assert E.check_p(inc, True, M, N, K, grid, lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched, dact=True, scale=1.0 / 0.9) == 0
+
+
 def test_the_model_catches_a_wrong_wait_a_missing_barrier_and_a_wrong_slot(inc, tmp_path):
     """the emulator is only worth something if it rejects broken schedules: three mutations of the generated text"""
     src = open(inc).read()

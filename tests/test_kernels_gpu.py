@@ -520,7 +520,8 @@ def test_experimental_gemm_kernels_are_bit_identical(opt, val, tag):
 @pytest.mark.parametrize("kind,M,N,K,ep", [
     ("NT", 512, 512, 384, ""), ("NN", 768, 512, 512, ""), ("NT", 2048, 768, 768, ""), ("NN", 1024, 1536, 640, ""),      # persistent form (plain, whole tiles)
     ("NT", 1000, 520, 384, ""), ("NT", 2000, 768, 768, "res"), ("NT", 1300, 1544, 384, "act"), ("NT", 600, 520, 256, "f32"),
-    ("NN", 777, 392, 256, "dact"), ("NT", 768, 768, 2048, "bias")])
+    ("NN", 777, 392, 256, "dact"), ("NT", 768, 768, 2048, "bias"),
+    ("NN", 1024, 768, 640, "dact"), ("NN", 1000, 1544, 512, "dactdrop")])                                               # persistent form with the ReLU-mask epilogue
 def test_gemm_a4_kernel(kind, M, N, K, ep):
     """gemm_a4_kernel / gemm_a4p_kernel (generated asm K loop, 4 waves, 128 x 128 wave tiles in AGPRs, v_mfma 32x32x16): against fp32 torch on
     the bf16 inputs, plain and fused epilogues, ragged edges, both weight layouts; where the persistent deferred-write-out form is legal it
@@ -537,6 +538,9 @@ def test_gemm_a4_kernel(kind, M, N, K, ep):
         b = rnd(N, seed=9, dtype=torch.float32); kw.update(bias=b, act=L.ACT_GELU); ref = torch.nn.functional.gelu(ref + b)
     if ep == "dact":
         z = torch.relu(rnd(M, N, seed=9)); kw.update(dact=L.ACT_RELU, z=z); ref = ref * (z.float() > 0)
+    if ep == "dactdrop":          # z = the forward's post-dropout activation: the mask is z > 0, the scale 1 / (1 - p) (p16-rounded like the library's)
+        z = torch.relu(rnd(M, N, seed=9)) * (rnd(M, N, seed=10) > -1.0); kw.update(dact=L.ACT_RELU, z=z, dropout_p=0.1, dropout_seed=3)
+        ref = ref * (z.float() > 0) * (1.0 / (1.0 - round(0.1 * 65536) / 65536.0))
     outs = {}
     try:
         for mode in (2, 3):
@@ -546,7 +550,8 @@ def test_gemm_a4_kernel(kind, M, N, K, ep):
             outs[mode] = (C_, L.lib().v2s_last_gemm_kernel().decode())
     finally:
         L.set_option("gemm_a4", 1)
-    whole = ep == "" and N >= 512 and K >= 384           # the persistent form: plain bf16 epilogue (ragged edges: the last tile row / column overlaps)
+    # the persistent form: plain bf16 epilogue (ragged edges: the last tile row / column overlaps) or the ReLU-mask dgrad epilogue
+    whole = (ep == "" and N >= 512 and K >= 384) or (ep in ("dact", "dactdrop") and kind == "NN" and N >= 512 and K >= 512)
     assert ("gemm_a4p_kernel" in outs[2][1]) == whole and "gemm_a4_kernel" in outs[3][1], (outs[2][1], outs[3][1])
     for mode in (2, 3):
         assert relerr(outs[mode][0], ref) < (2e-5 if ep == "f32" else 5e-3), (mode, kind, M, N, K, ep)      # bf16 half-ulp of the largest element: up to 2^-8
@@ -571,6 +576,14 @@ def test_gemm_a4_weight_gradient(M, N, K, split):
         L.set_option("gemm_a4", 1)
     assert kern == "gemm_a4_kernel<true, true>", kern
     assert relerr(C_, ref) < 2e-5
+
+
+def test_sum_n():
+    """v2s_sum_n: fp32 sum of bf16 parts, one rounding (the decoder layers' d(memory) contributions)"""
+    parts = rnd(5, 1000, 72, seed=3)
+    y = torch.empty(1000, 72, dtype=torch.bfloat16, device=DEV)
+    L.sum_n(parts, 1000 * 72, 5, y, 1000 * 72)
+    assert torch.equal(y, parts.float().sum(0).to(torch.bfloat16))
 
 
 def test_fp32_io_debug_mode_norm_ce_attention():

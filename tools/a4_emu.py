@@ -302,6 +302,54 @@ class Block:
                 complete(); w.vm.append(lambda: None)
             assert len(w.vm) <= 63
             return
+        if op == "v_mul_f32":
+            a, b = V(ops[1]).view(np.float32), V(ops[2]).view(np.float32)
+            with np.errstate(all="ignore"):
+                self.setv(w, ops[0], (a * b).astype(np.float32).view(np.uint32))
+            return
+        if op in ("v_pk_sub_i16", "v_pk_ashrrev_i16"):
+            clamp = bool(re.search(r"\bclamp\b", rest))
+            opsel = "op_sel_hi:[0,1]" in rest
+            clean = re.sub(r"op_sel_hi:\[[^\]]*\]|\bclamp\b", "", rest).strip()
+            toks = [t.strip() for t in clean.split(",")]
+
+            def halves(t, inline_lo_for_hi=False):
+                x = V(t).astype(np.uint32)
+                lo = (x & np.uint32(0xFFFF)).astype(np.uint16).view(np.int16).astype(np.int64)
+                hi = (x >> np.uint32(16)).astype(np.uint16).view(np.int16).astype(np.int64)
+                return lo, (lo if inline_lo_for_hi else hi)
+            inline1 = re.fullmatch(r"-?\d+", toks[1]) is not None
+            a_lo, a_hi = halves(toks[1], inline_lo_for_hi=(opsel and inline1))
+            b_lo, b_hi = halves(toks[2])
+            if op == "v_pk_sub_i16":
+                r_lo, r_hi = a_lo - b_lo, a_hi - b_hi
+                if clamp:
+                    r_lo, r_hi = np.clip(r_lo, -32768, 32767), np.clip(r_hi, -32768, 32767)
+            else:                                              # D = S1 >> S0 (arithmetic), per half
+                r_lo, r_hi = b_lo >> (a_lo & 15), b_hi >> (a_hi & 15)
+            r = (r_lo.astype(np.int16).view(np.uint16).astype(np.uint32)) | (r_hi.astype(np.int16).view(np.uint16).astype(np.uint32) << np.uint32(16))
+            self.setv(w, toks[0], r)
+            return
+        if op == "buffer_load_dwordx4":
+            # buffer_load_dwordx4 vdst[4], voffset, srd[4], soffset offen [offset:N]   (out of range -> zeros)
+            kd, d0, dn = self.rng(ops[0]); assert dn == 4 and kd == "v"
+            voff = V(ops[1]).astype(np.int64)
+            k, sb, n = self.rng(ops[2]); assert n == 4
+            base = int(w.s[sb]) | ((int(w.s[sb + 1]) & 0xFFFF) << 32)
+            nrec = int(w.s[sb + 2])
+            soff = int(S(ops[3].replace("offen", "").strip()))
+            w.v[d0:d0 + 4] = POISON
+            addrs = [(base + soff + int(voff[l]) + offset) if int(voff[l]) + offset + 16 <= nrec else None for l in range(64)]
+
+            def complete(d0=d0, addrs=addrs):
+                for l in range(64):
+                    w.v[d0:d0 + 4, l] = 0 if addrs[l] is None else self.gread(addrs[l], 16).view(np.uint32)
+            if self.lazy_dma:
+                w.vm.append(complete)
+            else:
+                complete(); w.vm.append(lambda: None)
+            assert len(w.vm) <= 63
+            return
         if op == "buffer_store_dwordx4":
             # buffer_store_dwordx4 vdata[4], voffset, srd[4], soffset offen   (raw buffer: out of range when voffset + 16 > num_records)
             assert ops[3].endswith("offen"), ins
@@ -441,10 +489,10 @@ def check(inc, tb, M, N, K, tile=(0, 0), seed=1, lazy_ds=True, lazy_dma=True, sc
 
 
 SUB_P = dict(tid="v250", pa0="s8", pa1="s9", pb0="s10", pb1="s11", lda="s12", ldb="s13", pc0="s14", pc1="s15", ldc="s16", cbytes="s17",
-             niter="s18", lds="s19", bid="s20", grid="s21", q="s22", r="s23", magic="s24", tilesn="s25", nmy="s26", mlast="s27", nlast="s28")
+             niter="s18", lds="s19", bid="s20", grid="s21", q="s22", r="s23", magic="s24", tilesn="s25", nmy="s26", mlast="s27", nlast="s28", pz0="s29", pz1="s30", zbytes="s31", scale="s32")
 
 
-def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="random", verbose=False):
+def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="random", verbose=False, dact=False, scale=1.0):
     """the persistent deferred-write-out kernel: `grid` blocks walk the (M / 256) x (N / 256) tiles; returns the max abs error of the bf16
     output against the fp64 product rounded to bf16 inputs"""
     macros = parse_inc(inc)
@@ -461,11 +509,17 @@ def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="
         Bmem, ldb = Wb, K
     ldc = N
     Cmem = np.full(M * ldc, 0x7FC0, np.uint16)            # NaN-filled output
-    PA, PB, PC = 0x10000000, 0x30000000, 0x50000000
+    PA, PB, PC, PZ = 0x10000000, 0x30000000, 0x50000000, 0x70000000
     gmem = [(PA, Xb.view(np.uint8).reshape(-1)), (PB, Bmem.view(np.uint8).reshape(-1)), (PC, Cmem.view(np.uint8))]
+    if dact:                                              # z: the forward's post-dropout ReLU output: zeros (incl. -0) and positive values, some negative
+        zf = rs.randn(M, ldc).astype(np.float32)
+        zf[rs.rand(M, ldc) < 0.4] = 0.0
+        Zb = to_bf(zf)
+        Zb[rs.rand(M, ldc) < 0.02] = 0x8000              # -0
+        gmem.append((PZ, Zb.view(np.uint8).reshape(-1)))
     tilesM, tilesN = (M + 255) // 256, (N + 255) // 256
     ntiles = tilesM * tilesN
-    prog = render(macros["A4P_MAIN_NN" if tb else "A4P_MAIN_NT"], SUB_P)
+    prog = render(macros["A4P_MAIN_NN_DACT" if dact else ("A4P_MAIN_NN" if tb else "A4P_MAIN_NT")], SUB_P)
     for bid in range(grid):
         blk = Block(prog, gmem, lazy_ds, lazy_dma)
         for w in blk.waves:
@@ -482,9 +536,13 @@ def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="
             w.s[24], w.s[25] = ((1 << 32) + tilesN - 1) // tilesN, tilesN
             w.s[26] = (ntiles - bid + grid - 1) // grid
             w.s[27], w.s[28] = M - 256, N - 256
+            w.s[29], w.s[30], w.s[31] = PZ & 0xFFFFFFFF, PZ >> 32, M * ldc * 2
+            w.s[32] = int(np.float32(scale).view(np.uint32))
         blk.run(sched=sched, seed=seed + bid)
         assert all(not w.vm and not w.lgkm for w in blk.waves)
     got = bf16_to_f32(Cmem).reshape(M, ldc).astype(np.float64)
+    if dact:
+        ref = np.where(bf16_to_f32(Zb).reshape(M, ldc)[:, :N] > 0, ref.astype(np.float32) * np.float32(scale), 0.0).astype(np.float64)
     refb = bf16_to_f32(to_bf(ref.astype(np.float32))).astype(np.float64)
     err = np.abs(got - refb)
     bad = ~(err <= 0.0079 * np.abs(refb) + 1e-6)          # one bf16 ulp: the fp32 sums differ from fp64 in the last bits
@@ -508,7 +566,7 @@ if __name__ == "__main__":
         grid = int(args[3]) if len(args) > 3 else 2
         nbad = 0
         for lazy_ds, lazy_dma, sched in ((False, False, "fwd"), (True, True, "random"), (True, False, "random"), (False, True, "rev"), (True, True, "fwd")):
-            nbad += check_p(inc, tb, M, N, K, grid, lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched, verbose=True)
+            nbad += check_p(inc, tb, M, N, K, grid, lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched, verbose=True, dact="--dact" in sys.argv, scale=1.0 / 0.9 if "--dact" in sys.argv else 1.0)
         print("OK" if nbad == 0 else "FAILED")
         sys.exit(0 if nbad == 0 else 1)
     worst = 0.0

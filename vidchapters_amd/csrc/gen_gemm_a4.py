@@ -447,19 +447,31 @@ V_HELD = 104                 # v104..v231
 V_STW = 232                  # staging write addresses: 4 variants q = 2 (bj & 1) + half
 V_STR = 236                  # staging read addresses: row-group parity 0 / 1
 V_STO = 238                  # store offset: (lane >> 4) * ldc_bytes + (lane & 15) * 16
-NV_CLOBBER_P = 240
+V_ZO = 239                   # (dact form) load offset of the mask operand z in the accumulator layout: (lane & 31) * ldc_bytes + (lane >> 5) * 32
+V_ZM = 240                   # (dact form) eight mask temporaries v240..v247
+NV_CLOBBER_P = 248
 S_K, S_NMY = 44, 45          # tile ordinal of this block, its tile count
 S_SRD = 56                   # s56..s59 buffer descriptor of C
 S_ST_PREV, S_ST_CUR, S_ST_NEXT = 60, 61, 62   # store offsets (bytes): running one of the held tile, base of the current / next tile
 S_ST_WAVE = 63               # (wm * 128) * ldc_bytes + wn * 256
 S_ST_STEP = 64               # 4 rows: 4 * ldc_bytes
 S_X = 68                     # temporaries s68..s79 (tile coordinates)
+S_ZSRD = 80                  # (dact form) s80..s83 buffer descriptor of z
+S_SCALE = 84                 # (dact form) 1 / (1 - p) of the forward's dropout, fp32 bits
+S_ZROW = 85                  # (dact form) s85..s88: z offsets of the wave's four block rows of the CURRENT tile
+NS_CLOBBER_P = 90
 RING = 4 * STAGE
 
 
 class GenP(Gen):
-    def __init__(self, tb):
+    def __init__(self, tb, epi=""):
+        """epi: "" = plain; "dact" = the ReLU-mask epilogue of a dgrad (v2s_gemm dact = RELU with z = the forward's post-dropout activation):
+        out = z > 0 ? acc * scale : 0.  The z tile of the CURRENT tile is prefetched during the tile's third iteration ("Z") straight into the
+        128 held registers, in the accumulator layout (row per lane, 32 contiguous bytes per block), long before the conversion needs it;
+        the conversion multiplies by the scale in fp32, rounds, and ANDs with a per-half mask derived from z (sat16(0 - z) >> 15: all ones
+        iff the bf16 is > 0).  Requires ldz == ldc and K >= 512."""
         super().__init__(tb)
+        self.epi = epi
         self.bg = []
         self.bg_rate = 1
 
@@ -515,6 +527,16 @@ class GenP(Gen):
         e(f"s_mov_b32 s{S_SRD + 3}, 0x00020000")
         e(f"s_mov_b32 s{S_K}, 0")
         e(f"s_mov_b32 s{S_NMY}, %[nmy]")
+        if self.epi == "dact":
+            e(f"v_and_b32 v{T + 5}, 31, v{T}")
+            e(f"v_lshrrev_b32 v{T + 6}, 5, v{T}")
+            e(f"v_mul_lo_u32 v{T + 5}, v{T + 5}, %[ldc]")
+            e(f"v_lshl_add_u32 v{V_ZO}, v{T + 6}, 5, v{T + 5}")
+            e(f"s_mov_b32 s{S_ZSRD}, %[pz0]")
+            e(f"s_and_b32 s{S_ZSRD + 1}, %[pz1], 0xffff")
+            e(f"s_mov_b32 s{S_ZSRD + 2}, %[zbytes]")
+            e(f"s_mov_b32 s{S_ZSRD + 3}, 0x00020000")
+            e(f"s_mov_b32 s{S_SCALE}, %[scale]")
 
     def tile_setup(self, sk, store_dst):
         """scalar only: tile ordinal in s{sk} -> running source bases (s36..s39) and the tile's store offset base in s{store_dst}"""
@@ -561,11 +583,37 @@ class GenP(Gen):
 
     # ---- write-out pieces
     def conv(self, b):
+        e = self.e
         for i in range(8):
-            self.e(f"v_accvgpr_read_b32 v{V_T + 2 * i}, a{16 * b + 2 * i}")
-            self.e(f"v_accvgpr_read_b32 v{V_T + 2 * i + 1}, a{16 * b + 2 * i + 1}")
+            e(f"v_accvgpr_read_b32 v{V_T + 2 * i}, a{16 * b + 2 * i}")
+            e(f"v_accvgpr_read_b32 v{V_T + 2 * i + 1}, a{16 * b + 2 * i + 1}")
+        if self.epi == "dact":
+            assert "z" not in self.vm, "the z tile must have landed long before its conversion"
+            for i in range(8):                       # held[8 b + i] still holds z (two bf16): mask = all ones per half iff z > 0
+                e(f"v_pk_sub_i16 v{V_ZM + i}, 0, v{V_HELD + 8 * b + i} clamp")
+                e(f"v_mul_f32 v{V_T + 2 * i}, s{S_SCALE}, v{V_T + 2 * i}")
+                e(f"v_mul_f32 v{V_T + 2 * i + 1}, s{S_SCALE}, v{V_T + 2 * i + 1}")
+            for i in range(8):
+                e(f"v_pk_ashrrev_i16 v{V_ZM + i}, 15, v{V_ZM + i} op_sel_hi:[0,1]")
+                e(f"v_cvt_pk_bf16_f32 v{V_HELD + 8 * b + i}, v{V_T + 2 * i}, v{V_T + 2 * i + 1}")
+            for i in range(8):
+                e(f"v_and_b32 v{V_HELD + 8 * b + i}, v{V_HELD + 8 * b + i}, v{V_ZM + i}")
+            return
         for i in range(8):
-            self.e(f"v_cvt_pk_bf16_f32 v{V_HELD + 8 * b + i}, v{V_T + 2 * i}, v{V_T + 2 * i + 1}")
+            e(f"v_cvt_pk_bf16_f32 v{V_HELD + 8 * b + i}, v{V_T + 2 * i}, v{V_T + 2 * i + 1}")
+
+    def zload_stream(self):
+        """(dact form) 32 loads of the current tile's z into the held registers, one per MFMA gap of the Z iteration's first stage: issued
+        that early they are OLDER than the DMA requests the iteration's last wait retires, so the queue is back to its steady shape when the
+        loop iterations that follow begin"""
+        out = []
+        for bi in range(4):
+            for bj in range(4):
+                for half in range(2):
+                    reg = V_HELD + (bi * 4 + bj) * 8 + half * 4
+                    out.append(lambda reg=reg, bi=bi, bj=bj, half=half: self.vm_op(
+                        "z", f"buffer_load_dwordx4 v[{reg}:{reg + 3}], v{V_ZO}, s[{S_ZSRD}:{S_ZSRD + 3}], s{S_ZROW + bi} offen offset:{bj * 64 + half * 16}"))
+        return out
 
     def wops(self, c):
         out = []
@@ -608,6 +656,13 @@ class GenP(Gen):
             gaps, pre = {}, {}
             self.fill_even(st, gaps)
             first = kind == "T" and st == 0
+            if kind == "Z" and st == 0:
+                # z offsets of the wave's four block rows of the CURRENT tile (= its store offsets: ldz == ldc), then the load stream
+                self.e(f"s_lshl_b32 s{S_X}, %[ldc], 5")
+                self.e(f"s_mov_b32 s{S_ZROW}, s{S_ST_CUR}")
+                for bi in range(1, 4):
+                    self.e(f"s_add_u32 s{S_ZROW + bi}, s{S_ZROW + bi - 1}, s{S_X}")
+                self.bg = self.zload_stream()
             if first:
                 for b in range(16):
                     pre[b] = [lambda b=b: self.conv(b)]
@@ -622,7 +677,7 @@ class GenP(Gen):
             self.fill_odd(st, gaps, self.advance_p(), extra_sync=self.tile_switch if (kind == "P" and st == 0) else None)
             self.step(1, gaps)
             self.stage_ctr += 1
-        assert not self.bg or kind == "T", "write-out stream did not finish in two iterations"
+        assert not self.bg or kind == "T", "background stream did not finish"
 
     def tile_switch(self):
         """in the LAST iteration of a tile, after the tile's last stage has been requested: point the DMA stream at the block's next tile
@@ -650,7 +705,10 @@ class GenP(Gen):
         self.body_p("T")
         self.body_p("S")
         assert shape() == entry_shape, (shape(), entry_shape)
-        e(f"s_sub_u32 s{S_IT}, %[niter], 2")
+        if self.epi == "dact":
+            self.body_p("Z")
+            assert "z" not in self.vm and (list(self.lgkm), ["d"] * len(self.vm)) == (entry_shape[0], ["d"] * 20), (self.lgkm, self.vm)
+        e(f"s_sub_u32 s{S_IT}, %[niter], {3 if self.epi == 'dact' else 2}")
         e("L_a4p_loop_%=:")
         self.vm = [f"stage{self.stage_ctr + 1}"] * 8 + [f"stage{self.stage_ctr + 2}"] * 8 + [f"stage{self.stage_ctr + 3}"] * 4
         self.body_p("P")
@@ -680,7 +738,7 @@ def clobbers_p():
     c = ['"memory"', '"scc"', '"vcc"']
     c += [f'"v{i}"' for i in range(NV_CLOBBER_P)]
     c += [f'"a{i}"' for i in range(256)]
-    c += [f'"s{i}"' for i in range(36, 80)]
+    c += [f'"s{i}"' for i in range(36, NS_CLOBBER_P)]
     return ", ".join(c)
 
 
@@ -734,6 +792,12 @@ def main():
         parts.append(f"#define A4P_MAIN_{'NN' if tb else 'NT'} \\")
         parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in lines))
         parts.append("")
+    g = GenP(True, "dact")
+    lines = g.main_p()
+    stats[("p", "dact")] = (len(lines), g.nmfma)
+    parts.append("#define A4P_MAIN_NN_DACT \\")
+    parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in lines))
+    parts.append("")
     parts.append(f"#define A4P_CLOBBERS {clobbers_p()}")
     for bi in range(4):
         parts.append(f"#define A4_DUMP_{bi} \\")

@@ -2040,9 +2040,19 @@ static bool w128_auto(const v2s_gemm_args* a) {
 // 32000x768x3072 154 / 133 / 163, 8192x2304x768 45 / 42, 8192x3072x768 52 / 45; with fewer tiles than CUs the 128 x 128 kernels win
 // (8192x768x768 18.8 / 20.2, 8192x768x3072 47 / 59).  The one-tile form (synchronous epilogue, any epilogue) loses to the default dispatch
 // everywhere (1 block per CU: nothing runs beside its epilogue) and is only taken when forced.
+// Epilogues the persistent deferred-write-out kernel has: 0 = none of them, 1 = plain bf16, 2 = the ReLU-mask dgrad (dact = RELU with z laid out like C,
+// optional 1 / (1 - p) scale of the forward's dropout: out = z > 0 ? acc * scale : 0)
+static int a4p_epilogue(const v2s_gemm_args* a) {
+  if (a->transA || a->c_dtype != V2S_BF16 || a->accumulate || a->bias || a->pre || a->residual || a->act != V2S_ACT_NONE || a->alpha != 1.0f ||
+      a->M < 256 || a->N < 512 || (a->N % 8) != 0)
+    return 0;
+  if (a->dact == V2S_ACT_NONE) return (a->dropout_p == 0.f && a->K >= 384) ? 1 : 0;
+  if (a->dact == V2S_ACT_RELU && a->transB && a->z && a->ldz == a->ldc && a->K >= 512) return 2;
+  return 0;
+}
+
 static bool a4_auto(const v2s_gemm_args* a, long t256) {
-  const bool persistent_ok = a->c_dtype == V2S_BF16 && !a->accumulate && !a->bias && !a->pre && !a->residual && a->dact == V2S_ACT_NONE &&
-                             a->act == V2S_ACT_NONE && a->dropout_p == 0.f && a->alpha == 1.0f && a->N >= 512 && a->K >= 384;
+  const bool persistent_ok = a4p_epilogue(a) != 0;
   if (a->transA)      // split-K weight gradients with a long contraction (tools/gemm_wgrad_ab.py, profiles/r05_c_gemm_a4_wgrad_ab.txt; us before / a4):
                       // 2304x768x32000 134 / 112, 3072x768x32000 159 / 144, 768x3072x32000 157 / 145, 1536x768x35200 91 / 86; 768x768x32000 (9 tiles) 54 / 56
     return v2s_opt_gemm_a4() == 4 && a->workspace != nullptr && a->c_dtype == V2S_F32 && a->K >= 16384 && t256 >= 18;
@@ -2293,9 +2303,7 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     if (a_ok && (amode == 2 || amode == 3 || ((amode == 1 || amode == 4) && v2s_opt_gemm_p8() == 1 && a4_auto(a, t256)))) {
       a4 = true; bm = 256; bn = 256; p8 = 0; p8d = false; w4 = false; w128 = false; ps = false;
       // persistent form with the deferred write-out: plain bf16 epilogue, whole tiles (gemm_a4 = 3: never)
-      a4p = amode != 3 && !a->transA && a->c_dtype == V2S_BF16 && !a->accumulate && !a->bias && !a->pre && !a->residual && a->dact == V2S_ACT_NONE &&
-            a->act == V2S_ACT_NONE && a->dropout_p == 0.f && a->alpha == 1.0f && a->N >= 512 && a->K >= 384 &&
-            !plain_split && (long)a->M * a->ldc * 2 < (1L << 31) && t256 < 65536;
+      a4p = amode != 3 && a4p_epilogue(a) != 0 && !plain_split && (long)a->M * a->ldc * 2 < (1L << 31) && t256 < 65536;
     }
   }
   p.tilesM = (a->M + bm - 1) / bm; p.tilesN = (a->N + bn - 1) / bn;
@@ -2334,16 +2342,19 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
   if (a4p && p.splitk == 1) {
     static bool attr_a4p = false;
     if (!attr_a4p) {
-      (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
       attr_a4p = true;
     }
     const int ncu = num_cus();
     const int nt = p.tilesM * p.tilesN;
     const dim3 grid((unsigned)(nt < ncu ? nt : ncu)), block(256);
-    g_last_gemm = a->transB ? "gemm_a4p_kernel<true>" : "gemm_a4p_kernel<false>";
-    if (a->transB) hipLaunchKernelGGL((gemm_a4p_kernel<true>), grid, block, A4P_LDS, s, p);
-    else hipLaunchKernelGGL((gemm_a4p_kernel<false>), grid, block, A4P_LDS, s, p);
+    const int epi = a4p_epilogue(a);
+    g_last_gemm = epi == 2 ? "gemm_a4p_kernel<true, 1>" : (a->transB ? "gemm_a4p_kernel<true, 0>" : "gemm_a4p_kernel<false, 0>");
+    if (epi == 2) hipLaunchKernelGGL((gemm_a4p_kernel<true, 1>), grid, block, A4P_LDS, s, p);
+    else if (a->transB) hipLaunchKernelGGL((gemm_a4p_kernel<true, 0>), grid, block, A4P_LDS, s, p);
+    else hipLaunchKernelGGL((gemm_a4p_kernel<false, 0>), grid, block, A4P_LDS, s, p);
   } else if (a4) {
     static bool attr_a4 = false;
     if (!attr_a4) {

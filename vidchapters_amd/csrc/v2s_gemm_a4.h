@@ -150,16 +150,20 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmP p) {
 // body is the asm statement.
 constexpr int A4P_LDS = 4 * 32768 + 4 * 8192;      // ring + one 8 KiB staging block per wave = all 160 KiB
 
-template <bool TB>
+template <bool TB, int EPI>      // EPI 0: plain; 1: ReLU-mask epilogue (dact = RELU, z, optional 1 / (1 - p) scale; TB only)
 __global__ __launch_bounds__(256, 1) void gemm_a4p_kernel(const GemmP p) {
+  static_assert(EPI == 0 || TB, "the mask epilogue is generated for the dgrad layout only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const uint32_t lds = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   const uint32_t pa0 = (uint32_t)(uintptr_t)p.A, pa1 = (uint32_t)((uintptr_t)p.A >> 32);
   const uint32_t pb0 = (uint32_t)(uintptr_t)p.B, pb1 = (uint32_t)((uintptr_t)p.B >> 32);
   const uint32_t pc0 = (uint32_t)(uintptr_t)p.C, pc1 = (uint32_t)((uintptr_t)p.C >> 32);
+  const uint32_t pz0 = (uint32_t)(uintptr_t)p.z, pz1 = (uint32_t)((uintptr_t)p.z >> 32);
   const uint32_t lda = (uint32_t)(p.lda * 2), ldb = (uint32_t)(p.ldb * 2), ldc = (uint32_t)(p.ldc * 2);
   const uint32_t cbytes = p.dbg == 1 ? 0u : (uint32_t)((long)p.M * p.ldc * 2);      // gemm_dbg = 1: every store out of range (ablation)
+  const uint32_t zbytes = (uint32_t)((long)p.M * p.ldc * 2);                         // (ldz == ldc: dispatcher)
+  const uint32_t scale = __float_as_uint(p.inv_keep);
   const uint32_t niter = (uint32_t)(p.K / 128);
   const uint32_t ntiles = (uint32_t)(p.tilesM * p.tilesN), tilesn = (uint32_t)p.tilesN;
   const uint32_t bid = blockIdx.x, grid = gridDim.x;
@@ -167,21 +171,18 @@ __global__ __launch_bounds__(256, 1) void gemm_a4p_kernel(const GemmP p) {
   const uint32_t magic = (uint32_t)(((1ull << 32) + tilesn - 1) / tilesn);
   const uint32_t nmy = (ntiles - bid + grid - 1) / grid;
   const uint32_t mlast = (uint32_t)(p.M - 256), nlast = (uint32_t)(p.N - 256);
-  if constexpr (TB) {
-    asm volatile(A4P_MAIN_NN
-                 :
-                 : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb),
-                   [pc0] "s"(pc0), [pc1] "s"(pc1), [ldc] "s"(ldc), [cbytes] "s"(cbytes), [niter] "s"(niter), [lds] "s"(lds),
-                   [bid] "s"(bid), [grid] "s"(grid), [q] "s"(q), [r] "s"(r), [magic] "s"(magic), [tilesn] "s"(tilesn), [nmy] "s"(nmy),
-                   [mlast] "s"(mlast), [nlast] "s"(nlast)
-                 : A4P_CLOBBERS);
+#define A4P_ARGS                                                                                                                          \
+  : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb), [pc0] "s"(pc0),       \
+    [pc1] "s"(pc1), [ldc] "s"(ldc), [cbytes] "s"(cbytes), [niter] "s"(niter), [lds] "s"(lds), [bid] "s"(bid), [grid] "s"(grid), [q] "s"(q), \
+    [r] "s"(r), [magic] "s"(magic), [tilesn] "s"(tilesn), [nmy] "s"(nmy), [mlast] "s"(mlast), [nlast] "s"(nlast), [pz0] "s"(pz0),          \
+    [pz1] "s"(pz1), [zbytes] "s"(zbytes), [scale] "s"(scale)                                                                               \
+  : A4P_CLOBBERS
+  if constexpr (EPI == 1) {
+    asm volatile(A4P_MAIN_NN_DACT : A4P_ARGS);
+  } else if constexpr (TB) {
+    asm volatile(A4P_MAIN_NN : A4P_ARGS);
   } else {
-    asm volatile(A4P_MAIN_NT
-                 :
-                 : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb),
-                   [pc0] "s"(pc0), [pc1] "s"(pc1), [ldc] "s"(ldc), [cbytes] "s"(cbytes), [niter] "s"(niter), [lds] "s"(lds),
-                   [bid] "s"(bid), [grid] "s"(grid), [q] "s"(q), [r] "s"(r), [magic] "s"(magic), [tilesn] "s"(tilesn), [nmy] "s"(nmy),
-                   [mlast] "s"(mlast), [nlast] "s"(nlast)
-                 : A4P_CLOBBERS);
+    asm volatile(A4P_MAIN_NT : A4P_ARGS);
   }
+#undef A4P_ARGS
 }

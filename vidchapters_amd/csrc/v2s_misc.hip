@@ -79,6 +79,21 @@ __global__ __launch_bounds__(256) void ew_kernel(const bf16_t* __restrict__ x, c
   }
 }
 
+// y = sum over p < nparts of parts[p * stride ..]: fp32 sum of bf16 terms, ONE rounding (the twelve cross-attention memory gradients of the
+// decoder layers, each written by a plain GEMM: engine._cross_attn_bwd)
+__global__ __launch_bounds__(256) void sum_n_kernel(const bf16_t* __restrict__ parts, long stride, int nparts, bf16_t* __restrict__ y, long n8) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n8; t += (long)gridDim.x * 256) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < nparts; ++p) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(parts + (long)p * stride + t * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+    *reinterpret_cast<uint4*>(y + t * 8) = pack8(acc);
+  }
+}
+
 __global__ __launch_bounds__(256) void bcast_grad_kernel(const bf16_t* __restrict__ dy, float* __restrict__ out, long n8,
                                                          long add_n8) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -249,6 +264,15 @@ extern "C" int v2s_add(const void* a, const void* b, void* y, int64_t n, void* s
   V2S_CHECK(n > 0 && (n % 8) == 0, V2S_ERR_SHAPE, "v2s_add: n must be a positive multiple of 8");
   hipLaunchKernelGGL(ew_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b,
                      (bf16_t*)y, (long)(n / 8), (long)(n / 8), 2, 0u, 1.f, 0u, (const uint32_t*)nullptr);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_sum_n(const void* parts, int64_t stride, int32_t nparts, void* y, int64_t n, void* stream) {
+  V2S_CHECK(parts && y && n > 0 && (n % 8) == 0 && (stride % 8) == 0 && stride >= n && nparts >= 1 && nparts <= 64, V2S_ERR_SHAPE,
+            "v2s_sum_n: n (%ld) and stride (%ld) must be multiples of 8, stride >= n, 1..64 parts (%d)", (long)n, (long)stride, nparts);
+  hipLaunchKernelGGL(sum_n_kernel, dim3(grid_for(n / 8, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)parts, (long)stride, nparts,
+                     (bf16_t*)y, (long)(n / 8));
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

@@ -98,6 +98,7 @@ class Engine:
         self.beam_on_device = True    # beam search (no sampling, <= 16 beams): hypothesis bookkeeping on the device (v2s_beam_advance): no host round trip per step
         self.group_flush_layers = 4  # ... every this many decoder layers (the launches then run beside the NEXT layers' under-filled 8192-row kernels)
         self._wgrad_groups: Dict = {}
+        self.dmem_parts = 1       # 1: the decoder layers' d(memory) contributions are plain GEMMs into separate slices, summed once (round 5); 0: residual chain
         self.shadow_events = None # sharded optimizer: {"vit" | "enc" | "dec": event after which that group's bf16 shadow weights are whole}
         self.arena.refresh_shadow(force=True)
 
@@ -438,20 +439,24 @@ class Engine:
         self._wgrad(dq, r.n, ca + "q.weight", inner, d, Mq, group="dec.ca.q")
         dn = self._dgrad(dq, a.w(ca + "q.weight"), Mq, d, inner)
         self._wgrad(dkv, r.mem, ca + "k.weight", 2 * inner, d, Mk, shape=(2 * inner, d))
-        # dmem accumulates over the decoder layers (residual add in the GEMM epilogue, in place).  Nothing in the decoder's backward
-        # reads it, so the chain runs on the K|V stream beside the decoder's small launches; t5_loss_backward joins before using it.
+        # d(memory) of this layer.  ``dmem`` is either the accumulator (a chain of residual epilogues, in place: the form of rounds 2-4) or --
+        # round 5, ``dmem_parts`` -- this layer's own [Mk, d] slice of a [n_dec, Mk, d] buffer: a PLAIN GEMM (which the persistent
+        # deferred-write-out kernel takes: 71 instead of 99 us at cfg-2), the twelve slices summed once in fp32 by t5_loss_backward
+        # (v2s_sum_n: one rounding instead of eleven).  Nothing in the decoder's backward reads it, so it runs on the K|V stream beside the
+        # decoder's small launches; t5_loss_backward joins before using it.
+        plain = isinstance(dmem, tuple)
+        out = dmem[0][dmem[1].pop()] if plain else dmem
+        epi = {} if (plain or first) else dict(residual=dmem)
         if self.overlap and self.overlap_kv:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.kstream.wait_event(ev)
             with torch.cuda.stream(self.kstream):
-                self._dgrad(dkv, a.w(ca + "k.weight", (2 * inner, d)), Mk, d, 2 * inner, out=dmem,
-                            **({} if first else dict(residual=dmem)))
+                self._dgrad(dkv, a.w(ca + "k.weight", (2 * inner, d)), Mk, d, 2 * inner, out=out, **epi)
             dkv.record_stream(self.kstream)
-            dmem.record_stream(self.kstream)
+            out.record_stream(self.kstream)
         else:
-            self._dgrad(dkv, a.w(ca + "k.weight", (2 * inner, d)), Mk, d, 2 * inner, out=dmem,
-                        **({} if first else dict(residual=dmem)))
+            self._dgrad(dkv, a.w(ca + "k.weight", (2 * inner, d)), Mk, d, 2 * inner, out=out, **epi)
         return self._norm_bwd_next(r.h, self._ln("decoder", r.i, 1), r.rstd, dn, dh, Mq, nxt)
 
     def _ffn_bwd(self, r, dh, df=None, nxt=None):
@@ -937,9 +942,22 @@ class Engine:
             L.gemm(dlog, Epad, dhs, Md, d, self.ldv, transB=True, lda=self.ldv, ldb=d, alpha=tape["alpha"])
             del dlog
         dmem = self._bf(tape["Mk"], d)
-        self._stack_backward(tape["dec"], dhs, "decoder", Lo, dmem=dmem)
+        n_cross = sum(1 for r in tape["dec"] if r.kind == "cross")
+        if self.dmem_parts and n_cross > 1:
+            parts = self._bf(n_cross, tape["Mk"], d)                       # one plain GEMM output per decoder layer, summed below
+            self._stack_backward(tape["dec"], dhs, "decoder", Lo, dmem=(parts, list(range(n_cross))))
+            if self.overlap and self.overlap_kv:
+                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+                self.kstream.wait_event(ev)
+                with torch.cuda.stream(self.kstream):
+                    L.sum_n(parts, tape["Mk"] * d, n_cross, dmem, tape["Mk"] * d)
+                parts.record_stream(self.kstream); dmem.record_stream(self.kstream)
+            else:
+                L.sum_n(parts, tape["Mk"] * d, n_cross, dmem, tape["Mk"] * d)
+        else:
+            self._stack_backward(tape["dec"], dhs, "decoder", Lo, dmem=dmem)
         if self.overlap and self.overlap_kv:
-            torch.cuda.current_stream().wait_stream(self.kstream)          # the d(memory) chain of _cross_attn_bwd
+            torch.cuda.current_stream().wait_stream(self.kstream)          # the d(memory) work of _cross_attn_bwd
         packed_mem = bool(tape.get("mem_packed"))
         dmem3 = None if packed_mem else dmem.view(B, S, d)
         dvis = None

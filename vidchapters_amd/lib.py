@@ -86,6 +86,7 @@ SYMBOLS = {
     "v2s_add_bcast": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "v2s_dropout": (C.c_int, [_vp, _vp, _i64, _f32, _u32, _vp]),
     "v2s_add": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "v2s_sum_n": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
     "v2s_bcast_grad": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "v2s_ce_fwd": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "v2s_ce_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _i64, _vp]),
@@ -459,6 +460,11 @@ def add_bcast(x, add, y, n, add_n):
 
 def add(a, b, y, n):
     _check(lib().v2s_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), n, stream_ptr()), "v2s_add")
+
+
+def sum_n(parts, stride, nparts, y, n):
+    """y[n] = sum_p parts[p * stride + :n] (bf16 in / out, fp32 sum)"""
+    _check(lib().v2s_sum_n(parts.data_ptr(), stride, nparts, y.data_ptr(), n, stream_ptr()), "v2s_sum_n")
 
 
 def dropout(x, y, n, p, seed):
