@@ -59,7 +59,8 @@ const char* v2s_last_error(void);
  *                   (default), 2: wherever legal
  *   "gemm_a4"       4-wave 256x256 kernels with a generated, hand-scheduled asm K loop (128x128 wave tiles in AGPRs, v_mfma 32x32x16, counted
  *                   waits; round 5): 1: where they measured faster (default: the persistent deferred-write-out form on plain bf16 GEMMs with
- *                   >= 256 tiles), 0: never, 2: wherever legal, 3: the one-tile form wherever legal, 4: like 1 plus long-contraction weight gradients
+ *                   >= 256 tiles), 0: never, 2: wherever legal, 3: the one-tile form wherever legal, 4: like 1 plus long-contraction weight gradients, 5: like 1 plus the ReLU-mask dgrad
+ *                   epilogue (4 and 5: faster alone, slower inside the train step)
  *   "gemm_dbg"      profiling ablations of the tiled kernels (results invalid when non-zero): 1 = no global store, 2 = no epilogue, 3 = no hand-off
  *   "fp32_io"       DEBUG: 1 = v2s_*norm_fwd/bwd, v2s_ce_bwd and v2s_attn_fwd/bwd take and return FP32 activations (attention: fp32-arithmetic
  *                   reference kernels, dense layout only); parity work against fp32 references (<= 1e-4), never set by the product path

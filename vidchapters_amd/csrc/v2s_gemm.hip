@@ -2047,7 +2047,11 @@ static int a4p_epilogue(const v2s_gemm_args* a) {
       a->M < 256 || a->N < 512 || (a->N % 8) != 0)
     return 0;
   if (a->dact == V2S_ACT_NONE) return (a->dropout_p == 0.f && a->K >= 384) ? 1 : 0;
-  if (a->dact == V2S_ACT_RELU && a->transB && a->z && a->ldz == a->ldc && a->K >= 512) return 2;
+  // Measured (profiles/r05_a4p_dact_ab.txt, r05_step_ab_a4.txt): the encoder wo dgrad 32000x3072x768 with its mask operand 251.5 -> 189.7 us alone,
+  // but +0.74 ms per train step -- the 2-blocks-per-CU kernel it replaces shares the chip with the weight-gradient stream, a persistent
+  // one-block-per-CU kernel does not.  So only when forced (gemm_a4 = 2) or asked for (gemm_a4 = 5).
+  const int mode = v2s_opt_gemm_a4();
+  if (a->dact == V2S_ACT_RELU && a->transB && a->z && a->ldz == a->ldc && a->K >= 512 && (mode == 2 || mode == 5)) return 2;
   return 0;
 }
 
@@ -2300,7 +2304,7 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
                       (a->transA ? (a->M % 8) == 0 : !(plain_split && t256 < 512)) &&
                       (a->transA ? 32 * a->lda + a->M : (long)a->M * a->lda) < (1L << 30) &&
                       (a->transB ? 32 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 30);
-    if (a_ok && (amode == 2 || amode == 3 || ((amode == 1 || amode == 4) && v2s_opt_gemm_p8() == 1 && a4_auto(a, t256)))) {
+    if (a_ok && (amode == 2 || amode == 3 || ((amode == 1 || amode == 4 || amode == 5) && v2s_opt_gemm_p8() == 1 && a4_auto(a, t256)))) {
       a4 = true; bm = 256; bn = 256; p8 = 0; p8d = false; w4 = false; w128 = false; ps = false;
       // persistent form with the deferred write-out: plain bf16 epilogue, whole tiles (gemm_a4 = 3: never)
       a4p = amode != 3 && a4p_epilogue(a) != 0 && !plain_split && (long)a->M * a->ldc * 2 < (1L << 31) && t256 < 65536;

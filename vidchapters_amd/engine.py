@@ -98,7 +98,8 @@ class Engine:
         self.beam_on_device = True    # beam search (no sampling, <= 16 beams): hypothesis bookkeeping on the device (v2s_beam_advance): no host round trip per step
         self.group_flush_layers = 4  # ... every this many decoder layers (the launches then run beside the NEXT layers' under-filled 8192-row kernels)
         self._wgrad_groups: Dict = {}
-        self.dmem_parts = 1       # 1: the decoder layers' d(memory) contributions are plain GEMMs into separate slices, summed once (round 5); 0: residual chain
+        self.dmem_parts = 0       # 1: the decoder layers' d(memory) contributions are plain GEMMs into separate slices, summed once (round 5: each GEMM
+                                  # 99 -> 71 us alone, +-0 in the step, +650 MB: off); 0: residual chain
         self.shadow_events = None # sharded optimizer: {"vit" | "enc" | "dec": event after which that group's bf16 shadow weights are whole}
         self.arena.refresh_shadow(force=True)
 
