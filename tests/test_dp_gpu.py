@@ -114,3 +114,28 @@ def test_two_ranks_equal_one_large_batch(shard):
     # may step in different directions: compare update DIRECTIONS per tensor (as test_dropin_optimizer_path_matches_trainer does)
     steps = 4 if shard else 2
     assert ret["worst"] > (0.90 if shard else 0.93) and ret["maxdiff"] <= steps * 2.1 * 1e-3      # measured r02 (2 steps): 0.9466 (block-0 bias table), 3.97e-3
+
+
+def test_bench_two_ranks_gloo_control_flow():
+    """bench.py's multi-rank control flow exactly as the driver launches it (python -m torch.distributed.run --nproc-per-node 2 ... bench.py
+    --gpus 2), with the two ranks sharing the one visible GPU over gloo (V2S_DIST_BACKEND): barriers, max-over-ranks timing, the rank-0 JSON
+    line.  RCCL itself needs a second GPU; this keeps everything around it driver-run every round (VERDICT r04 next #8)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, V2S_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "1", "--batch", "4", "--asr-tokens", "256",
+           "--target-tokens", "64", "--no-cpu-baseline", "--no-generate", "--no-roofline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, out.stdout[-1000:]                      # rank 0 only
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and j["config"]["global_batch"] == 8
+    assert j["data_parallel"]["ranks_seen_by_rccl"] == 2 and j["data_parallel"]["collectives_per_step"] >= 1

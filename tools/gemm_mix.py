@@ -7,17 +7,20 @@ import torch
 from vidchapters_amd import lib as L
 
 # (M, N, K, launches per step) of the two dominant kernel variants in the cfg-2 step
-# gemm_dma_kernel<false, true>: dx = dy @ W (transB), N < 1024 or fewer than 1200 256x256 tiles
-SHAPES_DGRAD = [(32000, 768, 3072, 12), (32000, 768, 2304, 12), (35200, 768, 1536, 12), (32000, 768, 768, 12), (8192, 768, 768, 36),
-                (8192, 768, 3072, 12), (8192, 768, 2304, 12), (8192, 3072, 768, 12), (3200, 768, 2304, 12), (3200, 768, 2048, 12),
-                (3200, 2048, 768, 12), (3200, 768, 768, 12),
-                (32000, 3072, 768, 12, "dact")]      # round 3: the encoder wo dgrad with its ReLU-mask operand stays on the 128x128 tiles
+# gemm_dma_kernel<false, true>: dx = dy @ W (transB) -- round 5: what is LEFT on it after the persistent gemm_a4p kernel took the plain dgrads with
+# >= 256 tiles (encoder o / qkv / wi dgrads, the first cross K|V dgrad, decoder wo): the decoder's and ViT's short launches, the cross K|V
+# accumulate chain (residual epilogue) and the two masked wo dgrads
+SHAPES_DGRAD = [(35200, 768, 1536, 11, "res"), (8192, 768, 768, 36), (8192, 768, 3072, 12), (8192, 768, 2304, 12), (3200, 768, 2304, 12),
+                (3200, 768, 2048, 12), (3200, 2048, 768, 12), (3200, 768, 768, 12),
+                (32000, 3072, 768, 12, "dact"), (8192, 3072, 768, 12, "dact")]
+# gemm_a4p_kernel<true, 0>: the plain dgrads the persistent kernel takes
+SHAPES_A4P_DGRAD = [(32000, 768, 3072, 12), (32000, 768, 2304, 12), (32000, 768, 768, 12), (35200, 768, 1536, 1)]
 # gemm_dma_kernel<false, false>: y = x @ W^T (forward): encoder qkv/o/wo, every decoder and ViT projection, cross K/V
 SHAPES_NT = [(32000, 2304, 768, 12), (32000, 768, 768, 12), (32000, 768, 3072, 12), (35200, 1536, 768, 12), (8192, 2304, 768, 12),
              (8192, 768, 768, 36), (8192, 3072, 768, 12), (8192, 768, 3072, 12), (3200, 2304, 768, 12), (3200, 768, 768, 12),
              (3200, 2048, 768, 12), (3200, 768, 2048, 12)]
 VARIANT = sys.argv[1] if len(sys.argv) > 1 else "nt"
-SHAPES = SHAPES_NT if VARIANT == "nt" else SHAPES_DGRAD
+SHAPES = SHAPES_NT if VARIANT == "nt" else (SHAPES_A4P_DGRAD if VARIANT == "a4p" else SHAPES_DGRAD)
 if __name__ == "__main__":
     dev = "cuda"
     names = []
@@ -28,6 +31,8 @@ if __name__ == "__main__":
         kw = {}
         if ep == ["dact"]:                       # d(hidden) masked by the saved dropout(relu(.)) activations, 1/(1-p) scale
             kw = dict(dact=L.ACT_RELU, z=torch.relu(torch.randn(M, N, device=dev)).to(torch.bfloat16), dropout_p=0.1, dropout_seed=3)
+        if ep == ["res"]:                        # d(memory) accumulated in place over the decoder layers
+            kw = dict(residual=C)
         for _ in range(3):
             L.gemm(A, B, C, M, N, K, transB=(VARIANT != "nt"), **kw)
         names.append(L.lib().v2s_last_gemm_kernel().decode())

@@ -18,7 +18,7 @@ for i, (M, N, K, cnt, *ep) in enumerate(SHAPES):
     name = f[3 * i + 2][0]
     fetch_kb = f[3 * i + 2][1]; write_kb = w[3 * i + 2][1]          # third (warm) launch of the shape
     traffic = (2.0 * fetch_kb + write_kb) * 1024
-    alg = 2.0 * (M * K + K * N + M * N) + (2.0 * M * N if ep == ["dact"] else 0.0)      # + the mask operand z
+    alg = 2.0 * (M * K + K * N + M * N) + (2.0 * M * N if ep in (["dact"], ["res"]) else 0.0)      # + the mask operand z / the residual
     shapes.append({"M": M, "N": N, "K": K, "epilogue": ep[0] if ep else "", "launches_per_step": cnt, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
                    "traffic_bytes": traffic, "algorithmic_bytes": alg, "ratio": round(traffic / alg, 3)})
     tot_t += traffic * cnt; tot_a += alg * cnt; tot_n += cnt

@@ -2351,7 +2351,8 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
       (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
       attr_a4p = true;
     }
-    const int ncu = num_cus();
+    int ncu = num_cus();
+    if (v2s_opt_gemm_a4_grid() > 0 && v2s_opt_gemm_a4_grid() < ncu) ncu = v2s_opt_gemm_a4_grid();
     const int nt = p.tilesM * p.tilesN;
     const dim3 grid((unsigned)(nt < ncu ? nt : ncu)), block(256);
     const int epi = a4p_epilogue(a);
