@@ -35,8 +35,9 @@ extern "C" {
 /* 3 (round 4): v2s_attn_bwd's `delta` became a [B][H][Nq][4] workspace it WRITES, v2s_topp_sample_step gained top_k, dact=RELU with
  * dropout expects z = the post-dropout activation (round 3 changes that a version-2 caller would corrupt memory with);
  * + v2s_rowsumsq_range / v2s_timetoken_renorm_sq, options gemm_ps / gemm_ps_nst / gemm_w128
- * 4 (round 4): + v2s_decode_qfold / v2s_decode_memattn_plan / v2s_decode_memattn / v2s_decode_ctxfold, v2s_beam_advance (additions only) */
-#define V2S_ABI_VERSION 4
+ * 4 (round 4): + v2s_decode_qfold / v2s_decode_memattn_plan / v2s_decode_memattn / v2s_decode_ctxfold, v2s_beam_advance (additions only)
+ * 5 (round 5): + v2s_sum_n, options gemm_a4 / gemm_a4_grid (additions only) */
+#define V2S_ABI_VERSION 5
 
 int v2s_version(void);
 const char* v2s_last_error(void);

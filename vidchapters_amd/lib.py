@@ -58,7 +58,7 @@ class DecodeAttnArgs(C.Structure):
                 ("kv_group", _i32), ("new_k", _vp), ("new_v", _vp), ("new_bs", _i64), ("row_map", _vp), ("row_map_ld", _i64)]
 
 
-ABI_VERSION = 4   # V2S_ABI_VERSION this binding was written against (include/vid2seq_hip.h)
+ABI_VERSION = 5   # V2S_ABI_VERSION this binding was written against (include/vid2seq_hip.h)
 
 #: every symbol include/vid2seq_hip.h declares (checked by tests/test_oracle_cpu.py::test_c_abi_exports_every_declared_symbol)
 SYMBOLS = {
