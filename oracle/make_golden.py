@@ -1019,7 +1019,7 @@ def case_shapes(v2s):
     case_shape(v2s, "full_cfg2", R.RefConfig(), B=2, T=100, L=1000, Lo=256, seed=2024)
     case_shape_bf16("full_cfg2", R.RefConfig(), B=2, T=100, L=1000, Lo=256, seed=2024)
     large = R.RefConfig(d_model=1024, d_kv=64, heads=16, d_ff=4096, n_enc=24, n_dec=24, num_features=200)
-    case_shape(v2s, "large_cfg5", large, B=1, T=200, L=2000, Lo=256, seed=2025)
+    case_shape(v2s, "large_cfg5", large, B=2, T=200, L=2000, Lo=256, seed=2025)      # ~7 min, ~30 GB of host memory
     case_greedy_full(v2s)
     case_beam_full(v2s)
 
