@@ -100,6 +100,11 @@ class Engine:
         self._wgrad_groups: Dict = {}
         self.dmem_parts = 0       # 1: the decoder layers' d(memory) contributions are plain GEMMs into separate slices, summed once (round 5: each GEMM
                                   # 99 -> 71 us alone, +-0 in the step, +650 MB: off); 0: residual chain
+        self.defer_wgrads = 0     # encoder backward: 1 = the FFN / O weight gradients of a layer are held back until its attention backward is enqueued (they
+                                  # then run beside the VALU-bound attention kernels instead of beside the dgrad GEMMs); 2 = the QKV weight gradient too
+                                  # (beside the NEXT layer's attention).  _flush_deferred
+        self._deferred: List = []
+        self._defer_open = False
         self.shadow_events = None # sharded optimizer: {"vit" | "enc" | "dec": event after which that group's bf16 shadow weights are whole}
         self.arena.refresh_shadow(force=True)
 
@@ -255,6 +260,9 @@ class Engine:
                 torch.cuda.current_stream().wait_stream(self.wstream)
             launch()
             return
+        if self._defer_open:
+            self._deferred.append((launch, dy, x))
+            return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.wstream.wait_event(ev)
@@ -262,6 +270,21 @@ class Engine:
             launch()
         dy.record_stream(self.wstream)
         x.record_stream(self.wstream)
+
+    def _flush_deferred(self) -> None:
+        """launch the held-back weight-gradient GEMMs (defer_wgrads) on the weight-gradient stream, behind everything enqueued so far"""
+        items, self._deferred = self._deferred, []
+        if not items:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.wstream.wait_event(ev)
+        with torch.cuda.stream(self.wstream):
+            for launch, _, _ in items:
+                launch()
+        for _, dy, x in items:
+            dy.record_stream(self.wstream)
+            x.record_stream(self.wstream)
 
     def flush_wgrads(self) -> None:
         """Launch the collected weight-gradient groups (see _wgrad) on the weight-gradient stream, behind everything the current stream
@@ -410,8 +433,11 @@ class Engine:
         if df is None:
             df = self._drop(dh, r.p, r.seed_o)
         grp = "dec.sa." if r.stack == "decoder" else None           # the encoder's (32000-row contraction) stay single launches
+        self._defer_open = bool(self.defer_wgrads) and self.overlap and r.stack == "encoder"
         self._wgrad(df, r.ctx, sa + "o.weight", d, inner, M, group=grp and grp + "o")
         dctx = self._dgrad(df, a.w(sa + "o.weight"), M, inner, d)
+        self._flush_deferred()                                      # (defer_wgrads) ... beside the attention kernels that follow
+        self._defer_open = self._defer_open and self.defer_wgrads >= 2
         dqkv = self._bf(M, 3 * inner)
         delta = self._f32(B, self.H, N, 4)       # row statistics handed from the dQ to the dK/dV kernel (v2s_attn_bwd workspace)
         st = (N * 3 * inner, 3 * inner)
@@ -420,6 +446,7 @@ class Engine:
                    dbias_diag=dbias_diag, far=self._far[(N, N, r.stack == "encoder")])
         self._wgrad(dqkv, r.n, sa + "q.weight", 3 * inner, d, M, shape=(3 * inner, d), group=grp and grp + "qkv")
         dn = self._dgrad(dqkv, a.w(sa + "q.weight", (3 * inner, d)), M, d, 3 * inner)
+        self._defer_open = False
         return self._norm_bwd_next(r.h, self._ln(r.stack, r.i, 0), r.rstd, dn, dh, M, nxt)
 
     def _cross_attn_bwd(self, r, dh, dmem, first: bool, df=None, nxt=None):
@@ -467,12 +494,14 @@ class Engine:
         if df is None:
             df = self._drop(dh, r.p, r.seed_o)
         grp = "dec.ff." if r.stack == "decoder" else None
+        self._defer_open = bool(self.defer_wgrads) and self.overlap and r.stack == "encoder"
         self._wgrad(df, r.u, fp + "wo.weight", d, ff, M, group=grp and grp + "wo")
         # (timing probe, round 3: without the ReLU-mask operand z this launch would take the deferred-epilogue kernel and the step
         # 55.48 -> 54.33 ms; a byte mask written by the wi forward would have to be packed inside that kernel's slack-free write-out phases)
         du = self._dgrad(df, a.w(fp + "wo.weight"), M, ff, d, dact=L.ACT_RELU, z=r.u, dropout_p=r.p, dropout_seed=r.seed_u)
         self._wgrad(du, r.n, fp + "wi.weight", ff, d, M, group=grp and grp + "wi")
         dn = self._dgrad(du, a.w(fp + "wi.weight"), M, d, ff)
+        self._defer_open = False
         return self._norm_bwd_next(r.h, self._ln(r.stack, r.i, 2 if r.stack == "decoder" else 1), r.rstd, dn, dh, M, nxt)
 
     def _final_norm_bwd(self, r, dout, nxt=None):
@@ -678,9 +707,11 @@ class Engine:
                 if stack == "decoder" and r.i % self.group_flush_layers == 0:
                     self.flush_wgrads()               # the collected decoder layers' weight gradients: one grouped launch per projection
                 if layer_done is not None:        # all parameter gradients of block r.i are enqueued (except block 0's bias table)
+                    self._flush_deferred()
                     layer_done(r.i)
             elif r.kind == "embed":
                 self._embed_bwd(r, dh)
+        self._flush_deferred()
         self.flush_wgrads()
         L.bias_bucket_bwd(ddiag, lut, a.g(self._sa(stack, 0) + "relative_attention_bias.weight"), self.H, 2 * nq - 1,
                           self.cfg.buckets)
