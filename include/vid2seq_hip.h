@@ -36,7 +36,7 @@ extern "C" {
  * dropout expects z = the post-dropout activation (round 3 changes that a version-2 caller would corrupt memory with);
  * + v2s_rowsumsq_range / v2s_timetoken_renorm_sq, options gemm_ps / gemm_ps_nst / gemm_w128
  * 4 (round 4): + v2s_decode_qfold / v2s_decode_memattn_plan / v2s_decode_memattn / v2s_decode_ctxfold, v2s_beam_advance (additions only)
- * 5 (round 5): + v2s_sum_n, options gemm_a4 / gemm_a4_grid (additions only) */
+ * 5 (round 5): + v2s_sum_n, options gemm_a4 / gemm_a4_grid / gemm_a4_relu (additions only) */
 #define V2S_ABI_VERSION 5
 
 int v2s_version(void);
@@ -62,6 +62,8 @@ const char* v2s_last_error(void);
  *                   waits; round 5): 1: where they measured faster (default: the persistent deferred-write-out form on plain bf16 GEMMs with
  *                   >= 256 tiles), 0: never, 2: wherever legal, 3: the one-tile form wherever legal, 4: like 1 plus long-contraction weight gradients, 5: like 1 plus the ReLU-mask dgrad
  *                   epilogue (4 and 5: faster alone, slower inside the train step)
+ *   "gemm_a4_relu"  1 (default): the persistent form also takes forward GEMMs with a ReLU or ReLU + dropout epilogue (the FFN's wi: the
+ *                   dropout mask of the library's counter-based generator is recomputed inside the kernel's MFMA gaps), 0: plain epilogues only
  *   "gemm_dbg"      profiling ablations of the tiled kernels (results invalid when non-zero): 1 = no global store, 2 = no epilogue, 3 = no hand-off
  *   "fp32_io"       DEBUG: 1 = v2s_*norm_fwd/bwd, v2s_ce_bwd and v2s_attn_fwd/bwd take and return FP32 activations (attention: fp32-arithmetic
  *                   reference kernels, dense layout only); parity work against fp32 references (<= 1e-4), never set by the product path

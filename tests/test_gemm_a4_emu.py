@@ -61,6 +61,15 @@ def test_persistent_relu_mask_epilogue(inc):
         assert E.check_p(inc, True, M, N, K, grid, lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched, dact=True, scale=1.0 / 0.9) == 0
 
 
+def test_persistent_relu_and_dropout_forward_epilogues(inc):
+    """gemm_a4p with act = RELU (bf16 sign test after the rounding) and with ReLU + dropout: the keep masks of the library's counter-based
+    generator (v2s_keep8, restated in numpy: a4_emu.keep_mask) are computed into the held registers in the MFMA gaps of the tile's second to
+    fourth iteration and applied at the conversion; ragged tiles overlap, so their rows are masked by GLOBAL index twice, identically"""
+    assert E.check_p(inc, False, 512, 768, 384, 2, lazy_ds=True, lazy_dma=True, sched="random", epi="relu") == 0
+    for (M, N, K, grid, p16, hs), (lazy_ds, lazy_dma, sched) in zip(((512, 768, 640, 2, 6554, 0x1234567), (600, 520, 768, 1, 32768, 0xdeadbeef)), (MODES[1], MODES[3])):
+        assert E.check_p(inc, False, M, N, K, grid, lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched, epi="reludrop", scale=1.0 / 0.9, p16=p16, hseed=hs) == 0
+
+
 def test_the_model_catches_a_wrong_wait_a_missing_barrier_and_a_wrong_slot(inc, tmp_path):
     """the emulator is only worth something if it rejects broken schedules: three mutations of the generated text"""
     src = open(inc).read()

@@ -521,7 +521,8 @@ def test_experimental_gemm_kernels_are_bit_identical(opt, val, tag):
     ("NT", 512, 512, 384, ""), ("NN", 768, 512, 512, ""), ("NT", 2048, 768, 768, ""), ("NN", 1024, 1536, 640, ""),      # persistent form (plain, whole tiles)
     ("NT", 1000, 520, 384, ""), ("NT", 2000, 768, 768, "res"), ("NT", 1300, 1544, 384, "act"), ("NT", 600, 520, 256, "f32"),
     ("NN", 777, 392, 256, "dact"), ("NT", 768, 768, 2048, "bias"),
-    ("NN", 1024, 768, 640, "dact"), ("NN", 1000, 1544, 512, "dactdrop")])                                               # persistent form with the ReLU-mask epilogue
+    ("NN", 1024, 768, 640, "dact"), ("NN", 1000, 1544, 512, "dactdrop"),                                                # persistent form with the ReLU-mask epilogue
+    ("NT", 1024, 768, 640, "act"), ("NT", 1300, 1544, 640, "actdrop"), ("NT", 2048, 3072, 768, "actdrop")])             # ... with the ReLU / ReLU + dropout forward epilogue
 def test_gemm_a4_kernel(kind, M, N, K, ep):
     """gemm_a4_kernel / gemm_a4p_kernel (generated asm K loop, 4 waves, 128 x 128 wave tiles in AGPRs, v_mfma 32x32x16): against fp32 torch on
     the bf16 inputs, plain and fused epilogues, ragged edges, both weight layouts; where the persistent deferred-write-out form is legal it
@@ -541,18 +542,30 @@ def test_gemm_a4_kernel(kind, M, N, K, ep):
     if ep == "dactdrop":          # z = the forward's post-dropout activation: the mask is z > 0, the scale 1 / (1 - p) (p16-rounded like the library's)
         z = torch.relu(rnd(M, N, seed=9)) * (rnd(M, N, seed=10) > -1.0); kw.update(dact=L.ACT_RELU, z=z, dropout_p=0.1, dropout_seed=3)
         ref = ref * (z.float() > 0) * (1.0 / (1.0 - round(0.1 * 65536) / 65536.0))
+    if ep == "actdrop":           # the mask is the library's counter-based generator: the reference is the default dispatch with the same seed
+        kw.update(act=L.ACT_RELU, dropout_p=0.1, dropout_seed=5)
     outs = {}
     try:
-        for mode in (2, 3):
+        for mode in (2, 3) + ((0,) if ep == "actdrop" else ()):
             L.set_option("gemm_a4", mode)
             C_ = torch.full((M, N), float("nan"), dtype=torch.float32 if ep == "f32" else torch.bfloat16, device=DEV)
             L.gemm(A, B, C_, M, N, K, **kw)
             outs[mode] = (C_, L.lib().v2s_last_gemm_kernel().decode())
     finally:
         L.set_option("gemm_a4", 1)
-    # the persistent form: plain bf16 epilogue (ragged edges: the last tile row / column overlaps) or the ReLU-mask dgrad epilogue
-    whole = (ep == "" and N >= 512 and K >= 384) or (ep in ("dact", "dactdrop") and kind == "NN" and N >= 512 and K >= 512)
+    # the persistent form: plain bf16 epilogue (ragged edges: the last tile row / column overlaps), the ReLU-mask dgrad epilogue, or the forward's
+    # ReLU (+ dropout: the mask regenerated inside the kernel)
+    whole = (ep == "" and N >= 512 and K >= 384) or (ep in ("dact", "dactdrop") and kind == "NN" and N >= 512 and K >= 512) or \
+        (ep == "act" and kind == "NT" and N >= 512 and K >= 384) or (ep == "actdrop" and kind == "NT" and N >= 512 and K >= 640)
     assert ("gemm_a4p_kernel" in outs[2][1]) == whole and "gemm_a4_kernel" in outs[3][1], (outs[2][1], outs[3][1])
+    if ep == "actdrop":
+        assert "gemm_a4" not in outs[0][1]
+        keep = outs[0][0] != 0
+        scale = 1.0 / (1.0 - round(0.1 * 65536) / 65536.0)
+        assert 0.40 < float(keep.float().mean()) < 0.50                                    # half the pre-activations are negative, 10 % of the rest dropped
+        assert torch.equal(outs[2][0], outs[0][0]) and torch.equal(outs[3][0], outs[0][0])  # same mask, same single rounding
+        assert relerr(torch.where(keep, outs[2][0].float(), torch.zeros_like(ref)), torch.where(keep, torch.relu(ref) * scale, torch.zeros_like(ref))) < 5e-3
+        return
     for mode in (2, 3):
         assert relerr(outs[mode][0], ref) < (2e-5 if ep == "f32" else 5e-3), (mode, kind, M, N, K, ep)      # bf16 half-ulp of the largest element: up to 2^-8
     assert torch.equal(outs[2][0], outs[3][0])

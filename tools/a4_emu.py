@@ -198,6 +198,23 @@ class Block:
                  "v_mul_lo_u32": lambda: a * b, "v_lshlrev_b32": lambda: b << (a & np.uint64(31)),
                  "v_lshrrev_b32": lambda: b >> (a & np.uint64(31))}[op]()
             self.setv(w, ops[0], (r & np.uint64(0xFFFFFFFF)).astype(np.uint32)); return
+        if op == "v_add3_u32":
+            r = u64(V(ops[1])) + u64(V(ops[2])) + u64(V(ops[3]))
+            self.setv(w, ops[0], (r & np.uint64(0xFFFFFFFF)).astype(np.uint32)); return
+        if op == "v_alignbit_b32":                             # D = ({S0, S1} >> S2[4:0]) & 0xffffffff
+            sh = u64(V(ops[3])) & np.uint64(31)
+            r = ((u64(V(ops[1])) << np.uint64(32)) | u64(V(ops[2]))) >> sh
+            self.setv(w, ops[0], (r & np.uint64(0xFFFFFFFF)).astype(np.uint32)); return
+        if op == "v_mul_u32_u24":
+            r = (u64(V(ops[1])) & np.uint64(0xFFFFFF)) * (u64(V(ops[2])) & np.uint64(0xFFFFFF))
+            self.setv(w, ops[0], (r & np.uint64(0xFFFFFFFF)).astype(np.uint32)); return
+        if op == "v_pk_mul_f32":
+            (kd, d0, dn), (ka, a0, an), (kb, b0, bn) = self.rng(ops[0]), self.rng(ops[1]), self.rng(ops[2])
+            assert dn == an == bn == 2 and kd == ka == kb == "v", ins
+            with np.errstate(all="ignore"):
+                lo = (w.v[a0].view(np.float32) * w.v[b0].view(np.float32)).astype(np.float32).view(np.uint32)
+                hi = (w.v[a0 + 1].view(np.float32) * w.v[b0 + 1].view(np.float32)).astype(np.float32).view(np.uint32)
+            w.v[d0], w.v[d0 + 1] = lo.copy(), hi.copy(); return
         if op == "v_lshl_add_u32":
             r = (u64(V(ops[1])) << (u64(V(ops[2])) & np.uint64(31))) + u64(V(ops[3]))
             self.setv(w, ops[0], (r & np.uint64(0xFFFFFFFF)).astype(np.uint32)); return
@@ -307,7 +324,7 @@ class Block:
             with np.errstate(all="ignore"):
                 self.setv(w, ops[0], (a * b).astype(np.float32).view(np.uint32))
             return
-        if op in ("v_pk_sub_i16", "v_pk_ashrrev_i16"):
+        if op in ("v_pk_sub_i16", "v_pk_ashrrev_i16", "v_pk_max_i16"):
             clamp = bool(re.search(r"\bclamp\b", rest))
             opsel = "op_sel_hi:[0,1]" in rest
             clean = re.sub(r"op_sel_hi:\[[^\]]*\]|\bclamp\b", "", rest).strip()
@@ -325,6 +342,8 @@ class Block:
                 r_lo, r_hi = a_lo - b_lo, a_hi - b_hi
                 if clamp:
                     r_lo, r_hi = np.clip(r_lo, -32768, 32767), np.clip(r_hi, -32768, 32767)
+            elif op == "v_pk_max_i16":
+                r_lo, r_hi = np.maximum(a_lo, b_lo), np.maximum(a_hi, b_hi)
             else:                                              # D = S1 >> S0 (arithmetic), per half
                 r_lo, r_hi = b_lo >> (a_lo & 15), b_hi >> (a_hi & 15)
             r = (r_lo.astype(np.int16).view(np.uint16).astype(np.uint32)) | (r_hi.astype(np.int16).view(np.uint16).astype(np.uint32) << np.uint32(16))
@@ -489,10 +508,25 @@ def check(inc, tb, M, N, K, tile=(0, 0), seed=1, lazy_ds=True, lazy_dma=True, sc
 
 
 SUB_P = dict(tid="v250", pa0="s8", pa1="s9", pb0="s10", pb1="s11", lda="s12", ldb="s13", pc0="s14", pc1="s15", ldc="s16", cbytes="s17",
-             niter="s18", lds="s19", bid="s20", grid="s21", q="s22", r="s23", magic="s24", tilesn="s25", nmy="s26", mlast="s27", nlast="s28", pz0="s29", pz1="s30", zbytes="s31", scale="s32")
+             niter="s18", lds="s19", bid="s20", grid="s21", q="s22", r="s23", magic="s24", tilesn="s25", nmy="s26", mlast="s27", nlast="s28", pz0="s29", pz1="s30", zbytes="s31", scale="s32", hseed="s33", hpp="s34")
 
 
-def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="random", verbose=False, dact=False, scale=1.0):
+def keep_mask(M, N, seed, p16, row0=0):
+    """numpy restatement of v2s_keep8 (csrc/v2s_common.h) for a whole [M][N] matrix (N % 8 == 0, (row0 + M) * N < 2^35): True = kept"""
+    u32 = lambda x: np.asarray(x, np.uint64) & np.uint64(0xFFFFFFFF)
+    chunk = (np.arange(M, dtype=np.uint64)[:, None] + np.uint64(row0)) * np.uint64(N // 8) + np.arange(N // 8, dtype=np.uint64)[None, :]
+    x = u32(np.uint64((seed * 0x9E3779B1) & 0xFFFFFFFF) + chunk)
+    x = u32(x * np.uint64(0x9E3779B1)); x ^= x >> np.uint64(15); x = u32(x * np.uint64(0x85EBCA77)); x ^= x >> np.uint64(13)
+    keep = np.zeros((M, N // 8, 8), bool)
+    for i in range(4):
+        wv = u32((x >> np.uint64(8 * i)) | (x << np.uint64(32 - 8 * i))) if i else x
+        h = u32((wv & np.uint64(0xFFFFFF)) * np.uint64(0x00EBCA77 + 0x2468 * i))
+        keep[:, :, 2 * i] = (h & np.uint64(0xFFFF)) >= p16
+        keep[:, :, 2 * i + 1] = (h >> np.uint64(16)) >= p16
+    return keep.reshape(M, N)
+
+
+def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="random", verbose=False, dact=False, scale=1.0, epi="", p16=6554, hseed=0x1234567):
     """the persistent deferred-write-out kernel: `grid` blocks walk the (M / 256) x (N / 256) tiles; returns the max abs error of the bf16
     output against the fp64 product rounded to bf16 inputs"""
     macros = parse_inc(inc)
@@ -519,7 +553,9 @@ def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="
         gmem.append((PZ, Zb.view(np.uint8).reshape(-1)))
     tilesM, tilesN = (M + 255) // 256, (N + 255) // 256
     ntiles = tilesM * tilesN
-    prog = render(macros["A4P_MAIN_NN_DACT" if dact else ("A4P_MAIN_NN" if tb else "A4P_MAIN_NT")], SUB_P)
+    if epi:
+        assert not tb and not dact
+    prog = render(macros[f"A4P_MAIN_NT_{epi.upper()}" if epi else ("A4P_MAIN_NN_DACT" if dact else ("A4P_MAIN_NN" if tb else "A4P_MAIN_NT"))], SUB_P)
     for bid in range(grid):
         blk = Block(prog, gmem, lazy_ds, lazy_dma)
         for w in blk.waves:
@@ -538,14 +574,22 @@ def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="
             w.s[27], w.s[28] = M - 256, N - 256
             w.s[29], w.s[30], w.s[31] = PZ & 0xFFFFFFFF, PZ >> 32, M * ldc * 2
             w.s[32] = int(np.float32(scale).view(np.uint32))
+            w.s[33] = (hseed * 0x9E3779B1) & 0xFFFFFFFF                       # seed term (row0 = 0)
+            w.s[34] = (((p16 ^ 0x8000) - 1) & 0xFFFF) * 0x10001
         blk.run(sched=sched, seed=seed + bid)
         assert all(not w.vm and not w.lgkm for w in blk.waves)
     got = bf16_to_f32(Cmem).reshape(M, ldc).astype(np.float64)
     if dact:
         ref = np.where(bf16_to_f32(Zb).reshape(M, ldc)[:, :N] > 0, ref.astype(np.float32) * np.float32(scale), 0.0).astype(np.float64)
+    atol = 1e-6
+    if epi:                                               # ReLU (+ dropout with the library's counter-based mask, scale 1 / (1 - p))
+        ref = np.maximum(ref, 0.0)
+        if epi == "reludrop":
+            ref = np.where(keep_mask(M, N, hseed, p16), ref.astype(np.float32) * np.float32(scale), 0.0).astype(np.float64)
+        atol = 2e-4                                       # a sum within fp32 rounding of zero may land on either side of the ReLU
     refb = bf16_to_f32(to_bf(ref.astype(np.float32))).astype(np.float64)
     err = np.abs(got - refb)
-    bad = ~(err <= 0.0079 * np.abs(refb) + 1e-6)          # one bf16 ulp: the fp32 sums differ from fp64 in the last bits
+    bad = ~(err <= 0.0079 * np.abs(refb) + atol)          # one bf16 ulp: the fp32 sums differ from fp64 in the last bits
     if verbose:
         print(f"persistent tb={tb} M={M} N={N} K={K} grid={grid} lazy_ds={lazy_ds} lazy_dma={lazy_dma} sched={sched}: "
               f"{int(bad.sum())} wrong of {bad.size}, NaN {int(np.isnan(got).sum())}, max abs err {np.nanmax(err):.3e}")
@@ -566,7 +610,9 @@ if __name__ == "__main__":
         grid = int(args[3]) if len(args) > 3 else 2
         nbad = 0
         for lazy_ds, lazy_dma, sched in ((False, False, "fwd"), (True, True, "random"), (True, False, "random"), (False, True, "rev"), (True, True, "fwd")):
-            nbad += check_p(inc, tb, M, N, K, grid, lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched, verbose=True, dact="--dact" in sys.argv, scale=1.0 / 0.9 if "--dact" in sys.argv else 1.0)
+            epi = "reludrop" if "--reludrop" in sys.argv else ("relu" if "--relu" in sys.argv else "")
+            nbad += check_p(inc, tb, M, N, K, grid, lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched, verbose=True, dact="--dact" in sys.argv,
+                            scale=1.0 / 0.9 if ("--dact" in sys.argv or epi == "reludrop") else 1.0, epi=epi)
         print("OK" if nbad == 0 else "FAILED")
         sys.exit(0 if nbad == 0 else 1)
     worst = 0.0

@@ -47,7 +47,7 @@ for m in re.finditer(r"^(_ZN\S*gemm_a4p?_kernel\S*):[^\n]*\n(.*?)\n\s*s_endpgm",
     hits = [l for l in body.splitlines() if re.search(r"v_accvgpr|scratch_|buffer_(load|store).*offen.*s\[0:3\]", l)]
     print(m.group(1), "compiler-emitted AGPR/scratch instructions:", len(hits))
     bad += len(hits); nk += 1
-print("BAD" if bad else ("CLEAN" if nk == 6 else "NOT-FOUND"))
+print("BAD" if bad else ("CLEAN" if nk == 8 else "NOT-FOUND"))
 PYEOF
   cat build/v2s_gemm_a4.audit
   if grep -q BAD build/v2s_gemm_a4.audit; then echo "ERROR: the compiler touched AGPRs / scratch inside gemm_a4_kernel" >&2; rm -f build/v2s_gemm.o; exit 1; fi

@@ -66,6 +66,9 @@ else:
     ODD_REQ = [4, 7, 10, 14]
 
 
+BG_UNIT = int(os.environ.get("A4_BG_UNIT", "3"))     # background-stream budget of one MFMA gap (units; one full-rate VALU instruction = 1)
+
+
 class Gen:
     def __init__(self, tb, ta=False, abl=""):
         self.tb, self.ta = tb, ta
@@ -178,9 +181,15 @@ class Gen:
                 self.mfma(fs, bi, bj, first)
                 for f in gaps.get(j, []):
                     f()
-                for _ in range(getattr(self, "bg_rate", 0)):
-                    if getattr(self, "bg", None):
-                        self.bg.pop(0)()
+                left = getattr(self, "bg_rate", 0) * BG_UNIT          # a write-out / load entry fills a gap's budget, a hash instruction costs 1-2 units
+                while left > 0 and getattr(self, "bg", None):
+                    ent = self.bg[0]
+                    w, f = ent if isinstance(ent, tuple) else (BG_UNIT, ent)
+                    if w > left:
+                        break
+                    self.bg.pop(0)
+                    f()
+                    left -= w
                 j += 1
 
     # ---- address arithmetic shared by the one-tile and the persistent kernel.  v{V_T} = lane, s{S_T} = wave, s{S_T+1} = wm, s{S_T+2} = wn.
@@ -449,7 +458,7 @@ V_STR = 236                  # staging read addresses: row-group parity 0 / 1
 V_STO = 238                  # store offset: (lane >> 4) * ldc_bytes + (lane & 15) * 16
 V_ZO = 239                   # (dact form) load offset of the mask operand z in the accumulator layout: (lane & 31) * ldc_bytes + (lane >> 5) * 32
 V_ZM = 240                   # (dact form) eight mask temporaries v240..v247
-NV_CLOBBER_P = 248
+NV_CLOBBER_P = 250
 S_K, S_NMY = 44, 45          # tile ordinal of this block, its tile count
 S_SRD = 56                   # s56..s59 buffer descriptor of C
 S_ST_PREV, S_ST_CUR, S_ST_NEXT = 60, 61, 62   # store offsets (bytes): running one of the held tile, base of the current / next tile
@@ -459,7 +468,14 @@ S_X = 68                     # temporaries s68..s79 (tile coordinates)
 S_ZSRD = 80                  # (dact form) s80..s83 buffer descriptor of z
 S_SCALE = 84                 # (dact form) 1 / (1 - p) of the forward's dropout, fp32 bits
 S_ZROW = 85                  # (dact form) s85..s88: z offsets of the wave's four block rows of the CURRENT tile
-NS_CLOBBER_P = 90
+S_HK1, S_HK2 = 89, 90        # (reludrop form) the two multipliers of v2s_mix32
+S_HXS = 91                   # 0x80008000: unsigned -> signed 16-bit draws
+S_HPP = 92                   # both halves: ((p16 ^ 0x8000) - 1) & 0xffff
+S_HC = 93                    # s93..s96: the four pair multipliers of v2s_keep8
+NS_CLOBBER_P = 98
+V_HL = 239                   # (reludrop form; = V_ZO's register) lane part of the chunk index + seed term
+V_HB, V_HT = 240, 241        # hash temporaries
+V_SC2 = 248                  # v248..v249: the dropout scale twice (v_pk_mul_f32 operand)
 RING = 4 * STAGE
 
 
@@ -527,6 +543,23 @@ class GenP(Gen):
         e(f"s_mov_b32 s{S_SRD + 3}, 0x00020000")
         e(f"s_mov_b32 s{S_K}, 0")
         e(f"s_mov_b32 s{S_NMY}, %[nmy]")
+        if self.epi == "reludrop":
+            # chunk index of the lane's first 8 columns in row (lane & 31) relative to the wave's sub-tile (ldc == N: the byte offset / 16), plus
+            # the launch's seed term (seed * 0x9E3779B1 + row0 * N / 8)
+            e(f"v_and_b32 v{T + 5}, 31, v{T}")
+            e(f"v_lshrrev_b32 v{T + 6}, 5, v{T}")
+            e(f"v_mul_lo_u32 v{T + 5}, v{T + 5}, %[ldc]")
+            e(f"v_lshl_add_u32 v{T + 5}, v{T + 6}, 5, v{T + 5}")
+            e(f"v_lshrrev_b32 v{T + 5}, 4, v{T + 5}")
+            e(f"v_add_u32 v{V_HL}, %[hseed], v{T + 5}")
+            e(f"s_mov_b32 s{S_HK1}, 0x9E3779B1")
+            e(f"s_mov_b32 s{S_HK2}, 0x85EBCA77")
+            e(f"s_mov_b32 s{S_HXS}, 0x80008000")
+            e(f"s_mov_b32 s{S_HPP}, %[hpp]")
+            for i in range(4):
+                e(f"s_mov_b32 s{S_HC + i}, 0x{0x00EBCA77 + 0x2468 * i:x}")
+            e(f"v_mov_b32 v{V_SC2}, %[scale]")
+            e(f"v_mov_b32 v{V_SC2 + 1}, %[scale]")
         if self.epi == "dact":
             e(f"v_and_b32 v{T + 5}, 31, v{T}")
             e(f"v_lshrrev_b32 v{T + 6}, 5, v{T}")
@@ -599,8 +632,50 @@ class GenP(Gen):
             for i in range(8):
                 e(f"v_and_b32 v{V_HELD + 8 * b + i}, v{V_HELD + 8 * b + i}, v{V_ZM + i}")
             return
+        if self.epi == "reludrop":                   # held[8 b + i] holds the keep masks of the pair (hash_stream): out = max(round(acc * scale), 0) & mask
+            for i in range(8):
+                e(f"v_pk_mul_f32 v[{V_T + 2 * i}:{V_T + 2 * i + 1}], v[{V_T + 2 * i}:{V_T + 2 * i + 1}], v[{V_SC2}:{V_SC2 + 1}]")
+            for i in range(8):
+                e(f"v_cvt_pk_bf16_f32 v{V_T + 2 * i}, v{V_T + 2 * i}, v{V_T + 2 * i + 1}")
+            for i in range(8):
+                e(f"v_and_b32 v{V_HELD + 8 * b + i}, v{V_HELD + 8 * b + i}, v{V_T + 2 * i}")
+            for i in range(8):
+                e(f"v_pk_max_i16 v{V_HELD + 8 * b + i}, v{V_HELD + 8 * b + i}, 0")
+            return
         for i in range(8):
             e(f"v_cvt_pk_bf16_f32 v{V_HELD + 8 * b + i}, v{V_T + 2 * i}, v{V_T + 2 * i + 1}")
+        if self.epi == "relu":                       # a negative bf16 is a negative int16
+            for i in range(8):
+                e(f"v_pk_max_i16 v{V_HELD + 8 * b + i}, v{V_HELD + 8 * b + i}, 0")
+
+    def hash_stream(self):
+        """(reludrop form) the keep masks of the CURRENT tile, computed into the 128 held registers in the MFMA gaps after the previous tile's
+        write-out has left them: v2s_keep8 (v2s_common.h) per aligned chunk of 8 elements -- one 32-bit mix of (seed, chunk index), then per
+        element PAIR a rotate + 24-bit multiply = two 16-bit draws, kept iff draw >= p16.  The compare runs on both halves at once: draws and
+        threshold are mapped to signed 16-bit (xor 0x8000), sat16((p' - 1) - d') is negative iff d' >= p', its sign spread over the half is
+        the AND mask of the bf16.  Entries are (cost, emit): a quarter-rate v_mul_lo_u32 costs 2 units of a gap's budget."""
+        e = self.e
+        out = [(1, lambda: e(f"s_lshl_b32 s{S_X}, %[ldc], 1")),                      # 32 rows * ldc bytes / 16
+               (1, lambda: e(f"s_lshr_b32 s{S_ZROW}, s{S_ST_CUR}, 4"))]
+        for bi in range(1, 4):
+            out.append((1, lambda bi=bi: e(f"s_add_u32 s{S_ZROW + bi}, s{S_ZROW + bi - 1}, s{S_X}")))
+        B, Tm = V_HB, V_HT
+        for bi in range(4):
+            for bj in range(4):
+                for half in range(2):
+                    d = V_HELD + (bi * 4 + bj) * 8 + half * 4
+                    ops = [(1, f"v_add3_u32 v{B}, v{V_HL}, s{S_ZROW + bi}, {bj * 4 + half}"),
+                           (2, f"v_mul_lo_u32 v{B}, v{B}, s{S_HK1}"), (1, f"v_lshrrev_b32 v{Tm}, 15, v{B}"), (1, f"v_xor_b32 v{B}, v{B}, v{Tm}"),
+                           (2, f"v_mul_lo_u32 v{B}, v{B}, s{S_HK2}"), (1, f"v_lshrrev_b32 v{Tm}, 13, v{B}"), (1, f"v_xor_b32 v{B}, v{B}, v{Tm}")]
+                    for j in range(4):
+                        if j:
+                            ops.append((1, f"v_alignbit_b32 v{d + j}, v{B}, v{B}, {8 * j}"))
+                        ops.append((1, f"v_mul_u32_u24 v{d + j}, v{d + j if j else B}, s{S_HC + j}"))
+                        ops.append((1, f"v_xor_b32 v{d + j}, s{S_HXS}, v{d + j}"))
+                        ops.append((1, f"v_pk_sub_i16 v{d + j}, s{S_HPP}, v{d + j} clamp"))
+                        ops.append((1, f"v_pk_ashrrev_i16 v{d + j}, 15, v{d + j} op_sel_hi:[0,1]"))
+                    out.extend((w, (lambda t=t: e(t))) for w, t in ops)
+        return out
 
     def zload_stream(self):
         """(dact form) 32 loads of the current tile's z into the held registers, one per MFMA gap of the Z iteration's first stage: issued
@@ -673,11 +748,13 @@ class GenP(Gen):
             self.bg_rate = rate
             if first:
                 self.bg = self.writeout_stream()
+                if self.epi == "reludrop":
+                    self.bg = self.bg + self.hash_stream()
             gaps = {}
             self.fill_odd(st, gaps, self.advance_p(), extra_sync=self.tile_switch if (kind == "P" and st == 0) else None)
             self.step(1, gaps)
             self.stage_ctr += 1
-        assert not self.bg or kind == "T", "background stream did not finish"
+        assert not self.bg or kind == "T" or (self.epi == "reludrop" and kind in ("S", "H")), "background stream did not finish"
 
     def tile_switch(self):
         """in the LAST iteration of a tile, after the tile's last stage has been requested: point the DMA stream at the block's next tile
@@ -708,7 +785,12 @@ class GenP(Gen):
         if self.epi == "dact":
             self.body_p("Z")
             assert "z" not in self.vm and (list(self.lgkm), ["d"] * len(self.vm)) == (entry_shape[0], ["d"] * 20), (self.lgkm, self.vm)
-        e(f"s_sub_u32 s{S_IT}, %[niter], {3 if self.epi == 'dact' else 2}")
+        if self.epi == "reludrop":                   # the hash stream needs the gaps of two more iterations (K >= 640)
+            self.body_p("H")
+            self.body_p("H")
+            assert not self.bg, f"hash stream did not finish: {len(self.bg)} entries left"
+            assert shape() == entry_shape
+        e(f"s_sub_u32 s{S_IT}, %[niter], {3 if self.epi == 'dact' else (4 if self.epi == 'reludrop' else 2)}")
         e("L_a4p_loop_%=:")
         self.vm = [f"stage{self.stage_ctr + 1}"] * 8 + [f"stage{self.stage_ctr + 2}"] * 8 + [f"stage{self.stage_ctr + 3}"] * 4
         self.body_p("P")
@@ -798,6 +880,13 @@ def main():
     parts.append("#define A4P_MAIN_NN_DACT \\")
     parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in lines))
     parts.append("")
+    for epi in ("relu", "reludrop"):
+        g = GenP(False, epi)
+        lines = g.main_p()
+        stats[("p", epi)] = (len(lines), g.nmfma)
+        parts.append(f"#define A4P_MAIN_NT_{epi.upper()} \\")
+        parts.append(" \\\n".join('  "' + ln + '\\n\\t"' for ln in lines))
+        parts.append("")
     parts.append(f"#define A4P_CLOBBERS {clobbers_p()}")
     for bi in range(4):
         parts.append(f"#define A4_DUMP_{bi} \\")

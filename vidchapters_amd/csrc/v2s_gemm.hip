@@ -2042,10 +2042,18 @@ static bool w128_auto(const v2s_gemm_args* a) {
 // everywhere (1 block per CU: nothing runs beside its epilogue) and is only taken when forced.
 // Epilogues the persistent deferred-write-out kernel has: 0 = none of them, 1 = plain bf16, 2 = the ReLU-mask dgrad (dact = RELU with z laid out like C,
 // optional 1 / (1 - p) scale of the forward's dropout: out = z > 0 ? acc * scale : 0)
+// 3 = ReLU (forward, act = RELU), 4 = ReLU + dropout (the FFN's wi forward; the mask of v2s_keep8 regenerated in the kernel: ldc == N, K >= 640)
 static int a4p_epilogue(const v2s_gemm_args* a) {
-  if (a->transA || a->c_dtype != V2S_BF16 || a->accumulate || a->bias || a->pre || a->residual || a->act != V2S_ACT_NONE || a->alpha != 1.0f ||
+  if (a->transA || a->c_dtype != V2S_BF16 || a->accumulate || a->bias || a->pre || a->residual || a->alpha != 1.0f ||
       a->M < 256 || a->N < 512 || (a->N % 8) != 0)
     return 0;
+  if (a->act == V2S_ACT_RELU) {
+    if (a->transB || a->dact != V2S_ACT_NONE || v2s_opt_gemm_a4_relu() == 0) return 0;
+    if (a->dropout_p == 0.f) return a->K >= 384 ? 3 : 0;
+    const uint32_t p16 = (uint32_t)(a->dropout_p * 65536.0f + 0.5f);
+    return (a->K >= 640 && a->ldc == a->N && (long)a->M * a->N < (1L << 35) && p16 >= 1 && p16 <= 65535) ? 4 : 0;
+  }
+  if (a->act != V2S_ACT_NONE) return 0;
   if (a->dact == V2S_ACT_NONE) return (a->dropout_p == 0.f && a->K >= 384) ? 1 : 0;
   // Measured (profiles/r05_a4p_dact_ab.txt, r05_step_ab_a4.txt): the encoder wo dgrad 32000x3072x768 with its mask operand 251.5 -> 189.7 us alone,
   // but +0.74 ms per train step -- the 2-blocks-per-CU kernel it replaces shares the chip with the weight-gradient stream, a persistent
@@ -2349,6 +2357,8 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
       (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_a4p_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, A4P_LDS);
       attr_a4p = true;
     }
     int ncu = num_cus();
@@ -2356,8 +2366,11 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     const int nt = p.tilesM * p.tilesN;
     const dim3 grid((unsigned)(nt < ncu ? nt : ncu)), block(256);
     const int epi = a4p_epilogue(a);
-    g_last_gemm = epi == 2 ? "gemm_a4p_kernel<true, 1>" : (a->transB ? "gemm_a4p_kernel<true, 0>" : "gemm_a4p_kernel<false, 0>");
+    g_last_gemm = epi == 2 ? "gemm_a4p_kernel<true, 1>" : epi == 3 ? "gemm_a4p_kernel<false, 2>" : epi == 4 ? "gemm_a4p_kernel<false, 3>" :
+                  (a->transB ? "gemm_a4p_kernel<true, 0>" : "gemm_a4p_kernel<false, 0>");
     if (epi == 2) hipLaunchKernelGGL((gemm_a4p_kernel<true, 1>), grid, block, A4P_LDS, s, p);
+    else if (epi == 3) hipLaunchKernelGGL((gemm_a4p_kernel<false, 2>), grid, block, A4P_LDS, s, p);
+    else if (epi == 4) hipLaunchKernelGGL((gemm_a4p_kernel<false, 3>), grid, block, A4P_LDS, s, p);
     else if (a->transB) hipLaunchKernelGGL((gemm_a4p_kernel<true, 0>), grid, block, A4P_LDS, s, p);
     else hipLaunchKernelGGL((gemm_a4p_kernel<false, 0>), grid, block, A4P_LDS, s, p);
   } else if (a4) {

@@ -150,9 +150,10 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmP p) {
 // body is the asm statement.
 constexpr int A4P_LDS = 4 * 32768 + 4 * 8192;      // ring + one 8 KiB staging block per wave = all 160 KiB
 
-template <bool TB, int EPI>      // EPI 0: plain; 1: ReLU-mask epilogue (dact = RELU, z, optional 1 / (1 - p) scale; TB only)
+template <bool TB, int EPI>      // EPI 0: plain; 1: ReLU-mask epilogue (dact = RELU, z, optional 1 / (1 - p) scale; TB only); 2: ReLU; 3: ReLU + dropout
+                                 // (the library's counter-based mask v2s_keep8 regenerated in the MFMA gaps, scale 1 / (1 - p); ldc == N, K >= 640) -- !TB only
 __global__ __launch_bounds__(256, 1) void gemm_a4p_kernel(const GemmP p) {
-  static_assert(EPI == 0 || TB, "the mask epilogue is generated for the dgrad layout only");
+  static_assert(EPI == 0 || (EPI == 1) == TB, "the mask epilogue is generated for the dgrad layout only, the ReLU ones for the forward layout");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const uint32_t lds = __builtin_amdgcn_readfirstlane(lds_addr(smem));
@@ -171,14 +172,21 @@ __global__ __launch_bounds__(256, 1) void gemm_a4p_kernel(const GemmP p) {
   const uint32_t magic = (uint32_t)(((1ull << 32) + tilesn - 1) / tilesn);
   const uint32_t nmy = (ntiles - bid + grid - 1) / grid;
   const uint32_t mlast = (uint32_t)(p.M - 256), nlast = (uint32_t)(p.N - 256);
+  // dropout: element (gm, gn) belongs to chunk ((gm + row0) * N + gn) / 8 of the launch's mask stream (v2s_keep8)
+  const uint32_t hseed = v2s_salted(p.seed, p.salt) * 0x9E3779B1u + (uint32_t)p.row0 * (uint32_t)(p.N / 8);
+  const uint32_t hpp = (((p.p16 ^ 0x8000u) - 1u) & 0xffffu) * 0x10001u;
 #define A4P_ARGS                                                                                                                          \
   : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb), [pc0] "s"(pc0),       \
     [pc1] "s"(pc1), [ldc] "s"(ldc), [cbytes] "s"(cbytes), [niter] "s"(niter), [lds] "s"(lds), [bid] "s"(bid), [grid] "s"(grid), [q] "s"(q), \
     [r] "s"(r), [magic] "s"(magic), [tilesn] "s"(tilesn), [nmy] "s"(nmy), [mlast] "s"(mlast), [nlast] "s"(nlast), [pz0] "s"(pz0),          \
-    [pz1] "s"(pz1), [zbytes] "s"(zbytes), [scale] "s"(scale)                                                                               \
+    [pz1] "s"(pz1), [zbytes] "s"(zbytes), [scale] "s"(scale), [hseed] "s"(hseed), [hpp] "s"(hpp)                                           \
   : A4P_CLOBBERS
   if constexpr (EPI == 1) {
     asm volatile(A4P_MAIN_NN_DACT : A4P_ARGS);
+  } else if constexpr (EPI == 2) {
+    asm volatile(A4P_MAIN_NT_RELU : A4P_ARGS);
+  } else if constexpr (EPI == 3) {
+    asm volatile(A4P_MAIN_NT_RELUDROP : A4P_ARGS);
   } else if constexpr (TB) {
     asm volatile(A4P_MAIN_NN : A4P_ARGS);
   } else {
