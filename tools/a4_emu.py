@@ -371,6 +371,8 @@ class Block:
             return
         if op == "buffer_store_dwordx4":
             # buffer_store_dwordx4 vdata[4], voffset, srd[4], soffset offen   (raw buffer: out of range when voffset + 16 > num_records)
+            ops[3] = re.sub(r"\s+(sc0|sc1|nt)\b", "", ops[3])           # cache-policy modifiers: no functional effect
+            ops[3] = re.sub(r"\s+(sc0|sc1|nt)\b", "", ops[3])
             assert ops[3].endswith("offen"), ins
             kd, d0, dn = self.rng(ops[0]); assert dn == 4
             voff = V(ops[1]).astype(np.int64)

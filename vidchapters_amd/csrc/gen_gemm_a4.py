@@ -66,6 +66,7 @@ else:
     ODD_REQ = [4, 7, 10, 14]
 
 
+STORE_MOD = (" " + os.environ["A4_STORE_MOD"]) if os.environ.get("A4_STORE_MOD") else ""      # cache policy of the output stores (experiment: "sc1", "nt", "sc0 sc1")
 BG_UNIT = int(os.environ.get("A4_BG_UNIT", "3"))     # background-stream budget of one MFMA gap (units; one full-rate VALU instruction = 1)
 
 
@@ -713,7 +714,7 @@ class GenP(Gen):
 
             def st(reg=reg, i=i, c=c):
                 self.need({f"R{c}_{i}"})
-                self.vm_op("st", f"buffer_store_dwordx4 v[{reg}:{reg + 3}], v{V_STO}, s[{S_SRD}:{S_SRD + 3}], s{S_ST_PREV} offen")
+                self.vm_op("st", f"buffer_store_dwordx4 v[{reg}:{reg + 3}], v{V_STO}, s[{S_SRD}:{S_SRD + 3}], s{S_ST_PREV} offen{STORE_MOD}")
             out.append(st)
             out.append(lambda: self.e(f"s_add_u32 s{S_ST_PREV}, s{S_ST_PREV}, s{S_ST_STEP}"))
         return out

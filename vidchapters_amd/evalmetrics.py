@@ -15,10 +15,11 @@ used at vc.py:169-170 -- as ONE data-parallel job over the whole prediction file
     same batch; the order-preserving matching is a row-wise dynamic program (`np.maximum.accumulate` per row).
 
 What is NOT reproduced, because the reference itself shells out to Java for it and the jars are neither in the reference tree
-(`.MISSING_LARGE_BLOBS`) nor in this image: METEOR, and the Stanford PTB tokenizer.  `ptb_tokenize` below is an approximation of the
+(`.MISSING_LARGE_BLOBS`) nor in this image: full METEOR (its exact + stem stages are restated in meteor_lite.py and reported as `METEOR-lite` /
+`soda_c_meteor_lite`; WordNet synonyms, paraphrase tables and the function-word discount are not), and the Stanford PTB tokenizer.  `ptb_tokenize` below is an approximation of the
 latter (lower-casing, punctuation split off and dropped like pycocoevalcap's PUNCTUATIONS list); pass `tokenize=` to use another one.
 SODA_c is therefore computed with the reference's own alternative scorer choice `Cider` (soda.py:224) and reported under the key
-`soda_c_cider`; METEOR is absent from the results.  BLEU-1..4 and ROUGE-L are computed, but pycocoevalcap's bleu/ and rouge/ are not
+`soda_c_cider` (or with METEOR-lite under `soda_c_meteor_lite`); no key is called METEOR or soda_c unless the caller brings a scorer.  BLEU-1..4 and ROUGE-L are computed, but pycocoevalcap's bleu/ and rouge/ are not
 vendored in the reference either: they are restated from the published package and their parity is UNPINNED (hand-checked cases and
 the plain-Python restatement in the oracle only).  Parity with the reference's modules (run on
 pre-tokenised text): tests/golden/eval_metrics.json, tests/test_oracle_cpu.py.
@@ -285,7 +286,7 @@ def _blocks(n_a: np.ndarray, n_b: np.ndarray):
 
 
 def eval_dvc(submission, references, tious=[0.3, 0.5, 0.7, 0.9], distances=[1, 3, 5, 10, 30, 60], max_proposals_per_video=1000,
-             verbose=False, no_lang_eval=False, tokenize: Optional[Callable[[str], str]] = None) -> Dict[str, float]:
+             verbose=False, no_lang_eval=False, tokenize: Optional[Callable[[str], str]] = None, meteor_lite: bool = True) -> Dict[str, float]:
     """dvc_eval/eval_dvc.py:305-333.  `submission`: {"results": {vid: [{"sentence", "timestamp": [s, e]}]}} or a json path;
     `references`: annotation dicts ({vid: {"timestamps", "sentences"}}) or json paths.  Returns CIDEr (mean over `tious` of the
     per-video CIDEr of the tIoU-matched pairs) and Recall / Precision / F1 @tIoU, their means over the first four thresholds, and
@@ -367,6 +368,16 @@ def eval_dvc(submission, references, tious=[0.3, 0.5, 0.7, 0.9], distances=[1, 3
             out[f"Bleu_{k + 1}"] = float(bl[:, k].reshape(len(tious), NV).mean(1).mean())
         rg = np.bincount(grp, _rouge_batch(words, h, r), len(tious) * NV) / np.maximum(n_items, 1)
         out["Rouge-L"] = float(rg.reshape(len(tious), NV).mean(1).mean())
+        if meteor_lite:
+            # METEOR (eval_dvc.py:67) restated without the jar for its exact + stem stages only (meteor_lite.py: labelled, unpinned): per
+            # (tIoU, video) group the score of the group's SUMMED alignment statistics, like Meteor.compute_score's first return value
+            from . import meteor_lite as ML
+            ml = ML.MeteorLite()
+            pairs, inv = np.unique(np.stack([h, r], 1), axis=0, return_inverse=True)
+            st = np.array([ml.pair_stats(sents.rows[a], sents.rows[b] if b != garbage else "#garbage#") for a, b in pairs], np.float64).reshape(-1, 5)
+            agg = np.stack([np.bincount(grp, st[inv.reshape(-1), k], len(tious) * NV) for k in range(5)], 1)
+            mg = np.array([ML._score(x) for x in agg]) * (n_items > 0)
+            out["METEOR-lite"] = float(mg.reshape(len(tious), NV).mean(1).mean())
     for i, x in enumerate(tious):
         out[f"Recall@{x}"], out[f"Precision@{x}"], out[f"F1@{x}"] = float(R[i]), float(P[i]), float(F[i])
     out["Recall"], out["Precision"], out["F1"] = float(R[:4].mean()), float(P[:4].mean()), float(F[:4].mean())
@@ -433,9 +444,16 @@ def soda_c(submission, reference, tokenize: Optional[Callable[[str], str]] = Non
 
 def eval_soda(p, ref_list, verbose=False, tokenize: Optional[Callable[[str], str]] = None, scorer=None) -> Dict[str, float]:
     """dvc_eval/eval_soda.py:35-43: mean over the annotation files of the SODA_c F-measure.  The key is `soda_c_cider` with the
-    built-in CIDEr scorer and `soda_c` when the caller supplies a scorer object (e.g. their own METEOR wrapper)."""
+    built-in CIDEr scorer, `soda_c_meteor_lite` with scorer="meteor_lite" (meteor_lite.py: METEOR's exact + stem stages, no jar) and
+    `soda_c` when the caller supplies a scorer object (e.g. their own METEOR wrapper)."""
+    key = "soda_c_cider" if scorer is None else "soda_c"
+    if isinstance(scorer, str):
+        if scorer != "meteor_lite":
+            raise ValueError(f"unknown scorer {scorer!r}")
+        from .meteor_lite import MeteorLite
+        scorer, key = MeteorLite(), "soda_c_meteor_lite"          # the README's SODA_c is IoU x METEOR: this is its exact + stem restatement, labelled
     f = float(np.mean([soda_c(p, ref, tokenize, scorer)[2] for ref in ref_list]))
-    return {"soda_c_cider" if scorer is None else "soda_c": f}
+    return {key: f}
 
 
 # ------------------------------------------------------------------------------------------------------------ vc.py
