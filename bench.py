@@ -287,6 +287,16 @@ def main():
                            "algorithmic_gflop_per_launch": round(work / n / 1e9, 2),
                            "note": "achieved = sum over the step's launches of this kernel of 2*M*N*K (attention: 4*B*H*Nq*Nk*64 fwd, "
                                    "8*... bwd) / their summed HIP-event durations, measured with stream overlap disabled"}
+        # the round-5 kernel family (persistent asm-scheduled GEMM) next to the dominant symbol: its launches, time and rate in this same step
+        fam = [(k, v) for k, v in summ.items() if k.startswith("gemm_a4p_kernel")]
+        if fam:
+            fn_, fms, fwork = sum(v[0] for _, v in fam), sum(v[1] for _, v in fam), sum(v[2] for _, v in fam)
+            fach = fwork / (fms / 1e3) / 1e12
+            out["roofline"]["gemm_a4p_family"] = {"symbols": sorted(k for k, _ in fam), "launches_per_step": fn_, "ms_per_step": round(fms, 3),
+                                                  "achieved": round(fach, 1), "unit": "TFLOP/s", "frac": round(fach / PEAK_BF16_TFLOPS, 4),
+                                                  "frac_of_sustained_mfma": round(fach / 1650.0, 4),
+                                                  "note": "all instantiations of gemm_a4p_kernel in this step; sustained = 1650 TF/s, pure v_mfma on random bf16 operands "
+                                                          "on this chip (profiles/r05_mfma_power_ubench.txt)"}
         # HBM traffic of that kernel: from the committed PMC passes (tools/pmc_traffic.sh -> profiles/*.json; rocprofv3 --pmc cannot
         # wrap this whole script on this stack -- it crashes in torch's integer kernels), launch-weighted over the step's shapes
         try:
