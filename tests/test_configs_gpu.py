@@ -154,6 +154,53 @@ def test_t5_large_cfg5_shape_vs_reference_golden(golden_dir):
     _check_against_shape_golden(g, model, 24, min_cos=0.975, min_cos_1d=0.960, tag="cfg-5 shape (t5-large)")     # measured at B = 2 (round 5): 0.9786 / 0.9667 (B = 1: 0.9790 / 0.9743)
 
 
+def test_cfg2_step_is_bit_identical_with_the_relu_dropout_epilogue_on_either_kernel():
+    """A whole forward + backward with dropout ON (cfg-2 shapes, B = 4) must not change by one bit when the FFN's wi forward moves from
+    the older kernels (gemm_a4_relu = 0) to the persistent asm kernel, which recomputes the same counter-based keep mask inside its MFMA
+    gaps (gemm_a4_relu = 1): same mask, same single rounding -> same loss, same gradients.  gemm_a4 = 2 takes the persistent kernel wherever
+    it is legal, so that the 4000-row problems of this batch reach it like the 32000-row ones of the bench do."""
+    from vidchapters_amd import lib as L
+    B = 4
+    model = Vid2Seq("t5-base", tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.1, enc_drop=0.1, dec_drop=0.1, init_seed=5, device=DEV).train()
+    eng = model.engine()
+    b = synth.make_batch(B, 100, 1000, 256, 32200, 77, 768)
+    video, ids, out = b["video"].to(DEV).to(torch.bfloat16), b["input_ids"].to(DEV), b["output_ids"].to(DEV)
+    names = ["t5_model.encoder.block.0.layer.1.DenseReluDense.wi.weight", "t5_model.encoder.block.11.layer.1.DenseReluDense.wo.weight",
+             "t5_model.decoder.block.3.layer.2.DenseReluDense.wi.weight", "t5_model.encoder.block.0.layer.0.SelfAttention.q.weight"]      # (not the embedding: fp32 atomics)
+
+    def run(relu_opt):
+        L.set_option("gemm_a4", 2); L.set_option("gemm_a4_relu", relu_opt)
+        try:
+            eng.set_rng_state((1234, 0))
+            eng.prepare()
+            eng.arena.grad.zero_()
+            vt, tp = {}, {}
+            vis = eng.vit_forward(video, vt).view(-1, 100, eng.d)
+            loss = eng.t5_loss_forward(vis, ids, ids != 0, out, out != 0, tp)
+            dvis = eng.t5_loss_backward(tp, torch.ones(1, device=DEV))
+            eng.vit_backward(vt, dvis)
+            eng.join_wgrads()
+            torch.cuda.synchronize()
+            return loss.item(), {k: eng.arena.g(k).clone() for k in names}
+        finally:
+            L.set_option("gemm_a4", 1); L.set_option("gemm_a4_relu", 1)
+
+    kern = {}
+    for v in (0, 1):                                  # which kernel the encoder's wi forward takes under each setting
+        L.set_option("gemm_a4", 2); L.set_option("gemm_a4_relu", v)
+        x = torch.randn(4000, 768, device=DEV).to(torch.bfloat16); w = torch.randn(3072, 768, device=DEV).to(torch.bfloat16)
+        y = torch.empty(4000, 3072, device=DEV, dtype=torch.bfloat16)
+        L.gemm(x, w, y, 4000, 3072, 768, act=L.ACT_RELU, dropout_p=0.1, dropout_seed=1)
+        kern[v] = L.lib().v2s_last_gemm_kernel().decode()
+    L.set_option("gemm_a4", 1); L.set_option("gemm_a4_relu", 1)
+    assert kern[1] == "gemm_a4p_kernel<false, 3>" and "a4p" not in kern[0], kern
+    l0, g0 = run(0)
+    l1, g1 = run(1)
+    assert l0 == l1, (l0, l1)
+    for k in names:
+        assert torch.equal(g0[k], g1[k]), k
+
+
 SLICE_NAMES = ["t5_model.encoder.block.0.layer.0.SelfAttention.q.weight", "t5_model.encoder.block.11.layer.1.DenseReluDense.wi.weight",
                "t5_model.encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight",
                "t5_model.decoder.block.5.layer.1.EncDecAttention.k.weight", "t5_model.decoder.block.11.layer.2.DenseReluDense.wo.weight",
