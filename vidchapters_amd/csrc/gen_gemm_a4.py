@@ -67,6 +67,7 @@ else:
 
 
 STORE_MOD = (" " + os.environ["A4_STORE_MOD"]) if os.environ.get("A4_STORE_MOD") else ""      # cache policy of the output stores (experiment: "sc1", "nt", "sc0 sc1")
+ZSPREAD = int(os.environ.get("A4_ZSPREAD", "0"))      # (dact form, experiment) > 0: the z loads go out one per ZSPREAD gaps over TWO iterations instead of back to back (K >= 640)
 BG_UNIT = int(os.environ.get("A4_BG_UNIT", "3"))     # background-stream budget of one MFMA gap (units; one full-rate VALU instruction = 1)
 
 
@@ -739,6 +740,8 @@ class GenP(Gen):
                 for bi in range(1, 4):
                     self.e(f"s_add_u32 s{S_ZROW + bi}, s{S_ZROW + bi - 1}, s{S_X}")
                 self.bg = self.zload_stream()
+                if ZSPREAD > 1:
+                    self.bg = [x for ld in self.bg for x in [ld] + [lambda: None] * (ZSPREAD - 1)]
             if first:
                 for b in range(16):
                     pre[b] = [lambda b=b: self.conv(b)]
@@ -755,7 +758,7 @@ class GenP(Gen):
             self.fill_odd(st, gaps, self.advance_p(), extra_sync=self.tile_switch if (kind == "P" and st == 0) else None)
             self.step(1, gaps)
             self.stage_ctr += 1
-        assert not self.bg or kind == "T" or (self.epi == "reludrop" and kind in ("S", "H")), "background stream did not finish"
+        assert not self.bg or kind == "T" or (self.epi == "reludrop" and kind in ("S", "H")) or (kind == "Z" and ZSPREAD > 1), "background stream did not finish"
 
     def tile_switch(self):
         """in the LAST iteration of a tile, after the tile's last stage has been requested: point the DMA stream at the block's next tile
@@ -785,13 +788,16 @@ class GenP(Gen):
         assert shape() == entry_shape, (shape(), entry_shape)
         if self.epi == "dact":
             self.body_p("Z")
+            if ZSPREAD > 1:
+                self.body_p("Z2")
+                assert not self.bg
             assert "z" not in self.vm and (list(self.lgkm), ["d"] * len(self.vm)) == (entry_shape[0], ["d"] * 20), (self.lgkm, self.vm)
         if self.epi == "reludrop":                   # the hash stream needs the gaps of two more iterations (K >= 640)
             self.body_p("H")
             self.body_p("H")
             assert not self.bg, f"hash stream did not finish: {len(self.bg)} entries left"
             assert shape() == entry_shape
-        e(f"s_sub_u32 s{S_IT}, %[niter], {3 if self.epi == 'dact' else (4 if self.epi == 'reludrop' else 2)}")
+        e(f"s_sub_u32 s{S_IT}, %[niter], {(4 if ZSPREAD > 1 else 3) if self.epi == 'dact' else (4 if self.epi == 'reludrop' else 2)}")
         e("L_a4p_loop_%=:")
         self.vm = [f"stage{self.stage_ctr + 1}"] * 8 + [f"stage{self.stage_ctr + 2}"] * 8 + [f"stage{self.stage_ctr + 3}"] * 4
         self.body_p("P")
