@@ -1,3 +1,5 @@
+# The round-end validation recipe as one gpurun command: full -m gpu suite, smoke, default bench line, rocprofv3 kernel stats of the same step,
+# t5-large GEMM A/B.  usage: gpurun --timeout 4500 -- bash tools/final_gpu_run.sh   (outputs under gpurun_out/, copied to profiles/ by hand)
 cd $GRAFT_REPO_ROOT
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/r05_final_pytest.txt
 cat gpurun_out/r05_final_pytest.txt
