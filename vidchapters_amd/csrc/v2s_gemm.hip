@@ -2056,8 +2056,8 @@ static int a4p_epilogue(const v2s_gemm_args* a) {
   if (a->act != V2S_ACT_NONE) return 0;
   if (a->dact == V2S_ACT_NONE) return (a->dropout_p == 0.f && a->K >= 384) ? 1 : 0;
   // Measured (profiles/r05_a4p_dact_ab.txt, r05_step_ab_a4.txt): the encoder wo dgrad 32000x3072x768 with its mask operand 251.5 -> 189.7 us alone,
-  // but +0.74 ms per train step -- the 2-blocks-per-CU kernel it replaces shares the chip with the weight-gradient stream, a persistent
-  // one-block-per-CU kernel does not.  So only when forced (gemm_a4 = 2) or asked for (gemm_a4 = 5).
+  // but +0.5 ... +0.8 ms per train step on three boxes (co-scheduling with the weight-gradient stream, cold operands and the burst of mask-operand
+  // loads were each tested as the cause and ruled out: DESIGN.md 8a-r5).  So only when forced (gemm_a4 = 2) or asked for (gemm_a4 = 5).
   const int mode = v2s_opt_gemm_a4();
   if (a->dact == V2S_ACT_RELU && a->transB && a->z && a->ldz == a->ldc && a->K >= 512 && (mode == 2 || mode == 5)) return 2;
   return 0;
