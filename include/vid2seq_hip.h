@@ -62,6 +62,8 @@ const char* v2s_last_error(void);
  *                   waits; round 5): 1: where they measured faster (default: the persistent deferred-write-out form on plain bf16 GEMMs with
  *                   >= 256 tiles), 0: never, 2: wherever legal, 3: the one-tile form wherever legal, 4: like 1 plus long-contraction weight gradients, 5: like 1 plus the ReLU-mask dgrad
  *                   epilogue (4 and 5: faster alone, slower inside the train step)
+ *   "gemm_a4_grid"  blocks of the persistent form: 0 (default) one per CU, n > 0 at most n, -1 the fewest that need the same number of rounds (A/B knobs: the
+ *                   step is work-bound, none of them moves it)
  *   "gemm_a4_relu"  1 (default): the persistent form also takes forward GEMMs with a ReLU or ReLU + dropout epilogue (the FFN's wi: the
  *                   dropout mask of the library's counter-based generator is recomputed inside the kernel's MFMA gaps), 0: plain epilogues only
  *   "gemm_dbg"      profiling ablations of the tiled kernels (results invalid when non-zero): 1 = no global store, 2 = no epilogue, 3 = no hand-off

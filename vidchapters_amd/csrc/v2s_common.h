@@ -52,7 +52,7 @@ int v2s_opt_gemm_a4();    // 4-wave asm-scheduled 256x256 kernels (128x128 wave 
                           // 2 = wherever legal (persistent deferred-write-out form where its epilogue allows, else the one-tile form), 3 = one-tile form wherever legal, 4 = like 1 plus the split-K weight gradients
                           // with a long contraction, 5 = like 1 plus the ReLU-mask dgrad epilogue (both faster alone, slower in the step:
                           // DESIGN.md 8a-r5)
-int v2s_opt_gemm_a4_grid(); // blocks of the persistent a4p kernel: 0 = one per CU (default), n = at most n (leaves CUs to concurrent streams: A/B knob)
+int v2s_opt_gemm_a4_grid(); // blocks of the persistent a4p kernel: 0 = one per CU (default), n = at most n (leaves CUs to concurrent streams: A/B knob), -1 = the fewest blocks with the same number of rounds
 int v2s_opt_gemm_a4_relu(); // 1 (default): the persistent a4p kernel also takes forward GEMMs with a ReLU (+ dropout) epilogue (the FFN's wi); 0: plain epilogues only
 int v2s_opt_gemm_big();  // 0 = never, 1 = 256x256/256x128 tiles where they pay (default), 2 = 256x128 only, 3 = 4-wave 256x128x32 ring kernel for every variant
 

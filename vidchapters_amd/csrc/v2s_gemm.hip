@@ -2362,8 +2362,12 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
       attr_a4p = true;
     }
     int ncu = num_cus();
-    if (v2s_opt_gemm_a4_grid() > 0 && v2s_opt_gemm_a4_grid() < ncu) ncu = v2s_opt_gemm_a4_grid();
     const int nt = p.tilesM * p.tilesN;
+    if (v2s_opt_gemm_a4_grid() > 0 && v2s_opt_gemm_a4_grid() < ncu) ncu = v2s_opt_gemm_a4_grid();
+    if (v2s_opt_gemm_a4_grid() < 0 && nt > ncu) {       // balanced: the fewest blocks that finish in the same number of rounds (375 tiles: 188 blocks x 2 instead of
+      const int rounds = (nt + ncu - 1) / ncu;          // 119 x 2 + 137 x 1; the other CUs are left to the concurrent streams)
+      ncu = (nt + rounds - 1) / rounds;
+    }
     const dim3 grid((unsigned)(nt < ncu ? nt : ncu)), block(256);
     const int epi = a4p_epilogue(a);
     g_last_gemm = epi == 2 ? "gemm_a4p_kernel<true, 1>" : epi == 3 ? "gemm_a4p_kernel<false, 2>" : epi == 4 ? "gemm_a4p_kernel<false, 3>" :
