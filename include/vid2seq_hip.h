@@ -36,7 +36,7 @@ extern "C" {
  * dropout expects z = the post-dropout activation (round 3 changes that a version-2 caller would corrupt memory with);
  * + v2s_rowsumsq_range / v2s_timetoken_renorm_sq, options gemm_ps / gemm_ps_nst / gemm_w128
  * 4 (round 4): + v2s_decode_qfold / v2s_decode_memattn_plan / v2s_decode_memattn / v2s_decode_ctxfold, v2s_beam_advance (additions only)
- * 5 (round 5): + v2s_sum_n, options gemm_a4 / gemm_a4_grid / gemm_a4_relu (additions only) */
+ * 5 (round 5): + v2s_sum_n, options gemm_a4 / gemm_a4_grid / gemm_a4_relu / gemm_a4_walk (additions only) */
 #define V2S_ABI_VERSION 5
 
 int v2s_version(void);
@@ -64,6 +64,7 @@ const char* v2s_last_error(void);
  *                   epilogue (4 and 5: faster alone, slower inside the train step)
  *   "gemm_a4_grid"  blocks of the persistent form: 0 (default) one per CU, n > 0 at most n, -1 the fewest that need the same number of rounds (A/B knobs: the
  *                   step is work-bound, none of them moves it)
+ *   "gemm_a4_walk"  tile walk of the persistent form: 0 (default) row-major below 16 tile columns, groups of 4 tile rows from there; n > 0: groups of n tile rows
  *   "gemm_a4_relu"  1 (default): the persistent form also takes forward GEMMs with a ReLU or ReLU + dropout epilogue (the FFN's wi: the
  *                   dropout mask of the library's counter-based generator is recomputed inside the kernel's MFMA gaps), 0: plain epilogues only
  *   "gemm_dbg"      profiling ablations of the tiled kernels (results invalid when non-zero): 1 = no global store, 2 = no epilogue, 3 = no hand-off

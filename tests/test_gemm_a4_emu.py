@@ -54,6 +54,25 @@ def test_persistent_deferred_writeout(inc, tb, M, N, K, grid):
         assert E.check_p(inc, tb, M, N, K, grid, lazy_ds=lazy_ds, lazy_dma=lazy_dma, sched=sched) == 0
 
 
+def test_persistent_grouped_tile_walk(inc):
+    """the scalar tile walk of gemm_a4p: groups of GM tile rows walked column by column (GM = 1: row-major); a short last group, a last group of
+    ONE row (no 32-bit division magic for 1) and GM > tile rows; every tile must be visited once: any miss leaves NaNs, any wrong address wrong values"""
+    for GM, (M, N, grid) in zip((2, 4, 3, 8), ((1280, 768, 3), (1280, 768, 2), (1024, 1024, 3), (768, 768, 2))):
+        assert E.check_p(inc, False, M, N, 384, grid, lazy_ds=True, lazy_dma=True, sched="random", GM=GM) == 0
+    # the host-side arithmetic on its own, exhaustively: (tile rows, tile columns, GM) -> a permutation of the tiles
+    for tm in range(1, 24):
+        for tn in (2, 3, 12, 16, 32):
+            for GM in (1, 2, 3, 4, 5, 8, 40):
+                gsz, mg, mm, ml, wk = E.walk_args(tm, tn, GM)
+                seen = set()
+                for t in range(tm * tn):
+                    grp = (t * mg) >> 32; r = t - grp * gsz
+                    gm, m = ((wk >> 8) & 0xFF, ml) if grp == wk >> 16 else (wk & 0xFF, mm)
+                    c = r if gm == 1 else (r * m) >> 32
+                    seen.add((grp * (wk & 0xFF) + r - c * gm, c))
+                assert seen == {(i, j) for i in range(tm) for j in range(tn)}, (tm, tn, GM)
+
+
 def test_persistent_relu_mask_epilogue(inc):
     """gemm_a4p with dact = RELU: the z tile prefetched into the held registers during the tile's third iteration, masked + scaled at the
     conversion (z > 0 incl. -0 and negative z; scale 1 / 0.9); K = 512 is the shortest contraction it takes (T, S, Z and one loop iteration)"""

@@ -510,7 +510,7 @@ def check(inc, tb, M, N, K, tile=(0, 0), seed=1, lazy_ds=True, lazy_dma=True, sc
 
 
 SUB_P = dict(tid="v250", pa0="s8", pa1="s9", pb0="s10", pb1="s11", lda="s12", ldb="s13", pc0="s14", pc1="s15", ldc="s16", cbytes="s17",
-             niter="s18", lds="s19", bid="s20", grid="s21", q="s22", r="s23", magic="s24", tilesn="s25", nmy="s26", mlast="s27", nlast="s28", pz0="s29", pz1="s30", zbytes="s31", scale="s32", hseed="s33", hpp="s34")
+             niter="s18", lds="s19", bid="s20", grid="s21", q="s22", r="s23", magicg="s24", gsz="s25", magicm="s100", magicl="s101", walk="s102", nmy="s26", mlast="s27", nlast="s28", pz0="s29", pz1="s30", zbytes="s31", scale="s32", hseed="s33", hpp="s34")
 
 
 def keep_mask(M, N, seed, p16, row0=0):
@@ -528,7 +528,16 @@ def keep_mask(M, N, seed, p16, row0=0):
     return keep.reshape(M, N)
 
 
-def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="random", verbose=False, dact=False, scale=1.0, epi="", p16=6554, hseed=0x1234567):
+def walk_args(tilesM, tilesN, GM):
+    """scalar arguments of the grouped tile walk (mirrors the host code in v2s_gemm_a4.h): gsz, magic(gsz), magic(GM), magic(gm_last), packed word"""
+    magic = lambda d: (((1 << 32) + d - 1) // d) if d >= 2 else 0
+    GM = max(1, min(GM, tilesM, 255))
+    gm_last = tilesM % GM
+    glast = tilesM // GM if gm_last else 0xFFFF
+    return GM * tilesN, magic(GM * tilesN), magic(GM), magic(gm_last), GM | (gm_last << 8) | (glast << 16)
+
+
+def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="random", verbose=False, dact=False, scale=1.0, epi="", p16=6554, hseed=0x1234567, GM=1):
     """the persistent deferred-write-out kernel: `grid` blocks walk the (M / 256) x (N / 256) tiles; returns the max abs error of the bf16
     output against the fp64 product rounded to bf16 inputs"""
     macros = parse_inc(inc)
@@ -571,7 +580,8 @@ def check_p(inc, tb, M, N, K, grid, seed=1, lazy_ds=True, lazy_dma=True, sched="
             w.s[18], w.s[19] = K // 128, 0
             w.s[20], w.s[21] = bid, grid
             w.s[22], w.s[23] = ntiles >> 3, ntiles & 7
-            w.s[24], w.s[25] = ((1 << 32) + tilesN - 1) // tilesN, tilesN
+            gsz, mg, mm, ml, wk = walk_args(tilesM, tilesN, GM)
+            w.s[24], w.s[25], w.s[100], w.s[101], w.s[102] = mg, gsz, mm, ml, wk
             w.s[26] = (ntiles - bid + grid - 1) // grid
             w.s[27], w.s[28] = M - 256, N - 256
             w.s[29], w.s[30], w.s[31] = PZ & 0xFFFFFFFF, PZ >> 32, M * ldc * 2

@@ -585,9 +585,28 @@ class GenP(Gen):
         e(f"s_min_u32 s{X + 4}, s{X + 1}, %[r]")
         e(f"s_add_u32 s{X + 3}, s{X + 3}, s{X + 4}")
         e(f"s_add_u32 s{X + 3}, s{X + 3}, s{X + 2}")        # logical tile
-        e(f"s_mul_hi_u32 s{X + 5}, s{X + 3}, %[magic]")     # tm = tile / tilesN
-        e(f"s_mul_i32 s{X + 6}, s{X + 5}, %[tilesn]")
-        e(f"s_sub_u32 s{X + 6}, s{X + 3}, s{X + 6}")        # tn
+        # grouped walk: groups of GM tile rows, column by column inside a group (GM = 1: row-major, the walk of the step's shapes, whose W fits
+        # the L2; large N: the ~32 tiles an XCD works on at a time cover GM rows x 32 / GM columns instead of one row x 32 columns).
+        #   grp = tile / (GM * tilesN), r = tile % (GM * tilesN), gm = rows of this group (GM, or the remainder in the last one),
+        #   tn = r / gm, tm = grp * GM + r % gm.   %[walk] = GM | gm_last << 8 | index of a short last group << 16 (0xffff: none)
+        e(f"s_mul_hi_u32 s{X + 5}, s{X + 3}, %[magicg]")    # grp
+        e(f"s_mul_i32 s{X + 6}, s{X + 5}, %[gsz]")
+        e(f"s_sub_u32 s{X + 6}, s{X + 3}, s{X + 6}")        # r
+        e(f"s_and_b32 s{X}, %[walk], 0xff")                 # GM
+        e(f"s_mul_i32 s{X + 7}, s{X + 5}, s{X}")            # first row of the group
+        e(f"s_lshr_b32 s{X + 1}, %[walk], 8")
+        e(f"s_and_b32 s{X + 1}, s{X + 1}, 0xff")            # gm_last
+        e(f"s_lshr_b32 s{X + 2}, %[walk], 16")              # index of the short group
+        e(f"s_cmp_eq_u32 s{X + 5}, s{X + 2}")
+        e(f"s_cselect_b32 s{X}, s{X + 1}, s{X}")            # gm
+        e(f"s_cselect_b32 s{X + 1}, %[magicl], %[magicm]")  # its division magic
+        e(f"s_mul_hi_u32 s{X + 8}, s{X + 6}, s{X + 1}")     # tn = r / gm ...
+        e(f"s_cmp_eq_u32 s{X}, 1")
+        e(f"s_cselect_b32 s{X + 8}, s{X + 6}, s{X + 8}")    # ... (gm = 1: r itself; 2^32 / 1 has no 32-bit magic)
+        e(f"s_mul_i32 s{X + 1}, s{X + 8}, s{X}")
+        e(f"s_sub_u32 s{X + 1}, s{X + 6}, s{X + 1}")        # r % gm
+        e(f"s_add_u32 s{X + 5}, s{X + 7}, s{X + 1}")        # tm
+        e(f"s_mov_b32 s{X + 6}, s{X + 8}")                  # tn
         e(f"s_lshl_b32 s{X + 5}, s{X + 5}, 8")              # m0
         e(f"s_lshl_b32 s{X + 6}, s{X + 6}, 8")              # n0
         # ragged M / N (>= 256): the last tile row / column is shifted up to END at the edge; it overlaps its neighbour, whose rows it

@@ -2369,6 +2369,8 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
       ncu = (nt + rounds - 1) / rounds;
     }
     const dim3 grid((unsigned)(nt < ncu ? nt : ncu)), block(256);
+    // tile walk of the persistent kernel: row-major while W (N x K) stays in an XCD's L2, groups of 4 tile rows beyond (option gemm_a4_walk forces GM)
+    p.order = v2s_opt_gemm_a4_walk() > 0 ? v2s_opt_gemm_a4_walk() : (p.tilesN >= 16 ? 4 : 1);
     const int epi = a4p_epilogue(a);
     g_last_gemm = epi == 2 ? "gemm_a4p_kernel<true, 1>" : epi == 3 ? "gemm_a4p_kernel<false, 2>" : epi == 4 ? "gemm_a4p_kernel<false, 3>" :
                   (a->transB ? "gemm_a4p_kernel<true, 0>" : "gemm_a4p_kernel<false, 0>");

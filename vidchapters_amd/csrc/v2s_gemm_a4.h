@@ -169,7 +169,15 @@ __global__ __launch_bounds__(256, 1) void gemm_a4p_kernel(const GemmP p) {
   const uint32_t ntiles = (uint32_t)(p.tilesM * p.tilesN), tilesn = (uint32_t)p.tilesN;
   const uint32_t bid = blockIdx.x, grid = gridDim.x;
   const uint32_t q = ntiles >> 3, r = ntiles & 7;
-  const uint32_t magic = (uint32_t)(((1ull << 32) + tilesn - 1) / tilesn);
+  // grouped tile walk (generator: tile_setup): GM tile rows per group, column by column inside a group; GM = 1 is the row-major walk
+  const uint32_t tilesm = (uint32_t)p.tilesM;
+  uint32_t GM = (uint32_t)(p.order > 0 ? p.order : 1);
+  if (GM > tilesm) GM = tilesm;
+  if (GM > 255) GM = 255;
+  const uint32_t gm_last = tilesm % GM, glast = gm_last ? tilesm / GM : 0xffffu;
+  const auto magic_of = [](uint32_t d) { return d >= 2 ? (uint32_t)(((1ull << 32) + d - 1) / d) : 0u; };
+  const uint32_t gsz = GM * tilesn, magicg = magic_of(gsz), magicm = magic_of(GM), magicl = magic_of(gm_last);
+  const uint32_t walk = GM | (gm_last << 8) | (glast << 16);
   const uint32_t nmy = (ntiles - bid + grid - 1) / grid;
   const uint32_t mlast = (uint32_t)(p.M - 256), nlast = (uint32_t)(p.N - 256);
   // dropout: element (gm, gn) belongs to chunk ((gm + row0) * N + gn) / 8 of the launch's mask stream (v2s_keep8)
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a4p_kernel(const GemmP p) {
 #define A4P_ARGS                                                                                                                          \
   : [tid] "v"(tid), [pa0] "s"(pa0), [pa1] "s"(pa1), [pb0] "s"(pb0), [pb1] "s"(pb1), [lda] "s"(lda), [ldb] "s"(ldb), [pc0] "s"(pc0),       \
     [pc1] "s"(pc1), [ldc] "s"(ldc), [cbytes] "s"(cbytes), [niter] "s"(niter), [lds] "s"(lds), [bid] "s"(bid), [grid] "s"(grid), [q] "s"(q), \
-    [r] "s"(r), [magic] "s"(magic), [tilesn] "s"(tilesn), [nmy] "s"(nmy), [mlast] "s"(mlast), [nlast] "s"(nlast), [pz0] "s"(pz0),          \
+    [r] "s"(r), [magicg] "s"(magicg), [gsz] "s"(gsz), [magicm] "s"(magicm), [magicl] "s"(magicl), [walk] "s"(walk), [nmy] "s"(nmy), [mlast] "s"(mlast), [nlast] "s"(nlast), [pz0] "s"(pz0),          \
     [pz1] "s"(pz1), [zbytes] "s"(zbytes), [scale] "s"(scale), [hseed] "s"(hseed), [hpp] "s"(hpp)                                           \
   : A4P_CLOBBERS
   if constexpr (EPI == 1) {
