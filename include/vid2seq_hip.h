@@ -36,7 +36,7 @@ extern "C" {
  * dropout expects z = the post-dropout activation (round 3 changes that a version-2 caller would corrupt memory with);
  * + v2s_rowsumsq_range / v2s_timetoken_renorm_sq, options gemm_ps / gemm_ps_nst / gemm_w128
  * 4 (round 4): + v2s_decode_qfold / v2s_decode_memattn_plan / v2s_decode_memattn / v2s_decode_ctxfold, v2s_beam_advance (additions only)
- * 5 (round 5): + v2s_sum_n, options gemm_a4 / gemm_a4_grid / gemm_a4_relu / gemm_a4_walk (additions only) */
+ * 5 (round 5): + v2s_sum_n, v2s_argmax_step_tail, options gemm_a4 / gemm_a4_grid / gemm_a4_relu / gemm_a4_walk (additions only) */
 #define V2S_ABI_VERSION 5
 
 int v2s_version(void);
@@ -381,6 +381,12 @@ int v2s_argmax_step(const float* logits, int64_t ld, int32_t rows, int32_t V, in
 int v2s_argmax_step_seq(const float* logits, int64_t ld, int32_t rows, int32_t V, int64_t* next_tok,
                         int32_t* unfinished, int32_t eos_id, int32_t pad_id, int64_t* seq_out, int64_t seq_ld,
                         const int32_t* pos_dev, void* stream);
+/* the whole tail of a greedy step in one launch (round 5): v2s_argmax_step_seq, then h_out[row, :] = table[token] (bf16 [vocab][d]: the
+ * embedding lookup that opens the NEXT step, modeling_t5.py:968-975 through greedy_search's loop) and, by the last block to finish,
+ * *pos_dev += 1 (what v2s_counter_add does).  ticket: one zero-initialised int32 the call owns between launches. */
+int v2s_argmax_step_tail(const float* logits, int64_t ld, int32_t rows, int32_t V, int64_t* next_tok, int32_t* unfinished,
+                         int32_t eos_id, int32_t pad_id, int64_t* seq_out, int64_t seq_ld, int32_t* pos_dev, const void* table,
+                         void* h_out, int32_t d, int32_t vocab, int32_t* ticket, void* stream);
 /* append new K/V rows ([B][H*64], strided) into the cache at position pos (or *pos_dev when pos_dev != NULL) */
 int v2s_kv_append(const void* src, int64_t src_bs, void* cache, int64_t cache_bs, int64_t cache_rs,
                   int32_t B, int32_t width, int32_t pos, const int32_t* pos_dev, void* stream);

@@ -627,6 +627,27 @@ def test_greedy_beyond_64_rows_vs_oracle():
     assert (small[:, :m] == got[:8, :m]).float().mean().item() > 0.9
 
 
+def test_greedy_fused_tail_equals_separate_launches():
+    """The greedy step's tail as ONE launch (v2s_argmax_step_tail: argmax + the next step's embedding row + the step counter's increment by the
+    last block to finish) against the three launches it replaces: the same tokens, step for step, in the replayed graph and eagerly, incl. rows that
+    finish early (pads after EOS) and the min_length / repetition-penalty processors that run before it; two launches fewer per step."""
+    cfg = R.RefConfig.small()
+    model = build(cfg, 43).eval()
+    eng = model.engine()
+    B = 9
+    b = synth.make_batch(B, cfg.num_features, 24, 12, cfg.vocab, 43, cfg.vit_dim)
+    video, ids = b["video"].to(DEV), tok(b["input_ids"])
+    for kw in (dict(), dict(use_graph=False), dict(min_length=5, repetition_penalty=1.3), dict(stop_at_eos=False)):
+        out, launches = {}, {}
+        for fused in (True, False):
+            eng.decode_fuse_tail = fused
+            out[fused] = eng.greedy(video, ids, max_new_tokens=14, **kw).cpu()
+            launches[fused] = eng.last_decode_launches
+        eng.decode_fuse_tail = True
+        assert torch.equal(out[True], out[False]), kw
+        assert launches[False] - launches[True] == 2, launches
+
+
 def test_fused_lm_head_equals_unfused():
     """Trainer path: LM head + label-smoothed CE + their backward run chunk by chunk inside the forward (Engine.fused_head; no
     [B*Lo, vocab] logits / d(logits) tensor).  Same kernels on row chunks: loss and every gradient must match the unfused head up to

@@ -431,6 +431,60 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   }
 }
 
+// the tail of a greedy decode step as ONE launch: argmax_kernel's work, then the block copies the chosen token's embedding row into the
+// residual-stream buffer the NEXT step starts from (what v2s_embed_fwd would do as the next step's first launch), and the last block to
+// finish advances the device-resident step counter (what v2s_counter_add did as this step's last launch).  Every block reads the counter
+// before it takes its ticket, so the increment cannot overtake a reader.
+__global__ __launch_bounds__(1024) void argmax_tail_kernel(const float* __restrict__ logits, long ld, int V, long* __restrict__ next_tok,
+                                                           int* __restrict__ unfinished, int eos_id, int pad_id, long* __restrict__ seq_out,
+                                                           long seq_ld, int* __restrict__ pos_dev, const bf16_t* __restrict__ table,
+                                                           bf16_t* __restrict__ h_out, int d, int vocab, int* __restrict__ ticket) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  __shared__ long s_tok;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* z = logits + (long)row * ld;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  auto take = [&](float v, int i) { if (v > best || (v == best && i < idx)) { best = v; idx = i; } };
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
+  const int V4 = vec ? (V & ~3) : 0;
+  for (int i = tid * 4; i < V4; i += 4096) {
+    const float4 q = *reinterpret_cast<const float4*>(z + i);
+    take(q.x, i); take(q.y, i + 1); take(q.z, i + 2); take(q.w, i + 3);
+  }
+  for (int i = V4 + tid; i < V; i += 1024) take(z[i], i);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v2 = __shfl_xor(best, o, 64);
+    const int i2 = __shfl_xor(idx, o, 64);
+    take(v2, i2);
+  }
+  if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w) take(bv[w], bi[w]);
+    const int un = unfinished[row];
+    const long tok = un ? (long)idx : (long)pad_id;       // finished rows emit pad
+    next_tok[row] = tok;
+    unfinished[row] = un && (tok != eos_id);
+    seq_out[(long)row * seq_ld + *pos_dev + 1] = tok;
+    s_tok = tok;
+  }
+  __syncthreads();
+  long id = s_tok;
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);       // (the clamp of embed_fwd_kernel)
+  for (int c = tid; c < (d >> 3); c += 1024)
+    *reinterpret_cast<uint4*>(h_out + (long)row * d + c * 8) = *reinterpret_cast<const uint4*>(table + id * d + c * 8);
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+      *ticket = 0;
+      *pos_dev += 1;
+    }
+  }
+}
+
 __global__ void counter_add_kernel(int* ctr, int delta) { *ctr += delta; }
 
 __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict__ src, long src_bs, bf16_t* __restrict__ cache,
@@ -1005,6 +1059,18 @@ extern "C" int v2s_argmax_step_seq(const float* logits, int64_t ld, int32_t rows
   V2S_CHECK(logits && next_tok && unfinished && seq_out && pos_dev && rows > 0 && V > 0, V2S_ERR_ARG, "v2s_argmax_step_seq: bad args");
   hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, (long)ld, V, (long*)next_tok, unfinished,
                      eos_id, pad_id, (long*)seq_out, (long)seq_ld, pos_dev);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_argmax_step_tail(const float* logits, int64_t ld, int32_t rows, int32_t V, int64_t* next_tok, int32_t* unfinished,
+                                    int32_t eos_id, int32_t pad_id, int64_t* seq_out, int64_t seq_ld, int32_t* pos_dev, const void* table,
+                                    void* h_out, int32_t d, int32_t vocab, int32_t* ticket, void* stream) {
+  V2S_CHECK(logits && next_tok && unfinished && seq_out && pos_dev && table && h_out && ticket && rows > 0 && V > 0 && vocab > 0, V2S_ERR_ARG,
+            "v2s_argmax_step_tail: bad args");
+  V2S_CHECK(d > 0 && (d % 8) == 0 && (((uintptr_t)table | (uintptr_t)h_out) & 15) == 0, V2S_ERR_ALIGN, "v2s_argmax_step_tail: d must be a multiple of 8, buffers 16-byte aligned");
+  hipLaunchKernelGGL(argmax_tail_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, (long)ld, V, (long*)next_tok, unfinished,
+                     eos_id, pad_id, (long*)seq_out, (long)seq_ld, pos_dev, (const bf16_t*)table, (bf16_t*)h_out, d, vocab, ticket);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

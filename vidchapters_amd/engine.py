@@ -100,6 +100,7 @@ class Engine:
         self._wgrad_groups: Dict = {}
         self.dmem_parts = 0       # 1: the decoder layers' d(memory) contributions are plain GEMMs into separate slices, summed once (round 5: each GEMM
                                   # 99 -> 71 us alone, +-0 in the step, +650 MB: off); 0: residual chain
+        self.decode_fuse_tail = True  # greedy(): argmax + next embedding + step counter as one launch (v2s_argmax_step_tail)
         self.defer_wgrads = 0     # encoder backward: 1 = the FFN / O weight gradients of a layer are held back until its attention backward is enqueued (they
                                   # then run beside the VALU-bound attention kernels instead of beside the dgrad GEMMs); 2 = the QKV weight gradient too
                                   # (beside the NEXT layer's attention).  _flush_deferred
@@ -1245,9 +1246,17 @@ class Engine:
                 L.rmsnorm_fwd(x, a.f(self._ln("decoder", i, ln_idx)), n, rstd, rows, d, eps)
                 L.gemm(n, a.w(wname, shape), out, rows, shape[0], d, **kw, decode=True)
 
+        # greedy tail as one launch (argmax + the next step's embedding row + the step counter): the step then neither opens with an embedding
+        # launch nor closes with a counter launch; the first step's embedding is looked up once, before the loop
+        fuse_tail = bool(self.decode_fuse_tail) and sample is None
+        ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if fuse_tail:
+            L.embed_fwd(nxt, E, ha, B, d, self.V)
+
         def step():
             h, h2 = ha, hb
-            L.embed_fwd(nxt, E, h, B, d, self.V)
+            if not fuse_tail:
+                L.embed_fwd(nxt, E, h, B, d, self.V)
             for i in range(nl):
                 sa, ca, fp = self._sa("decoder", i), self._ca(i), self._ffp("decoder", i)
                 proj(h, B, "qkv", i, sa + "q.weight", (3 * inner, d), 0, qkv)
@@ -1278,9 +1287,12 @@ class Engine:
                 L.topp_sample_step(logits, self.ldv, B, self.V, sample[0], sample[1], sample[2], nxt, unfinished, eos, c.pad_id,
                                    seq_out=seq, seq_ld=maxlen + 1, pos_dev=pos, min_length=min_length,
                                    top_k=sample[3] if len(sample) > 3 else 0)
+            elif fuse_tail:
+                L.argmax_step_tail(logits, self.ldv, B, self.V, nxt, unfinished, eos, c.pad_id, seq, maxlen + 1, pos, E, ha, d, self.V, ticket)
             else:
                 L.argmax_step_seq(logits, self.ldv, B, self.V, nxt, unfinished, eos, c.pad_id, seq, maxlen + 1, pos)
-            L.counter_add(pos, 1)
+            if not fuse_tail:
+                L.counter_add(pos, 1)
 
         c0 = L.launch_count
         step()                                   # step 0 eagerly (also warms every code path before capture)

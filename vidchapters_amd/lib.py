@@ -103,6 +103,7 @@ SYMBOLS = {
     "v2s_decode_ctxfold": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
     "v2s_argmax_step": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "v2s_argmax_step_seq": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "v2s_argmax_step_tail": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "v2s_kv_append": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "v2s_counter_add": (C.c_int, [_vp, _i32, _vp]),
     "v2s_last_gemm_kernel": (C.c_char_p, []),
@@ -597,6 +598,14 @@ def kv_append(src, src_bs, cache, cache_bs, cache_rs, B, width, pos, pos_dev=Non
 def argmax_step_seq(logits, ld, rows, V, next_tok, unfinished, eos_id, pad_id, seq_out, seq_ld, pos_dev):
     _check(lib().v2s_argmax_step_seq(logits.data_ptr(), ld, rows, V, next_tok.data_ptr(), unfinished.data_ptr(), eos_id, pad_id,
                                      seq_out.data_ptr(), seq_ld, pos_dev.data_ptr(), stream_ptr()), "v2s_argmax_step_seq")
+
+
+def argmax_step_tail(logits, ld, rows, V, next_tok, unfinished, eos_id, pad_id, seq_out, seq_ld, pos_dev, table, h_out, d, vocab, ticket):
+    """argmax_step_seq + the next step's embedding lookup + the step counter's increment as one launch (greedy decode tail)"""
+    _need(table, torch.bfloat16, "embed table"); _need(ticket, torch.int32, "ticket")
+    _check(lib().v2s_argmax_step_tail(logits.data_ptr(), ld, rows, V, next_tok.data_ptr(), unfinished.data_ptr(), eos_id, pad_id,
+                                      seq_out.data_ptr(), seq_ld, pos_dev.data_ptr(), table.data_ptr(), h_out.data_ptr(), d, vocab,
+                                      ticket.data_ptr(), stream_ptr()), "v2s_argmax_step_tail")
 
 
 def counter_add(ctr, delta):
