@@ -829,7 +829,7 @@ def case_shape(v2s, tag, cfg, B, T, L, Lo, seed, check_oracle=True):
     npz(f"{tag}_scalars.npz", **arrs)
 
 
-def case_shape_bf16(tag, cfg, B, T, L, Lo, seed):
+def case_shape_bf16(tag, cfg, B, T, L, Lo, seed, self_threads=3):
     """The same inputs and weights as case_shape, run through the ORACLE in its bf16 mode (oracle/vid2seq_ref.py: a round-to-bf16 wherever
     the HIP engine stores a bf16 tensor, forward and backward; fp32 accumulation): loss, per-tensor gradient norms and the same strided
     gradient samples -> <tag>_bf16mode.npz.  Needs no reference import (the mode is pinned against the fp32 golden of the reference by
@@ -851,12 +851,12 @@ def case_shape_bf16(tag, cfg, B, T, L, Lo, seed):
     arrs["grad_norm"] = tot ** 0.5
     arrs["grad_norm_keys"], arrs["grad_norm_vals"] = np.array(keys), np.array(vals)
     print(f"  loss = {float(out['loss']):.7f}; total grad norm = {tot ** 0.5:.6f}")
-    # SELF-NOISE FLOOR: the same computation with another fp32 summation order (3 BLAS threads instead of all).  At this depth bf16
+    # SELF-NOISE FLOOR: the same computation with another fp32 summation order (`self_threads` BLAS threads instead of all).  At this depth bf16
     # arithmetic is chaotic -- a different rounding of a handful of elements flips ReLU masks and shifts softmax rows downstream -- so two
     # correct implementations of the SAME rounding points decorrelate; the per-tensor cosine between the two runs is what a third correct
     # implementation (the HIP engine) can be expected to reach against either, and what the GPU test holds it to.
     nt = torch.get_num_threads()
-    torch.set_num_threads(3)
+    torch.set_num_threads(self_threads)
     P2 = oracle_params(cfg, seed, grad=True)
     with R.bf16_mode():
         out2, _ = R.vid2seq_forward(P2, cfg, batch["video"], batch["input_ids"], batch["input_ids"] != 0, batch["output_ids"], batch["output_ids"] != 0)
@@ -1020,6 +1020,7 @@ def case_shapes(v2s):
     case_shape_bf16("full_cfg2", R.RefConfig(), B=2, T=100, L=1000, Lo=256, seed=2024)
     large = R.RefConfig(d_model=1024, d_kv=64, heads=16, d_ff=4096, n_enc=24, n_dec=24, num_features=200)
     case_shape(v2s, "large_cfg5", large, B=2, T=200, L=2000, Lo=256, seed=2025)      # ~7 min, ~30 GB of host memory
+    case_shape_bf16("large_cfg5", large, B=2, T=200, L=2000, Lo=256, seed=2025, self_threads=max(4, (os.cpu_count() or 8) // 2 - 1))      # ~5 min
     case_greedy_full(v2s)
     case_beam_full(v2s)
 

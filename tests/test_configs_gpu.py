@@ -93,22 +93,15 @@ def test_cfg2_shape_vs_reference_golden(golden_dir):
     _check_against_shape_golden(g, model, 12, min_cos=0.972, min_cos_1d=0.970, tag="cfg-2 shape")
 
 
-def test_cfg2_shape_vs_bf16_mode_oracle(golden_dir):
-    """The same run against the ORACLE IN ITS BF16 MODE (oracle/vid2seq_ref.py: a round-to-bf16 wherever the engine stores a bf16 tensor,
-    forward and backward, fp32 accumulation; fixture full_cfg2_bf16mode.npz from oracle/make_golden.py --only-bf16-mode).  Against the fp32
-    reference the engine -- like the reference itself under bf16 autocast -- cannot score above ~0.975 on the deepest tensors, so that test
-    cannot tell a 2 % kernel bug from rounding noise; this one reproduces the rounding instead of tolerating it and holds every sampled
-    gradient tensor to a cosine that a wrong kernel would not reach (VERDICT r04 weak #1).  tests/test_oracle_cpu.py pins the mode itself
-    against the fp32 golden."""
-    g = np.load(os.path.join(golden_dir, "full_cfg2_bf16mode.npz"))
-    model = Vid2Seq("t5-base", tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
-                    init_seed=int(g["seed"]), device=DEV).eval()
+def _check_against_bf16_mode_oracle(g, model, tag, loss_rel, min_cos, mean_cos, below_self):
+    """engine vs the fixture of the oracle's bf16 mode: loss, visual tokens, total gradient norm, and per sampled gradient tensor the cosine,
+    which may fall below the oracle's OWN self-noise cosine (fixture keys "sc:") by at most ``below_self``"""
     seed, B, T, Lx, Lo = (int(g[k]) for k in ("seed", "B", "T", "L", "Lo"))
     b = synth.make_batch(B, T, Lx, Lo, 32200, seed, 768)
     out, vd = model(b["video"].to(DEV), tok(b["input_ids"]), tok(b["output_ids"]))
     ref = float(g["loss"])
     rel = abs(out["loss"].item() - ref) / ref
-    print(f"[cfg-2 shape, bf16-mode oracle] loss hip={out['loss'].item():.6f} oracle={ref:.6f} (rel {rel:.1e})")
+    print(f"[{tag}, bf16-mode oracle] loss hip={out['loss'].item():.6f} oracle={ref:.6f} (rel {rel:.1e}; the oracle against itself: {abs(float(g['self_loss']) - ref) / ref:.1e})")
     c = cos(vd["video"].float().cpu()[:, ::max(1, T // 8), :32], torch.from_numpy(g["memory_slice"]))
     print(f"  visual tokens cosine: {c:.6f}")
     out["loss"].backward()
@@ -129,10 +122,23 @@ def test_cfg2_shape_vs_bf16_mode_oracle(golden_dir):
     below = sorted((c_ - float(g["sc:" + n_]), round(c_, 5), round(float(g["sc:" + n_]), 5), n_) for c_, n_ in cs)
     print(f"  engine cosine minus the oracle's self-noise cosine, per tensor: min {below[0][0]:+.4f} ({below[0][3]}), "
           f"median {below[len(below) // 2][0]:+.4f}, max {below[-1][0]:+.4f}")
-    assert rel <= A_BF16MODE_LOSS_REL and c > 0.9999
-    assert cs[0][0] > A_BF16MODE_MIN_COS and sum(c_ for c_, _ in cs) / len(cs) > A_BF16MODE_MEAN_COS, cs[:4]
-    assert below[0][0] > -A_BF16MODE_BELOW_SELF, below[:4]
+    assert rel <= loss_rel and c > 0.9999
+    assert cs[0][0] > min_cos and sum(c_ for c_, _ in cs) / len(cs) > mean_cos, cs[:4]
+    assert below[0][0] > -below_self, below[:4]
     assert abs(tot - float(g["grad_norm"])) <= 1e-2 * float(g["grad_norm"])
+
+
+def test_cfg2_shape_vs_bf16_mode_oracle(golden_dir):
+    """The same run against the ORACLE IN ITS BF16 MODE (oracle/vid2seq_ref.py: a round-to-bf16 wherever the engine stores a bf16 tensor,
+    forward and backward, fp32 accumulation; fixture full_cfg2_bf16mode.npz from oracle/make_golden.py --only-bf16-mode).  Against the fp32
+    reference the engine -- like the reference itself under bf16 autocast -- cannot score above ~0.975 on the deepest tensors, so that test
+    cannot tell a 2 % kernel bug from rounding noise; this one reproduces the rounding instead of tolerating it and holds every sampled
+    gradient tensor to a cosine that a wrong kernel would not reach (VERDICT r04 weak #1).  tests/test_oracle_cpu.py pins the mode itself
+    against the fp32 golden."""
+    g = np.load(os.path.join(golden_dir, "full_cfg2_bf16mode.npz"))
+    model = Vid2Seq("t5-base", tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
+                    init_seed=int(g["seed"]), device=DEV).eval()
+    _check_against_bf16_mode_oracle(g, model, "cfg-2 shape", A_BF16MODE_LOSS_REL, A_BF16MODE_MIN_COS, A_BF16MODE_MEAN_COS, A_BF16MODE_BELOW_SELF)
 
 
 # Thresholds (measured, profiles/r05_bf16mode_parity.txt): loss rel 3.8e-6 (2.7e-5 against the fp32 reference); per-tensor cosine worst 0.986 /
@@ -199,6 +205,18 @@ def test_cfg2_step_is_bit_identical_with_the_relu_dropout_epilogue_on_either_ker
     assert l0 == l1, (l0, l1)
     for k in names:
         assert torch.equal(g0[k], g1[k]), k
+
+
+def test_t5_large_cfg5_shape_vs_bf16_mode_oracle(golden_dir):
+    """cfg-5 (t5-large, 200 frames x 2000 ASR tokens, B = 2) against the oracle's bf16 mode (fixture large_cfg5_bf16mode.npz, written by
+    oracle/make_golden.py:case_shape_bf16 with the self-noise run on half the threads): same bars as at the cfg-2 shape -- every sampled gradient
+    tensor within a measured margin of the oracle's OWN self-noise cosine."""
+    g = np.load(os.path.join(golden_dir, "large_cfg5_bf16mode.npz"))
+    model = Vid2Seq("t5-large", num_features=200, tokenizer=SyntheticTokenizer(32100, 100), vis_drop=0.0, enc_drop=0.0, dec_drop=0.0,
+                    init_seed=int(g["seed"]), device=DEV).eval()
+    # measured (round 5): loss rel 1.5e-5 (the oracle against itself 1.5e-6); worst cosine 0.98622 (the encoder's relative-position bias table), mean 0.99315;
+    # engine minus self-noise cosine: min -0.0113, median -0.0047 (the self-noise run of this fixture used 4 of 8 threads: worst self cosine 0.9937)
+    _check_against_bf16_mode_oracle(g, model, "cfg-5 shape (t5-large)", 1e-4, 0.98, 0.988, 0.016)
 
 
 SLICE_NAMES = ["t5_model.encoder.block.0.layer.0.SelfAttention.q.weight", "t5_model.encoder.block.11.layer.1.DenseReluDense.wi.weight",
