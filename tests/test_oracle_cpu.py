@@ -743,6 +743,25 @@ def test_bf16_mode_of_the_oracle_is_pinned_by_the_fp32_golden(golden_dir):
     assert sum(c for c, _ in cs) / len(cs) >= 0.985
 
 
+def test_bf16_mode_fixture_at_cfg5_is_pinned_by_the_fp32_golden(golden_dir):
+    """the same pin at cfg-5 (t5-large, 200 frames x 2000 tokens, B = 2): large_cfg5_bf16mode.npz against the REFERENCE's fp32 large_cfg5_scalars.npz:
+    loss within 1e-4 (measured 1.1e-5), gradient norm within 1 %, every one of the 271 sampled tensors >= 0.96 (measured worst 0.9678: the encoder's
+    relative-position bias table, the tensor the engine is weakest on too), mean >= 0.985 (0.9911)"""
+    a = np.load(os.path.join(golden_dir, "large_cfg5_scalars.npz"))
+    b = np.load(os.path.join(golden_dir, "large_cfg5_bf16mode.npz"))
+    assert all(int(a[k]) == int(b[k]) for k in ("seed", "B", "T", "L", "Lo")) and int(b["B"]) == 2
+    assert abs(float(a["loss"]) - float(b["loss"])) <= 1e-4 * float(a["loss"])
+    assert abs(float(a["grad_norm"]) - float(b["grad_norm"])) <= 1e-2 * float(a["grad_norm"])
+
+    def cos(x, y):
+        x, y = torch.from_numpy(x).double().flatten(), torch.from_numpy(y).double().flatten()
+        return float(x @ y / (x.norm() * y.norm() + 1e-30))
+    cs = sorted((cos(a[k], b[k]), k) for k in a.files if k.startswith("gs:"))
+    assert len(cs) == 271 and cs[0][0] >= 0.96, cs[:3]
+    assert sum(c for c, _ in cs) / len(cs) >= 0.985
+    assert all(("sc:" + k[3:]) in b.files for _, k in cs)              # the self-noise cosine the GPU test measures the engine against
+
+
 def test_bf16_mode_live_on_the_small_config():
     """the mode's code path on a small model: close to fp32 (it only rounds), different from it (it does round), gradients for every parameter"""
     cfg = R.RefConfig.small()
