@@ -150,13 +150,21 @@ def main():
     if a.warmup:
         log(f"{a.warmup} warmup steps done, loss {float(losses['loss'].item()):.4f}")
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
-    t0 = time.perf_counter()
-    evs[0].record()
-    for i in range(a.steps):
-        losses = trainer.step(batch)
-        evs[i + 1].record()
-    barrier()
-    dt = time.perf_counter() - t0
+    # telemetry of the timed region (rank 0's GPU): average shader clock from two stamps of the hardware counters (two 8-block launches,
+    # ~3 us each, inside the region) and socket power / temperature sampled from sysfs by a host thread -- what tells a slow BOX or a
+    # power-throttled step from a slow kernel (tools/telemetry.py)
+    from tools.telemetry import ClockRegion, Sampler
+    clk = ClockRegion(dev)
+    with Sampler(local) as tele:
+        t0 = time.perf_counter()
+        evs[0].record()
+        clk.begin()
+        for i in range(a.steps):
+            losses = trainer.step(batch)
+            evs[i + 1].record()
+        clk.end()
+        barrier()
+        dt = time.perf_counter() - t0
     step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))      # HIP events on the step's main stream
     med_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     comm_ms = trainer.sync.exposed_ms() if world > 1 else 0.0
@@ -206,7 +214,8 @@ def main():
                                f"{', encoder rows of pad tokens not computed (exact)' if a.packing else ', pad rows computed like the reference'}",
                    "global_batch": world * B, "parallelism": f"dp{world}", "weights": "deterministic synthetic init (no checkpoints offline)"},
         "ms_per_step_hipevent_median": round(med_ms, 3), "samples_per_s_hipevent_median": round(world * B / (med_ms / 1e3), 2),
-        "timing_note": "value = steps / wall time between the two barrier+synchronize brackets (max over ranks); the median is over per-step HIP-event intervals on rank 0",
+        "timing_note": f"value = steps / wall time between the two barrier+synchronize brackets (max over ranks): a {dt:.2f} s region of {a.steps} steps "
+                       f"(the driver passes --steps itself; this script's own default is 60 = 3 s); the median is over per-step HIP-event intervals on rank 0",
         "ms_per_step_hipevent_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
         "repeats": {"regions": len(region_ms), "ms_per_step": [round(x, 3) for x in region_ms],
                     "samples_per_s_min_median_max": [round(world * B / (x / 1e3), 2) for x in (max(region_ms), sorted(region_ms)[len(region_ms) // 2], min(region_ms))],
@@ -217,6 +226,10 @@ def main():
         "achieved_executed_tflops_per_gpu": round(exec_tflop / (ms_per_step / 1e3), 1),
         "frac_of_mfma_peak_whole_step": round(exec_tflop / (ms_per_step / 1e3) / PEAK_BF16_TFLOPS, 4),
     }
+    out["clock_power"] = dict(effective_sclk_mhz=clk.mhz(), sclk_max_mhz=2400, **tele.summary(),
+                              note="timed region 0 on rank 0's GPU.  effective_sclk = shader cycles clocked / wall time (s_memtime vs the 100 MHz "
+                                   "s_memrealtime, per XCD, averaged): the step is power-bound, so a box that sustains a lower clock at the same "
+                                   "socket power is slower by that ratio whatever the kernels do (DESIGN.md 8a-r6)")
 
     if world > 1:
         out["data_parallel"] = {"ranks_seen_by_rccl": dist.get_world_size(), "backend": dist.get_backend(),
@@ -283,6 +296,7 @@ def main():
         ach = work / (ms / 1e3) / 1e12
         out["roofline"] = {"kernel": tag, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "effective_sclk_mhz": out["clock_power"].get("effective_sclk_mhz"), "power_w_avg": out["clock_power"].get("power_w_avg"),
                            "launches_per_step": n, "avg_launch_us": round(ms / n * 1e3, 2),
                            "algorithmic_gflop_per_launch": round(work / n / 1e9, 2),
                            "note": "achieved = sum over the step's launches of this kernel of 2*M*N*K (attention: 4*B*H*Nq*Nk*64 fwd, "

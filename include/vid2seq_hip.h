@@ -36,8 +36,9 @@ extern "C" {
  * dropout expects z = the post-dropout activation (round 3 changes that a version-2 caller would corrupt memory with);
  * + v2s_rowsumsq_range / v2s_timetoken_renorm_sq, options gemm_ps / gemm_ps_nst / gemm_w128
  * 4 (round 4): + v2s_decode_qfold / v2s_decode_memattn_plan / v2s_decode_memattn / v2s_decode_ctxfold, v2s_beam_advance (additions only)
- * 5 (round 5): + v2s_sum_n, v2s_argmax_step_tail, options gemm_a4 / gemm_a4_grid / gemm_a4_relu / gemm_a4_walk (additions only) */
-#define V2S_ABI_VERSION 5
+ * 5 (round 5): + v2s_sum_n, v2s_argmax_step_tail, options gemm_a4 / gemm_a4_grid / gemm_a4_relu / gemm_a4_walk (additions only)
+ * 6 (round 6): + v2s_clock_probe (additions only) */
+#define V2S_ABI_VERSION 6
 
 int v2s_version(void);
 const char* v2s_last_error(void);
@@ -268,6 +269,11 @@ int v2s_add(const void* a, const void* b, void* y, int64_t n, void* stream);
  * decoder layers' cross-attention memory gradients are written by plain GEMMs and summed once (modeling_t5.py:528-536 backward) instead of
  * a chain of residual epilogues. */
 int v2s_sum_n(const void* parts, int64_t stride, int32_t nparts, void* y, int64_t n, void* stream);
+/* Measurement aid, no counterpart in the reference: one wave per XCD writes out[xcd][4] = (shader-clock cycle counter s_memtime, constant
+ * 100 MHz counter s_memrealtime, xcd id, 1) as uint64 (out: 8 x 4 words, zeroed by the caller).  Two probes around a region on the same
+ * stream give the average shader clock it ran at -- (cycles1 - cycles0) / (ticks1 - ticks0) x 100 MHz -- which is what separates a slow
+ * box or a power-throttled step from a slow kernel (bench.py: roofline.effective_sclk_mhz). */
+int v2s_clock_probe(uint64_t* out, void* stream);
 /* out_f32[i mod add_n] += sum over broadcast copies of dy (pos_embed gradient) */
 int v2s_bcast_grad(const void* dy, float* out, int64_t n, int64_t add_n, void* stream);
 

@@ -284,6 +284,26 @@ def causal_ext_mask(mask: torch.Tensor) -> torch.Tensor:
     return (1.0 - keep) * FMIN
 
 
+def t5_self_sublayer(P: Params, p: str, cfg: RefConfig, h: torch.Tensor, bias: torch.Tensor, past=None):
+    """T5LayerSelfAttention, modeling_t5.py:598-626: h + SelfAttention(layer_norm(h)) (dropout 0).  ``p`` = "t5_model.<stack>.block.<i>.layer.".
+    Returns (h', (k, v)).  One sublayer = one unit of the teacher-forced per-layer GPU parity test (tests/test_layers_gpu.py)."""
+    a, kv = t5_attention(P, p + "0.SelfAttention.", cfg, rms_norm(h, P[p + "0.layer_norm.weight"], cfg.rms_eps), bias, past=past)
+    return _ra(h + a), kv                                       # :618
+
+
+def t5_cross_sublayer(P: Params, p: str, cfg: RefConfig, h: torch.Tensor, cbias: torch.Tensor, memory: torch.Tensor, past=None):
+    """T5LayerCrossAttention, modeling_t5.py:629-667: h + EncDecAttention(layer_norm(h), memory)."""
+    c, kv = t5_attention(P, p + "1.EncDecAttention.", cfg, rms_norm(h, P[p + "1.layer_norm.weight"], cfg.rms_eps), cbias,
+                         kv_src=memory, past=past, cross=True)
+    return _ra(h + c), kv
+
+
+def t5_ff_sublayer(P: Params, p: str, j: int, cfg: RefConfig, h: torch.Tensor) -> torch.Tensor:
+    """T5LayerFF with T5DenseActDense (ReLU), modeling_t5.py:304-311,338-354: h + wo(relu(wi(layer_norm(h)))).  ``j`` = 1 (encoder) / 2 (decoder)."""
+    n = rms_norm(h, P[p + f"{j}.layer_norm.weight"], cfg.rms_eps)
+    return _ra(h + _ra(torch.relu(n @ _rf(P[p + f"{j}.DenseReluDense.wi.weight"]).T)) @ _rf(P[p + f"{j}.DenseReluDense.wo.weight"]).T)
+
+
 def t5_encoder(P: Params, cfg: RefConfig, embeds: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """modeling_t5.py:930-1138 with is_decoder=False, dropout 0 (T5Stack.forward)."""
     h = embeds
@@ -292,10 +312,8 @@ def t5_encoder(P: Params, cfg: RefConfig, embeds: torch.Tensor, mask: torch.Tens
     bias = position_bias(tab, L, L, True, cfg.buckets, cfg.max_distance) + ext_mask(mask)
     for i in range(cfg.n_enc):
         p = f"t5_model.encoder.block.{i}.layer."
-        a, _ = t5_attention(P, p + "0.SelfAttention.", cfg, rms_norm(h, P[p + "0.layer_norm.weight"], cfg.rms_eps), bias)
-        h = _ra(h + a)                                          # :618
-        n = rms_norm(h, P[p + "1.layer_norm.weight"], cfg.rms_eps)
-        h = _ra(h + _ra(torch.relu(n @ _rf(P[p + "1.DenseReluDense.wi.weight"]).T)) @ _rf(P[p + "1.DenseReluDense.wo.weight"]).T)
+        h, _ = t5_self_sublayer(P, p, cfg, h, bias)
+        h = t5_ff_sublayer(P, p, 1, cfg, h)
     return rms_norm(h, P["t5_model.encoder.final_layer_norm.weight"], cfg.rms_eps)
 
 
@@ -321,16 +339,9 @@ def t5_decoder(P: Params, cfg: RefConfig, dec_ids: torch.Tensor, dec_mask: torch
     for i in range(cfg.n_dec):
         p = f"t5_model.decoder.block.{i}.layer."
         pl = past[i] if past is not None else None
-        a, skv = t5_attention(P, p + "0.SelfAttention.", cfg,
-                              rms_norm(h, P[p + "0.layer_norm.weight"], cfg.rms_eps), sbias,
-                              past=(pl[0], pl[1]) if pl is not None else None)
-        h = _ra(h + a)
-        c, ckv = t5_attention(P, p + "1.EncDecAttention.", cfg,
-                              rms_norm(h, P[p + "1.layer_norm.weight"], cfg.rms_eps), cbias,
-                              kv_src=memory, past=(pl[2], pl[3]) if pl is not None else None, cross=True)
-        h = _ra(h + c)
-        n = rms_norm(h, P[p + "2.layer_norm.weight"], cfg.rms_eps)
-        h = _ra(h + _ra(torch.relu(n @ _rf(P[p + "2.DenseReluDense.wi.weight"]).T)) @ _rf(P[p + "2.DenseReluDense.wo.weight"]).T)
+        h, skv = t5_self_sublayer(P, p, cfg, h, sbias, past=(pl[0], pl[1]) if pl is not None else None)
+        h, ckv = t5_cross_sublayer(P, p, cfg, h, cbias, memory, past=(pl[2], pl[3]) if pl is not None else None)
+        h = t5_ff_sublayer(P, p, 2, cfg, h)
         if use_cache:
             present.append((skv[0], skv[1], ckv[0], ckv[1]))
     h = rms_norm(h, P["t5_model.decoder.final_layer_norm.weight"], cfg.rms_eps)
@@ -366,28 +377,33 @@ def smoothed_ce(logits: torch.Tensor, labels: torch.Tensor, eps: float) -> torch
 # ----------------------------------------------------------------------------------------------
 # temporal ViT
 # ----------------------------------------------------------------------------------------------
+def vit_block(P: Params, p: str, cfg: RefConfig, x: torch.Tensor) -> torch.Tensor:
+    """model/vit.py:73-76 (Block.forward) with Attention :38-55 and Mlp :16-22, dropout 0.  ``p`` = "visual_encoder.blocks.<i>."."""
+    B, N, C = x.shape
+    H = cfg.vit_heads
+    scale = (C // H) ** -0.5
+    n = _ra(F.layer_norm(x, (C,), P[p + "norm1.weight"], P[p + "norm1.bias"], cfg.ln_eps))
+    qkv = _ra(n @ _rf(P[p + "attn.qkv.weight"]).T + P[p + "attn.qkv.bias"]).reshape(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
+    if BF16_MODE:
+        o = _AttnCoreBf16.apply(qkv[0], qkv[1], qkv[2], torch.zeros(1, 1, 1, 1), scale).transpose(1, 2).reshape(B, N, C)
+    else:
+        att = torch.softmax((qkv[0] @ qkv[1].transpose(-1, -2)) * scale, dim=-1)
+        o = (att @ qkv[2]).transpose(1, 2).reshape(B, N, C)
+    x = _ra(x + (o @ _rf(P[p + "attn.proj.weight"]).T + P[p + "attn.proj.bias"]))
+    n = _ra(F.layer_norm(x, (C,), P[p + "norm2.weight"], P[p + "norm2.bias"], cfg.ln_eps))
+    hdn = _ra(F.gelu(n @ _rf(P[p + "mlp.fc1.weight"]).T + P[p + "mlp.fc1.bias"]))
+    return _ra(x + (hdn @ _rf(P[p + "mlp.fc2.weight"]).T + P[p + "mlp.fc2.bias"]))
+
+
 def vit_forward(P: Params, cfg: RefConfig, x: torch.Tensor) -> torch.Tensor:
     """model/vit.py:117-133 (+ Block :73-76, Attention :38-55, Mlp :16-22), dropout 0."""
     pos = P["visual_encoder.pos_embed"]
     if x.shape[1] != pos.shape[1]:                               # :119-123 nearest resize
         pos = F.interpolate(pos.transpose(1, 2), size=x.shape[1], mode="nearest").transpose(1, 2)
     x = _ra(_rf(x) + _rf(pos))
-    B, N, C = x.shape
-    H = cfg.vit_heads
-    scale = (C // H) ** -0.5
     for i in range(cfg.vit_depth):
-        p = f"visual_encoder.blocks.{i}."
-        n = _ra(F.layer_norm(x, (C,), P[p + "norm1.weight"], P[p + "norm1.bias"], cfg.ln_eps))
-        qkv = _ra(n @ _rf(P[p + "attn.qkv.weight"]).T + P[p + "attn.qkv.bias"]).reshape(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
-        if BF16_MODE:
-            o = _AttnCoreBf16.apply(qkv[0], qkv[1], qkv[2], torch.zeros(1, 1, 1, 1), scale).transpose(1, 2).reshape(B, N, C)
-        else:
-            att = torch.softmax((qkv[0] @ qkv[1].transpose(-1, -2)) * scale, dim=-1)
-            o = (att @ qkv[2]).transpose(1, 2).reshape(B, N, C)
-        x = _ra(x + (o @ _rf(P[p + "attn.proj.weight"]).T + P[p + "attn.proj.bias"]))
-        n = _ra(F.layer_norm(x, (C,), P[p + "norm2.weight"], P[p + "norm2.bias"], cfg.ln_eps))
-        hdn = _ra(F.gelu(n @ _rf(P[p + "mlp.fc1.weight"]).T + P[p + "mlp.fc1.bias"]))
-        x = _ra(x + (hdn @ _rf(P[p + "mlp.fc2.weight"]).T + P[p + "mlp.fc2.bias"]))
+        x = vit_block(P, f"visual_encoder.blocks.{i}.", cfg, x)
+    C = x.shape[-1]
     return _ra(F.layer_norm(x, (C,), P["visual_encoder.norm.weight"], P["visual_encoder.norm.bias"], cfg.ln_eps))
 
 

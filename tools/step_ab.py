@@ -45,17 +45,20 @@ for s in a.settings:
     apply(s); tr.step(batch)
 torch.cuda.synchronize()
 times = {s: [] for s in a.settings}
+clk = {s: [] for s in a.settings}     # effective shader clock of each timed block (v2s_clock_probe: s_memtime cycles / 100 MHz ticks)
 for i in range(a.steps):
     for s in a.settings:
         apply(s)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        p0 = torch.zeros(8, 4, dtype=torch.int64, device=dev); p1 = torch.zeros(8, 4, dtype=torch.int64, device=dev)
+        e0.record(); L.clock_probe(p0)
         for _ in range(a.block):
             tr.step(batch)
-        e1.record(); torch.cuda.synchronize()
+        L.clock_probe(p1); e1.record(); torch.cuda.synchronize()
         times[s].append(e0.elapsed_time(e1) / a.block)
+        clk[s].append(L.effective_sclk_mhz(p0.cpu(), p1.cpu()) or 0.0)
 for s in a.settings:
     med = statistics.median(times[s])
-    print(f"{s:40s} median {med:7.2f} ms  min {min(times[s]):7.2f}  -> {32 / med * 1e3:6.1f} samples/s")
+    print(f"{s:40s} median {med:7.2f} ms  min {min(times[s]):7.2f}  -> {32 / med * 1e3:6.1f} samples/s   sclk {statistics.median(clk[s]):6.0f} MHz")
 for k, v in defaults.items():
     L.set_option(k, v)

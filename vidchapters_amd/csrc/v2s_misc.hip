@@ -228,6 +228,17 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
   }
 }
 
+// Measurement aid (bench.py `roofline.effective_sclk_mhz`): one wave per XCD stamps the shader-clock cycle counter (s_memtime: ticks at the
+// CURRENT shader clock, so it slows down when the chip clocks down to its power budget) beside the constant 100 MHz counter
+// (s_memrealtime).  Two probes around a region give the average shader clock the region ran at: d(cycles) / d(ticks) x 100 MHz.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;     // HW_REG_XCC_ID[3:0]
+  const unsigned long long cyc = __builtin_amdgcn_s_memtime();
+  const unsigned long long tick = __builtin_amdgcn_s_memrealtime();
+  out[xcc * 4 + 0] = cyc; out[xcc * 4 + 1] = tick; out[xcc * 4 + 2] = xcc; out[xcc * 4 + 3] = 1;
+}
+
 }  // namespace
 
 extern "C" int v2s_embed_fwd(const int64_t* ids, const void* table, void* out, int64_t n, int32_t d, int32_t vocab,
@@ -316,6 +327,13 @@ extern "C" int v2s_ce_bwd(const float* logits, int64_t ld, const int64_t* labels
   else
     hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, (const long*)labels, row_lse,
                        V, eps, gscale, (bf16_t*)dlogits, (long)ldd);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_clock_probe(uint64_t* out, void* stream) {
+  V2S_CHECK(out != nullptr, V2S_ERR_ARG, "v2s_clock_probe: out is NULL");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(8), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out);
   V2S_LAUNCH_CHECK();
   return V2S_OK;
 }

@@ -58,7 +58,7 @@ class DecodeAttnArgs(C.Structure):
                 ("kv_group", _i32), ("new_k", _vp), ("new_v", _vp), ("new_bs", _i64), ("row_map", _vp), ("row_map_ld", _i64)]
 
 
-ABI_VERSION = 5   # V2S_ABI_VERSION this binding was written against (include/vid2seq_hip.h)
+ABI_VERSION = 6   # V2S_ABI_VERSION this binding was written against (include/vid2seq_hip.h)
 
 #: every symbol include/vid2seq_hip.h declares (checked by tests/test_oracle_cpu.py::test_c_abi_exports_every_declared_symbol)
 SYMBOLS = {
@@ -87,6 +87,7 @@ SYMBOLS = {
     "v2s_dropout": (C.c_int, [_vp, _vp, _i64, _f32, _u32, _vp]),
     "v2s_add": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "v2s_sum_n": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
+    "v2s_clock_probe": (C.c_int, [_vp, _vp]),
     "v2s_bcast_grad": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "v2s_ce_fwd": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "v2s_ce_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _i64, _vp]),
@@ -466,6 +467,20 @@ def add(a, b, y, n):
 def sum_n(parts, stride, nparts, y, n):
     """y[n] = sum_p parts[p * stride + :n] (bf16 in / out, fp32 sum)"""
     _check(lib().v2s_sum_n(parts.data_ptr(), stride, nparts, y.data_ptr(), n, stream_ptr()), "v2s_sum_n")
+
+
+def clock_probe(out):
+    """out: int64 [8, 4] (zeroed) <- per XCD (shader-clock cycles, 100 MHz ticks, xcd id, 1) at the point of the current stream"""
+    _check(lib().v2s_clock_probe(out.data_ptr(), stream_ptr()), "v2s_clock_probe")
+
+
+def effective_sclk_mhz(p0, p1):
+    """average shader clock (MHz) between two clock_probe() results (host tensors / arrays [8, 4]); None if no XCD reported both times"""
+    vals = []
+    for a, b in zip(p0.tolist(), p1.tolist()):
+        if a[3] == 1 and b[3] == 1 and b[1] > a[1]:
+            vals.append((b[0] - a[0]) / (b[1] - a[1]) * 100.0)
+    return sum(vals) / len(vals) if vals else None
 
 
 def dropout(x, y, n, p, seed):
