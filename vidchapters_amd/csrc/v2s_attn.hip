@@ -42,6 +42,26 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float MASKED2 = -3.0e38f;     // finite stand-in for finfo(float32).min in the log2 domain
 constexpr float REAL_MIN = -1.0e37f;    // running max above this <=> the row has seen an unmasked key
 constexpr int HD = 64;
+// blocks per CU the two backward kernels are compiled for (register budget 512 / (2 * blocks) per lane) -- an experiment knob
+// (tools/build_attn_variants.sh): 3 needs <= 168 registers and the two-copy bias window
+#ifndef ATTN_BWD_OCC
+#define ATTN_BWD_OCC 2
+#endif
+#ifndef ATTN_DKV_KBW
+#define ATTN_DKV_KBW 2
+#endif
+#ifndef ATTN_DKV_OCC
+#define ATTN_DKV_OCC ATTN_BWD_OCC
+#endif
+#ifndef ATTN_ABL
+#define ATTN_ABL 0
+#endif
+#ifndef ATTN_DKV_PREF
+#define ATTN_DKV_PREF 1
+#endif
+#ifndef ATTN_PRIO
+#define ATTN_PRIO 0
+#endif
 
 struct AttnP {
   int B, H, Nq, Nk;
@@ -181,6 +201,23 @@ __device__ __forceinline__ void mfma_settle(f32x4& a0, f32x4& a1, f32x4& a2, f32
   asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
 }
 
+__device__ __forceinline__ void mfma_settle4(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3) {
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+}
+
+// wave priority: the wave that is in an MFMA phase (latency-bound: LDS fragment reads -> MFMA) is preferred by the issue arbiter over a wave of
+// another block that is in its long VALU phase (ATTN_PRIO experiment)
+__device__ __forceinline__ void prio_hi() {
+#if ATTN_PRIO
+  __builtin_amdgcn_s_setprio(ATTN_PRIO);
+#endif
+}
+__device__ __forceinline__ void prio_lo() {
+#if ATTN_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // ---- attention-probability dropout ------------------------------------------------------------------------
 // One 32-bit hash serves the key pair (2j, 2j+1) of a row:
 //     h(row, j) = mul24( (rowseed(b,h,q) ^ pairhash(j)) & 0xFFFFFF, C2 )        (low 32 bits of the 24 x 24 bit product)
@@ -243,12 +280,14 @@ __device__ __forceinline__ f32x4 bias_read4(const char* win, int CS, int i0) {
   }
 }
 // window entry i <-> relative position d = i + dbase; value = bias_diag[h][d + Nq - 1] * mul (0 outside the table)
-template <int NC>
+// REV: the window is stored mirrored (entry i holds relative position (WL - 1 - i) + dbase), so that a lane whose four elements sit at
+// DEcreasing relative positions (the dK/dV kernel: four consecutive query rows of one key) reads them in order with one aligned read
+template <int NC, bool REV = false>
 __device__ __forceinline__ void bias_stage(char* win, int CS, int WL, int dbase, const float* __restrict__ diag_h, int ndiag, int nq, float mul,
                                            int tid) {
   float* b = reinterpret_cast<float*>(win);
   for (int i = tid; i < WL; i += 256) {
-    const int gi = i + dbase + nq - 1;
+    const int gi = (REV ? WL - 1 - i : i) + dbase + nq - 1;
     const float w = (gi >= 0 && gi < ndiag) ? diag_h[gi] * mul : 0.f;
 #pragma unroll
     for (int s = 0; s < NC; ++s)
@@ -518,7 +557,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p, float* _
 // statistics the dK/dV kernel needs (p.rowstat), so v2s_attn_bwd launches the dK/dV kernel AFTER this one.
 // LDS: [2 x (K tile | V tile)] [bias-gradient window: (Nk + 128) x 8 bytes] [bias window] [key flags] [tile states]
 template <bool TR, bool BIAS, bool CAUSAL, bool DROP, int NC>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, ATTN_BWD_OCC) void attn_bwd_dq_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // scalar: the per-block bias-gradient routing below branches on it
@@ -561,6 +600,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 
   bf16x8 qf[2][2], dof[2][2];
   float m2[2], xmask[2], dl[2];
+  const float lg2ik = DROP ? __log2f(p.inv_keep) : 0.f, rik = DROP ? 1.0f / p.inv_keep : 1.0f;
   uint32_t rowseed[2] = {0u, 0u};
   bool rows_real = true;
 #pragma unroll
@@ -597,7 +637,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
       m2[qb] = real ? mm + l2 : 0.f;
       xmask[qb] = real ? -3.0e38f : -l2;
       dl[qb] = dsum;
-      if (g == 0) *reinterpret_cast<float4*>(p.rowstat + r * 4) = make_float4(-m2[qb], xmask[qb], -dsum, __uint_as_float(rs24));
+      // for the dK/dV kernel, with the keep scale 1/(1-p) folded in: it evaluates P' = exp2(x + log2 ik) = ik * P directly (kept elements of
+      // Pd = P', no multiply) and dS = Pd * dP - P' * (delta / ik)
+      if (g == 0) *reinterpret_cast<float4*>(p.rowstat + r * 4) = make_float4(-m2[qb] + lg2ik, real ? xmask[qb] : xmask[qb] + lg2ik, -dsum * rik,
+                                                                              __uint_as_float(rs24));
     }
     rows_real = rows_real && real;
     rowseed[qb] = rs24 ^ ((uint32_t)(2 * g) * DROP_C1);
@@ -649,6 +692,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
           st[qb][kb] = BIAS ? bias_read4<NC>(s_bias, CS, k0 + kb * 16 + bidx0 - qb * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
           dp[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+      prio_hi();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -663,6 +707,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
         }
       mfma_settle(st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1], st[1][2], st[1][3]);
       mfma_settle(dp[0][0], dp[0][1], dp[0][2], dp[0][3], dp[1][0], dp[1][1], dp[1][2], dp[1][3]);
+      prio_lo();
       const bool clean = !any_flag && !edge;
       // bias-gradient routing (after the dS of the whole tile are formed, below): relative positions d = k - q of a 16x16 block
       // (qb, kb) span a 31-wide range; blocks entirely in a far bucket just sum their dS (1: far-low, 2: far-high), only the
@@ -755,6 +800,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
         dsf[qb][1] = __builtin_bit_cast(bf16x8, make_uint4(cvt_pk(st[qb][2][0], st[qb][2][1]), cvt_pk(st[qb][2][2], st[qb][2][3]),
                                                              cvt_pk(st[qb][3][0], st[qb][3][1]), cvt_pk(st[qb][3][2], st[qb][3][3])));
       }
+      prio_hi();
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -763,6 +809,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
           for (int qb = 0; qb < 2; ++qb) dqt[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qb][kh], dqt[qb][db], 0, 0, 0);
         }
+      prio_lo();
     }
     if (t + 1 < ntiles) {
       char* nx = smem + ((t + 1) & 1) * STAGE2;
@@ -806,19 +853,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnP p) {
 }
 
 // ====================================================================================== backward: dK, dV
-// wave = 32 keys (2 key blocks), block = 128 keys, loop over 64-query tiles (Q and dO tiles in LDS).
+// wave = 16 * KBW keys (KBW key blocks), block = 64 * KBW keys, loop over 64-query tiles (Q and dO tiles in LDS).  KBW = 2: 224 registers,
+// two blocks per CU; KBW = 1: half the accumulators / K, V fragments / score registers per wave -> three waves per SIMD, twice the LDS
+// fragment reads and Q / dO tile traffic per MFMA (round 6, ATTN_DKV_KBW).
 // LDS: [2 x (Q tile | dO tile | row statistics 4 x 64 floats | state)] [bias window]
 constexpr int DKV_MS = STAGE2;                   // -(m + log2 l)[64], masked-element exponent[64], -delta[64], dropout row seed[64]
 constexpr int DKV_STATE = DKV_MS + 4 * 64 * 4;   // int: every row of the tile has real statistics
 constexpr int DKV_STAGE = DKV_STATE + 16;
+constexpr int KBW = ATTN_DKV_KBW, DKV_BK = 64 * KBW;
+// key of (key block kb, lane column li) inside the wave's 16 * KBW keys.  KBW = 2: the two key blocks hold the EVEN and the ODD key of the
+// pairs (2 li, 2 li + 1), so that ONE dropout hash per query row serves both of a lane's elements of that row (its low / high 16-bit draw:
+// drop_dropmask32, the same evaluation as the dQ kernel) instead of one hash, one shift and one compare per element (round 6: the mask
+// was 40 of the 64 VALU instructions per 16 x 32 block of this kernel)
+__device__ __forceinline__ int dkv_key(int kb, int li) { return KBW == 2 ? 2 * li + kb : kb * 16 + li; }
 template <bool TR, bool BIAS, bool CAUSAL, bool DROP, int NC>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int nkb = (p.Nk + 127) >> 7;
+  const int nkb = (p.Nk + DKV_BK - 1) / DKV_BK;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int kblk = id % nkb, bh = id / nkb, h = bh % p.H, b = bh / p.H;
-  const int K0 = kblk * 128, wk0 = wave * 32;
+  const int K0 = kblk * DKV_BK, wk0 = wave * 16 * KBW;
   const int row0_ = p.seq_off ? p.seq_off[b] : 0;
   const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq;
   const int* kso_ = p.kv_seq_off ? p.kv_seq_off : ((p.seq_off && !p.seq_q_only) ? p.seq_off : nullptr);     // row offsets of the key side
@@ -826,7 +881,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   if (K0 >= nk_) return;
 
   const int len64 = (p.Nq + 63) & ~63;
-  const int CS = BIAS ? bias_cs(len64) : 0;
+  const int CS = BIAS ? bias_cs(len64 + DKV_BK - 128) : 0;
   char* s_bias = smem + 2 * DKV_STAGE;
 
   const bf16_t* qp = p.q + (p.seq_off ? (long)row0_ * p.q_rs : (long)b * p.q_bs) + h * HD;
@@ -844,11 +899,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   float4 rstat = make_float4(-1.0e30f, -3.0e38f, 0.f, 0.f);
   if (tid < 64 && tid < nq_) rstat = *reinterpret_cast<const float4*>(rsp + (long)tid * 4);
 
-  bf16x8 kf[2][2], vf[2][2];
-  uint32_t kflag[2], kc[2], cmul[2];
+  bf16x8 kf[KBW][2], vf[KBW][2];
+  uint32_t kflag[KBW], kc[KBW], cmul[KBW];
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int k = K0 + wk0 + kb * 16 + li;
+  for (int kb = 0; kb < KBW; ++kb) {
+    const int k = K0 + wk0 + dkv_key(kb, li);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       uint4 a = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
@@ -863,25 +918,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     kc[kb] = drop_pairhash((uint32_t)k >> 1);
     cmul[kb] = (k & 1) ? 0u : 16u;                       // shift that moves this key's 16-bit half of the pair hash into the top half
   }
-  const bool keys_clean = __all(kflag[0] == 0u && kflag[1] == 0u);
-  const int kmin = K0 + wk0, kmax = kmin + 31;
-  f32x4 dkt[2][4], dvt[2][4];
+  const bool keys_clean = __all(kflag[0] == 0u && kflag[KBW - 1] == 0u);
+  const int kmin = K0 + wk0, kmax = kmin + 16 * KBW - 1;
+  f32x4 dkt[KBW][4], dvt[KBW][4];
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
+  for (int kb = 0; kb < KBW; ++kb)
 #pragma unroll
     for (int db = 0; db < 4; ++db) { dkt[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[kb][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   // bias window of this key block: entry i <-> relative position d = i + (K0 - len64 + 1)  (q < len64, k - K0 in [0, 128))
-  if (BIAS) bias_stage<NC>(s_bias, CS, len64 + 128, K0 - len64 + 1, p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
+  if (BIAS) bias_stage<NC, true>(s_bias, CS, len64 + DKV_BK, K0 - len64 + 1, p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
 
   const int ntiles = (nq_ + 63) >> 6;
   const float sc2 = p.scale * LOG2E;
   const f32x2 sc22 = {sc2, sc2};
   const float ik = DROP ? p.inv_keep : 1.0f;
   const f32x2 ik2 = {ik, ik};
-  // window index of element (q, k): (k - q) - (K0 - len64 + 1); a lane's four rows r = 0..3 of a block sit at DEcreasing indices
-  // i0 - r, read as one aligned float4 at i0 - 3
-  const int bidx0 = wk0 + li + len64 - 1 - 4 * g - 3;
+  // window index of element (q, k): (k - q) - (K0 - len64 + 1) = i0 - r for a lane's four rows r = 0..3 of a block; the window is stored
+  // MIRRORED (entry WL - 1 - i), so they are the four consecutive floats from WL - 1 - i0 on
+  const int bidx0 = (len64 + DKV_BK - 1) - (wk0 + len64 - 1 - 4 * g);
 
   auto commit = [&](int s) {
     char* st = smem + s * DKV_STAGE;
@@ -898,13 +953,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
   commit(0);
   __syncthreads();
 
-  const bool keys_all_masked = __all(kflag[0] != 0u && kflag[1] != 0u);
+  const bool keys_all_masked = __all(kflag[0] != 0u && kflag[KBW - 1] != 0u);
   for (int t = 0; t < ntiles; ++t) {
     const char* sQ = smem + (t & 1) * DKV_STAGE;
     const char* sDO = sQ + KV_TILE;
     const float* ms = reinterpret_cast<const float*>(sQ + DKV_MS);
     const int q0 = t * 64;
-    if (t + 1 < ntiles) {
+    if (t + 1 < ntiles && !(ATTN_ABL == 2 && t > 0)) {
       qvoff += 2 * qstep32; dovoff += 2 * dostep32;
       tile_load(qrs, qvoff, qstep32, rq);
       tile_load(dors, dovoff, dostep32, rdo);
@@ -920,19 +975,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 
     if (!skip) {
       const bool clean = keys_clean && !edge && (q0 + 63 < nq_);
-      // two halves of 32 query rows each (keeps the live score registers at 2x2 fragments)
-#pragma unroll
-      for (int qh = 0; qh < 2; ++qh) {
-        // S[q][key] and dP[q][key]:  D[row = q = qb*16 + 4g + r][col = key = kb*16 + li]; score accumulators start from bias / scale
-        f32x4 st[2][2], dp[2][2];
+      // two halves of 32 query rows each (keeps the live score registers at 2 x KBW fragments per half)
+      // S[q][key] and dP[q][key]:  D[row = q = qb*16 + 4g + r][col = key = kb*16 + li]; score accumulators start from bias / scale
+      auto scores = [&](const int qh, f32x4 (&st)[2][KBW], f32x4 (&dp)[2][KBW]) {
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
+          for (int kb = 0; kb < KBW; ++kb) {
             f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
             if (BIAS) {
-              const f32x4 bw = bias_read4<NC>(s_bias, CS, kb * 16 + bidx0 - q0 - (2 * qh + qi) * 16);
-              init = f32x4{bw[3], bw[2], bw[1], bw[0]};
+              init = bias_read4<NC>(s_bias, CS, bidx0 - dkv_key(kb, li) + q0 + (2 * qh + qi) * 16);
             }
             st[qi][kb] = init; dp[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
           }
@@ -943,33 +995,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
             const bf16x8 qfr = row_frag(sQ, (2 * qh + qi) * 16, ks, lane);
             const bf16x8 dfr = row_frag(sDO, (2 * qh + qi) * 16, ks, lane);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < KBW; ++kb) {
+#if ATTN_ABL == 4       // ablation: no MFMA (the fragments still count as used), results invalid
+              st[qi][kb][0] += __builtin_bit_cast(f32x4, qfr)[ks]; dp[qi][kb][0] += __builtin_bit_cast(f32x4, dfr)[ks];
+#else
               st[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kb][ks], st[qi][kb], 0, 0, 0);
               dp[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[kb][ks], dp[qi][kb], 0, 0, 0);
+#endif
             }
           }
-        mfma_settle(st[0][0], st[0][1], st[1][0], st[1][1], dp[0][0], dp[0][1], dp[1][0], dp[1][1]);
-        // P (dropped) -> dp registers become Pd ; st registers become dS
+      };
+      // P (dropped) -> dp registers become Pd ; st registers become dS ; packed to the B operands of the second products
+      auto softmax_ds = [&](const int qh, f32x4 (&st)[2][KBW], f32x4 (&dp)[2][KBW], bf16x8 (&pdf)[KBW], bf16x8 (&dsf)[KBW]) {
+        if (KBW == 2) mfma_settle(st[0][0], st[0][KBW - 1], st[1][0], st[1][KBW - 1], dp[0][0], dp[0][KBW - 1], dp[1][0], dp[1][KBW - 1]);
+        else mfma_settle4(st[0][0], st[1][0], dp[0][0], dp[1][0]);
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
+        for (int qi = 0; qi < (ATTN_ABL == 3 ? 0 : 2); ++qi) {      // (ablation 3: no softmax / dS arithmetic, results invalid)
           const int qb = 2 * qh + qi;
-          const f32x4 nm4 = *reinterpret_cast<const f32x4*>(ms + qb * 16 + 4 * g);          // -(m + log2 l) of rows r = 0..3
+          const f32x4 nm4 = *reinterpret_cast<const f32x4*>(ms + qb * 16 + 4 * g);          // -(m + log2 l) + log2 ik of rows r = 0..3
           const f32x4 lv = *reinterpret_cast<const f32x4*>(ms + 64 + qb * 16 + 4 * g);      // exponent of a masked element
-          const f32x4 nd4 = *reinterpret_cast<const f32x4*>(ms + 128 + qb * 16 + 4 * g);    // -delta
+          const f32x4 nd4 = *reinterpret_cast<const f32x4*>(ms + 128 + qb * 16 + 4 * g);    // -delta / ik
           u32x4 sd4 = u32x4{0u, 0u, 0u, 0u};
           if (DROP) sd4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(ms) + 192 + qb * 16 + 4 * g);
           const f32x2 nm01 = {nm4[0], nm4[1]}, nm23 = {nm4[2], nm4[3]}, nd01 = {nd4[0], nd4[1]}, nd23 = {nd4[2], nd4[3]};
           // exponent arguments of the 16 x 32 block first (ONE clean / masked decision), in place
           if (clean) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < KBW; ++kb) {
               const f32x2 x01 = pk_fma(f32x2{st[qi][kb][0], st[qi][kb][1]}, sc22, nm01), x23 = pk_fma(f32x2{st[qi][kb][2], st[qi][kb][3]}, sc22, nm23);
               st[qi][kb] = f32x4{x01[0], x01[1], x23[0], x23[1]};
             }
           } else {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-              const int k = K0 + wk0 + kb * 16 + li;
+            for (int kb = 0; kb < KBW; ++kb) {
+              const int k = K0 + wk0 + dkv_key(kb, li);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int q = q0 + qb * 16 + 4 * g + r;
@@ -979,11 +1038,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
               }
             }
           }
+          // dropout: one hash per query row and key PAIR (KBW = 2: the lane's two elements of the row; drop masks all-ones / zero)
+          uint32_t mlo[4] = {0u, 0u, 0u, 0u}, mhi[4] = {0u, 0u, 0u, 0u};
+          if (DROP && KBW == 2) {
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
-            const f32x2 p01 = {fast_exp2(st[qi][kb][0]), fast_exp2(st[qi][kb][1])}, p23 = {fast_exp2(st[qi][kb][2]), fast_exp2(st[qi][kb][3])};   // already divided by l
-            f32x2 pd01 = pk_mul_t(p01, ik2), pd23 = pk_mul_t(p23, ik2);
-            if (DROP) {
+            for (int r = 0; r < 4; ++r) drop_dropmask32(sd4[r] ^ kc[0], p.tpk, mlo[r], mhi[r]);
+          }
+#pragma unroll
+          for (int kb = 0; kb < KBW; ++kb) {
+            // P' = ik * P (the row statistics carry log2 ik: see the dQ kernel's prologue), already divided by l
+            const f32x2 p01 = {fast_exp2(st[qi][kb][0]), fast_exp2(st[qi][kb][1])}, p23 = {fast_exp2(st[qi][kb][2]), fast_exp2(st[qi][kb][3])};
+            f32x2 pd01 = p01, pd23 = p23;
+            if (DROP && KBW == 2) {
+              const uint32_t* mk = kb ? mhi : mlo;
+              pd01 = f32x2{clear_if(mk[0], p01[0]), clear_if(mk[1], p01[1])}; pd23 = f32x2{clear_if(mk[2], p23[0]), clear_if(mk[3], p23[1])};
+            } else if (DROP) {
               float pdv[4] = {pd01[0], pd01[1], pd23[0], pd23[1]};
 #pragma unroll
               for (int r = 0; r < 4; ++r)
@@ -991,7 +1060,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
                                                                                                               // (a 32-bit v_mul_lo_u32 by a per-lane constant is quarter rate)
               pd01 = f32x2{pdv[0], pdv[1]}; pd23 = f32x2{pdv[2], pdv[3]};
             }
-            // dS = Pd * dP - P * delta
+            // dS = Pd * dP - P' * (delta / ik)
             const f32x2 s01 = pk_fma(pd01, f32x2{dp[qi][kb][0], dp[qi][kb][1]}, pk_mul_t(p01, nd01));
             const f32x2 s23 = pk_fma(pd23, f32x2{dp[qi][kb][2], dp[qi][kb][3]}, pk_mul_t(p23, nd23));
             st[qi][kb] = f32x4{s01[0], s01[1], s23[0], s23[1]};
@@ -999,33 +1068,74 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
           }
         }
         // dV^T[d][key] += dO^T[d][q] * Pd[q][key] ; dK^T[d][key] += Q^T[d][q] * dS[q][key]
-        bf16x8 pdf[2], dsf[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < KBW; ++kb) {
           pdf[kb] = __builtin_bit_cast(bf16x8, make_uint4(cvt_pk(dp[0][kb][0], dp[0][kb][1]), cvt_pk(dp[0][kb][2], dp[0][kb][3]),
                                                            cvt_pk(dp[1][kb][0], dp[1][kb][1]), cvt_pk(dp[1][kb][2], dp[1][kb][3])));
           dsf[kb] = __builtin_bit_cast(bf16x8, make_uint4(cvt_pk(st[0][kb][0], st[0][kb][1]), cvt_pk(st[0][kb][2], st[0][kb][3]),
                                                            cvt_pk(st[1][kb][0], st[1][kb][1]), cvt_pk(st[1][kb][2], st[1][kb][3])));
         }
+      };
+      // dV^T[d][key] += dO^T[d][q] * Pd[q][key] ; dK^T[d][key] += Q^T[d][q] * dS[q][key]
+      // (ATTN_DKV_PREF: the transposed Q / dO fragments of the second products are requested BEFORE the softmax / dS phase, so that their
+      // LDS latency passes under its VALU work instead of in front of the MFMAs)
+      auto colfrags = [&](const int qh, bf16x8 (&dot)[4], bf16x8 (&qt)[4]) {
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          const bf16x8 dot = col_frag<TR>(sDO, qh * 32, db * 16, lane);
-          const bf16x8 qt = col_frag<TR>(sQ, qh * 32, db * 16, lane);
+          dot[db] = col_frag<TR>(sDO, qh * 32, db * 16, lane);
+          qt[db] = col_frag<TR>(sQ, qh * 32, db * 16, lane);
+        }
+      };
+      auto accumulate = [&](const bf16x8 (&dot)[4], const bf16x8 (&qt)[4], const bf16x8 (&pdf)[KBW], const bf16x8 (&dsf)[KBW]) {
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
-            dvt[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pdf[kb], dvt[kb][db], 0, 0, 0);
-            dkt[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb], dkt[kb][db], 0, 0, 0);
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+          for (int kb = 0; kb < KBW; ++kb) {
+#if ATTN_ABL == 4
+            dvt[kb][db][0] += __builtin_bit_cast(f32x4, dot[db])[kb] * __builtin_bit_cast(f32x4, pdf[kb])[db];
+            dkt[kb][db][0] += __builtin_bit_cast(f32x4, qt[db])[kb] * __builtin_bit_cast(f32x4, dsf[kb])[db];
+#else
+            dvt[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[db], pdf[kb], dvt[kb][db], 0, 0, 0);
+            dkt[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[db], dsf[kb], dkt[kb][db], 0, 0, 0);
+#endif
           }
         }
+      };
+      bf16x8 pdf[KBW], dsf[KBW];
+      bf16x8 dot[4], qt[4];
+#pragma unroll
+      for (int qh = 0; qh < 2; ++qh) {
+        f32x4 st[2][KBW], dp[2][KBW];
+        prio_hi();
+        scores(qh, st, dp);
+#if ATTN_DKV_PREF
+        colfrags(qh, dot, qt);
+        __builtin_amdgcn_sched_barrier(0);
+        prio_lo();
+        softmax_ds(qh, st, dp, pdf, dsf);
+#else
+        prio_lo();
+        softmax_ds(qh, st, dp, pdf, dsf);
+        colfrags(qh, dot, qt);
+#endif
+        prio_hi();
+        accumulate(dot, qt, pdf, dsf);
+        prio_lo();
       }
     }
+#if ATTN_ABL == 2
+    if (t == 0 && ntiles > 1) commit(1);        // ablation: stages written once, no per-tile LDS writes (results invalid)
+#else
     if (t + 1 < ntiles) commit((t + 1) & 1);
-    __syncthreads();
+#endif
+#if ATTN_ABL != 1 && ATTN_ABL != 2
+    __syncthreads();                            // (ablation 1 / 2: no per-tile barrier, results invalid)
+#endif
   }
 
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int k = K0 + wk0 + kb * 16 + li;
+  for (int kb = 0; kb < KBW; ++kb) {
+    const int k = K0 + wk0 + dkv_key(kb, li);
     if (k < nk_) {
       bf16_t* dkp = p.dk + (kso_ ? (long)krow0_ * p.dk_rs : (long)b * p.dk_bs) + (long)k * p.dk_rs + h * HD;
       bf16_t* dvp = p.dv + (kso_ ? (long)krow0_ * p.dv_rs : (long)b * p.dv_bs) + (long)k * p.dv_rs + h * HD;
@@ -1313,7 +1423,7 @@ size_t lds_dq(const AttnP& p, bool bias, int nc) {
 }
 size_t lds_dkv(const AttnP& p, bool bias, int nc) {
   const int len64 = (p.Nq + 63) & ~63;
-  return 2 * (size_t)DKV_STAGE + (bias ? (size_t)nc * bias_cs(len64) * 4 : 0);
+  return 2 * (size_t)DKV_STAGE + (bias ? (size_t)nc * bias_cs(len64 + DKV_BK - 128) * 4 : 0);
 }
 constexpr size_t LDS_PER_CU = 160 * 1024;
 
@@ -1406,7 +1516,7 @@ extern "C" int v2s_attn_bwd(const v2s_attn_args* a, void* stream) {
   }
   const bool tr = v2s_opt_tr_read() != 0, bias = p.bias_diag != nullptr, causal = p.causal != 0, drop = p.p16 != 0;
   const int gq = ((p.Nq + 127) / 128) * p.H * p.B;
-  const int nc_q = (bias && lds_dq(p, bias, 4) * 2 > LDS_PER_CU) ? 2 : 4, nc_kv = (bias && lds_dkv(p, bias, 4) * 2 > LDS_PER_CU) ? 2 : 4;   // two blocks per CU
+  const int nc_q = (bias && lds_dq(p, bias, 4) * ATTN_BWD_OCC > LDS_PER_CU) ? 2 : 4, nc_kv = (bias && lds_dkv(p, bias, 4) * ATTN_DKV_OCC > LDS_PER_CU) ? 2 : 4;   // two blocks per CU
   const size_t dyn_q = lds_dq(p, bias, nc_q), dyn_kv = lds_dkv(p, bias, nc_kv);
   V2S_CHECK(dyn_q <= 160 * 1024 && dyn_kv <= 160 * 1024, V2S_ERR_SHAPE, "v2s_attn_bwd: Nq=%d Nk=%d too large for the LDS bias windows", p.Nq, p.Nk);
   const int part = v2s_opt_attn_bwd_part();      // profiling aid: 1 = dQ kernel only, 2 = dK/dV kernel only (needs the row statistics of an
@@ -1416,7 +1526,7 @@ extern "C" int v2s_attn_bwd(const v2s_attn_args* a, void* stream) {
     V2S_LAUNCH_CHECK();
   }
   if (part != 1) {
-    const int gk = ((p.Nk + 127) / 128) * p.H * p.B;
+    const int gk = ((p.Nk + DKV_BK - 1) / DKV_BK) * p.H * p.B;
     V2S_DISPATCH4(attn_bwd_dkv_kernel, tr, bias, causal, drop, nc_kv, dim3(gk), dyn_kv, s, p);
     V2S_LAUNCH_CHECK();
   }
