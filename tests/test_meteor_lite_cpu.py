@@ -70,12 +70,12 @@ def test_reported_only_under_lite_keys():
     perfect = {"results": {v: [{"sentence": s, "timestamp": list(t)} for t, s in zip(r["timestamps"], r["sentences"])] for v, r in ref.items()}}
     noisy = {"results": {v: [{"sentence": sent(), "timestamp": [t[0] + 1.0, t[1] + 1.0]} for t in r["timestamps"]] for v, r in ref.items()}}
     tok = lambda s: " ".join(s.lower().split())
-    out_p, out_n = M.eval_dvc(perfect, [ref], tokenize=tok), M.eval_dvc(noisy, [ref], tokenize=tok)
+    out_p, out_n = M.eval_dvc(perfect, [ref], tokenize=tok, meteor_lite=True), M.eval_dvc(noisy, [ref], tokenize=tok, meteor_lite=True)
     # a perfect submission: per (tIoU, video) group four identical pairs, one chunk each -- the jar's aggregate fragmentation is chunks / matches
     # of the SUMS, so a group of several segments scores below 1 even when every segment is perfect
     want = np.mean([1.0 - 0.6 * (4.0 / sum(len(s.split()) for s in r["sentences"])) ** 0.2 for r in ref.values()])
     assert "METEOR" not in out_p and out_p["METEOR-lite"] == pytest.approx(want) and 0.0 <= out_n["METEOR-lite"] < 0.8 * want
-    assert "METEOR-lite" not in M.eval_dvc(perfect, [ref], tokenize=tok, meteor_lite=False)
+    assert "METEOR-lite" not in M.eval_dvc(perfect, [ref], tokenize=tok)          # opt-in
     sp, sn = M.eval_soda(perfect, [ref], tokenize=tok, scorer="meteor_lite"), M.eval_soda(noisy, [ref], tokenize=tok, scorer="meteor_lite")
     assert list(sp) == ["soda_c_meteor_lite"] and sp["soda_c_meteor_lite"] == pytest.approx(1.0) and 0.0 <= sn["soda_c_meteor_lite"] < sp["soda_c_meteor_lite"]
     # the string is a shorthand for passing the scorer object, which goes through the reference's call convention (soda.py:66-72)

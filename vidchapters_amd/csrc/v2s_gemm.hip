@@ -2059,7 +2059,9 @@ static int a4p_epilogue(const v2s_gemm_args* a) {
   // but +0.5 ... +0.8 ms per train step on three boxes (co-scheduling with the weight-gradient stream, cold operands and the burst of mask-operand
   // loads were each tested as the cause and ruled out: DESIGN.md 8a-r5).  So only when forced (gemm_a4 = 2) or asked for (gemm_a4 = 5).
   const int mode = v2s_opt_gemm_a4();
-  if (a->dact == V2S_ACT_RELU && a->transB && a->z && a->ldz == a->ldc && a->K >= 512 && (mode == 2 || mode == 5)) return 2;
+  // (not in place: ragged M / N are covered by an OVERLAPPING last tile row / column, whose second visit would read z after the first wrote the
+  // masked gradient over it -- the generic kernels are in-place safe, so C == z keeps them)
+  if (a->dact == V2S_ACT_RELU && a->transB && a->z && a->z != a->C && a->ldz == a->ldc && a->K >= 512 && (mode == 2 || mode == 5)) return 2;
   return 0;
 }
 

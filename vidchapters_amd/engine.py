@@ -107,6 +107,11 @@ class Engine:
         self._deferred: List = []
         self._defer_open = False
         self.shadow_events = None # sharded optimizer: {"vit" | "enc" | "dec": event after which that group's bf16 shadow weights are whole}
+        # parity taps (tests only; None = off, the default): ``dbg_logits`` = list that receives the fp32 logits [rows, vocab] of every head
+        # launch (whole tensor on the autograd route, one entry per chunk of the fused head); ``dbg_tap`` = list that receives, per sublayer of
+        # a stack's backward, (stack, kind, block, d(output) as it arrived, d(input) as it left)
+        self.dbg_logits: Optional[List] = None
+        self.dbg_tap: Optional[List] = None
         self.arena.refresh_shadow(force=True)
 
     # ------------------------------------------------------------------------------------------ names / arena order
@@ -696,6 +701,7 @@ class Engine:
             # sublayer's norm backward (second output)
             nr = recs[idx + 1] if idx + 1 < len(recs) else None
             nxt = (nr.p, nr.seed_o) if (nr is not None and nr.kind in ("ffn", "cross", "self")) else None
+            dh_arrived = dh
             if r.kind == "final":
                 dh, df = self._final_norm_bwd(r, dh, nxt)
             elif r.kind == "ffn":
@@ -712,6 +718,8 @@ class Engine:
                     layer_done(r.i)
             elif r.kind == "embed":
                 self._embed_bwd(r, dh)
+            if self.dbg_tap is not None and r.kind != "embed":
+                self.dbg_tap.append((stack, r.kind, r.get("i", -1), dh_arrived, dh))
         self._flush_deferred()
         self.flush_wgrads()
         L.bias_bucket_bwd(ddiag, lut, a.g(self._sa(stack, 0) + "relative_attention_bias.weight"), self.H, 2 * nq - 1,
@@ -802,6 +810,7 @@ class Engine:
         dx, df2 = ln_bwd(tape["xf"], "visual_encoder.norm.", tape["meanf"], tape["rstdf"], dvis, None, first_seed)
         for idx, r in enumerate(recs):
             pre = r.pre
+            d_arrived = dx
             L.colsum(df2, M, C, a.g(pre + "mlp.fc2.bias"))
             self._wgrad(df2, r.u, pre + "mlp.fc2.weight", C, mlp, M, group="vit.fc2")
             du = self._dgrad(df2, a.w(pre + "mlp.fc2.weight"), M, mlp, C, dact=L.ACT_GELU, z=r.upre, dropout_p=p,
@@ -821,6 +830,8 @@ class Engine:
             dn1 = self._dgrad(dqkv, a.w(pre + "attn.qkv.weight"), M, C, 3 * C)
             nseed = recs[idx + 1].seed_2 if idx + 1 < len(recs) else tape["seed0"]      # next block's fc2 dropout, or the input dropout
             dx, df2 = ln_bwd(r.x, pre + "norm1.", r.mean1, r.rstd1, dn1, dx1, nseed)
+            if self.dbg_tap is not None:
+                self.dbg_tap.append(("vit", "block", len(recs) - 1 - idx, d_arrived, dx))
         self.flush_wgrads()
         dx = df2                                                   # = dropout(dx; seed0), vit.py:126
         gpos = a.g("visual_encoder.pos_embed", (m.num_features, C))
@@ -927,6 +938,8 @@ class Engine:
                 n = min(R_, Md - r0)
                 L.gemm(hs[r0:r0 + n], E, lg, n, self.V, self.d, ldc=self.ldv, alpha=alpha)
                 L.ce_fwd(lg, self.ldv, labels[r0:r0 + n], n, self.V, m.label_smoothing, row[r0:r0 + n], acc[0:1], acc[1:2])
+                if self.dbg_logits is not None:
+                    self.dbg_logits.append(lg[:n, :self.V].clone())
                 dlog = self._bf(n, self.ldv)                      # fresh per chunk: the weight-gradient stream may still read the previous one
                 L.ce_bwd(lg, self.ldv, labels[r0:r0 + n], row[r0:r0 + n], n, self.V, m.label_smoothing, gscale, dlog, self.ldv)
                 # embedding weight gradient on the weight-gradient stream (the scatter-adds into the same tensor wait for the event
@@ -942,6 +955,8 @@ class Engine:
             logits = self._f32(Md, self.ldv)
             L.gemm(hs, E, logits, Md, self.V, self.d, ldc=self.ldv, alpha=alpha)
             L.ce_fwd(logits, self.ldv, labels, Md, self.V, m.label_smoothing, row, acc[0:1], acc[1:2])
+            if self.dbg_logits is not None:
+                self.dbg_logits.append(logits[:, :self.V].clone())
         loss = acc[0] / acc[1]
         if tape is not None:
             tape.update(enc=enc_tape, dec=dec_tape, B=B, T=T, Lx=Lx, Lo=Lo, S=S, Md=Md, hs=hs, logits=logits, labels=labels, row=row,
@@ -1142,16 +1157,17 @@ class Engine:
         H, inner = self.H, self.inner
         if not self.decode_mem_attn or (G > 1 and self.decode_mem_attn < 3) or d != 768 or inner != H * 64 or G * H > 48:
             return None
+        # small batches: the K/V-cache kernels' shorter launch chain wins.  The choice is made from the call's SHAPE (B x S memory positions,
+        # pad positions included: the threshold was calibrated on batches of ~90 % valid keys), never from the batch's content, so that which
+        # path a sequence takes -- the two differ by bf16 rounding -- does not depend on its neighbours' lengths; and it is made BEFORE the mask
+        # is read back, so that the early-out costs no host synchronisation
+        if self.decode_mem_attn == 1 and B * S < self.decode_mem_attn_min_keys:
+            return None
         m = mem_mask.to(torch.bool)
         ok = bool((m[:, 1:] <= m[:, :-1]).all().item()) if S > 1 else True
         klen = m.sum(1).to(torch.int32)
         klen_h = klen.tolist()
         if not ok or min(klen_h) < 1:
-            return None
-        # small batches: the K/V-cache kernels' shorter launch chain wins.  The choice is made from the call's SHAPE (B x S memory positions),
-        # never from the batch's content, so that which path a sequence takes -- the two differ by bf16 rounding -- does not depend on its
-        # neighbours' lengths; Engine.last_cross_path records it
-        if self.decode_mem_attn == 1 and B * S < self.decode_mem_attn_min_keys:
             return None
         assert mem.is_contiguous() and mem.dtype == torch.bfloat16
         plan = L.MemAttnPlan(klen_h, G * H, self.device)

@@ -22,7 +22,7 @@ implementation to hand-computed alignments.  Everything that reports it says "li
 from __future__ import annotations
 
 import re
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 ALPHA, BETA, GAMMA = 0.85, 0.2, 0.6
 W_EXACT, W_STEM = 1.0, 0.6
@@ -215,3 +215,14 @@ class MeteorLite:
             scores.append(s)
             agg = [a + b for a, b in zip(agg, st)]
         return _score(agg), scores
+
+
+_SHARED: Optional["MeteorLite"] = None
+
+
+def shared_scorer() -> "MeteorLite":
+    """One module-level scorer: its (hypothesis, reference) pair cache is kept across eval_dvc / eval_soda calls instead of being rebuilt by each."""
+    global _SHARED
+    if _SHARED is None:
+        _SHARED = MeteorLite()
+    return _SHARED

@@ -301,7 +301,7 @@ class Trainer:
                 t = me()
                 if t is not None:
                     t._stale_guard(what)
-            a.stale_guard = guard
+            a.stale_guard = self._guard = guard
             self._sd_hook = model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: guard("model.state_dict()"))
         # arena ranges (engine._arena_order): decoder matrices | encoder matrices | ViT matrices + pos_embed | the small fp32-consumed
         # parameters | the tied embedding, whose last rows (time tokens + the zero tail) every rank keeps whole (renorm reads them)
@@ -326,8 +326,11 @@ class Trainer:
         if h is not None:
             h.remove()
             self._sd_hook = None
-        if getattr(self.eng.arena, "stale_guard", None) is not None and self.sync.shard:
+        # only OUR guard: a Trainer that replaced this one on the same model has installed its own since (this object's finaliser may run later)
+        mine = getattr(self, "_guard", None)
+        if mine is not None and getattr(self.eng.arena, "stale_guard", None) is mine:
             self.eng.arena.stale_guard = None
+        self._guard = None
 
     def __del__(self):
         try:
