@@ -37,7 +37,7 @@ extern "C" {
  * + v2s_rowsumsq_range / v2s_timetoken_renorm_sq, options gemm_ps / gemm_ps_nst / gemm_w128
  * 4 (round 4): + v2s_decode_qfold / v2s_decode_memattn_plan / v2s_decode_memattn / v2s_decode_ctxfold, v2s_beam_advance (additions only)
  * 5 (round 5): + v2s_sum_n, v2s_argmax_step_tail, options gemm_a4 / gemm_a4_grid / gemm_a4_relu / gemm_a4_walk (additions only)
- * 6 (round 6): + v2s_clock_probe (additions only) */
+ * 6 (round 6): + v2s_clock_probe, v2s_lmhead_ce_fwd / _bwd / _workspace_floats (additions only) */
 #define V2S_ABI_VERSION 6
 
 int v2s_version(void);
@@ -291,6 +291,21 @@ int v2s_ce_fwd(const float* logits, int64_t ld, const int64_t* labels, int32_t r
                float* row_lse, float* loss_sum, float* count, void* stream);
 int v2s_ce_bwd(const float* logits, int64_t ld, const int64_t* labels, const float* row_lse, int32_t rows,
                int32_t V, float eps, const float* gscale, void* dlogits, int64_t ldd, void* stream);
+
+/* Tied LM head + label-smoothed cross entropy WITHOUT logits in memory (round 6; modeling_t5.py:1709-1721: lm_logits = (h * d_model^-0.5) E^T, then
+ * F.cross_entropy(ignore_index = -100, label_smoothing = eps)).  h: bf16 [rows][ldh] (decoder output), E: bf16 [Vpad][d] (the tied embedding; rows
+ * V..Vpad-1 exist and are zero), labels: int64 [rows] (-100 = ignored), alpha = d_model^-0.5 for a tied head.
+ *   v2s_lmhead_ce_fwd: logits are computed 128 x 128 tiles at a time and reduced on the spot to per-(row, 64-column half tile) statistics in `part`
+ *     (v2s_lmhead_ce_workspace_floats(rows, Vpad) floats, 16-byte aligned); row_out[rows][2] = (log-sum-exp, smoothed loss) per row -- the same
+ *     two numbers v2s_ce_fwd leaves --, *loss_sum += sum of the row losses, *count += number of non-ignored rows (deterministic reduction).
+ *   v2s_lmhead_ce_bwd: recomputes the tiles and writes d(logits)[rows][ldd] = (softmax - (1 - eps) onehot - eps / V) * *gscale as bf16 (columns
+ *     V..ldd-1 zero: the d(hidden) GEMM contracts over the padded vocabulary); ignored rows are zero.  The two consumers are ordinary v2s_gemm
+ *     calls (d(hidden) = d(logits) E alpha, d(E) += d(logits)^T h alpha). */
+int64_t v2s_lmhead_ce_workspace_floats(int32_t rows, int32_t Vpad);
+int v2s_lmhead_ce_fwd(const void* h, int64_t ldh, const void* E, int32_t rows, int32_t V, int32_t Vpad, int32_t d, float alpha,
+                      const int64_t* labels, float eps, float* part, float* row_out, float* loss_sum, float* count, void* stream);
+int v2s_lmhead_ce_bwd(const void* h, int64_t ldh, const void* E, int32_t rows, int32_t V, int32_t Vpad, int32_t d, float alpha,
+                      const int64_t* labels, const float* row_out, float eps, const float* gscale, void* dlogits, int64_t ldd, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser over the flat parameter arena (dvc.py:112-126: clip_grad_norm_, torch.optim.Adam step,

@@ -928,6 +928,48 @@ def test_cross_entropy(rows, V):
     assert (dl[:, V:] == 0).all()
 
 
+@pytest.mark.parametrize("rows,V,d", [(300, 612, 128), (2048 + 40, 32200, 768), (130, 1000, 64)])
+def test_lm_head_cross_entropy_without_logits(rows, V, d):
+    """v2s_lmhead_ce_fwd / _bwd (round 6): tied LM head + label-smoothed CE with the logits reduced / recomputed inside the GEMM epilogue, against
+    fp32 torch on the same bf16 operands (modeling_t5.py:1709-1721); ragged rows, a vocabulary that is not a multiple of the tile, ignored rows,
+    bf16 d(logits) of a row CHUNK (as the engine calls it) incl. its zero pad columns."""
+    Vpad = (V + 63) // 64 * 64
+    h = rnd(rows, d, seed=1, scale=1.0)
+    E = torch.zeros(Vpad, d, dtype=torch.bfloat16, device=DEV)
+    E[:V] = rnd(V, d, seed=2, scale=1.5)
+    alpha = d ** -0.5
+    labels = torch.randint(0, V, (rows,), device=DEV)
+    labels[::7] = -100
+    labels[1] = V - 1                                                     # a target in the last, partial column tile
+    part = torch.empty(L.lmhead_ce_workspace_floats(rows, Vpad), dtype=torch.float32, device=DEV)
+    row = torch.full((rows, 2), float("nan"), dtype=torch.float32, device=DEV)
+    acc = torch.zeros(2, dtype=torch.float32, device=DEV)
+    L.lmhead_ce_fwd(h, d, E, rows, V, Vpad, d, alpha, labels, 0.1, part, row, acc[0:1], acc[1:2])
+    hf = h.float().requires_grad_(True)
+    lg = (hf * alpha) @ E[:V].float().T
+    ref = torch.nn.functional.cross_entropy(lg, labels, ignore_index=-100, label_smoothing=0.1)
+    got = (acc[0] / acc[1]).item()
+    keep = labels >= 0
+    lse_err = float((row[keep, 0] - torch.logsumexp(lg.detach(), -1)[keep]).abs().max())
+    print(f"LM head + CE {rows} x {V} x {d}: loss {got:.6f} vs {ref.item():.6f}; count {acc[1].item():.0f}; log-sum-exp max error {lse_err:.2e}")
+    assert acc[1].item() == float(keep.sum()) and abs(got - ref.item()) < 2e-5 * abs(ref.item()) and lse_err < 2e-4
+    assert (row[~keep] == 0).all()
+    ref.backward(retain_graph=True)
+    dlg = torch.autograd.grad(ref, lg, retain_graph=True)[0]
+    gs = (1.0 / acc[1:2]).contiguous()
+    r0, n = 3, rows - 5                                                   # a chunk that starts and ends off the tile grid
+    dl = torch.full((n, Vpad), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L.lmhead_ce_bwd(h[r0:r0 + n], d, E, n, V, Vpad, d, alpha, labels[r0:r0 + n], row[r0:r0 + n], 0.1, gs, dl, Vpad)
+    assert relerr(dl[:, :V], dlg[r0:r0 + n]) < 1e-2 and cos(dl[:, :V], dlg[r0:r0 + n]) > 0.9999
+    assert (dl[:, V:] == 0).all() and (dl[~keep[r0:r0 + n]] == 0).all()
+    # the split-K reduction that rounds to bf16 itself (d(hidden) = d(logits) E alpha without the fp32 chunk + cast)
+    ws = torch.empty(16 * n * d, dtype=torch.float32, device=DEV)
+    dh = torch.full((n, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L.gemm(dl, E, dh, n, d, Vpad, transB=True, lda=Vpad, ldb=d, alpha=alpha, workspace=ws)
+    want = (dl.float() @ E.float()) * alpha
+    assert relerr(dh, want) < 1e-2 and cos(dh, want) > 0.99999
+
+
 def test_optimizer_kernels():
     n = 100003 * 4
     p = rnd(n, seed=1, dtype=torch.float32); g = rnd(n, seed=2, dtype=torch.float32, scale=0.01)

@@ -655,20 +655,24 @@ def test_fused_lm_head_equals_unfused():
     cfg = R.RefConfig.small()
     b = {k: v.to(DEV) for k, v in synth.make_batch(3, 10, 40, 23, cfg.vocab, 29, cfg.vit_dim, denoising=True).items()}
     res = {}
-    for fused in (True, False):
+    # "ce": round 6, the logits are never written (v2s_lmhead_ce_fwd / _bwd: statistics in the GEMM epilogue, tiles recomputed for d(logits));
+    # "chunk": round 2, an fp32 logits chunk per 16 rows through v2s_ce_fwd / v2s_ce_bwd; "whole": the unfused head
+    for mode in ("ce", "chunk", "whole"):
         model = build(cfg, 13).train()
         eng = model.engine()
-        eng.fused_head, eng.head_rows = fused, 16           # 69 decoder rows -> 5 chunks, the last one ragged
+        eng.fused_head, eng.head_ce_fused, eng.head_rows = mode != "whole", mode == "ce", 16           # 69 decoder rows -> 5 chunks, the last one ragged
         tr = Trainer(model, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=0.5)
         losses = tr.step(b)
-        res[fused] = (losses["loss"].item(), losses["denoising_loss"].item(), tr.grad_norm().item(),
-                      {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()})
-    (l1, d1, n1, g1), (l0, d0, n0, g0) = res[True], res[False]
-    print(f"fused head: loss {l1:.6f}/{l0:.6f} den {d1:.6f}/{d0:.6f} gnorm {n1:.5f}/{n0:.5f}")
-    assert abs(l1 - l0) <= 1e-5 * abs(l0) and abs(d1 - d0) <= 1e-5 * abs(d0) and abs(n1 - n0) <= 1e-3 * n0
-    worst = min(cos(g1[k], g0[k]) for k in g0 if g0[k].abs().max() > 0)
-    print(f"  worst gradient cosine fused vs unfused: {worst:.6f}")
-    assert worst > 0.9995
+        res[mode] = (losses["loss"].item(), losses["denoising_loss"].item(), tr.grad_norm().item(),
+                     {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()})
+    l0, d0, n0, g0 = res["whole"]
+    for mode in ("ce", "chunk"):
+        l1, d1, n1, g1 = res[mode]
+        print(f"fused head ({mode}): loss {l1:.6f}/{l0:.6f} den {d1:.6f}/{d0:.6f} gnorm {n1:.5f}/{n0:.5f}")
+        assert abs(l1 - l0) <= 1e-5 * abs(l0) and abs(d1 - d0) <= 1e-5 * abs(d0) and abs(n1 - n0) <= 1e-3 * n0
+        worst = min(cos(g1[k], g0[k]) for k in g0 if g0[k].abs().max() > 0)
+        print(f"  worst gradient cosine {mode} vs unfused: {worst:.6f}")
+        assert worst > 0.9995
 
 
 def test_skip_grad_memset_equals_zeroed_arena_and_survives_an_exception():

@@ -437,20 +437,13 @@ __device__ __forceinline__ void dma_issue8(const uint32_t (&oa)[4], const uint32
       : "memory", "scc");
 }
 
+// main loop of the 128 x 128 LDS-DMA kernels: acc (transposed fragments, see gemm_epilogue) = A[m0.., kbeg..kend) x B[n0.., kbeg..kend)
 template <bool TA, bool TB>
-__device__ __forceinline__ void gemm_dma_body(const GemmP& p, const int bid, char* smem) {
+__device__ __forceinline__ void gemm_dma_mainloop(const GemmP& p, char* smem, const int m0, const int n0, const int kbeg, const int kend, f32x4 (&acc)[4][4]) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int nwg = p.tilesM * p.tilesN * p.splitk;
-  const int id0 = xcd_remap(bid, nwg);
-  int tm, tn, slice;
-  tile_coords(p, id0, tm, tn, slice);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = slice * p.kper, kend = min(p.K, kbeg + p.kper);
   const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
-
-  f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -494,6 +487,21 @@ __device__ __forceinline__ void gemm_dma_body(const GemmP& p, const int bid, cha
     dma_wait();
     __syncthreads();
   }
+}
+
+template <bool TA, bool TB>
+__device__ __forceinline__ void gemm_dma_body(const GemmP& p, const int bid, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = p.tilesM * p.tilesN * p.splitk;
+  const int id0 = xcd_remap(bid, nwg);
+  int tm, tn, slice;
+  tile_coords(p, id0, tm, tn, slice);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = slice * p.kper, kend = min(p.K, kbeg + p.kper);
+  f32x4 acc[4][4];
+  gemm_dma_mainloop<TA, TB>(p, smem, m0, n0, kbeg, kend, acc);
   uint4 gop[8];
   const bool ahead = epilogue_prefetch(p, m0, n0, tid, gop);
   gemm_epilogue(p, smem, acc, m0, n0, slice, tid, lane, wm, wn, gop, ahead);
@@ -523,6 +531,145 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_grouped_kernel(const Gem
   GemmP p = g.p;
   p.A = g.A[gi]; p.B = g.B[gi]; p.C = g.C[gi];
   gemm_dma_body<true, true>(p, (int)blockIdx.x - gi * per, smem);
+}
+
+// ---- tied LM head + label-smoothed cross entropy WITHOUT logits in memory (round 6; model/modeling_t5.py:1709-1721) ------------------------
+// logits[r][c] = alpha * h[r] . E[c] are computed tile by tile by the 128 x 128 LDS-DMA main loop above and consumed in the epilogue:
+//   MODE 0 (forward): each 128 x 128 tile is reduced to per-row partial statistics over its two 64-column halves -- (max, sum exp(v - max), sum v,
+//          the target's logit if it lies there) -- one float4 per (row, half tile); lmhead_finish_kernel merges a row's halves
+//          into its log-sum-exp and its smoothed loss (the same two numbers v2s_ce_fwd leaves per row);
+//   MODE 1 (backward): the tile is RECOMPUTED and turned into d(logits) = (softmax - (1 - eps) onehot - eps / V) * gscale, stored as bf16
+//          for the two GEMMs that consume it (d(hidden) = d(logits) E, d(E) += d(logits)^T h).
+// N of the GemmP is the vocabulary padded to the tile (the arena keeps zero rows behind the embedding); columns >= V are excluded from the
+// statistics and written as zeros.
+struct HeadX {
+  int V, tilesN;
+  const long* labels;
+  float4* part;          // MODE 0: [rows][2 * tilesN] (one entry per 64-column half of a column tile)
+  const float* row;      // MODE 1: [rows][2] (log-sum-exp, loss) from lmhead_finish_kernel
+  float eps;
+  const float* gscale;   // MODE 1: device scalar d(total loss) / d(sum of row losses)
+  bf16_t* dl; long ldd;  // MODE 1: d(logits) [rows][ldd]
+};
+
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void lmhead_ce_kernel(const GemmP p, const HeadX x) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int id0 = xcd_remap(blockIdx.x, p.tilesM * p.tilesN);
+  int tm, tn, slice;
+  tile_coords(p, id0, tm, tn, slice);
+  const int m0 = tm * BM, n0 = tn * BN;
+  f32x4 acc[4][4];
+  gemm_dma_mainloop<false, false>(p, smem, m0, n0, 0, p.K, acc);
+  // fragment (i, j) of a wave: lane (g = lane >> 4, li = lane & 15) holds row wm*64 + i*16 + li, columns wn*64 + j*16 + 4g .. +3 (see gemm_epilogue)
+  const int g4 = (lane >> 4) * 4, li = lane & 15;
+  if (MODE == 0) {
+    // statistics straight from the accumulators -- no LDS staging, no barrier: a lane reduces its 16 columns of a row, the four lane groups that
+    // share the row are merged with two xor-shuffles, and each wave writes ITS 64-column half: part[row][2 * tn + wn]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gm = m0 + wm * 64 + i * 16 + li;
+      const bool live = gm < p.M;
+      const int y = live ? (int)x.labels[gm] : -1;
+      float mx = -INFINITY, tot = 0.f, tg = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gn = n0 + wn * 64 + j * 16 + g4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r] * p.alpha;
+          acc[i][j][r] = v;
+          const bool in = gn + r < x.V;
+          mx = in ? fmaxf(mx, v) : mx;
+          tot += in ? v : 0.f;
+          tg += (gn + r == y) ? v : 0.f;
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mref = mx == -INFINITY ? 0.f : mx;          // (a half tile entirely beyond V: no valid column, sum 0)
+      float se = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gn = n0 + wn * 64 + j * 16 + g4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) se += (gn + r < x.V) ? __expf(acc[i][j][r] - mref) : 0.f;
+      }
+      se += __shfl_xor(se, 16, 64); tot += __shfl_xor(tot, 16, 64); tg += __shfl_xor(tg, 16, 64);
+      se += __shfl_xor(se, 32, 64); tot += __shfl_xor(tot, 32, 64); tg += __shfl_xor(tg, 32, 64);
+      if (live && lane < 16) x.part[(long)gm * (2 * x.tilesN) + 2 * tn + wn] = make_float4(mx, se, tot, tg);
+    }
+  } else {
+    // d(logits) in registers, rounded to bf16, staged through LDS as a bf16 [128][128] tile (16-byte chunks XOR-swizzled with (row & 7)) so that the
+    // global stores are whole 256-byte row segments
+    const float sm = x.eps / x.V, g = x.gscale[0], keep = 1.f - x.eps;
+    bf16_t* cs = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wm * 64 + i * 16 + li, gm = m0 + row;
+      const bool live = gm < p.M;
+      const int y = live ? (int)x.labels[gm] : -1;
+      const float lse = y >= 0 ? x.row[(long)gm * 2] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cn = wn * 64 + j * 16 + g4, gn = n0 + cn;
+        float f[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pr = __expf(acc[i][j][r] * p.alpha - lse) - sm;
+          if (gn + r == y) pr -= keep;
+          f[r] = (y >= 0 && gn + r < x.V) ? pr * g : 0.f;
+        }
+        const int c8 = cn >> 3;                                // 16-byte chunk of the row; this lane fills half of it
+        *reinterpret_cast<uint2*>(cs + row * BN + ((c8 ^ (row & 7)) << 3) + (cn & 4)) = make_uint2(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int c = tid + it * NTHREADS;                        // 16 consecutive lanes = the 16 chunks of one row
+      const int row = c >> 4, c8 = c & 15;
+      const int gm = m0 + row, gn = n0 + c8 * 8;
+      if (gm >= p.M || gn >= x.ldd) continue;
+      *reinterpret_cast<uint4*>(x.dl + (long)gm * x.ldd + gn) = *reinterpret_cast<const uint4*>(cs + row * BN + ((c8 ^ (row & 7)) << 3));
+    }
+  }
+}
+
+// one wave per row: merge the (max, sum exp, sum, target) partials of the row's column tiles -> row_out[row] = (log-sum-exp, smoothed loss)
+__global__ __launch_bounds__(256) void lmhead_finish_kernel(const float4* __restrict__ part, const long* __restrict__ labels, int rows, int tilesN, int V,
+                                                            float eps, float* __restrict__ row_out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const long y = labels[row];
+  if (y < 0) {
+    if (lane == 0) { row_out[row * 2] = 0.f; row_out[row * 2 + 1] = 0.f; }
+    return;
+  }
+  float m = -INFINITY, s = 0.f, tot = 0.f, tg = 0.f;
+  for (int t = lane; t < 2 * tilesN; t += 64) {          // two 64-column halves per column tile
+    const float4 q = part[(long)row * (2 * tilesN) + t];
+    if (q.x == -INFINITY) continue;                       // a half entirely beyond V
+    const float mn = fmaxf(m, q.x);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + q.y * __expf(q.x - mn);
+    m = mn; tot += q.z; tg += q.w;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    const float mn = fmaxf(m, m2);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mn)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mn));
+    m = mn;
+    tot += __shfl_xor(tot, o, 64); tg += __shfl_xor(tg, o, 64);
+  }
+  if (lane == 0) {
+    const float lse = m + logf(s);
+    row_out[row * 2] = lse;
+    row_out[row * 2 + 1] = (1.f - eps) * (lse - tg) + eps * (lse - tot / V);
+  }
 }
 
 // =====================================================================================================================
@@ -1919,7 +2066,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_kernel(const GemmP p) {
 
 // C[m][n] (+)= alpha * sum_z ws[z][m][n]   (deterministic: fixed slice order)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc, int M,
-                                                            int N, int S, float alpha, int accumulate) {
+                                                            int N, int S, float alpha, int accumulate, int c_bf16) {
   const int n4 = N >> 2;
   const long total = (long)M * n4;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
@@ -1929,8 +2076,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       const float4 v = *reinterpret_cast<const float4*>(ws + ((long)z * M + m) * N + c);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    float* cp = C + (long)m * ldc + c;
     float4 o = make_float4(s.x * alpha, s.y * alpha, s.z * alpha, s.w * alpha);
+    if (c_bf16) {          // bf16 output (round 6: the LM head's d(hidden) leaves its split-K reduction rounded once, no separate cast launch)
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + (long)m * ldc + c) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+      continue;
+    }
+    float* cp = C + (long)m * ldc + c;
     if (accumulate) {
       const float4 c0 = *reinterpret_cast<const float4*>(cp);
       o.x += c0.x; o.y += c0.y; o.z += c0.z; o.w += c0.w;
@@ -2170,7 +2321,7 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
   p.row0 = row0;
   hipStream_t s = (hipStream_t)stream;
   const bool tr = v2s_opt_tr_read() != 0;
-  const bool plain_split = a->workspace && a->c_dtype == V2S_F32 && !a->bias && !a->act && !a->dact && !a->residual && !a->pre &&
+  const bool plain_split = a->workspace && (a->c_dtype == V2S_F32 || !a->accumulate) && !a->bias && !a->act && !a->dact && !a->residual && !a->pre &&
                            a->dropout_p == 0.f && a->K >= 1024 && (a->N % 8) == 0;
   // decode-step projections: M = batch x beams rows (<= 512).  Past 64 rows the 49 MB LM head goes back to the general tiles
   // (enough of them there), the layer projections stay here: 256 x 768 is 12 tiles of 128 x 128 on 256 CUs.
@@ -2540,9 +2691,74 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     long blocks = ((long)a->M * (a->N / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.ws, (float*)a->C, (long)a->ldc, a->M, a->N,
-                       p.splitk, a->alpha, a->accumulate);
+                       p.splitk, a->alpha, a->accumulate, a->c_dtype == V2S_BF16 ? 1 : 0);
     V2S_LAUNCH_CHECK();
   }
+  return V2S_OK;
+}
+
+// ---- tied LM head + label-smoothed cross entropy, logits never written (lmhead_ce_kernel above) --------------------------------------------------
+namespace {
+__global__ __launch_bounds__(1024) void lmhead_reduce_kernel(const float* __restrict__ row_out, const long* __restrict__ labels, int rows,
+                                                             float* __restrict__ loss_sum, float* __restrict__ count) {
+  __shared__ float a[1024], c[1024];      // deterministic single-block reduction (same order as v2s_ce_fwd's)
+  float s = 0.f, n = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 1024)
+    if (labels[r] >= 0) { s += row_out[r * 2 + 1]; n += 1.f; }
+  a[threadIdx.x] = s; c[threadIdx.x] = n;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { a[threadIdx.x] += a[threadIdx.x + o]; c[threadIdx.x] += c[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { *loss_sum += a[0]; *count += c[0]; }
+}
+int lmhead_fill(GemmP& p, const char* who, const void* h, int64_t ldh, const void* E, int32_t rows, int32_t V, int32_t Vpad, int32_t d, float alpha) {
+  V2S_CHECK(h && E && rows > 0 && V > 0 && Vpad >= V && (Vpad % 8) == 0 && d >= 64 && (d % 64) == 0 && (ldh % 8) == 0 && ldh >= d, V2S_ERR_SHAPE,
+            "%s: rows=%d V=%d Vpad=%d (multiple of 8, >= V) d=%d (multiple of 64) ldh=%ld", who, rows, V, Vpad, d, (long)ldh);
+  V2S_CHECK((long)rows * ldh < (1L << 30) && (long)Vpad * d < (1L << 30), V2S_ERR_SHAPE, "%s: operand beyond the 32-bit lane offsets of the LDS-DMA loop", who);
+  p = GemmP{};
+  p.M = rows; p.N = Vpad; p.K = d;
+  p.A = (const bf16_t*)h; p.B = (const bf16_t*)E; p.lda = ldh; p.ldb = d;
+  p.alpha = alpha;
+  p.tilesM = (rows + BM - 1) / BM; p.tilesN = (Vpad + BN - 1) / BN; p.splitk = 1; p.kper = d;
+  p.order = 8;            // grouped walk, 8 tile rows deep: the blocks an XCD runs together share a few E column slabs in its L2
+  return V2S_OK;
+}
+}  // namespace
+
+extern "C" int64_t v2s_lmhead_ce_workspace_floats(int32_t rows, int32_t Vpad) {
+  return (int64_t)rows * ((Vpad + BN - 1) / BN) * 2 * 4;
+}
+
+extern "C" int v2s_lmhead_ce_fwd(const void* h, int64_t ldh, const void* E, int32_t rows, int32_t V, int32_t Vpad, int32_t d, float alpha,
+                                 const int64_t* labels, float eps, float* part, float* row_out, float* loss_sum, float* count, void* stream) {
+  GemmP p;
+  if (int e = lmhead_fill(p, "v2s_lmhead_ce_fwd", h, ldh, E, rows, V, Vpad, d, alpha)) return e;
+  V2S_CHECK(labels && part && row_out && loss_sum && count && ((uintptr_t)part & 15) == 0, V2S_ERR_ARG, "v2s_lmhead_ce_fwd: labels / part (16-byte aligned) / row_out / loss_sum / count");
+  HeadX x{};
+  x.V = V; x.tilesN = p.tilesN; x.labels = (const long*)labels; x.part = (float4*)part; x.eps = eps;
+  hipStream_t s = (hipStream_t)stream;
+  g_last_gemm = "lmhead_ce_kernel<0>";
+  hipLaunchKernelGGL((lmhead_ce_kernel<0>), dim3((unsigned)(p.tilesM * p.tilesN)), dim3(NTHREADS), 0, s, p, x);
+  V2S_LAUNCH_CHECK();
+  hipLaunchKernelGGL(lmhead_finish_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const float4*)part, (const long*)labels, rows, p.tilesN, V, eps, row_out);
+  V2S_LAUNCH_CHECK();
+  hipLaunchKernelGGL(lmhead_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)row_out, (const long*)labels, rows, loss_sum, count);
+  V2S_LAUNCH_CHECK();
+  return V2S_OK;
+}
+
+extern "C" int v2s_lmhead_ce_bwd(const void* h, int64_t ldh, const void* E, int32_t rows, int32_t V, int32_t Vpad, int32_t d, float alpha,
+                                 const int64_t* labels, const float* row_out, float eps, const float* gscale, void* dlogits, int64_t ldd, void* stream) {
+  GemmP p;
+  if (int e = lmhead_fill(p, "v2s_lmhead_ce_bwd", h, ldh, E, rows, V, Vpad, d, alpha)) return e;
+  V2S_CHECK(labels && row_out && gscale && dlogits && (ldd % 8) == 0 && ldd >= Vpad, V2S_ERR_ARG, "v2s_lmhead_ce_bwd: labels / row_out / gscale / dlogits, ldd (%ld) a multiple of 8 >= Vpad", (long)ldd);
+  HeadX x{};
+  x.V = V; x.tilesN = p.tilesN; x.labels = (const long*)labels; x.row = row_out; x.eps = eps; x.gscale = gscale; x.dl = (bf16_t*)dlogits; x.ldd = ldd;
+  g_last_gemm = "lmhead_ce_kernel<1>";
+  hipLaunchKernelGGL((lmhead_ce_kernel<1>), dim3((unsigned)(p.tilesM * p.tilesN)), dim3(NTHREADS), 0, (hipStream_t)stream, p, x);
+  V2S_LAUNCH_CHECK();
   return V2S_OK;
 }
 

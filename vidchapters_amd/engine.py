@@ -82,6 +82,9 @@ class Engine:
         self._fresh_grads = None  # Trainer.step only: names of the weight matrices whose gradient has been written in this step (begin_grad_step)
         self.fused_head = True    # Trainer path: LM head + CE + their backward chunk by chunk inside the forward (no [B*Lo, vocab] tensor)
         self.head_rows = 2048     # decoder rows per chunk: 264 MB of fp32 logits + 132 MB of bf16 d(logits) scratch at vocab 32200
+        self.head_ce_fused = True # (round 6) ... and the logits are never WRITTEN: v2s_lmhead_ce_fwd reduces each 128 x 128 logits tile to row statistics in
+                                  # the GEMM epilogue (one launch over all rows), v2s_lmhead_ce_bwd recomputes the tiles of a chunk into bf16 d(logits); False =
+                                  # the round-2 flow (fp32 logits chunk -> v2s_ce_fwd -> v2s_ce_bwd)
         self.pack = True          # run the text encoder on the valid (non-pad) tokens only: exact, see _pack_plan
         self.pack_dec = True      # likewise the decoder rows of pad targets (labels -100, masked as keys): see _pack_plan_dec
         self.pack_mem = True      # and the [video ; text] memory the decoder attends to: see _mem_plan
@@ -931,23 +934,37 @@ class Engine:
             gscale = (float(head_grad_scale) / (labels != -100).sum().clamp(min=1).float()).reshape(1).contiguous()
             dhs = self._bf(Md, self.d)
             R_ = min(self.head_rows, Md)
-            lg = self._f32(R_, self.ldv)                          # logits scratch, reused by every chunk (stream-ordered)
-            dh32 = self._f32(R_, self.d)
             Epad = self.arena.shadow[self.arena.offsets["t5_model.shared.weight"]:][:self.ldv * self.d].view(self.ldv, self.d)
+            ce_fused = self.head_ce_fused and self.d % 64 == 0 and Md * self.d < (1 << 30) and self.ldv * self.d < (1 << 30)
+            lg = self._f32(R_, self.ldv) if (not ce_fused or self.dbg_logits is not None) else None      # logits scratch, reused by every chunk (stream-ordered)
+            dh32 = self._f32(R_, self.d) if not ce_fused else None
+            if ce_fused:                                          # statistics of ALL rows in one launch: no logits in memory
+                part = self._f32(L.lmhead_ce_workspace_floats(Md, self.ldv))
+                L.lmhead_ce_fwd(hs, self.d, Epad, Md, self.V, self.ldv, self.d, alpha, labels, m.label_smoothing, part, row, acc[0:1], acc[1:2])
             for r0 in range(0, Md, R_):
                 n = min(R_, Md - r0)
-                L.gemm(hs[r0:r0 + n], E, lg, n, self.V, self.d, ldc=self.ldv, alpha=alpha)
-                L.ce_fwd(lg, self.ldv, labels[r0:r0 + n], n, self.V, m.label_smoothing, row[r0:r0 + n], acc[0:1], acc[1:2])
-                if self.dbg_logits is not None:
-                    self.dbg_logits.append(lg[:n, :self.V].clone())
                 dlog = self._bf(n, self.ldv)                      # fresh per chunk: the weight-gradient stream may still read the previous one
-                L.ce_bwd(lg, self.ldv, labels[r0:r0 + n], row[r0:r0 + n], n, self.V, m.label_smoothing, gscale, dlog, self.ldv)
+                if ce_fused:
+                    L.lmhead_ce_bwd(hs[r0:r0 + n], self.d, Epad, n, self.V, self.ldv, self.d, alpha, labels[r0:r0 + n], row[r0:r0 + n], m.label_smoothing,
+                                    gscale, dlog, self.ldv)
+                    if self.dbg_logits is not None:               # (tests only: the logits this head never writes, from a plain GEMM)
+                        L.gemm(hs[r0:r0 + n], E, lg, n, self.V, self.d, ldc=self.ldv, alpha=alpha)
+                        self.dbg_logits.append(lg[:n, :self.V].clone())
+                else:
+                    L.gemm(hs[r0:r0 + n], E, lg, n, self.V, self.d, ldc=self.ldv, alpha=alpha)
+                    L.ce_fwd(lg, self.ldv, labels[r0:r0 + n], n, self.V, m.label_smoothing, row[r0:r0 + n], acc[0:1], acc[1:2])
+                    if self.dbg_logits is not None:
+                        self.dbg_logits.append(lg[:n, :self.V].clone())
+                    L.ce_bwd(lg, self.ldv, labels[r0:r0 + n], row[r0:r0 + n], n, self.V, m.label_smoothing, gscale, dlog, self.ldv)
                 # embedding weight gradient on the weight-gradient stream (the scatter-adds into the same tensor wait for the event
                 # recorded after the last chunk, see _embed_bwd); d(hidden): contraction over the padded vocabulary (zero pad columns x zero pad rows), few
                 # output tiles -> fp32 split-K, then one rounding to bf16
                 self._wgrad(dlog, hs[r0:r0 + n], "t5_model.shared.weight", self.V, self.d, n, ld_dy=self.ldv, alpha=alpha, side_ok=True)
-                L.gemm(dlog, Epad, dh32[:n], n, self.d, self.ldv, transB=True, lda=self.ldv, ldb=self.d, alpha=alpha, workspace=self._head_ws())
-                L.cast_bf16(dh32[:n].view(-1), dhs[r0:r0 + n].view(-1), n * self.d)
+                if ce_fused:      # the split-K reduction rounds to bf16 itself (no fp32 d(hidden) chunk, no cast launch)
+                    L.gemm(dlog, Epad, dhs[r0:r0 + n], n, self.d, self.ldv, transB=True, lda=self.ldv, ldb=self.d, alpha=alpha, workspace=self._head_ws())
+                else:
+                    L.gemm(dlog, Epad, dh32[:n], n, self.d, self.ldv, transB=True, lda=self.ldv, ldb=self.d, alpha=alpha, workspace=self._head_ws())
+                    L.cast_bf16(dh32[:n].view(-1), dhs[r0:r0 + n].view(-1), n * self.d)
             if self.overlap:                                      # _embed_bwd waits for this before its scatter-add into the same tensor
                 self._head_wgrad_ev = torch.cuda.Event()
                 self._head_wgrad_ev.record(self.wstream)

@@ -91,6 +91,9 @@ SYMBOLS = {
     "v2s_bcast_grad": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "v2s_ce_fwd": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "v2s_ce_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _i64, _vp]),
+    "v2s_lmhead_ce_workspace_floats": (_i64, [_i32, _i32]),
+    "v2s_lmhead_ce_fwd": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "v2s_lmhead_ce_bwd": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _f32, _vp, _vp, _i64, _vp]),
     "v2s_sqnorm": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "v2s_adam_step": (C.c_int, [C.POINTER(AdamArgs), _vp]),
     "v2s_cast_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
@@ -467,6 +470,34 @@ def add(a, b, y, n):
 def sum_n(parts, stride, nparts, y, n):
     """y[n] = sum_p parts[p * stride + :n] (bf16 in / out, fp32 sum)"""
     _check(lib().v2s_sum_n(parts.data_ptr(), stride, nparts, y.data_ptr(), n, stream_ptr()), "v2s_sum_n")
+
+
+def lmhead_ce_workspace_floats(rows, vpad):
+    return int(lib().v2s_lmhead_ce_workspace_floats(rows, vpad))
+
+
+def lmhead_ce_fwd(h, ldh, E, rows, V, vpad, d, alpha, labels, eps, part, row_out, loss_sum, count):
+    """tied LM head + label-smoothed CE forward without logits in memory: row_out[rows, 2] = (log-sum-exp, loss), loss_sum / count accumulate"""
+    _need(h, torch.bfloat16, "lmhead h"); _need(E, torch.bfloat16, "lmhead E"); _need(part, torch.float32, "lmhead workspace")
+    kt = KernelTimer.active
+    if kt is not None:
+        e0 = kt.begin()
+    _check(lib().v2s_lmhead_ce_fwd(h.data_ptr(), ldh, E.data_ptr(), rows, V, vpad, d, alpha, labels.data_ptr(), eps, part.data_ptr(), row_out.data_ptr(),
+                                   loss_sum.data_ptr(), count.data_ptr(), stream_ptr()), "v2s_lmhead_ce_fwd")
+    if kt is not None:
+        kt.end("lmhead_ce_kernel<0>" if kt.by_symbol else "lmhead_ce_fwd", 2.0 * rows * vpad * d, e0)
+
+
+def lmhead_ce_bwd(h, ldh, E, rows, V, vpad, d, alpha, labels, row_out, eps, gscale, dlogits, ldd):
+    """d(logits) (bf16 [rows, ldd]) of the same head, tiles recomputed"""
+    _need(h, torch.bfloat16, "lmhead h"); _need(E, torch.bfloat16, "lmhead E"); _need(dlogits, torch.bfloat16, "lmhead d(logits)")
+    kt = KernelTimer.active
+    if kt is not None:
+        e0 = kt.begin()
+    _check(lib().v2s_lmhead_ce_bwd(h.data_ptr(), ldh, E.data_ptr(), rows, V, vpad, d, alpha, labels.data_ptr(), row_out.data_ptr(), eps, gscale.data_ptr(),
+                                   dlogits.data_ptr(), ldd, stream_ptr()), "v2s_lmhead_ce_bwd")
+    if kt is not None:
+        kt.end("lmhead_ce_kernel<1>" if kt.by_symbol else "lmhead_ce_bwd", 2.0 * rows * vpad * d, e0)
 
 
 def clock_probe(out):
