@@ -37,7 +37,8 @@ extern "C" {
  * + v2s_rowsumsq_range / v2s_timetoken_renorm_sq, options gemm_ps / gemm_ps_nst / gemm_w128
  * 4 (round 4): + v2s_decode_qfold / v2s_decode_memattn_plan / v2s_decode_memattn / v2s_decode_ctxfold, v2s_beam_advance (additions only)
  * 5 (round 5): + v2s_sum_n, v2s_argmax_step_tail, options gemm_a4 / gemm_a4_grid / gemm_a4_relu / gemm_a4_walk (additions only)
- * 6 (round 6): + v2s_clock_probe, v2s_lmhead_ce_fwd / _bwd / _workspace_floats (additions only) */
+ * 6 (round 6): + v2s_clock_probe, v2s_lmhead_ce_fwd / _bwd / _workspace_floats; the round-4 experiment options gemm_ps / gemm_ps_nst / gemm_w128 are gone
+ *   (v2s_set_option returns V2S_ERR_ARG for them) */
 #define V2S_ABI_VERSION 6
 
 int v2s_version(void);
@@ -55,10 +56,6 @@ const char* v2s_last_error(void);
  *   "gemm_split"    1: split-K slice count from the rounds x length cost model (default), 0: fixed block-count target
  *   "gemm_p8"       8-phase ping-pong kernel (256-row tiles, counted vmcnt LDS-DMA ring): 1: where it measured faster (default),
  *                   0: never, 2: 256x256 tiles wherever legal, 3: 256x128 tiles wherever legal
- *   "gemm_ps"       persistent 128x128 kernel with dedicated write-out waves (round-4 experiment, bit-identical, not faster): 0: never (default),
- *                   2: wherever legal, 3: wherever legal with more tiles than block slots; "gemm_ps_nst" = its ring depth (2 | 3 | 4)
- *   "gemm_w128"     4-wave 256x192 kernel with 128x96 wave tiles in AGPRs (round-4 experiment, NT only, bit-identical, not faster): 0: never
- *                   (default), 2: wherever legal
  *   "gemm_a4"       4-wave 256x256 kernels with a generated, hand-scheduled asm K loop (128x128 wave tiles in AGPRs, v_mfma 32x32x16, counted
  *                   waits; round 5): 1: where they measured faster (default: the persistent deferred-write-out form on plain bf16 GEMMs with
  *                   >= 256 tiles), 0: never, 2: wherever legal, 3: the one-tile form wherever legal, 4: like 1 plus long-contraction weight gradients, 5: like 1 plus the ReLU-mask dgrad

@@ -489,34 +489,6 @@ def test_gemm_grouped_weight_gradients(M, N, K, G, acc):
         L.gemm_grouped(As[:1] * 17, Bs[:1] * 17, Cs[:1] * 17, M, N, K)
 
 
-@pytest.mark.parametrize("opt,val,tag", [("gemm_ps", 2, "gemm_ps_kernel"), ("gemm_w128", 2, "gemm_wt_kernel")])
-def test_experimental_gemm_kernels_are_bit_identical(opt, val, tag):
-    """The two round-4 structural kernels (dedicated write-out waves; 128 x 96 wave tiles in AGPRs) stay in the library behind options:
-    same K order and epilogue arithmetic as the default dispatch -> bit-identical outputs (plain, residual + dropout, ReLU + dropout,
-    fp32 output, ragged edge, transposed weight operand where the kernel has it)."""
-    cases = [("NT", 1000, 392, 256, "res"), ("NT", 2000, 768, 768, ""), ("NT", 1300, 1544, 320, "act"), ("NT", 600, 520, 192, "f32")]
-    if opt == "gemm_ps":
-        cases += [("NN", 777, 136, 192, "dact"), ("NN", 2048, 768, 2304, "")]
-    for kind, M, N, K, ep in cases:
-        A = rnd(M, K, seed=M, scale=0.5)
-        B = rnd(*((K, N) if kind == "NN" else (N, K)), seed=N, scale=0.5)
-        kw = dict(transB=(kind == "NN"), ldb=N if kind == "NN" else K)
-        if ep == "res": kw.update(residual=rnd(M, N, seed=7), dropout_p=0.1, dropout_seed=3)
-        if ep == "act": kw.update(act=L.ACT_RELU, dropout_p=0.1, dropout_seed=5)
-        if ep == "dact": kw.update(dact=L.ACT_RELU, z=torch.relu(rnd(M, N, seed=9)), dropout_p=0.1, dropout_seed=3)
-        outs = {}
-        try:
-            for v in (0, val):
-                L.set_option(opt, v)
-                C_ = torch.full((M, N), float("nan"), dtype=torch.float32 if ep == "f32" else torch.bfloat16, device=DEV)
-                L.gemm(A, B, C_, M, N, K, **kw)
-                outs[v] = (C_, L.lib().v2s_last_gemm_kernel().decode())
-        finally:
-            L.set_option(opt, 0)
-        assert tag in outs[val][1] and tag not in outs[0][1], (outs[val][1], outs[0][1])
-        assert torch.equal(outs[0][0], outs[val][0]), (kind, M, N, K, ep)
-
-
 @pytest.mark.parametrize("kind,M,N,K,ep", [
     ("NT", 512, 512, 384, ""), ("NN", 768, 512, 512, ""), ("NT", 2048, 768, 768, ""), ("NN", 1024, 1536, 640, ""),      # persistent form (plain, whole tiles)
     ("NT", 1000, 520, 384, ""), ("NT", 2000, 768, 768, "res"), ("NT", 1300, 1544, 384, "act"), ("NT", 600, 520, 256, "f32"),

@@ -43,9 +43,6 @@ int v2s_opt_gemm_split(); // 1 = split-K slice count from the rounds x length co
 int v2s_opt_gemm_p8();   // 8-phase ping-pong 256-row kernel: 0 = never, 1 = where it measured faster (default), 2 = 256x256 wherever legal, 3 = 256x128 wherever legal
 int v2s_opt_ce_fused();  // reserved
 int v2s_opt_gemm_dbg();  // profiling aid for the 8-phase kernel: 1 = epilogue without the global store, 2 = no epilogue (results invalid)
-int v2s_opt_gemm_ps();   // persistent 128x128 kernel with write-out waves: 0 = never, 1 = where it measured faster (default), 2 = wherever legal, 3 = wherever legal with more tiles than block slots
-int v2s_opt_gemm_ps_nst(); // ring depth of that kernel: 2 (80 KiB of LDS, two blocks per CU), 3, 4 (144 KiB, one block per CU)
-int v2s_opt_gemm_w128();  // 4-wave 256x256 kernel with 128x128 wave tiles: 0 = never, 1 = where it measured faster, 2 = wherever legal
 int v2s_opt_fp32_io();    // debug: 1 = the norm / cross-entropy / attention entry points take and return FP32 activations (attention: an fp32-arithmetic
                           // reference kernel); parity tests against fp32 references at <= 1e-4, never set by the product path
 int v2s_opt_gemm_a4();    // 4-wave asm-scheduled 256x256 kernels (128x128 wave tiles in AGPRs, 32x32x16 MFMA): 0 = never, 1 = where they measured faster (default),

@@ -1480,381 +1480,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p8d_kernel(const GemmP p) {
 }
 
 // =====================================================================================================================
-// Persistent 128 x 128 x 64 kernel with DEDICATED WRITE-OUT WAVES ("ps", round 4).
-// Where a K = 768 launch of gemm_dma_kernel loses its time (tools/gemm_k_sweep.py, round 3): the main loop alone runs at 1180 TF/s, a
-// launch costs a fixed 19-20 us on top, 10 us of it the acknowledgement of the output stores -- gfx950 counts loads and stores in ONE
-// in-order vmcnt queue, so a wave that stores cannot pass its next DMA wait (persistent kernel) or retire (non-persistent kernel)
-// before the HBM write burst has been acknowledged.  Here the waves that compute never store and never read an epilogue operand:
-//   * block = 8 waves, two per SIMD: waves 0-3 are the compute waves of gemm_dma_kernel (2 x 2 grid of 64 x 64 wave tiles, two-stage
-//     LDS-DMA ring), waves 4-7 are write-out waves; <= 128 VGPRs and 80 KiB of LDS, so TWO blocks per CU like the kernel it replaces;
-//   * a block walks its tiles (ids blockIdx.x + k * gridDim.x); the first stage of tile k+1 is requested during the last K-step of
-//     tile k, so only the block's first tile pays a prologue;
-//   * hand-off at the end of a tile, four quarters of 32 rows (fragment row q of all four compute waves) through a 16 KiB fp32
-//     staging block: barrier A_q (staging free) - compute waves dump acc[q][*] (4 ds_write_b128 per lane) - barrier B_q (staging
-//     full) - write-out waves read their two 8-wide row chunks into registers and run the usual epilogue (epilogue_chunk: bias /
-//     activation / mask / dropout / residual / fp32 or bf16 store) on them WHILE the compute waves dump the next quarter or have
-//     moved on to the next tile; the global operand of the epilogue (z or residual) is prefetched by the write-out waves during the
-//     tile's main loop (eight 16-byte loads per lane).  The write-out waves' loads, stores and their acknowledgements live on their
-//     own vmcnt queues.
-// Barrier protocol (s_barrier counts every wave of the block, so both roles execute the same sequence): per tile nk K-step
-// barriers, then A_0 B_0 A_1 B_1 A_2 B_2 A_3 B_3.  Raw s_barrier from asm with a "memory" clobber (a compiler fence): __syncthreads()
-// would add s_waitcnt vmcnt(0) and make the write-out waves wait for their stores at every K-step.
-// LDS hazards: ring as in gemm_dma_kernel (a slot is refilled after the barrier that follows its last read); staging written only
-// between A_q and B_q (lgkmcnt(0) before B_q), read only between B_q and A_q+1 (lgkmcnt(0) before A_q+1; after B_3 the next A_0 is
-// nk barriers away).  Results are bit-identical to gemm_dma_kernel (same K order, same fp32 epilogue arithmetic).
-constexpr int PS_STG = 32 * BN * 4;               // 16 KiB fp32 staging block behind the ring
-template <int NST> struct PS { static constexpr int RING = NST * STAGE_BYTES, LDS = RING + PS_STG; };   // NST = 2: 80 KiB (two blocks per CU), 4: 144 KiB (one)
-#define PS_BARRIER() asm volatile("s_barrier" ::: "memory")
-#define PS_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-// Ring of NST stages, prefetch distance NST - 1 K-steps.  Ablation (tools/gemm_ps_ablate.py, 32000x768x768): a K-step of the two-stage
-// ring takes 1.04 us per block = the issued -> landed latency of its ONE prefetched stage (MFMA time 0.25 us): the main loop is bound
-// by latency x bytes in flight, and the output stores cost their 8 us (of 50) by lengthening that latency, on whichever wave they are
-// issued.  The DMA stream never stops at a tile edge (the issue pointer runs NST - 1 stages ahead of the compute pointer, into the
-// block's next tile); counted waits: stage s has landed once at most 8 x (groups issued after it) loads of this wave are outstanding.
-template <bool TB, int NST>
-__device__ __forceinline__ void ps_compute(const GemmP& p, char* smem, int wave, int lane, int nmy, int G_) {
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntiles = p.tilesM * p.tilesN;
-  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
-  const int nk = p.K / BK;
-  const int total = nmy * nk;                       // stages of this block
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 4096);
-  uint32_t oa[4], ob[4];
-  auto setup = [&](int k) __attribute__((always_inline)) {
-    int tm, tn, sl;
-    tile_coords(p, xcd_remap((int)blockIdx.x + k * G_, ntiles), tm, tn, sl);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      oa[i] = dma_lane_off<false>(p.lda, tm * BM, p.M, M8, wave * 4 + i, lane);
-      ob[i] = dma_lane_off<TB>(p.ldb, tn * BN, p.N, N8, wave * 4 + i, lane);
-    }
-  };
-  const long stepA = (long)BK * 2, stepB = TB ? (long)BK * p.ldb * 2 : (long)BK * 2;
-  const char* ga = reinterpret_cast<const char*>(p.A);
-  const char* gb = reinterpret_cast<const char*>(p.B);
-  int iss = 0, it = 0, ik = 0, islot = 0;           // issue stream: stages issued, K-step inside its tile, its tile, ring slot of the next issue
-  auto issue = [&]() __attribute__((always_inline)) {
-    dma_issue8(oa, ob, ga, gb, sbase + islot * STAGE_BYTES);
-    islot = islot + 1 == NST ? 0 : islot + 1;
-    ++iss;
-    if (++it == nk) {
-      it = 0; ++ik;
-      if (ik < nmy) { setup(ik); ga = reinterpret_cast<const char*>(p.A); gb = reinterpret_cast<const char*>(p.B); }
-    } else {
-      ga += stepA; gb += stepB;
-    }
-  };
-  setup(0);
-#pragma unroll
-  for (int i = 0; i < NST - 1; ++i)
-    if (iss < total) issue();
-  int slot = 0, s = 0;                              // ring slot and index of the stage the next K-step reads
-  float* cs = reinterpret_cast<float*>(smem + PS<NST>::RING);
-  // staging address of this lane's fragment chunks: local row wm*16 + (lane & 15), 16-byte chunk (wn*64 + j*16 + (lane >> 4)*4) / 4
-  const int srow = wm * 16 + (lane & 15);
-  for (int k = 0; k < nmy; ++k) {
-    for (int t = 0; t < nk; ++t) {
-      const int ahead = iss - s - 1;                // DMA groups issued after stage s: NST - 2 in steady state, fewer at the block's end
-      if (NST == 2 || ahead <= 0) dma_wait_n<0>();
-      else if (NST == 3 || ahead == 1) dma_wait_n<8>();
-      else dma_wait_n<16>();
-      PS_BARRIER();                                 // stage s landed for every wave; every wave has finished reading stage s - 1
-      if (iss < total) issue();                     // into the slot of stage s - 1
-      const char* sa = smem + slot * STAGE_BYTES;
-      const char* sb = sa + A_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[4], bfr[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = read_frag<false, true>(sa, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB, true>(sb, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // transposed: see gemm_epilogue
-      }
-      slot = slot + 1 == NST ? 0 : slot + 1;
-      ++s;
-    }
-    if (p.dbg == 3) {                               // ablation: no hand-off (main loops back to back; results invalid)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-      continue;
-    }
-#pragma clang loop unroll(full)                     // acc[] is indexed by q
-    for (int q = 0; q < 4; ++q) {
-      PS_BARRIER();                                 // A_q: the write-out waves hold the previous quarter in registers
-      if (p.dbg != 2) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = (wn * 64 + j * 16 + (lane >> 4) * 4) >> 2;
-          *reinterpret_cast<f32x4*>(cs + srow * BN + ((c ^ (srow & 7)) << 2)) = acc[q][j];
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[q][j]));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      PS_LGKM0();
-      PS_BARRIER();                                 // B_q: quarter q is in the staging block
-    }
-  }
-}
-
-__device__ __forceinline__ void ps_store(const GemmP& p, char* smem, int ring_bytes, int sl, int nmy, int G_) {
-  const int ntiles = p.tilesM * p.tilesN;
-  const int nk = p.K / BK;
-  const float* cs = reinterpret_cast<const float*>(smem + ring_bytes);
-  const bf16_t* gsrc = p.dact != V2S_ACT_NONE ? p.z : p.residual;
-  const long gld = p.dact != V2S_ACT_NONE ? p.ldz : p.ldr;
-  const bool ahead = gsrc != nullptr;
-  // this lane's two 8-wide chunks of a quarter: c = sl + it*256 -> local row c >> 4, columns (c & 15)*8 .. +7
-  int lr[2], cc[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it) { const int c = sl + it * 256; lr[it] = c >> 4; cc[it] = (c & 15) * 8; }
-  for (int k = 0; k < nmy; ++k) {
-    int tm, tn, slc;
-    tile_coords(p, xcd_remap((int)blockIdx.x + k * G_, ntiles), tm, tn, slc);
-    const int m0 = tm * BM, n0 = tn * BN;
-    auto grow = [&](int q, int it) __attribute__((always_inline)) { return m0 + (lr[it] >> 4) * 64 + q * 16 + (lr[it] & 15); };
-    uint4 gop[8];
-    if (ahead) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int gm = grow(q, it), gn = n0 + cc[it];
-          gop[q * 2 + it] = (gm < p.M && gn < p.N) ? *reinterpret_cast<const uint4*>(gsrc + (long)gm * gld + gn) : make_uint4(0, 0, 0, 0);
-        }
-    }
-    for (int t = 0; t < nk; ++t) PS_BARRIER();
-    float v[2][8];
-    auto fetch = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int c0 = (cc[it] >> 2) ^ (lr[it] & 7), c1 = ((cc[it] >> 2) + 1) ^ (lr[it] & 7);
-        const float4 x0 = *reinterpret_cast<const float4*>(cs + lr[it] * BN + (c0 << 2));
-        const float4 x1 = *reinterpret_cast<const float4*>(cs + lr[it] * BN + (c1 << 2));
-        v[it][0] = x0.x; v[it][1] = x0.y; v[it][2] = x0.z; v[it][3] = x0.w; v[it][4] = x1.x; v[it][5] = x1.y; v[it][6] = x1.z; v[it][7] = x1.w;
-      }
-      PS_LGKM0();
-    };
-    auto epi = [&](auto Qc) __attribute__((always_inline)) {
-      constexpr int q = decltype(Qc)::value;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int gm = grow(q, it), gn = n0 + cc[it];
-        if (p.dbg == 1) {                            // ablation: everything but the post-ops and the global store
-          asm volatile("" ::"v"(v[it][0]), "v"(v[it][1]), "v"(v[it][2]), "v"(v[it][3]), "v"(v[it][4]), "v"(v[it][5]), "v"(v[it][6]), "v"(v[it][7]));
-        } else if (gm < p.M && gn < p.N) {
-          if (ahead) epilogue_chunk<true>(p, v[it], gm, gn, 0, gop[q * 2 + it]);
-          else epilogue_chunk<false>(p, v[it], gm, gn, 0);
-        }
-      }
-    };
-    if (p.dbg == 3) continue;
-    if (p.dbg == 2) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) PS_BARRIER();
-      continue;
-    }
-    PS_BARRIER();                                   // A_0
-    PS_BARRIER();                                   // B_0
-    fetch();
-    PS_BARRIER();                                   // A_1: quarter 0 is in registers, the compute waves may overwrite the staging block
-    epi(std::integral_constant<int, 0>{});
-    PS_BARRIER();                                   // B_1
-    fetch();
-    PS_BARRIER();                                   // A_2
-    epi(std::integral_constant<int, 1>{});
-    PS_BARRIER();                                   // B_2
-    fetch();
-    PS_BARRIER();                                   // A_3
-    epi(std::integral_constant<int, 2>{});
-    PS_BARRIER();                                   // B_3
-    fetch();
-    epi(std::integral_constant<int, 3>{});
-  }
-}
-
-template <bool TB, int NST>
-__global__ __launch_bounds__(512, 4) void gemm_ps_kernel(const GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];        // ring (NST x 32 KiB) + fp32 staging (16 KiB)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntiles = p.tilesM * p.tilesN;
-  const int G_ = gridDim.x;
-  const int nmy = (ntiles - (int)blockIdx.x + G_ - 1) / G_;          // tiles of this block: ids blockIdx.x + k * gridDim.x
-  if (wave < 4) ps_compute<TB, NST>(p, smem, wave, lane, nmy, G_);
-  else ps_store(p, smem, PS<NST>::RING, tid - 256, nmy, G_);
-}
-
-// =====================================================================================================================
-// 256 x 192 tile, FOUR waves with 128 x 96 WAVE TILES ("wt", round 4): 192 accumulators per lane in AGPRs (one wave per SIMD owns the
-// unified 512-register file), fragments double-buffered in VGPRs.  NT only (B = [N][K] weights).
-// Why: the ablation of the 128 x 128 kernels (tools/gemm_ps_ablate.py) and the LDS arithmetic behind it.  A 64 x 64 wave tile reads
-// 8 KiB of fragments per 16 MFMAs (256 matrix-pipe clocks): eight such waves ask for 256 B/clk, the whole LDS read bandwidth of a CU,
-// and the LDS-DMA path for 64 B/clk, the whole vector-L1 bandwidth -- both saturate at the rate the matrix pipe would run at, so
-// those kernels sit at ~50 % of it whatever the prefetch depth (a deeper ring, a persistent walk and write-out waves: all +-0).
-// The 128 x 64 wave tiles of the 8-phase kernel ask for 192 B/clk (75 %).  A 128 x 96 wave tile reads 14 KiB per 48 MFMAs: four waves
-// = 75 B/clk (29 %) of LDS and 37 B/clk of L1 -- and 192 divides every N of t5-base (768, 1536, 2304, 3072), 768 -> 500 tiles = 1.95
-// rounds of the chip instead of 375 = 1.46 (the vendor library picks 256 x 192 for these shapes too).
-// Loop (ONE barrier per 32-wide K stage; 48 MFMAs = 768 matrix-pipe clocks per wave and stage): the fragments of stage s are in
-// registers when iteration s starts (read during iteration s-1); the iteration waits for its own fragment reads (the slot they came
-// from is free once every wave has passed the barrier), waits for stage s+1 with a counted vmcnt, passes the barrier, refills the slot
-// of stage s with stage s+NST (NST-1 stages in flight), issues the fragment reads of stage s+1 into the second register set and runs
-// the 48 MFMAs of stage s under them.  The lgkmcnt waits are BUILTINS pinned by sched_barriers: an asm wait is invisible to the
-// compiler's scoreboard, which then puts its own lgkmcnt(0) in front of the first MFMA -- behind the next stage's reads.
-template <int NST>
-struct WT {
-  static constexpr int BM2 = 256, BN2 = 192;
-  static constexpr int A_B = BM2 * 32 * 2, B_B = BN2 * 32 * 2, STG = A_B + B_B;     // 16 + 12 = 28 KiB per stage
-  static constexpr int LDS = NST * STG > 33 * 1024 ? NST * STG : 33 * 1024;           // ring; the epilogue stages 32 x 196 floats in it
-  static constexpr int PER = 7;                                                        // DMA instructions per wave and stage
-};
-__device__ __forceinline__ void wt_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }    // lgkmcnt(0) only
-
-template <int NST>
-__global__ __launch_bounds__(256, 1) void gemm_wt_kernel(const GemmP p) {
-  using G = WT<NST>;
-  constexpr int A_B = G::A_B, STG = G::STG, PER = G::PER;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nwg = p.tilesM * p.tilesN;
-  int tm, tn, slice;
-  tile_coords(p, xcd_remap(blockIdx.x, nwg), tm, tn, slice);
-  const int m0 = tm * 256, n0 = tn * 192;
-  const int M8 = (p.M + 7) & ~7, N8 = (p.N + 7) & ~7;
-  const int nst = p.K / 32;                                          // >= NST (dispatcher)
-
-  f32x4 acc[8][6];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  uint32_t oa[4], ob[3];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) oa[i] = p8_lane_off<256, false>(p.lda, m0, p.M, M8, wave * 4 + i, lane);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) ob[i] = p8_lane_off<192, false>(p.ldb, n0, p.N, N8, wave * 3 + i, lane);
-  const char* ga = reinterpret_cast<const char*>(p.A);
-  const char* gb = reinterpret_cast<const char*>(p.B);
-  const uint32_t sbase = lds_addr(smem);
-  const uint32_t dstA = __builtin_amdgcn_readfirstlane(sbase + wave * 4096);
-  const uint32_t dstB = __builtin_amdgcn_readfirstlane(sbase + A_B + wave * 3072);
-  int islot = 0, iss = 0;
-  auto issue = [&]() __attribute__((always_inline)) {
-    p8_dma2(oa[0], oa[1], ga, dstA + islot);
-    p8_dma2(oa[2], oa[3], ga, dstA + islot + 2048);
-    p8_dma2(ob[0], ob[1], gb, dstB + islot);
-    p8_dma1(ob[2], gb, dstB + islot + 2048);
-    ga += 64; gb += 64; ++iss;
-    islot = islot + STG == NST * STG ? 0 : islot + STG;
-  };
-  const int arow = wm * 128, brow = wn * 96;
-  bf16x8 af[8], bfr[6];
-#pragma unroll
-  for (int i = 0; i < NST; ++i) issue();                             // stages 0 .. NST-1
-  dma_wait_n<PER * (NST - 1)>();
-  P8_BARRIER();
-#pragma unroll
-  for (int j = 0; j < 6; ++j) bfr[j] = read_frag_w4<192, false>(smem + A_B, brow + j * 16, lane);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) af[i] = read_frag_w4<256, false>(smem, arow + i * 16, lane);
-  int rslot = STG;                                                   // ring slot (byte offset) of stage s + 1
-#pragma unroll 1
-  for (int s = 0; s < nst; ++s) {
-    wt_lgkm0();                                                      // fragments of stage s are in registers: its slot may be refilled after the barrier
-    const int after = nst - 2 - s;                                   // stages after stage s + 1 that exist (in flight: min(after, NST - 2))
-    if (after >= NST - 2) dma_wait_n<PER * (NST - 2)>();
-    else if (NST > 3 && after == 2) dma_wait_n<PER * 2>();
-    else if (after == 1) dma_wait_n<PER>();
-    else dma_wait_n<0>();
-    P8_BARRIER();
-    // fragments of stage s + 1 (after the last stage: a stale slot, never used).  Issue order: B (second register set) and the LAST two
-    // A rows (second set) first, the MFMAs of row 0, the DMA of stage s + NST (into the slot of stage s), then per A row its refill
-    // read (in place, right behind the last MFMA that read it) and the next row's six MFMAs; the iteration ends with twelve MFMAs
-    // and no read behind them, so that the lgkmcnt(0) at the top of the next iteration finds every read complete
-    const char* sa = smem + rslot;
-    const char* sb = sa + A_B;
-    bf16x8 bn[6], an6, an7;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) bn[j] = read_frag_w4<192, false>(sb, brow + j * 16, lane);
-    an6 = read_frag_w4<256, false>(sa, arow + 6 * 16, lane);
-    an7 = read_frag_w4<256, false>(sa, arow + 7 * 16, lane);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[0], acc[0][j], 0, 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-    if (iss < nst) issue();
-#pragma unroll
-    for (int i = 1; i < 8; ++i) {
-      if (i <= 6) af[i - 1] = read_frag_w4<256, false>(sa, arow + (i - 1) * 16, lane);
-#pragma unroll
-      for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 1; i <= 6; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-    af[6] = an6; af[7] = an7;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) bfr[j] = bn[j];
-    rslot = rslot + STG == NST * STG ? 0 : rslot + STG;
-  }
-  __syncthreads();                                                   // every wave is done with the ring
-
-  if (p.dbg == 2) {                                                  // ablation: main loop only (accumulators kept live; results invalid)
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) asm volatile("" ::"a"(acc[i][j]));
-    return;
-  }
-  // epilogue: eight passes; pass ps = fragment row ps of every wave = tile rows {wm*128 + ps*16 + 0..15}, 32 rows x 192 columns through
-  // an fp32 staging block [32][192 + 4] (transposed accumulators: one ds_write_b128 per fragment), then 8-wide row chunks
-  constexpr int PB = 192 + 4;
-  float* cs = reinterpret_cast<float*>(smem);
-#pragma clang loop unroll(full)                                      // acc[] is indexed by ps
-  for (int ps = 0; ps < 8; ++ps) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      *reinterpret_cast<f32x4*>(cs + (wm * 16 + (lane & 15)) * PB + wn * 96 + j * 16 + (lane >> 4) * 4) = acc[ps][j];
-    __syncthreads();
-#pragma unroll 1
-    for (int c = tid; c < 32 * 24; c += 256) {
-      const int lr = c / 24, cc = (c % 24) * 8;
-      const int gm = m0 + (lr >> 4) * 128 + ps * 16 + (lr & 15), gn = n0 + cc;
-      if (gm >= p.M || gn >= p.N) continue;
-      float v[8];
-      const float4 x0 = *reinterpret_cast<const float4*>(cs + lr * PB + cc);
-      const float4 x1 = *reinterpret_cast<const float4*>(cs + lr * PB + cc + 4);
-      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-      if (p.dbg == 1) {
-        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-        continue;
-      }
-      epilogue_chunk(p, v, gm, gn, slice);
-    }
-    if (ps + 1 < 8) __syncthreads();
-  }
-}
+// (Round 4's two structural experiments lived here -- a persistent 128 x 128 kernel with dedicated write-out waves, "gemm_ps", and a 4-wave 256 x 192
+// kernel with 128 x 96 wave tiles in AGPRs, "gemm_wt" -- both bit-identical to the default dispatch and neither faster (DESIGN.md 8a-r4 keeps the
+// ablations and counters).  Removed in round 6: the generated gemm_a4p kernel is what that line of work led to.)
 
 // =====================================================================================================================
 // Skinny GEMM for cached decoding (M <= 64 rows: one token per live sequence / beam): C[M][N] = A[M][K] . B[N][K]^T.
@@ -2173,18 +1801,6 @@ static int p8_auto(const v2s_gemm_args* a, bool deferred_ok) {
   return 0;
 }
 
-// Shapes the persistent write-out-wave kernel takes by default (gemm_ps = 1).  Rules from tools/gemm_ps_ab.py (profiles/r04_gemm_ps_ab.txt).
-static bool ps_auto(const v2s_gemm_args* a, long t128, int slots, int p8, bool p8d) {
-  (void)a; (void)p8; (void)p8d;
-  return t128 > slots;
-}
-
-// Shapes the 128 x 128-wave-tile kernel takes by default (gemm_w128 = 1).
-static bool w128_auto(const v2s_gemm_args* a) {
-  (void)a;
-  return false;
-}
-
 // Shapes the 4-wave asm-scheduled 256 x 256 kernels take by default (gemm_a4 = 1).  Measured with tools/gemm_a4_ab.py, variants interleaved in
 // one process (profiles/r05_b_gemm_a4p_ab.txt; us default / persistent a4p / vendor): 32000x2304x768 139 / 108 / 108, 32000x768x768 52 / 44 / 47,
 // 32000x3072x768 168 / 135 / 134, 32000x768x3072 150 / 139 / 125, dgrads 32000x768x2304 122 / 104 / 103, 32000x3072x768 172 / 127 / 154,
@@ -2429,33 +2045,6 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
   bool p8d = false;
   if (p8_force != 0) p8_decide(a, tr, p8, p8d);
   if (p8) { bm = 256; bn = p8; w4 = false; }
-  // persistent 128 x 128 kernel with write-out waves (gemm_ps_kernel): forward / dgrad shapes with more tiles than the chip has block
-  // slots (a block must walk >= 2 tiles for its write-out to run under a main loop), any epilogue, never split-K
-  // 4-wave 128 x 128-wave-tile kernel (gemm_w128_kernel): option gemm_w128 = 2 wherever legal, 1 = where it measured faster
-  bool w128 = false;
-  {
-    const int wmode = v2s_opt_gemm_w128();
-    const bool w_ok = wmode != 0 && p8_force != 0 && tr && !a->transA && !a->transB && (a->K % 32) == 0 && a->K >= 160 && a->M >= 256 && a->N >= 96 &&
-                      !plain_split && (long)a->M * a->lda < (1L << 30) && (long)a->N * a->ldb < (1L << 30);
-    if (w_ok && (wmode == 2 || (wmode == 1 && v2s_opt_gemm_p8() == 1 && w128_auto(a)))) { w128 = true; bm = 256; bn = 192; p8 = 0; p8d = false; w4 = false; }
-  }
-  bool ps = false;
-  int ps_nst = v2s_opt_gemm_ps_nst();
-  if (ps_nst < 2 || ps_nst > 4) ps_nst = 2;
-  {
-    const int ps_mode = v2s_opt_gemm_ps();
-    const long t128 = (long)((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
-    const int slots = (ps_nst == 2 ? 2 : 1) * num_cus();
-    const bool ps_ok = ps_mode != 0 && !w128 && p8_force != 0 && tr && !a->transA && (a->K % BK) == 0 && a->M >= 8 && a->N >= 8 &&
-                       !(plain_split && t128 < 768) && (long)a->M * a->lda < (1L << 30) &&
-                       (a->transB ? 64 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 30);
-    if (ps_ok) {
-      if (ps_mode == 2) ps = true;
-      else if (ps_mode == 3) ps = t128 > slots;
-      else ps = v2s_opt_gemm_p8() == 1 && ps_auto(a, t128, slots, p8, p8d);      // a forced 8-phase mode (tests, A/B tools) keeps its kernel
-    }
-    if (ps) { bm = BM; bn = BN; p8 = 0; p8d = false; w4 = false; }
-  }
   // 4-wave asm-scheduled 256 x 256 kernel (gemm_a4_kernel): forward / dgrad shapes, any epilogue, never split-K
   bool a4 = false, a4p = false;
   {
@@ -2466,7 +2055,7 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
                       (a->transA ? 32 * a->lda + a->M : (long)a->M * a->lda) < (1L << 30) &&
                       (a->transB ? 32 * a->ldb + a->N : (long)a->N * a->ldb) < (1L << 30);
     if (a_ok && (amode == 2 || amode == 3 || ((amode == 1 || amode == 4 || amode == 5) && v2s_opt_gemm_p8() == 1 && a4_auto(a, t256)))) {
-      a4 = true; bm = 256; bn = 256; p8 = 0; p8d = false; w4 = false; w128 = false; ps = false;
+      a4 = true; bm = 256; bn = 256; p8 = 0; p8d = false; w4 = false;
       // persistent form with the deferred write-out: plain bf16 epilogue, whole tiles (gemm_a4 = 3: never)
       a4p = amode != 3 && a4p_epilogue(a) != 0 && !plain_split && (long)a->M * a->ldc * 2 < (1L << 31) && t256 < 65536;
     }
@@ -2545,40 +2134,6 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     if (a->transA) hipLaunchKernelGGL((gemm_a4_kernel<true, true>), grid, block, A4_LDS, s, p);
     else if (a->transB) hipLaunchKernelGGL((gemm_a4_kernel<false, true>), grid, block, A4_LDS, s, p);
     else hipLaunchKernelGGL((gemm_a4_kernel<false, false>), grid, block, A4_LDS, s, p);
-  } else if (w128 && p.splitk == 1) {
-    static bool attr_w = false;
-    if (!attr_w) {
-      (void)hipFuncSetAttribute((const void*)gemm_wt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WT<4>::LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_wt_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, WT<5>::LDS);
-      attr_w = true;
-    }
-    const dim3 grid(nblocks), block(256);
-    const bool five = v2s_opt_gemm_ps_nst() == 5 && a->K >= 160;
-    g_last_gemm = five ? "gemm_wt_kernel<5>" : "gemm_wt_kernel<4>";
-    if (five) hipLaunchKernelGGL((gemm_wt_kernel<5>), grid, block, WT<5>::LDS, s, p);
-    else hipLaunchKernelGGL((gemm_wt_kernel<4>), grid, block, WT<4>::LDS, s, p);
-  } else if (ps && p.splitk == 1) {
-    static bool attr_ps = false;
-    if (!attr_ps) {
-      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PS<2>::LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PS<2>::LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, PS<3>::LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, PS<3>::LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PS<4>::LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_ps_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PS<4>::LDS);
-      attr_ps = true;
-    }
-    const int nst = ps_nst;
-    const int slots = (nst == 2 ? 2 : 1) * num_cus();
-    const int nt = p.tilesM * p.tilesN;
-    const dim3 grid((unsigned)(nt < slots ? nt : slots)), block(512);
-    static const char* names_ps[3][2] = {{"gemm_ps_kernel<false, 2>", "gemm_ps_kernel<true, 2>"}, {"gemm_ps_kernel<false, 3>", "gemm_ps_kernel<true, 3>"},
-                                         {"gemm_ps_kernel<false, 4>", "gemm_ps_kernel<true, 4>"}};
-    g_last_gemm = names_ps[nst - 2][a->transB ? 1 : 0];
-#define V2S_PS(NST_) do { if (!a->transB) hipLaunchKernelGGL((gemm_ps_kernel<false, NST_>), grid, block, PS<NST_>::LDS, s, p); \
-                          else hipLaunchKernelGGL((gemm_ps_kernel<true, NST_>), grid, block, PS<NST_>::LDS, s, p); } while (0)
-    if (nst == 2) V2S_PS(2); else if (nst == 3) V2S_PS(3); else V2S_PS(4);
-#undef V2S_PS
   } else if (p8d) {
     static bool attr8d = false;
     const int ncu = num_cus();

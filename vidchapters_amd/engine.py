@@ -101,14 +101,7 @@ class Engine:
         self.beam_on_device = True    # beam search (no sampling, <= 16 beams): hypothesis bookkeeping on the device (v2s_beam_advance): no host round trip per step
         self.group_flush_layers = 4  # ... every this many decoder layers (the launches then run beside the NEXT layers' under-filled 8192-row kernels)
         self._wgrad_groups: Dict = {}
-        self.dmem_parts = 0       # 1: the decoder layers' d(memory) contributions are plain GEMMs into separate slices, summed once (round 5: each GEMM
-                                  # 99 -> 71 us alone, +-0 in the step, +650 MB: off); 0: residual chain
         self.decode_fuse_tail = True  # greedy(): argmax + next embedding + step counter as one launch (v2s_argmax_step_tail)
-        self.defer_wgrads = 0     # encoder backward: 1 = the FFN / O weight gradients of a layer are held back until its attention backward is enqueued (they
-                                  # then run beside the VALU-bound attention kernels instead of beside the dgrad GEMMs); 2 = the QKV weight gradient too
-                                  # (beside the NEXT layer's attention).  _flush_deferred
-        self._deferred: List = []
-        self._defer_open = False
         self.shadow_events = None # sharded optimizer: {"vit" | "enc" | "dec": event after which that group's bf16 shadow weights are whole}
         # parity taps (tests only; None = off, the default): ``dbg_logits`` = list that receives the fp32 logits [rows, vocab] of every head
         # launch (whole tensor on the autograd route, one entry per chunk of the fused head); ``dbg_tap`` = list that receives, per sublayer of
@@ -269,9 +262,6 @@ class Engine:
                 torch.cuda.current_stream().wait_stream(self.wstream)
             launch()
             return
-        if self._defer_open:
-            self._deferred.append((launch, dy, x))
-            return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.wstream.wait_event(ev)
@@ -279,21 +269,6 @@ class Engine:
             launch()
         dy.record_stream(self.wstream)
         x.record_stream(self.wstream)
-
-    def _flush_deferred(self) -> None:
-        """launch the held-back weight-gradient GEMMs (defer_wgrads) on the weight-gradient stream, behind everything enqueued so far"""
-        items, self._deferred = self._deferred, []
-        if not items:
-            return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.wstream.wait_event(ev)
-        with torch.cuda.stream(self.wstream):
-            for launch, _, _ in items:
-                launch()
-        for _, dy, x in items:
-            dy.record_stream(self.wstream)
-            x.record_stream(self.wstream)
 
     def flush_wgrads(self) -> None:
         """Launch the collected weight-gradient groups (see _wgrad) on the weight-gradient stream, behind everything the current stream
@@ -442,11 +417,8 @@ class Engine:
         if df is None:
             df = self._drop(dh, r.p, r.seed_o)
         grp = "dec.sa." if r.stack == "decoder" else None           # the encoder's (32000-row contraction) stay single launches
-        self._defer_open = bool(self.defer_wgrads) and self.overlap and r.stack == "encoder"
         self._wgrad(df, r.ctx, sa + "o.weight", d, inner, M, group=grp and grp + "o")
         dctx = self._dgrad(df, a.w(sa + "o.weight"), M, inner, d)
-        self._flush_deferred()                                      # (defer_wgrads) ... beside the attention kernels that follow
-        self._defer_open = self._defer_open and self.defer_wgrads >= 2
         dqkv = self._bf(M, 3 * inner)
         delta = self._f32(B, self.H, N, 4)       # row statistics handed from the dQ to the dK/dV kernel (v2s_attn_bwd workspace)
         st = (N * 3 * inner, 3 * inner)
@@ -455,7 +427,6 @@ class Engine:
                    dbias_diag=dbias_diag, far=self._far[(N, N, r.stack == "encoder")])
         self._wgrad(dqkv, r.n, sa + "q.weight", 3 * inner, d, M, shape=(3 * inner, d), group=grp and grp + "qkv")
         dn = self._dgrad(dqkv, a.w(sa + "q.weight", (3 * inner, d)), M, d, 3 * inner)
-        self._defer_open = False
         return self._norm_bwd_next(r.h, self._ln(r.stack, r.i, 0), r.rstd, dn, dh, M, nxt)
 
     def _cross_attn_bwd(self, r, dh, dmem, first: bool, df=None, nxt=None):
@@ -476,14 +447,11 @@ class Engine:
         self._wgrad(dq, r.n, ca + "q.weight", inner, d, Mq, group="dec.ca.q")
         dn = self._dgrad(dq, a.w(ca + "q.weight"), Mq, d, inner)
         self._wgrad(dkv, r.mem, ca + "k.weight", 2 * inner, d, Mk, shape=(2 * inner, d))
-        # d(memory) of this layer.  ``dmem`` is either the accumulator (a chain of residual epilogues, in place: the form of rounds 2-4) or --
-        # round 5, ``dmem_parts`` -- this layer's own [Mk, d] slice of a [n_dec, Mk, d] buffer: a PLAIN GEMM (which the persistent
-        # deferred-write-out kernel takes: 71 instead of 99 us at cfg-2), the twelve slices summed once in fp32 by t5_loss_backward
-        # (v2s_sum_n: one rounding instead of eleven).  Nothing in the decoder's backward reads it, so it runs on the K|V stream beside the
-        # decoder's small launches; t5_loss_backward joins before using it.
-        plain = isinstance(dmem, tuple)
-        out = dmem[0][dmem[1].pop()] if plain else dmem
-        epi = {} if (plain or first) else dict(residual=dmem)
+        # d(memory) of this layer: a chain of residual epilogues into the accumulator ``dmem``, in place.  Nothing in the decoder's backward reads it,
+        # so it runs on the K|V stream beside the decoder's small launches; t5_loss_backward joins before using it.  (Round 5 tried twelve plain GEMMs
+        # into separate slices + one fp32 sum: each GEMM 99 -> 71 us alone, +-0 in the step, +650 MB -- removed in round 6.)
+        out = dmem
+        epi = {} if first else dict(residual=dmem)
         if self.overlap and self.overlap_kv:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -503,14 +471,12 @@ class Engine:
         if df is None:
             df = self._drop(dh, r.p, r.seed_o)
         grp = "dec.ff." if r.stack == "decoder" else None
-        self._defer_open = bool(self.defer_wgrads) and self.overlap and r.stack == "encoder"
         self._wgrad(df, r.u, fp + "wo.weight", d, ff, M, group=grp and grp + "wo")
         # (timing probe, round 3: without the ReLU-mask operand z this launch would take the deferred-epilogue kernel and the step
         # 55.48 -> 54.33 ms; a byte mask written by the wi forward would have to be packed inside that kernel's slack-free write-out phases)
         du = self._dgrad(df, a.w(fp + "wo.weight"), M, ff, d, dact=L.ACT_RELU, z=r.u, dropout_p=r.p, dropout_seed=r.seed_u)
         self._wgrad(du, r.n, fp + "wi.weight", ff, d, M, group=grp and grp + "wi")
         dn = self._dgrad(du, a.w(fp + "wi.weight"), M, d, ff)
-        self._defer_open = False
         return self._norm_bwd_next(r.h, self._ln(r.stack, r.i, 2 if r.stack == "decoder" else 1), r.rstd, dn, dh, M, nxt)
 
     def _final_norm_bwd(self, r, dout, nxt=None):
@@ -717,13 +683,11 @@ class Engine:
                 if stack == "decoder" and r.i % self.group_flush_layers == 0:
                     self.flush_wgrads()               # the collected decoder layers' weight gradients: one grouped launch per projection
                 if layer_done is not None:        # all parameter gradients of block r.i are enqueued (except block 0's bias table)
-                    self._flush_deferred()
                     layer_done(r.i)
             elif r.kind == "embed":
                 self._embed_bwd(r, dh)
             if self.dbg_tap is not None and r.kind != "embed":
                 self.dbg_tap.append((stack, r.kind, r.get("i", -1), dh_arrived, dh))
-        self._flush_deferred()
         self.flush_wgrads()
         L.bias_bucket_bwd(ddiag, lut, a.g(self._sa(stack, 0) + "relative_attention_bias.weight"), self.H, 2 * nq - 1,
                           self.cfg.buckets)
@@ -1007,20 +971,7 @@ class Engine:
             L.gemm(dlog, Epad, dhs, Md, d, self.ldv, transB=True, lda=self.ldv, ldb=d, alpha=tape["alpha"])
             del dlog
         dmem = self._bf(tape["Mk"], d)
-        n_cross = sum(1 for r in tape["dec"] if r.kind == "cross")
-        if self.dmem_parts and n_cross > 1:
-            parts = self._bf(n_cross, tape["Mk"], d)                       # one plain GEMM output per decoder layer, summed below
-            self._stack_backward(tape["dec"], dhs, "decoder", Lo, dmem=(parts, list(range(n_cross))))
-            if self.overlap and self.overlap_kv:
-                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
-                self.kstream.wait_event(ev)
-                with torch.cuda.stream(self.kstream):
-                    L.sum_n(parts, tape["Mk"] * d, n_cross, dmem, tape["Mk"] * d)
-                parts.record_stream(self.kstream); dmem.record_stream(self.kstream)
-            else:
-                L.sum_n(parts, tape["Mk"] * d, n_cross, dmem, tape["Mk"] * d)
-        else:
-            self._stack_backward(tape["dec"], dhs, "decoder", Lo, dmem=dmem)
+        self._stack_backward(tape["dec"], dhs, "decoder", Lo, dmem=dmem)
         if self.overlap and self.overlap_kv:
             torch.cuda.current_stream().wait_stream(self.kstream)          # the d(memory) work of _cross_attn_bwd
         packed_mem = bool(tape.get("mem_packed"))
