@@ -45,6 +45,9 @@ def main():
             saved = []
             for kv in v.split(","):
                 k, x = kv.split("=")
+                if k == "lib":                        # another build of the library (same ABI): "lib=tools/libvid2seq_hip_nt.so"
+                    L.LIB_PATH = os.path.abspath(x); L._LIB = None; L.lib()
+                    continue
                 if k.startswith("eng:"):              # engine attribute, e.g. "eng:decode_mem_attn=0"
                     saved.append((k, getattr(eng, k[4:])))
                     setattr(eng, k[4:], int(x))

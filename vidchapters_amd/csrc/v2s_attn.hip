@@ -56,6 +56,9 @@ constexpr int HD = 64;
 #ifndef ATTN_ABL
 #define ATTN_ABL 0
 #endif
+#ifndef ATTN_DQ_PREF
+#define ATTN_DQ_PREF 0
+#endif
 #ifndef ATTN_DKV_PREF
 #define ATTN_DKV_PREF 1
 #endif
@@ -708,6 +711,13 @@ __global__ __launch_bounds__(256, ATTN_BWD_OCC) void attn_bwd_dq_kernel(const At
       mfma_settle(st[0][0], st[0][1], st[0][2], st[0][3], st[1][0], st[1][1], st[1][2], st[1][3]);
       mfma_settle(dp[0][0], dp[0][1], dp[0][2], dp[0][3], dp[1][0], dp[1][1], dp[1][2], dp[1][3]);
       prio_lo();
+#if ATTN_DQ_PREF
+      // the transposed K fragments of the first half of the dQ product, requested before the softmax / dS phase (LDS latency under its VALU work)
+      bf16x8 ktf0[ATTN_DQ_PREF == 2 ? 8 : 4];
+#pragma unroll
+      for (int db = 0; db < (ATTN_DQ_PREF == 2 ? 8 : 4); ++db) ktf0[db] = col_frag<TR>(sK, (db >> 2) * 32, (db & 3) * 16, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       const bool clean = !any_flag && !edge;
       // bias-gradient routing (after the dS of the whole tile are formed, below): relative positions d = k - q of a 16x16 block
       // (qb, kb) span a 31-wide range; blocks entirely in a far bucket just sum their dS (1: far-low, 2: far-high), only the
@@ -801,6 +811,16 @@ __global__ __launch_bounds__(256, ATTN_BWD_OCC) void attn_bwd_dq_kernel(const At
                                                              cvt_pk(st[qb][3][0], st[qb][3][1]), cvt_pk(st[qb][3][2], st[qb][3][3])));
       }
       prio_hi();
+#if ATTN_DQ_PREF
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const bf16x8 ktf = (kh == 0 || ATTN_DQ_PREF == 2) ? ktf0[kh * 4 + db] : col_frag<TR>(sK, kh * 32, db * 16, lane);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) dqt[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qb][kh], dqt[qb][db], 0, 0, 0);
+        }
+#else
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -809,6 +829,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_OCC) void attn_bwd_dq_kernel(const At
 #pragma unroll
           for (int qb = 0; qb < 2; ++qb) dqt[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qb][kh], dqt[qb][db], 0, 0, 0);
         }
+#endif
       prio_lo();
     }
     if (t + 1 < ntiles) {

@@ -1485,6 +1485,21 @@ __global__ __launch_bounds__(512, 2) void gemm_p8d_kernel(const GemmP p) {
 // ablations and counters).  Removed in round 6: the generated gemm_a4p kernel is what that line of work led to.)
 
 // =====================================================================================================================
+// 16-byte load of a weight slice that is read ONCE per decode step (SKINNY_NT: non-temporal hint, the line is not kept in the caches the
+// activations and the KV cache live in)
+#ifndef SKINNY_NT
+#define SKINNY_NT 0
+#endif
+__device__ __forceinline__ uint4 ld_stream(const bf16_t* ptr) {
+#if SKINNY_NT
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_;
+  const u32x4_ v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_*>(ptr));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const uint4*>(ptr);
+#endif
+}
+
 // Skinny GEMM for cached decoding (M <= 64 rows: one token per live sequence / beam): C[M][N] = A[M][K] . B[N][K]^T.
 // The weight matrix B is the only real traffic (read once); the 128-wide tiles above would occupy 6..24 CUs for it.  Here a block
 // owns 16 output columns: its 4 waves split K four ways, each streaming its [16][K/4] weight slab straight from HBM into MFMA
@@ -1540,7 +1555,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bq[s][t] = *reinterpret_cast<const uint4*>(bp[t] + k + s * 32);
+      for (int t = 0; t < NT; ++t) bq[s][t] = ld_stream(bp[t] + k + s * 32);
 #pragma unroll
       for (int i = 0; i < MT; ++i) aq[s][i] = *reinterpret_cast<const uint4*>(ap[i] + k + s * 32);
     }
@@ -1628,7 +1643,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_wide_kernel(const GemmP p) {
     int brow = t * 16 + r; brow = brow < p.N ? brow : p.N - 1;
     const bf16_t* bp = p.B + (long)brow * p.ldb + kc;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) bq[s] = *reinterpret_cast<const uint4*>(bp + s * 32);
+    for (int s = 0; s < KS; ++s) bq[s] = ld_stream(bp + s * 32);
   };
   if (tile < tiles) load_b(tile);
   const bool rms = p.rms_eps > 0.f;
