@@ -56,6 +56,9 @@ constexpr int HD = 64;
 #ifndef ATTN_ABL
 #define ATTN_ABL 0
 #endif
+#ifndef ATTN_DKV_PIPE2
+#define ATTN_DKV_PIPE2 0
+#endif
 #ifndef ATTN_DQ_PREF
 #define ATTN_DQ_PREF 0
 #endif
@@ -975,6 +978,38 @@ __global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const A
   __syncthreads();
 
   const bool keys_all_masked = __all(kflag[0] != 0u && kflag[KBW - 1] != 0u);
+#if ATTN_DKV_PIPE2
+  // operands of the NEXT score phase, requested one phase ahead: Q / dO row fragments [ks][qi] of a 32-row half and its bias window entries
+  bf16x8 pfq[2][2], pfd[2][2];
+  f32x4 pbw[2][KBW];
+  auto prefetch_half = [&](const char* tQ, const char* tDO, const int tq0, const int qh) {
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+#if ATTN_DKV_PIPE2 != 2
+#pragma unroll
+      for (int kb = 0; kb < KBW; ++kb)
+        pbw[qi][kb] = BIAS ? bias_read4<NC>(s_bias, CS, bidx0 - dkv_key(kb, li) + tq0 + (2 * qh + qi) * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        pfq[ks][qi] = row_frag(tQ, (2 * qh + qi) * 16, ks, lane);
+        pfd[ks][qi] = row_frag(tDO, (2 * qh + qi) * 16, ks, lane);
+      }
+    }
+  };
+  auto accumulate_tail = [&](const bf16x8 (&dot)[4], const bf16x8 (&qt)[4], const bf16x8 (&pdf)[KBW], const bf16x8 (&dsf)[KBW]) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int kb = 0; kb < KBW; ++kb) {
+        dvt[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[db], pdf[kb], dvt[kb][db], 0, 0, 0);
+        dkt[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[db], dsf[kb], dkt[kb][db], 0, 0, 0);
+      }
+  };
+  prefetch_half(smem, smem + KV_TILE, 0, 0);
+#endif
+  bf16x8 pdf[KBW], dsf[KBW];
+  bf16x8 dot[4], qt[4];
   for (int t = 0; t < ntiles; ++t) {
     const char* sQ = smem + (t & 1) * DKV_STAGE;
     const char* sDO = sQ + KV_TILE;
@@ -1026,6 +1061,40 @@ __global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const A
             }
           }
       };
+#if ATTN_DKV_PIPE2
+      // the same products from operands that were requested one phase earlier (prefetch_half below): no LDS wait in front of the MFMAs
+      auto scores_pf = [&](const int qh, f32x4 (&st)[2][KBW], f32x4 (&dp)[2][KBW]) {
+#if ATTN_DKV_PIPE2 == 2
+        // bias window entries requested here; the dP products (which start from zero) run first and cover their LDS latency
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+          for (int kb = 0; kb < KBW; ++kb)
+            st[qi][kb] = BIAS ? bias_read4<NC>(s_bias, CS, bidx0 - dkv_key(kb, li) + q0 + (2 * qh + qi) * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+          for (int kb = 0; kb < KBW; ++kb) st[qi][kb] = pbw[qi][kb];
+#endif
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+          for (int kb = 0; kb < KBW; ++kb) dp[qi][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int kb = 0; kb < KBW; ++kb) dp[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfd[ks][qi], vf[kb][ks], dp[qi][kb], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int kb = 0; kb < KBW; ++kb) st[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfq[ks][qi], kf[kb][ks], st[qi][kb], 0, 0, 0);
+      };
+#endif
       // P (dropped) -> dp registers become Pd ; st registers become dS ; packed to the B operands of the second products
       auto softmax_ds = [&](const int qh, f32x4 (&st)[2][KBW], f32x4 (&dp)[2][KBW], bf16x8 (&pdf)[KBW], bf16x8 (&dsf)[KBW]) {
         if (KBW == 2) mfma_settle(st[0][0], st[0][KBW - 1], st[1][0], st[1][KBW - 1], dp[0][0], dp[0][KBW - 1], dp[1][0], dp[1][KBW - 1]);
@@ -1122,8 +1191,42 @@ __global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const A
           }
         }
       };
-      bf16x8 pdf[KBW], dsf[KBW];
-      bf16x8 dot[4], qt[4];
+#if ATTN_DKV_PIPE2
+      // software pipeline across the phases of the loop (round 6): every MFMA group runs on operands that were requested a phase earlier --
+      // the score products on the Q / dO fragments and the bias window entries fetched under the PREVIOUS half's dV / dK products (prefetch_half,
+      // after the tile's commit + barrier when that half belongs to the next tile), the dV / dK products on transposed fragments fetched
+      // under the softmax phase
+      {
+        f32x4 st[2][KBW], dp[2][KBW];
+        scores_pf(0, st, dp);
+#if ATTN_DKV_PREF
+        colfrags(0, dot, qt);
+        __builtin_amdgcn_sched_barrier(0);
+        softmax_ds(0, st, dp, pdf, dsf);
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch_half(sQ, sDO, q0, 1);
+#else
+        softmax_ds(0, st, dp, pdf, dsf);
+        __builtin_amdgcn_sched_barrier(0);
+        colfrags(0, dot, qt);
+        prefetch_half(sQ, sDO, q0, 1);
+#endif
+        accumulate(dot, qt, pdf, dsf);
+      }
+      {
+        f32x4 st[2][KBW], dp[2][KBW];
+        scores_pf(1, st, dp);
+#if ATTN_DKV_PREF
+        colfrags(1, dot, qt);
+        __builtin_amdgcn_sched_barrier(0);
+        softmax_ds(1, st, dp, pdf, dsf);
+#else
+        softmax_ds(1, st, dp, pdf, dsf);
+        __builtin_amdgcn_sched_barrier(0);
+        colfrags(1, dot, qt);
+#endif
+      }
+#else
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh) {
         f32x4 st[2][KBW], dp[2][KBW];
@@ -1143,6 +1246,7 @@ __global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const A
         accumulate(dot, qt, pdf, dsf);
         prio_lo();
       }
+#endif
     }
 #if ATTN_ABL == 2
     if (t == 0 && ntiles > 1) commit(1);        // ablation: stages written once, no per-tile LDS writes (results invalid)
@@ -1151,6 +1255,11 @@ __global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const A
 #endif
 #if ATTN_ABL != 1 && ATTN_ABL != 2
     __syncthreads();                            // (ablation 1 / 2: no per-tile barrier, results invalid)
+#endif
+#if ATTN_DKV_PIPE2
+    // first half of the NEXT tile (its stage is visible now), under the second half's dV / dK products
+    if (t + 1 < ntiles) prefetch_half(smem + ((t + 1) & 1) * DKV_STAGE, smem + ((t + 1) & 1) * DKV_STAGE + KV_TILE, q0 + 64, 0);
+    if (!skip) accumulate_tail(dot, qt, pdf, dsf);
 #endif
   }
 
