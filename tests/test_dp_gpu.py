@@ -35,8 +35,13 @@ def _worker(rank, world, port, ret, shard):
     model = build()
     tr = Trainer(model, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=1.0, shard_optimizer=shard, bucket_bytes=1 << 18)
     assert tr.world == 2 and tr.sync.shard == shard
-    for _ in range(2):
-        losses = tr.step(mine)
+    losses = tr.step(mine)
+    torch.cuda.synchronize()
+    # (round 6) the REDUCED gradient itself after the first step, while both runs still hold the initial weights: Adam turns noise-level
+    # elements into full-size steps, so the update comparison below is loose by nature -- this one is not.  Replicated mode: every rank holds the SUM over
+    # ranks of its per-rank token-mean gradients (1 / world is folded into the Adam kernel)
+    g_dp = None if shard else {k: model.engine().arena.g(k).detach().double().cpu().clone() for k in model.engine().arena.names}
+    losses = tr.step(mine)
     if shard:
         # the masters of the other rank's stripes are stale now -- saving / re-casting them must fail loudly, not silently
         seen = model.engine().arena._seen_version
@@ -74,7 +79,24 @@ def _worker(rank, world, port, ret, shard):
         tr1 = Trainer(ref, lr=1e-3, clip_max_norm=1.0, generative=1.0, denoising=1.0, group=solo)
         assert tr1.world == 1
         allb = {k: v.cuda() for k, v in full.items()}
-        for _ in range(4 if shard else 2):
+        tr1.step(allb)
+        torch.cuda.synchronize()
+        if g_dp is not None:
+            wc, wk, wr = 1.0, "", 0.0
+            for k in ref.engine().arena.names:
+                g1 = ref.engine().arena.g(k).detach().double().cpu().flatten()
+                g2 = g_dp[k].flatten()
+                if k.endswith("attn.qkv.bias"):
+                    n3 = g1.numel() // 3
+                    g1, g2 = torch.cat([g1[:n3], g1[2 * n3:]]), torch.cat([g2[:n3], g2[2 * n3:]])
+                if float(g1.norm()) < 1e-12:
+                    continue
+                c = float(g1 @ g2 / (g1.norm() * g2.norm() + 1e-30))
+                if c < wc:
+                    wc, wk = c, k
+                wr = max(wr, abs(float(g2.norm() / g1.norm()) / world - 1.0))
+            ret["grad_worst"], ret["grad_worst_k"], ret["grad_norm_err"] = wc, wk, wr
+        for _ in range(3 if shard else 1):
             tr1.step(allb)
         torch.cuda.synchronize()
         worst, worst_k, maxdiff = 1.0, "", 0.0
@@ -109,6 +131,10 @@ def test_two_ranks_equal_one_large_batch(shard):
             {k: v for k, v in ret.items() if k.startswith("guard")}
         assert torch.equal(ret["tt0"], ret["tt1"]), "time-token rows differ between the ranks of a sharded-optimizer run"
         assert all(abs(ret[f"ratio{r}"] - 1.0) < 1e-5 for r in range(world)), (ret["ratio0"], ret["ratio1"])
+    if not shard:
+        print(f"DP (2 ranks) reduced gradient vs single process on the concatenated batch (first step): worst per-tensor cosine {ret['grad_worst']:.6f} "
+              f"({ret['grad_worst_k']}), worst |norm / (world x single) - 1| = {ret['grad_norm_err']:.2e}")
+        assert ret["grad_worst"] > 0.995 and ret["grad_norm_err"] < 2e-2
     print(f"DP (2 ranks) vs single process after 2 steps: worst update cosine {ret['worst']:.4f} ({ret['worst_k']}), max |dw| diff {ret['maxdiff']:.2e}")
     # Adam turns every gradient element into a step of ~lr whatever its size, so elements whose gradient is bf16/atomics-order noise
     # may step in different directions: compare update DIRECTIONS per tensor (as test_dropin_optimizer_path_matches_trainer does)
