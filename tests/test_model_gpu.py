@@ -63,6 +63,7 @@ def test_forward_backward_vs_reference_golden(golden_dir, tag, cfg, seed):
     assert abs(loss.item() - ref) <= 2e-2 * abs(ref)
     mem = torch.from_numpy(g["memory"])
     T = video.shape[1]
+    assert vd["video"].dtype == torch.float32 and vd["atts_vis"].dtype == torch.long          # the reference's video_dict (vid2seq.py:60-67)
     c = cos(vd["video"].float().cpu(), mem[:, :T])
     print(f"  ViT output cosine vs reference: {c:.6f}")
     assert c > 0.999

@@ -1023,10 +1023,14 @@ class Engine:
         if m.use_video:
             if isinstance(video, dict):
                 vis, atts = video["video"], video["atts_vis"]
+                video_dict = video
+                if vis.dtype != torch.bfloat16:      # the cached visual tokens come back in the dtype they were handed out in (fp32, like the
+                    vis = vis.to(torch.bfloat16)     # reference's vid2seq.py:61-66): exact, they were bf16 values
             else:
                 vis = _VitFn.apply(self.anchor, self, video, need_grad)
                 atts = torch.ones(vis.shape[:-1], dtype=torch.long, device=self.device)
-            video_dict = {"video": vis, "atts_vis": atts}
+                # the reference returns its visual tokens as fp32 (vid2seq.py:60-67); callers only hand them back for the second pass (dvc.py:95-101)
+                video_dict = {"video": vis.float(), "atts_vis": atts}
         in_ids = input_tokenized["input_ids"] if m.use_speech else None
         in_mask = input_tokenized["attention_mask"] if m.use_speech else None
         loss = _T5LossFn.apply(self.anchor, self, vis, in_ids, in_mask, output_tokenized["input_ids"], output_tokenized["attention_mask"],
