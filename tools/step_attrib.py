@@ -36,6 +36,17 @@ def load(path):
         k = short(n) + (f" g{g}" if a.grid else "")
         per[k][0] += e - s
         per[k][1] += 1
+    # union of the intervals in which ANY kernel runs (the rest of the window the GPU is idle: host / dependency gaps), and the time with exactly one / more kernels
+    ev = sorted([(s_, 1) for s_, e_, *_ in win] + [(e_, -1) for s_, e_, *_ in win])
+    busy = one = 0
+    depth, last = 0, t0
+    for t_, d_ in ev:
+        if depth > 0:
+            busy += t_ - last
+        if depth == 1:
+            one += t_ - last
+        depth += d_; last = t_
+    load.extra = (busy / a.steps / 1e6, one / a.steps / 1e6)
     return per, (t1 - t0) / a.steps / 1e6, sum(e - s for s, e, *_ in win) / a.steps / 1e6
 
 
@@ -44,6 +55,7 @@ for spec in a.arms:
     name, path = spec.split("=", 1)
     per, wall, ksum = load(path)
     arms.append((name, per, wall, ksum))
+    print(f"{name}: wall {wall:.3f} ms/step, some kernel running {load.extra[0]:.3f} ms ({100 * load.extra[0] / wall:.1f} %), exactly one kernel running {load.extra[1]:.3f} ms, idle {wall - load.extra[0]:.3f} ms")
 base = arms[0]
 print(f"window = last {a.steps} optimizer steps of each trace (streams overlapped: a kernel's duration includes what concurrent kernels cost it)")
 print("wall ms/step: " + "   ".join(f"{n} {w:.3f}" for n, _, w, _ in arms) + "     summed kernel ms/step: " + "   ".join(f"{n} {k:.3f}" for n, _, _, k in arms))
