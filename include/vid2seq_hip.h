@@ -68,7 +68,11 @@ const char* v2s_last_error(void);
  *   "gemm_dbg"      profiling ablations of the tiled kernels (results invalid when non-zero): 1 = no global store, 2 = no epilogue, 3 = no hand-off
  *   "fp32_io"       DEBUG: 1 = v2s_*norm_fwd/bwd, v2s_ce_bwd and v2s_attn_fwd/bwd take and return FP32 activations (attention: fp32-arithmetic
  *                   reference kernels, dense layout only); parity work against fp32 references (<= 1e-4), never set by the product path
- *   "attn_bwd_part" 0: v2s_attn_bwd launches dQ and dK/dV kernels (default), 1: dQ only, 2: dK/dV only (per-kernel timing) */
+ *   "attn_bwd_part" 0: v2s_attn_bwd launches dQ and dK/dV kernels (default), 1: dQ only, 2: dK/dV only (per-kernel timing)
+ *   "attn_order"    block -> (sequence, head, query / key block) of the three attention kernels: 0 (default, round 6): the (sequence, head) groups are dealt to
+ *                   the 8 XCDs round-robin (all XCDs work through the same sequences at the same time: the in-order workgroup dispatch no longer waits
+ *                   for the XCD with the longest sequences), the dK/dV kernel in two passes; 1: every XCD a contiguous range of groups (rounds 1-5);
+ *                   2: round-robin without the two passes; 400 + n / 500 + n: sweep knobs.  Results do not depend on it */
 int v2s_set_option(const char* name, int value);
 int v2s_get_option(const char* name);
 

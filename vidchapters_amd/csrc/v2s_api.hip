@@ -12,9 +12,9 @@ struct Opt { const char* name; std::atomic<int> v; };
 // index order = the V2S_OPT_* enumerators below
 Opt g_opts[] = {
     {"tr_read", {1}}, {"gemm_dma", {2}}, {"gemm_big", {1}}, {"gemm_split", {1}}, {"gemm_order", {4}}, {"gemm_skinny", {1}},
-    {"attn_bwd_part", {0}}, {"gemm_p8", {1}}, {"ce_fused", {1}}, {"gemm_dbg", {0}}, {"fp32_io", {0}}, {"gemm_a4", {1}}, {"gemm_a4_grid", {0}}, {"gemm_a4_relu", {1}}, {"gemm_a4_walk", {0}},
+    {"attn_bwd_part", {0}}, {"gemm_p8", {1}}, {"ce_fused", {1}}, {"gemm_dbg", {0}}, {"fp32_io", {0}}, {"gemm_a4", {1}}, {"gemm_a4_grid", {0}}, {"gemm_a4_relu", {1}}, {"gemm_a4_walk", {0}}, {"attn_order", {0}},
 };
-enum { O_TR_READ, O_GEMM_DMA, O_GEMM_BIG, O_GEMM_SPLIT, O_GEMM_ORDER, O_GEMM_SKINNY, O_ATTN_BWD_PART, O_GEMM_P8, O_CE_FUSED, O_GEMM_DBG, O_FP32_IO, O_GEMM_A4, O_GEMM_A4_GRID, O_GEMM_A4_RELU, O_GEMM_A4_WALK };
+enum { O_TR_READ, O_GEMM_DMA, O_GEMM_BIG, O_GEMM_SPLIT, O_GEMM_ORDER, O_GEMM_SKINNY, O_ATTN_BWD_PART, O_GEMM_P8, O_CE_FUSED, O_GEMM_DBG, O_FP32_IO, O_GEMM_A4, O_GEMM_A4_GRID, O_GEMM_A4_RELU, O_GEMM_A4_WALK, O_ATTN_ORDER };
 inline int opt(int i) { return g_opts[i].v.load(std::memory_order_relaxed); }
 Opt* find_opt(const char* name) {
   if (!name) return nullptr;
@@ -46,6 +46,7 @@ int v2s_opt_gemm_a4() { return opt(O_GEMM_A4); }
 int v2s_opt_gemm_a4_grid() { return opt(O_GEMM_A4_GRID); }
 int v2s_opt_gemm_a4_relu() { return opt(O_GEMM_A4_RELU); }
 int v2s_opt_gemm_a4_walk() { return opt(O_GEMM_A4_WALK); }
+int v2s_opt_attn_order() { return opt(O_ATTN_ORDER); }
 
 // Dropout seed salt of the launches ENQUEUED BY THE CALLING THREAD (a device word XOR-ed into every by-value seed, so that a captured
 // hipGraph draws new masks per replay).  Thread-local, not process-global: a capture running on one host thread

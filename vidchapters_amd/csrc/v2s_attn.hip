@@ -91,6 +91,8 @@ struct AttnP {
   const int* seq_off;   // packed self-attention: sequence b = rows [seq_off[b], seq_off[b+1]) of every operand (batch strides unused)
   int seq_q_only;       // seq_off applies to the query side only (q, o, d_o, dq); K / V / dK / dV stay dense [B][Nk] (cross-attention)
   const int* kv_seq_off; // K / V / dK / dV packed with their OWN row offsets (cross-attention over a padding-free memory); else see above
+  int order;             // option attn_order: 0 = groups dealt to the XCDs round-robin (default, see block_group), 1 = every XCD a contiguous range of groups (rounds 1-5),
+                         // 2 = round-robin without the dK / dV kernel's two passes, 400 + n / 500 + n = sweep knobs (tools/attn_order_sweep.py)
 };
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -313,6 +315,28 @@ __device__ __forceinline__ void flags_stage(uint8_t* flag, uint8_t* state, int l
   __syncthreads();
 }
 
+
+// Block -> (group, block within the group) for the three kernels; a group = the nper query / key blocks of one (sequence, head), which share its K / V
+// (or Q / dO) tiles in L2.  The hardware deals workgroups to the 8 XCDs round-robin and IN ORDER: when the XCD whose turn it is has no free slot, the
+// dispatch of every later block waits.  With each XCD walking its own contiguous range of groups (xcd_remap: XCD x owned sequences 4x .. 4x + 3 of a
+// 32-sequence batch), a batch with different sequence lengths -- masked / skipped tiles are cheap -- makes the XCDs free their slots at different rates and
+// the whole launch advances at the pace of the slowest one.  Round 6: the groups are dealt to the XCDs round-robin instead (group g -> XCD g mod 8, the
+// blocks of a group still adjacent on that XCD), so that all eight XCDs work through the SAME sequences at the same time: encoder layer, lengths uniform
+// in [0.7 N, N]: forward 172 -> 165, dQ 268 -> 258, dK/dV 318 -> 303 us; lengths in [0.4 N, N]: -8.6 % over the three; no padding: +-0 (profiles/r06_attn_dispatch_order.txt).
+__device__ __forceinline__ void block_group(int bid, int nwg, int nper, int ngroups, int plain, int& grp, int& blk) {
+  if (plain >= 400 && (ngroups & 7) == 0 && plain - 400 < nper) {      // two passes: the first (plain - 400) blocks of every group, then the others
+    const int xcd = bid & 7, loc = bid >> 3, nh = plain - 400, g8 = ngroups >> 3;
+    if (loc < nh * g8) { grp = (loc / nh) * 8 + xcd; blk = loc % nh; }
+    else { const int r = loc - nh * g8, nr = nper - nh; grp = (r / nr) * 8 + xcd; blk = nh + r % nr; }
+  } else if (plain != 1 && (ngroups & 7) == 0) {      // (plain == 2: round-robin only)
+    const int xcd = bid & 7, loc = bid >> 3;
+    grp = (loc / nper) * 8 + xcd; blk = loc - (loc / nper) * nper;
+  } else {
+    const int id = xcd_remap(bid, nwg);
+    blk = id % nper; grp = id / nper;
+  }
+}
+
 // ====================================================================================== forward
 // block = 4 waves x 32 query rows; loop over 64-key tiles.  Three blocks per CU (<= 168 VGPRs) instead of two: inside a wave the
 // score MFMAs, the softmax VALU work and the PV MFMAs are serial, and only waves in different phases overlap them, so a third
@@ -323,8 +347,9 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const Att
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int nqb = (p.Nq + 127) >> 7;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int qblk = id % nqb, bh = id / nqb, h = bh % p.H, b = bh / p.H;
+  int qblk, bh;
+  block_group(blockIdx.x, gridDim.x, nqb, p.B * p.H, p.order >= 500 ? p.order - 100 : (p.order >= 400 ? 0 : p.order), bh, qblk);
+  const int h = bh % p.H, b = bh / p.H;
   const int Q0 = qblk * 128, wq0 = wave * 32;
   const int row0_ = p.seq_off ? p.seq_off[b] : 0;                          // packed (varlen) self-attention: first row of sequence b
   const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq;
@@ -568,8 +593,9 @@ __global__ __launch_bounds__(256, ATTN_BWD_OCC) void attn_bwd_dq_kernel(const At
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // scalar: the per-block bias-gradient routing below branches on it
   const int nqb = (p.Nq + 127) >> 7;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int qblk = id % nqb, bh = id / nqb, h = bh % p.H, b = bh / p.H;
+  int qblk, bh;
+  block_group(blockIdx.x, gridDim.x, nqb, p.B * p.H, p.order >= 500 ? p.order - 100 : (p.order >= 400 ? 0 : p.order), bh, qblk);
+  const int h = bh % p.H, b = bh / p.H;
   const int Q0 = qblk * 128, wq0 = wave * 32;
   const int row0_ = p.seq_off ? p.seq_off[b] : 0;                          // packed (varlen) self-attention: first row of sequence b
   const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq;
@@ -885,6 +911,7 @@ constexpr int DKV_MS = STAGE2;                   // -(m + log2 l)[64], masked-el
 constexpr int DKV_STATE = DKV_MS + 4 * 64 * 4;   // int: every row of the tile has real statistics
 constexpr int DKV_STAGE = DKV_STATE + 16;
 constexpr int KBW = ATTN_DKV_KBW, DKV_BK = 64 * KBW;
+__device__ __forceinline__ const float* rsp_early(const AttnP& p, int b, int h) { return p.rowstat + ((long)(b * p.H + h)) * p.Nq * 4; }
 // key of (key block kb, lane column li) inside the wave's 16 * KBW keys.  KBW = 2: the two key blocks hold the EVEN and the ODD key of the
 // pairs (2 li, 2 li + 1), so that ONE dropout hash per query row serves both of a lane's elements of that row (its low / high 16-bit draw:
 // drop_dropmask32, the same evaluation as the dQ kernel) instead of one hash, one shift and one compare per element (round 6: the mask
@@ -895,12 +922,17 @@ __global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const A
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int nkb = (p.Nk + DKV_BK - 1) / DKV_BK;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int kblk = id % nkb, bh = id / nkb, h = bh % p.H, b = bh / p.H;
+  const int* kso_ = p.kv_seq_off ? p.kv_seq_off : ((p.seq_off && !p.seq_q_only) ? p.seq_off : nullptr);     // row offsets of the key side
+  int kblk, bh;
+  // (dK / dV only, EMPIRICAL: on top of the round-robin deal, dispatching the first 7 key blocks of every group in a first pass and the others in a second is worth
+  // another 3-4 % at every length tested -- N = 1000: 303 -> 294 us, 1100: 355 -> 341, 1200: 397 -> 380, 2000: 1004 -> 962, with or without padding; 5 of 6 at N = 768:
+  // 188 -> 179; even first-pass counts and the same split in the forward / dQ kernels gain nothing: tools/attn_order_sweep.py, profiles/r06_attn_dispatch_order.txt)
+  const int dkv_order = p.order != 0 ? (p.order >= 500 ? p.order - 100 : p.order) : (nkb >= 8 ? 407 : (nkb >= 6 ? 405 : 0));
+  block_group(blockIdx.x, gridDim.x, nkb, p.B * p.H, dkv_order, bh, kblk);
+  const int h = bh % p.H, b = bh / p.H;
   const int K0 = kblk * DKV_BK, wk0 = wave * 16 * KBW;
   const int row0_ = p.seq_off ? p.seq_off[b] : 0;
   const int nq_ = p.seq_off ? p.seq_off[b + 1] - row0_ : p.Nq;
-  const int* kso_ = p.kv_seq_off ? p.kv_seq_off : ((p.seq_off && !p.seq_q_only) ? p.seq_off : nullptr);     // row offsets of the key side
   const int krow0_ = kso_ ? kso_[b] : 0, nk_ = kso_ ? kso_[b + 1] - krow0_ : p.Nk;
   if (K0 >= nk_) return;
 
@@ -943,6 +975,38 @@ __global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const A
     cmul[kb] = (k & 1) ? 0u : 16u;                       // shift that moves this key's 16-bit half of the pair hash into the top half
   }
   const bool keys_clean = __all(kflag[0] == 0u && kflag[KBW - 1] == 0u);
+  // A key block whose keys are ALL masked (the padding tail of a dense batch) contributes exactly zero when every query row has real statistics
+  // (each tile would be skipped below): decide it once, write the zeros and leave -- instead of streaming the sequence's Q / dO through LDS with a
+  // barrier per tile for nothing (lengths uniform in [0.7 N, N]: one block in seven)
+  // (block-wide AND through the still unused dynamic LDS: __syncthreads_and would add a static allocation, and the kernel's LDS budget is set as dynamic)
+  auto block_and = [&](bool c) {
+    const bool w = __all(c);
+    __syncthreads();
+    if (lane == 0) reinterpret_cast<int*>(smem)[wave] = w ? 1 : 0;
+    __syncthreads();
+    const int4 v = *reinterpret_cast<const int4*>(smem);
+    return (v.x & v.y & v.z & v.w) != 0;
+  };
+  if (block_and(kflag[0] != 0u && kflag[KBW - 1] != 0u)) {
+    bool real = true;
+    for (int r = tid; r < nq_; r += 256) real = real && (rsp_early(p, b, h)[(long)r * 4 + 1] < REAL_MIN);
+    if (block_and(real)) {
+#pragma unroll
+      for (int kb = 0; kb < KBW; ++kb) {
+        const int k = K0 + wk0 + dkv_key(kb, li);
+        if (k < nk_) {
+          bf16_t* dkp = p.dk + (kso_ ? (long)krow0_ * p.dk_rs : (long)b * p.dk_bs) + (long)k * p.dk_rs + h * HD;
+          bf16_t* dvp = p.dv + (kso_ ? (long)krow0_ * p.dv_rs : (long)b * p.dv_bs) + (long)k * p.dv_rs + h * HD;
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            *reinterpret_cast<uint2*>(dkp + db * 16 + 4 * g) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(dvp + db * 16 + 4 * g) = make_uint2(0u, 0u);
+          }
+        }
+      }
+      return;
+    }
+  }
   const int kmin = K0 + wk0, kmax = kmin + 16 * KBW - 1;
   f32x4 dkt[KBW][4], dvt[KBW][4];
 #pragma unroll
@@ -1528,7 +1592,7 @@ int fill(AttnP& p, const v2s_attn_args* a, const char* who, bool bwd) {
   p.dq = (bf16_t*)a->dq; p.dk = (bf16_t*)a->dk; p.dv = (bf16_t*)a->dv;
   p.dq_bs = a->dq_bs; p.dq_rs = a->dq_rs; p.dk_bs = a->dk_bs; p.dk_rs = a->dk_rs; p.dv_bs = a->dv_bs; p.dv_rs = a->dv_rs;
   p.dbias_diag = a->dbias_diag;
-  p.seq_off = a->seq_off; p.seq_q_only = (a->seq_off && a->seq_q_only) ? 1 : 0; p.kv_seq_off = a->kv_seq_off;
+  p.seq_off = a->seq_off; p.seq_q_only = (a->seq_off && a->seq_q_only) ? 1 : 0; p.kv_seq_off = a->kv_seq_off; p.order = v2s_opt_attn_order();
   V2S_CHECK(!a->seq_off || a->seq_q_only || a->kv_seq_off || (a->Nq == a->Nk && !a->key_mask), V2S_ERR_ARG, "%s: seq_off (packed self-attention) needs Nq == Nk and no key_mask", who);
   V2S_CHECK(!a->kv_seq_off || !a->key_mask, V2S_ERR_ARG, "%s: kv_seq_off (packed keys) excludes key_mask: pad keys simply do not exist", who);
   // far buckets: disabled (every diagonal resolved) unless the caller states lo < hi

@@ -52,6 +52,7 @@ int v2s_opt_gemm_a4();    // 4-wave asm-scheduled 256x256 kernels (128x128 wave 
 int v2s_opt_gemm_a4_grid(); // blocks of the persistent a4p kernel: 0 = one per CU (default), n = at most n (leaves CUs to concurrent streams: A/B knob), -1 = the fewest blocks with the same number of rounds
 int v2s_opt_gemm_a4_relu(); // 1 (default): the persistent a4p kernel also takes forward GEMMs with a ReLU (+ dropout) epilogue (the FFN's wi); 0: plain epilogues only
 int v2s_opt_gemm_a4_walk(); // tile walk of the persistent a4p kernel: 0 = auto (row-major below 16 tile columns, groups of 4 tile rows from there), n = groups of n tile rows
+int v2s_opt_attn_order();   // dispatch order of the attention dK / dV kernel (experiment knob, see v2s_attn.hip)
 int v2s_opt_gemm_big();  // 0 = never, 1 = 256x256/256x128 tiles where they pay (default), 2 = 256x128 only, 3 = 4-wave 256x128x32 ring kernel for every variant
 
 // ---------------------------------------------------------------- device helpers

@@ -392,7 +392,7 @@ def attn_args(B, H, Nq, Nk, q, k, v, o, q_st, k_st, v_st, o_st, *, ml=None, scal
         _need(kv_seq_off, torch.int32, "attn kv_seq_off")
     a.kv_seq_off = ptr(kv_seq_off)
     # the struct only carries raw pointers: keep every tensor alive for as long as the struct (backward reuses it)
-    a._refs = (q, k, v, o, ml, bias_diag, key_mask, seq_off)
+    a._refs = (q, k, v, o, ml, bias_diag, key_mask, seq_off, kv_seq_off)
     return a
 
 
