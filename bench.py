@@ -13,6 +13,7 @@ import argparse
 import json
 import os
 import sys
+import math
 import time
 
 import torch
@@ -188,6 +189,9 @@ def main():
             dtr = float(t.item())
         region_ms.append(dtr / a.steps * 1e3)
     loss_val = float(losses["loss"].item())
+    if not math.isfinite(loss_val):
+        # a step that produced NaN / Inf is not the workload any more: no line rather than a number for a broken run
+        raise SystemExit(f"bench.py: the loss is {loss_val} after the timed region -- the step diverged, nothing is reported")
     log(f"timed region done: {dt / a.steps * 1e3:.1f} ms/step")
     ms_per_step = dt / a.steps * 1e3
     value = world * B * a.steps / dt

@@ -283,6 +283,29 @@ def test_cfg2_train_step_batch32_is_token_weighted_sum_of_samples():
     print(f"  worst cosine {worst[0]:.5f} ({worst[1]})")
 
 
+def test_cfg2_bench_workload_trains_for_six_steps():
+    """The bench's own workload (B = 32, ragged synthetic lengths, dropout 0.1, pad rows computed) through Trainer.step six times: the loss
+    falls monotonically from ln V, the gradient norm is the known one at step 0 and shrinks, nothing is NaN / Inf.  (Round 6: a race in
+    the dK / dV attention kernel passed every parity test -- they launch too few blocks or no dropout -- and sent this loop to -inf in
+    two steps; the bench line printed the loss and nobody asserted on it.)"""
+    tk = SyntheticTokenizer(32100, 100)
+    model = Vid2Seq("t5-base", num_features=100, tokenizer=tk, vis_drop=0.1, enc_drop=0.1, dec_drop=0.1, init_seed=1234, device=DEV).train()
+    model.engine().pack = False
+    tr = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=0.0)
+    batch = {k: v.to(DEV) for k, v in synth.make_batch(32, 100, 1000, 256, len(tk), 1234, 768).items()}
+    batch["video"] = batch["video"].to(torch.bfloat16)
+    hist = []
+    for _ in range(6):
+        out = tr.step(batch)
+        hist.append((float(out["loss"]), float(tr.grad_norm())))
+    print("cfg-2 bench workload, (loss, gradient norm) per step:", [(round(a, 4), round(b, 4)) for a, b in hist])
+    assert all(np.isfinite(a) and np.isfinite(b) for a, b in hist)
+    assert abs(hist[0][0] - 10.405) < 0.01 and 3.5 < hist[0][1] < 4.3           # measured 10.4046 .. 10.4053, 3.90 .. 3.91
+    assert all(hist[i + 1][0] < hist[i][0] for i in range(5))                   # measured 10.405, 10.373, 10.353, 10.342, 10.333, 10.328
+    assert hist[1][1] < 0.6 and all(hist[i][1] < 0.3 for i in range(2, 6))      # measured 0.36, 0.16, 0.11, 0.09, 0.08
+    assert all(torch.isfinite(p.detach().float()).all() for p in model.parameters())
+
+
 def test_cfg4_greedy_batch64_rows_equal_single_sequence_runs():
     """BASELINE cfg-4: greedy generate() at B=64, 100 frames + 1000 ASR tokens, the FULL 256 decode steps (demo_vid2seq.py path).
     Sequences are independent, so every row of the batch must reproduce the run of its sample in a different batch composition

@@ -470,6 +470,67 @@ def test_attention_fwd_bwd(B, H, Nq, Nk, scale, use_bias, use_mask, causal, tr_m
         assert c > 0.999 and e < 3e-2
 
 
+@pytest.mark.parametrize("Nq,Nk,use_bias", [(256, 1100, False), (1000, 1000, True)])
+def test_attention_backward_full_chip_is_repeatable_and_right(Nq, Nk, use_bias):
+    """cfg-2's full grids (32 sequences x 12 heads; ragged lengths whose tail key blocks are all masked, so that the dK / dV kernel's
+    early exit runs in thousands of blocks next to thousands that go on): five backward passes are bit-identical, and the first
+    sequences equal the fp32 statement.  The small cases above launch too few blocks to see a race between the waves of a block
+    (round 6: a block-wide vote read from LDS words that a faster wave was already overwriting with its Q tile)."""
+    B, H, W = 32, 12, 768
+    qkv_q = rnd(B, Nq, 3 * W, seed=11, scale=0.5)
+    qkv_k = qkv_q if Nq == Nk else rnd(B, Nk, 3 * W, seed=12, scale=0.5)
+    q = qkv_q[..., :W]; k = qkv_k[..., W:2 * W]; v = qkv_k[..., 2 * W:]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    lens = torch.randint(int(0.3 * Nk), Nk + 1, (B,), generator=g).to(DEV)
+    lens[0] = Nk; lens[1] = Nk // 2 + 3
+    mask = torch.arange(Nk, device=DEV)[None, :] < lens[:, None]
+    mk = mask.to(torch.uint8).contiguous()
+    diag = rnd(H, Nq + Nk - 1, seed=3, dtype=torch.float32) if use_bias else None
+    o = torch.empty(B, Nq, W, dtype=torch.bfloat16, device=DEV)
+    ml = torch.empty(B, H, Nq, 2, dtype=torch.float32, device=DEV)
+    a = L.attn_args(B, H, Nq, Nk, q, k, v, o, (Nq * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), (Nq * W, W),
+                    ml=ml, scale=1.0, bias_diag=diag, key_mask=mk, dropout_p=0.1, dropout_seed=77)
+    L.attn_fwd(a)
+    d_o = rnd(B, Nq, W, seed=5)
+    delta = torch.empty(B, H, Nq, 4, dtype=torch.float32, device=DEV)
+    runs = []
+    for _ in range(5):
+        dq_ = torch.full((B, Nq, 3 * W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        dk_ = dq_ if Nq == Nk else torch.full((B, Nk, 3 * W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ddiag = torch.zeros(H, Nq + Nk - 1, dtype=torch.float32, device=DEV) if use_bias else None
+        L.attn_bwd(a, d_o, (Nq * W, W), delta, dq_[..., :W], dk_[..., W:2 * W], dk_[..., 2 * W:],
+                   (Nq * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), dbias_diag=ddiag)
+        runs.append((dq_[..., :W].clone(), dk_[..., W:2 * W].clone(), dk_[..., 2 * W:].clone()))
+    torch.cuda.synchronize()
+    for name, j in (("dq", 0), ("dk", 1), ("dv", 2)):
+        assert torch.isfinite(runs[0][j].float()).all(), f"{name}: not finite"
+        for r in runs[1:]:
+            assert torch.equal(r[j], runs[0][j]), f"{name}: two launches on the same operands differ"
+    # masked keys of rows that saw a real key get exactly zero
+    dk0, dv0 = runs[0][1], runs[0][2]
+    dead = ~mask
+    assert float(dk0[dead].float().abs().max()) == 0.0 and float(dv0[dead].float().abs().max()) == 0.0
+    # without dropout, the first two sequences against fp32 torch
+    a2 = L.attn_args(B, H, Nq, Nk, q, k, v, o, (Nq * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), (Nq * W, W),
+                     ml=ml, scale=1.0, bias_diag=diag, key_mask=mk)
+    L.attn_fwd(a2)
+    dq_ = torch.zeros(B, Nq, 3 * W, dtype=torch.bfloat16, device=DEV)
+    dk_ = dq_ if Nq == Nk else torch.zeros(B, Nk, 3 * W, dtype=torch.bfloat16, device=DEV)
+    ddiag = torch.zeros(H, Nq + Nk - 1, dtype=torch.float32, device=DEV) if use_bias else None
+    L.attn_bwd(a2, d_o, (Nq * W, W), delta, dq_[..., :W], dk_[..., W:2 * W], dk_[..., 2 * W:],
+               (Nq * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), (Nk * 3 * W, 3 * W), dbias_diag=ddiag)
+    nb = 2
+    qf = q[:nb].float().reshape(nb, Nq, H, 64).requires_grad_(True)
+    kf = k[:nb].float().reshape(nb, Nk, H, 64).requires_grad_(True)
+    vf = v[:nb].float().reshape(nb, Nk, H, 64).requires_grad_(True)
+    ref = attn_ref(qf, kf, vf, 1.0, bias_from_diag(diag, Nq, Nk) if use_bias else None, mask[:nb], False, 0)
+    ref.backward(d_o[:nb].float().view(nb, Nq, H, 64))
+    for name, got, want in (("dq", dq_[:nb, :, :W], qf.grad), ("dk", dk_[:nb, :, W:2 * W], kf.grad), ("dv", dk_[:nb, :, 2 * W:], vf.grad)):
+        c = cos(got, want.reshape(nb, -1, W)); e = relerr(got, want.reshape(nb, -1, W))
+        print(f"  {name}: cos {c:.5f} relerr {e:.2e}")
+        assert c > 0.999 and e < 4e-2
+
+
 @pytest.mark.parametrize("M,N,K,G,acc", [(768, 768, 512, 12, False), (136, 264, 192, 3, True), (2304, 768, 256, 16, False)])
 def test_gemm_grouped_weight_gradients(M, N, K, G, acc):
     """v2s_gemm_grouped: G weight gradients of one shape (dY^T X, fp32 out) in one launch == the single launches / fp32 torch."""
@@ -1257,6 +1318,11 @@ def test_decode_kernels():
         nx = torch.empty(B, dtype=torch.int64, device=DEV); un = torch.ones(B, dtype=torch.int32, device=DEV)
         L.argmax_step(lg, V2, B, V2, nx, un, -1, 0)
         assert nx.tolist() == [V2 // 2, 3, V2 - 1]
+        # torch.argmax's answer on NaN / -inf rows (the first NaN wins; a row of -inf gives 0): never an out-of-range token
+        lg[0] = float("nan"); lg[1] = float("-inf"); lg[2, V2 - 2] = float("nan"); lg[2, 2] = float("nan")
+        un.fill_(1)
+        L.argmax_step(lg, V2, B, V2, nx, un, -1, 0)
+        assert nx.tolist() == [0, 0, 2] == lg.argmax(-1).tolist()
     logits = rnd(B, 32200, seed=5, dtype=torch.float32)
     nxt = torch.empty(B, dtype=torch.int64, device=DEV); unf = torch.tensor([1, 0, 1], dtype=torch.int32, device=DEV)
     logits[2, 1] = 100.0                                          # row 2 emits EOS

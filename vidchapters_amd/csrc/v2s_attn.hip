@@ -53,6 +53,12 @@ constexpr int HD = 64;
 #ifndef ATTN_DKV_OCC
 #define ATTN_DKV_OCC ATTN_BWD_OCC
 #endif
+#ifndef ATTN_DKV_EARLY
+#define ATTN_DKV_EARLY 1        // 0: no early exit of all-masked key blocks (debug builds)
+#endif
+#ifndef ATTN_DKV_EARLY_SYNC
+#define ATTN_DKV_EARLY_SYNC 1
+#endif
 #ifndef ATTN_ABL
 #define ATTN_ABL 0
 #endif
@@ -985,9 +991,10 @@ __global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const A
     if (lane == 0) reinterpret_cast<int*>(smem)[wave] = w ? 1 : 0;
     __syncthreads();
     const int4 v = *reinterpret_cast<const int4*>(smem);
+    if (ATTN_DKV_EARLY_SYNC) __syncthreads();                // the words are stage 0 of the Q tile: nobody may commit() over them before every wave has read its answer
     return (v.x & v.y & v.z & v.w) != 0;
   };
-  if (block_and(kflag[0] != 0u && kflag[KBW - 1] != 0u)) {
+  if (ATTN_DKV_EARLY && block_and(kflag[0] != 0u && kflag[KBW - 1] != 0u)) {
     bool real = true;
     for (int r = tid; r < nq_; r += 256) real = real && (rsp_early(p, b, h)[(long)r * 4 + 1] < REAL_MIN);
     if (block_and(real)) {

@@ -405,7 +405,11 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   const float* z = logits + (long)row * ld;
   float best = -INFINITY;
   int idx = 0x7fffffff;
-  auto take = [&](float v, int i) { if (v > best || (v == best && i < idx)) { best = v; idx = i; } };
+  // torch.argmax's order: a NaN beats every number, the first one wins (a row of NaNs must not leave idx at its sentinel: it indexes the embedding table)
+  auto take = [&](float v, int i) {
+    const bool vn = v != v, bn = best != best;
+    if (vn ? (!bn || i < idx) : (!bn && (v > best || (v == best && i < idx)))) { best = v; idx = i; }
+  };
   const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
   const int V4 = vec ? (V & ~3) : 0;
   for (int i = tid * 4; i < V4; i += 4096) {
@@ -446,7 +450,11 @@ __global__ __launch_bounds__(1024) void argmax_tail_kernel(const float* __restri
   const float* z = logits + (long)row * ld;
   float best = -INFINITY;
   int idx = 0x7fffffff;
-  auto take = [&](float v, int i) { if (v > best || (v == best && i < idx)) { best = v; idx = i; } };
+  // torch.argmax's order: a NaN beats every number, the first one wins (a row of NaNs must not leave idx at its sentinel: it indexes the embedding table)
+  auto take = [&](float v, int i) {
+    const bool vn = v != v, bn = best != best;
+    if (vn ? (!bn || i < idx) : (!bn && (v > best || (v == best && i < idx)))) { best = v; idx = i; }
+  };
   const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
   const int V4 = vec ? (V & ~3) : 0;
   for (int i = tid * 4; i < V4; i += 4096) {
