@@ -846,6 +846,53 @@ def test_attention_fully_masked_row_is_uniform():
     assert relerr(dq, dS @ k.float()) < 3e-2 and relerr(dk, dS.transpose(1, 2) @ q.float()) < 3e-2
 
 
+@pytest.mark.parametrize("use_bias", [False, True])
+def test_attention_masks_with_holes_tails_and_an_invisible_sequence(use_bias):
+    """Key masks that are not prefixes: whole 64-key tiles masked in the middle of a sequence, a visible key after them, a long masked
+    tail (the tiles the forward / dQ loops cut off: tiles_to_visit), a sequence whose only visible key is its last one, and a sequence
+    without any visible key (uniform over every key, finfo.min arithmetic of modeling_t5.py:559) -- forward and backward against fp32."""
+    B, H, Nq, Nk, W = 5, 2, 200, 520, 128
+    q, k, v = rnd(B, Nq, W, seed=1, scale=0.5), rnd(B, Nk, W, seed=2, scale=0.5), rnd(B, Nk, W, seed=3)
+    mask = torch.zeros(B, Nk, dtype=torch.bool, device=DEV)
+    mask[0, :70] = True                                    # seven trailing tiles masked
+    mask[1, :10] = True; mask[1, 300:331] = True           # tiles 1-3 masked, visible keys again in tile 4-5, masked tail
+    mask[2, Nk - 1] = True                                 # the only visible key is the very last one
+    mask[3, :] = True                                      # nothing masked
+    # sequence 4: no visible key
+    diag = rnd(H, Nq + Nk - 1, seed=3, dtype=torch.float32) if use_bias else None
+    o = torch.empty(B, Nq, W, dtype=torch.bfloat16, device=DEV)
+    ml = torch.empty(B, H, Nq, 2, dtype=torch.float32, device=DEV)
+    st = ((Nq * W, W), (Nk * W, W), (Nk * W, W), (Nq * W, W))
+    a = L.attn_args(B, H, Nq, Nk, q, k, v, o, *st, ml=ml, bias_diag=diag, key_mask=mask.to(torch.uint8).contiguous())
+    L.attn_fwd(a)
+    qf = q.float().reshape(B, Nq, H, 64).requires_grad_(True)
+    kf = k.float().reshape(B, Nk, H, 64).requires_grad_(True)
+    vf = v.float().reshape(B, Nk, H, 64).requires_grad_(True)
+    df = diag.clone().requires_grad_(True) if use_bias else None
+    ref = attn_ref(qf, kf, vf, 1.0, bias_from_diag(df, Nq, Nk) if use_bias else None, mask, False, 0)
+    for b in range(B):
+        e = relerr(o.view(B, Nq, H, 64)[b], ref[b])
+        print(f"  sequence {b}: forward relerr {e:.2e}")
+        assert e < 2e-2
+    d_o = rnd(B, Nq, W, seed=5)
+    ref.backward(d_o.float().view(B, Nq, H, 64))
+    dq, dk, dv = (torch.full((B, n, W), float("nan"), dtype=torch.bfloat16, device=DEV) for n in (Nq, Nk, Nk))
+    delta = torch.empty(B, H, Nq, 4, dtype=torch.float32, device=DEV)
+    ddiag = torch.zeros(H, Nq + Nk - 1, dtype=torch.float32, device=DEV) if use_bias else None
+    L.attn_bwd(a, d_o, (Nq * W, W), delta, dq, dk, dv, (Nq * W, W), (Nk * W, W), (Nk * W, W), dbias_diag=ddiag)
+    for name, got, want in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
+        for b in range(B):
+            wb = want[b].reshape(-1, W)
+            e = float((got[b].float() - wb).abs().max() / (want.abs().max() + 1e-12))
+            c = cos(got[b], wb) if float(wb.abs().max()) > 0 else 1.0
+            print(f"  {name}[{b}]: cos {c:.5f} err/global max {e:.2e}")
+            assert c > 0.999 and e < 4e-2
+    if use_bias:
+        c = cos(ddiag, df.grad); e = relerr(ddiag, df.grad)
+        print(f"  dbias_diag: cos {c:.5f} relerr {e:.2e}")
+        assert c > 0.999 and e < 3e-2
+
+
 def test_attention_dropout_consistency():
     B, H, Nq, Nk, W = 2, 2, 128, 192, 128
     q, k, v = rnd(B, Nq, W, seed=1, scale=0.3), rnd(B, Nk, W, seed=2, scale=0.3), rnd(B, Nk, W, seed=3)
