@@ -893,6 +893,53 @@ def test_attention_masks_with_holes_tails_and_an_invisible_sequence(use_bias):
         assert c > 0.999 and e < 3e-2
 
 
+@pytest.mark.parametrize("Nq,Nk,use_bias,causal", [(1000, 1000, True, False), (256, 1100, False, False), (256, 256, True, True)])
+def test_attention_backward_skips_zero_gradient_rows_exactly(Nq, Nk, use_bias, causal):
+    """Query rows whose dO is all zero (+0 or -0: the pad rows of a dense batch) add nothing to any gradient; the dQ kernel marks them, leaves
+    early when its 128 rows are all marked, and the dK / dV kernel ends its query loop at the last unmarked row.  The same launch with the zeros
+    replaced by +-2^-100 takes the full path: every output agrees to 1e-25 absolute (the only difference left is the 1e-30 the stand-ins add), with
+    dropout, masks and the bias gradient on.  Plus a sequence whose dO is zero everywhere, and a zero block in the middle of a sequence."""
+    B, H, W = 4, 3, 192
+    q = rnd(B, Nq, W, seed=1, scale=0.5); k = rnd(B, Nk, W, seed=2, scale=0.5); v = rnd(B, Nk, W, seed=3)
+    lens = torch.tensor([Nk, int(0.71 * Nk), int(0.5 * Nk) + 1, Nk - 5], device=DEV)
+    mk = (torch.arange(Nk, device=DEV)[None, :] < lens[:, None]).to(torch.uint8).contiguous() if not causal else None
+    diag = rnd(H, Nq + Nk - 1, seed=3, dtype=torch.float32) if use_bias else None
+    o = torch.empty(B, Nq, W, dtype=torch.bfloat16, device=DEV)
+    ml = torch.empty(B, H, Nq, 2, dtype=torch.float32, device=DEV)
+    st = ((Nq * W, W), (Nk * W, W), (Nk * W, W), (Nq * W, W))
+    a = L.attn_args(B, H, Nq, Nk, q, k, v, o, *st, ml=ml, bias_diag=diag, key_mask=mk, causal=causal, dropout_p=0.1, dropout_seed=31)
+    L.attn_fwd(a)
+    d_o = rnd(B, Nq, W, seed=5)
+    zero = torch.zeros(B, Nq, dtype=torch.bool, device=DEV)
+    zero[0, int(0.87 * Nq):] = True                       # a pad tail
+    zero[1, int(0.4 * Nq):] = True                        # a long one: whole 128-row blocks of the dQ kernel
+    zero[1, 10:12] = True
+    zero[2, :] = True                                     # nothing to do for the whole sequence
+    zero[3, 128:256] = True                               # a zero block in the middle, non-zero rows after it
+    zero[3, Nq - 1] = True
+    sign = torch.where(torch.arange(W, device=DEV) % 3 == 0, -1.0, 1.0).to(torch.bfloat16)
+    d_zero = torch.where(zero[..., None], (0.0 * sign)[None, None, :].expand(B, Nq, W), d_o).contiguous()      # +0 and -0
+    d_tiny = torch.where(zero[..., None], (2.0 ** -100 * sign)[None, None, :].expand(B, Nq, W), d_o).contiguous()
+    assert bool((d_zero[2] == 0).all()) and bool((d_zero.view(torch.int16)[2] != 0).any())                     # -0 bit patterns are in
+    res = []
+    for d in (d_zero, d_tiny):
+        dq, dk, dv = (torch.full((B, n, W), float("nan"), dtype=torch.bfloat16, device=DEV) for n in (Nq, Nk, Nk))
+        delta = torch.empty(B, H, Nq, 4, dtype=torch.float32, device=DEV)
+        ddiag = torch.zeros(H, Nq + Nk - 1, dtype=torch.float32, device=DEV) if use_bias else None
+        L.attn_bwd(a, d, (Nq * W, W), delta, dq, dk, dv, (Nq * W, W), (Nk * W, W), (Nk * W, W), dbias_diag=ddiag)
+        res.append((dq, dk, dv, ddiag))
+    for name, x, y in zip(("dq", "dk", "dv", "dbias"), res[0], res[1]):
+        if x is None:
+            continue
+        assert torch.isfinite(x.float()).all() and torch.isfinite(y.float()).all(), name
+        e = float((x.float() - y.float()).abs().max())
+        print(f"  {name}: max |skip - full| = {e:.1e}")
+        # (the bias gradient is summed over blocks with fp32 atomics: the order of arrival moves its last bits from launch to launch)
+        assert e < (1e-6 * float(y.abs().max()) if name == "dbias" else 1e-25), (name, e)
+    assert float(res[0][0][zero].float().abs().max()) == 0.0          # dQ of a zero row is zero
+    assert float(res[0][1][2].float().abs().max()) == 0.0 and float(res[0][2][2].float().abs().max()) == 0.0
+
+
 def test_attention_dropout_consistency():
     B, H, Nq, Nk, W = 2, 2, 128, 192, 128
     q, k, v = rnd(B, Nq, W, seed=1, scale=0.3), rnd(B, Nk, W, seed=2, scale=0.3), rnd(B, Nk, W, seed=3)

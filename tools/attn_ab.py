@@ -22,6 +22,8 @@ def make(B, H, Nq, Nk, bias, masked, causal, drop, dbias):
     if masked:
         lens = torch.randint(int(0.7 * Nk), Nk + 1, (B,), device=dev)
         mask = (torch.arange(Nk, device=dev)[None, :] < lens[:, None]).to(torch.uint8).contiguous()
+        if os.environ.get("ZROWS") == "1" and Nq == Nk:      # dense self-attention: the pad rows' gradient is exactly zero (as in the train step)
+            d_o = torch.where((torch.arange(Nq, device=dev)[None, :] < lens[:, None])[..., None], d_o, torch.zeros_like(d_o)).contiguous()
     sq, sk = (Nq * W, W), (Nk * W, W)
     def fwd():
         a = L.attn_args(B, H, Nq, Nk, q, k, v, o, sq, sk, sk, sq, ml=ml, scale=1.0, bias_diag=diag, key_mask=mask, causal=causal,

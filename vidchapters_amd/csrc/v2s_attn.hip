@@ -53,14 +53,14 @@ constexpr int HD = 64;
 #ifndef ATTN_DKV_OCC
 #define ATTN_DKV_OCC ATTN_BWD_OCC
 #endif
+#ifndef ATTN_ZROWS
+#define ATTN_ZROWS 1            // 0: the backward kernels do not look for all-zero dO rows (A/B builds)
+#endif
 #ifndef ATTN_TRIM
 #define ATTN_TRIM 1             // 0: the forward / dQ loops stage the trailing all-masked key tiles too (rounds 1-5; A/B builds)
 #endif
 #ifndef ATTN_DKV_EARLY
 #define ATTN_DKV_EARLY 1        // 0: no early exit of all-masked key blocks (debug builds)
-#endif
-#ifndef ATTN_DKV_EARLY_SYNC
-#define ATTN_DKV_EARLY_SYNC 1
 #endif
 #ifndef ATTN_ABL
 #define ATTN_ABL 0
@@ -360,6 +360,35 @@ __device__ __forceinline__ void block_group(int bid, int nwg, int nper, int ngro
   }
 }
 
+// Block-wide AND / MAX of a per-thread value through four LDS words at `scratch` (dynamic LDS that is not live at the call; the kernels' LDS budget is
+// set as dynamic, a static array would add to it).  Three barriers: the words may be live before the call, and they are about to be overwritten after it
+// (round 6: without the last barrier a wave already committing its first tile overwrote the words before a slower wave had read its answer).
+__device__ __forceinline__ bool block_and(bool c, char* scratch, int lane, int wave) {
+  const bool w = __all(c);
+  __syncthreads();
+  if (lane == 0) reinterpret_cast<int*>(scratch)[wave] = w ? 1 : 0;
+  __syncthreads();
+  const int4 v = *reinterpret_cast<const int4*>(scratch);
+  __syncthreads();
+  return (v.x & v.y & v.z & v.w) != 0;
+}
+__device__ __forceinline__ int block_max(int x, char* scratch, int lane, int wave) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = max(x, __shfl_xor(x, o, 64));
+  __syncthreads();
+  if (lane == 0) reinterpret_cast<int*>(scratch)[wave] = x;
+  __syncthreads();
+  const int4 v = *reinterpret_cast<const int4*>(scratch);
+  __syncthreads();
+  return max(max(v.x, v.y), max(v.z, v.w));
+}
+// Rows whose dO is all zero (pad rows of a dense batch: nothing downstream reads them, so their gradient is exactly zero -- modeling_t5.py computes
+// them all the same).  For such a row dP = dO V^T = 0 and delta = rowsum(dO * O) = 0, hence dS = P * (dP - delta) = 0: it adds nothing to dQ, dK, dV or
+// the bias gradient, whatever its probabilities are.  The dQ kernel reads every dO row anyway (delta): it marks the zero rows in bit 31 of the row-seed
+// word of the row statistics, a block of 128 zero rows writes its zeros and leaves before the key loop, and the dK / dV kernel ends its query loop at
+// the last row that is not marked.  Bit-identical results (the skipped terms are +-0 added to an accumulator); -0 counts as zero.
+constexpr uint32_t ZROW_BIT = 0x80000000u;
+
 // ====================================================================================== forward
 // block = 4 waves x 32 query rows; loop over 64-key tiles.  Three blocks per CU (<= 168 VGPRs) instead of two: inside a wave the
 // score MFMAs, the softmax VALU work and the PV MFMAs are serial, and only waves in different phases overlap them, so a third
@@ -657,11 +686,12 @@ __global__ __launch_bounds__(256, ATTN_BWD_OCC) void attn_bwd_dq_kernel(const At
   float m2[2], xmask[2], dl[2];
   const float lg2ik = DROP ? __log2f(p.inv_keep) : 0.f, rik = DROP ? 1.0f / p.inv_keep : 1.0f;
   uint32_t rowseed[2] = {0u, 0u};
-  bool rows_real = true;
+  bool rows_real = true, blk_zero = true;
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int q = Q0 + wq0 + qb * 16 + li;
     float dsum = 0.f;
+    uint32_t nzw = 0u;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0), o = make_uint4(0, 0, 0, 0);
@@ -670,6 +700,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_OCC) void attn_bwd_dq_kernel(const At
         w = *reinterpret_cast<const uint4*>(dop + (long)q * p.do_rs + ks * 32 + g * 8);
         o = *reinterpret_cast<const uint4*>(op + (long)q * p.o_rs + ks * 32 + g * 8);
       }
+      nzw |= (w.x | w.y | w.z | w.w) & 0x7fff7fffu;
       qf[qb][ks] = __builtin_bit_cast(bf16x8, v);
       dof[qb][ks] = __builtin_bit_cast(bf16x8, w);
       float of[8], df[8];
@@ -679,6 +710,11 @@ __global__ __launch_bounds__(256, ATTN_BWD_OCC) void attn_bwd_dq_kernel(const At
     }
     dsum += __shfl_xor(dsum, 16, 64);            // delta = sum over the 64 columns of dO * O: the four lane groups hold 16 each
     dsum += __shfl_xor(dsum, 32, 64);
+    if (ATTN_ZROWS) {
+      nzw |= (uint32_t)__shfl_xor((int)nzw, 16, 64);
+      nzw |= (uint32_t)__shfl_xor((int)nzw, 32, 64);
+      blk_zero = blk_zero && (nzw == 0u);
+    }
     // 1/l is folded into the exponent: P = exp2(s - (m + log2 l)).  Rows >= Nq: huge offset => P = 0 => dS = 0.  A row whose
     // keys are ALL masked (m <= REAL_MIN) keeps the reference's uniform distribution: its masked elements evaluate to
     // exp2(-log2 l) = 1/l (xmask), every other row's masked elements to 0.
@@ -695,12 +731,26 @@ __global__ __launch_bounds__(256, ATTN_BWD_OCC) void attn_bwd_dq_kernel(const At
       // for the dK/dV kernel, with the keep scale 1/(1-p) folded in: it evaluates P' = exp2(x + log2 ik) = ik * P directly (kept elements of
       // Pd = P', no multiply) and dS = Pd * dP - P' * (delta / ik)
       if (g == 0) *reinterpret_cast<float4*>(p.rowstat + r * 4) = make_float4(-m2[qb] + lg2ik, real ? xmask[qb] : xmask[qb] + lg2ik, -dsum * rik,
-                                                                              __uint_as_float(rs24));
+                                                                              __uint_as_float(rs24 | ((ATTN_ZROWS && nzw == 0u) ? ZROW_BIT : 0u)));
     }
     rows_real = rows_real && real;
     rowseed[qb] = rs24 ^ ((uint32_t)(2 * g) * DROP_C1);
   }
   const bool seen = __all(rows_real);
+
+  // all 128 rows of the block have a zero dO: dQ = 0, no bias gradient (the row statistics above are written for the dK / dV kernel all the same)
+  if (ATTN_ZROWS && block_and(blk_zero, smem, lane, wave)) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int q = Q0 + wq0 + qb * 16 + li;
+      if (q < nq_) {
+        bf16_t* dqp = p.dq + (p.seq_off ? (long)row0_ * p.dq_rs : (long)b * p.dq_bs) + (long)q * p.dq_rs + h * HD;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) *reinterpret_cast<uint2*>(dqp + db * 16 + 4 * g) = make_uint2(0u, 0u);
+      }
+    }
+    return;
+  }
 
   if (BIAS) bias_stage<NC>(s_bias, CS, len64 + 128, -(Q0 + 127), p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
   flags_stage(s_flag, s_state, len64, nk_, p.key_mask ? p.key_mask + (long)b * p.Nk : nullptr, tid);
@@ -934,7 +984,6 @@ constexpr int DKV_MS = STAGE2;                   // -(m + log2 l)[64], masked-el
 constexpr int DKV_STATE = DKV_MS + 4 * 64 * 4;   // int: every row of the tile has real statistics
 constexpr int DKV_STAGE = DKV_STATE + 16;
 constexpr int KBW = ATTN_DKV_KBW, DKV_BK = 64 * KBW;
-__device__ __forceinline__ const float* rsp_early(const AttnP& p, int b, int h) { return p.rowstat + ((long)(b * p.H + h)) * p.Nq * 4; }
 // key of (key block kb, lane column li) inside the wave's 16 * KBW keys.  KBW = 2: the two key blocks hold the EVEN and the ODD key of the
 // pairs (2 li, 2 li + 1), so that ONE dropout hash per query row serves both of a lane's elements of that row (its low / high 16-bit draw:
 // drop_dropmask32, the same evaluation as the dQ kernel) instead of one hash, one shift and one compare per element (round 6: the mask
@@ -977,6 +1026,13 @@ __global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const A
   // per-row statistics of a query tile (written by the dQ kernel): rows >= Nq: P = 0
   float4 rstat = make_float4(-1.0e30f, -3.0e38f, 0.f, 0.f);
   if (tid < 64 && tid < nq_) rstat = *reinterpret_cast<const float4*>(rsp + (long)tid * 4);
+  // last query row whose dO is not all zero (marked by the dQ kernel): 16 KB of the sequence's statistics, requested with everything else of the prologue
+  int zlast = 0;
+  if (ATTN_ZROWS) {
+#pragma unroll 4
+    for (int r = tid; r < nq_; r += 256)
+      if (!(__float_as_uint(rsp[(long)r * 4 + 3]) & ZROW_BIT)) zlast = r + 1;
+  }
 
   bf16x8 kf[KBW][2], vf[KBW][2];
   uint32_t kflag[KBW], kc[KBW], cmul[KBW];
@@ -998,38 +1054,33 @@ __global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const A
     cmul[kb] = (k & 1) ? 0u : 16u;                       // shift that moves this key's 16-bit half of the pair hash into the top half
   }
   const bool keys_clean = __all(kflag[0] == 0u && kflag[KBW - 1] == 0u);
-  // A key block whose keys are ALL masked (the padding tail of a dense batch) contributes exactly zero when every query row has real statistics
-  // (each tile would be skipped below): decide it once, write the zeros and leave -- instead of streaming the sequence's Q / dO through LDS with a
-  // barrier per tile for nothing (lengths uniform in [0.7 N, N]: one block in seven)
-  // (block-wide AND through the still unused dynamic LDS: __syncthreads_and would add a static allocation, and the kernel's LDS budget is set as dynamic)
-  auto block_and = [&](bool c) {
-    const bool w = __all(c);
-    __syncthreads();
-    if (lane == 0) reinterpret_cast<int*>(smem)[wave] = w ? 1 : 0;
-    __syncthreads();
-    const int4 v = *reinterpret_cast<const int4*>(smem);
-    if (ATTN_DKV_EARLY_SYNC) __syncthreads();                // the words are stage 0 of the Q tile: nobody may commit() over them before every wave has read its answer
-    return (v.x & v.y & v.z & v.w) != 0;
-  };
-  if (ATTN_DKV_EARLY && block_and(kflag[0] != 0u && kflag[KBW - 1] != 0u)) {
+  // Two ways for a block to have nothing to do (decided once, block-wide, through the still unused dynamic LDS; then: write the zeros and leave
+  // instead of streaming the sequence's Q / dO through LDS with a barrier per tile for nothing):
+  //  * no query row of the sequence has a non-zero dO (nq_eff == 0, see ZROW_BIT; otherwise the query loop ends at the last such row);
+  //  * its keys are ALL masked (the padding tail of a dense batch) and every query row has real statistics: each tile would be skipped below
+  //    (lengths uniform in [0.7 N, N]: one block in seven).
+  const int nq_eff = ATTN_ZROWS ? block_max(zlast, smem, lane, wave) : nq_;
+  bool dead = nq_eff == 0;
+  if (!dead && ATTN_DKV_EARLY && block_and(kflag[0] != 0u && kflag[KBW - 1] != 0u, smem, lane, wave)) {
     bool real = true;
-    for (int r = tid; r < nq_; r += 256) real = real && (rsp_early(p, b, h)[(long)r * 4 + 1] < REAL_MIN);
-    if (block_and(real)) {
+    for (int r = tid; r < nq_; r += 256) real = real && (rsp[(long)r * 4 + 1] < REAL_MIN);
+    dead = block_and(real, smem, lane, wave);
+  }
+  if (dead) {
 #pragma unroll
-      for (int kb = 0; kb < KBW; ++kb) {
-        const int k = K0 + wk0 + dkv_key(kb, li);
-        if (k < nk_) {
-          bf16_t* dkp = p.dk + (kso_ ? (long)krow0_ * p.dk_rs : (long)b * p.dk_bs) + (long)k * p.dk_rs + h * HD;
-          bf16_t* dvp = p.dv + (kso_ ? (long)krow0_ * p.dv_rs : (long)b * p.dv_bs) + (long)k * p.dv_rs + h * HD;
+    for (int kb = 0; kb < KBW; ++kb) {
+      const int k = K0 + wk0 + dkv_key(kb, li);
+      if (k < nk_) {
+        bf16_t* dkp = p.dk + (kso_ ? (long)krow0_ * p.dk_rs : (long)b * p.dk_bs) + (long)k * p.dk_rs + h * HD;
+        bf16_t* dvp = p.dv + (kso_ ? (long)krow0_ * p.dv_rs : (long)b * p.dv_bs) + (long)k * p.dv_rs + h * HD;
 #pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            *reinterpret_cast<uint2*>(dkp + db * 16 + 4 * g) = make_uint2(0u, 0u);
-            *reinterpret_cast<uint2*>(dvp + db * 16 + 4 * g) = make_uint2(0u, 0u);
-          }
+        for (int db = 0; db < 4; ++db) {
+          *reinterpret_cast<uint2*>(dkp + db * 16 + 4 * g) = make_uint2(0u, 0u);
+          *reinterpret_cast<uint2*>(dvp + db * 16 + 4 * g) = make_uint2(0u, 0u);
         }
       }
-      return;
     }
+    return;
   }
   const int kmin = K0 + wk0, kmax = kmin + 16 * KBW - 1;
   f32x4 dkt[KBW][4], dvt[KBW][4];
@@ -1041,7 +1092,7 @@ __global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const A
   // bias window of this key block: entry i <-> relative position d = i + (K0 - len64 + 1)  (q < len64, k - K0 in [0, 128))
   if (BIAS) bias_stage<NC, true>(s_bias, CS, len64 + DKV_BK, K0 - len64 + 1, p.bias_diag + (long)h * (p.Nq + p.Nk - 1), p.Nq + p.Nk - 1, p.Nq, 1.0f / p.scale, tid);
 
-  const int ntiles = (nq_ + 63) >> 6;
+  const int ntiles = (nq_eff + 63) >> 6;
   const float sc2 = p.scale * LOG2E;
   const f32x2 sc22 = {sc2, sc2};
   const float ik = DROP ? p.inv_keep : 1.0f;
@@ -1056,7 +1107,7 @@ __global__ __launch_bounds__(256, ATTN_DKV_OCC) void attn_bwd_dkv_kernel(const A
     tile_store(st + KV_TILE, tid, rdo);
     if (tid < 64) {
       float* ms = reinterpret_cast<float*>(st + DKV_MS);
-      ms[tid] = rstat.x; ms[64 + tid] = rstat.y; ms[128 + tid] = rstat.z; ms[192 + tid] = rstat.w;
+      ms[tid] = rstat.x; ms[64 + tid] = rstat.y; ms[128 + tid] = rstat.z; ms[192 + tid] = __uint_as_float(__float_as_uint(rstat.w) & ~ZROW_BIT);
       // "every query row of this tile has real statistics": lets all-masked / all-future key blocks skip the tile
       const unsigned long long real = __ballot(rstat.y < REAL_MIN);
       if (tid == 0) reinterpret_cast<int*>(st + DKV_STATE)[0] = (real == ~0ull);
