@@ -193,7 +193,8 @@ int v2s_layernorm_bwd_drop(const void* x, const float* w, const float* mean, con
  *   Q/K/V/O are bf16 with element strides (batch stride, row stride); head h sits at column h*64.
  *   `ml` fp32 [B][H][Nq][2] = (row max, row sum) saved for backward.
  *   backward needs `o` (the forward output) and a caller-owned fp32 workspace `delta` [B][H][Nq][4] that v2s_attn_bwd fills
- *   itself (per row: -(m + log2 l), exponent of a masked element, -sum_d dO*O, dropout row seed: written by its dQ kernel, read
+ *   itself (per row: -(m + log2 l), exponent of a masked element, -sum_d dO*O, dropout row seed -- bit 31 of that word: the
+ *   row's dO is all zero (+-0), such rows add nothing to any gradient and are skipped exactly: written by its dQ kernel, read
  *   by its dK/dV kernel) and produces dQ,dK,dV
  *   (same strides as q/k/v via dq_*, dk_*, dv_*) and, if bias != NULL, dbias_diag fp32
  *   [H][Nq+Nk-1] accumulated (+=) per relative position (bucket-reduced by v2s_bias_bucket_bwd).
