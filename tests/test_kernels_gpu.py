@@ -1529,10 +1529,15 @@ def test_decode_cross_attention_on_the_shared_memory(G):
                 L.decode_memattn(qp, m, S * d, plan3, d)
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1)
-        t_plain, t_climb = timed(mem), timed(mem3)
+        # (a wall-clock comparison: the minimum of five interleaved measurements each -- one 0.5 ms loop alone lost a full-suite run of round 6 to
+        # a hiccup of the box; the defect this guards against was a factor 4)
+        tp, tc = [], []
+        for _ in range(5):
+            tp.append(timed(mem)); tc.append(timed(mem3))
+        t_plain, t_climb = min(tp), min(tc)
         L.decode_ctxfold(plan3, rows, G, H, wv, ctx3, d)
         assert torch.isfinite(ctx3.float()).all()
-        assert t_climb < 2.0 * t_plain + 0.2, (t_plain, t_climb)
+        assert t_climb < 2.0 * t_plain + 0.2, (t_plain, t_climb, tp, tc)
     with pytest.raises(RuntimeError):
         L.MemAttnPlan([5, 0, 7], G * H, DEV)
     with pytest.raises(ValueError):                   # a query buffer that does not match the plan
