@@ -283,14 +283,15 @@ def test_cfg2_train_step_batch32_is_token_weighted_sum_of_samples():
     print(f"  worst cosine {worst[0]:.5f} ({worst[1]})")
 
 
-def test_cfg2_bench_workload_trains_for_six_steps():
+@pytest.mark.parametrize("pack", [False, True], ids=["dense", "padding_free"])
+def test_cfg2_bench_workload_trains_for_six_steps(pack):
     """The bench's own workload (B = 32, ragged synthetic lengths, dropout 0.1, pad rows computed) through Trainer.step six times: the loss
     falls monotonically from ln V, the gradient norm is the known one at step 0 and shrinks, nothing is NaN / Inf.  (Round 6: a race in
     the dK / dV attention kernel passed every parity test -- they launch too few blocks or no dropout -- and sent this loop to -inf in
     two steps; the bench line printed the loss and nobody asserted on it.)"""
     tk = SyntheticTokenizer(32100, 100)
     model = Vid2Seq("t5-base", num_features=100, tokenizer=tk, vis_drop=0.1, enc_drop=0.1, dec_drop=0.1, init_seed=1234, device=DEV).train()
-    model.engine().pack = False
+    model.engine().pack = pack          # (the bench's headline: dense; the engine's default: the same loop on the non-pad rows only -- same trajectory)
     tr = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=0.0)
     batch = {k: v.to(DEV) for k, v in synth.make_batch(32, 100, 1000, 256, len(tk), 1234, 768).items()}
     batch["video"] = batch["video"].to(torch.bfloat16)
