@@ -189,9 +189,14 @@ def main():
             dtr = float(t.item())
         region_ms.append(dtr / a.steps * 1e3)
     loss_val = float(losses["loss"].item())
-    if not math.isfinite(loss_val):
+    bad = 0 if math.isfinite(loss_val) else 1
+    if world > 1:          # every rank leaves together (a lone exit would leave the others in the next collective)
+        t = torch.tensor([float(bad)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bad = int(t.item())
+    if bad:
         # a step that produced NaN / Inf is not the workload any more: no line rather than a number for a broken run
-        raise SystemExit(f"bench.py: the loss is {loss_val} after the timed region -- the step diverged, nothing is reported")
+        raise SystemExit(f"bench.py: the loss is {loss_val} on rank {rank} after the timed region -- the step diverged on some rank, nothing is reported")
     log(f"timed region done: {dt / a.steps * 1e3:.1f} ms/step")
     ms_per_step = dt / a.steps * 1e3
     value = world * B * a.steps / dt
