@@ -302,7 +302,7 @@ def test_cfg2_bench_workload_trains_for_six_steps(pack):
     print("cfg-2 bench workload, (loss, gradient norm) per step:", [(round(a, 4), round(b, 4)) for a, b in hist])
     assert all(np.isfinite(a) and np.isfinite(b) for a, b in hist)
     assert abs(hist[0][0] - 10.405) < 0.01 and 3.5 < hist[0][1] < 4.3           # measured 10.4046 .. 10.4053, 3.90 .. 3.91
-    assert all(hist[i + 1][0] < hist[i][0] for i in range(5))                   # measured 10.405, 10.373, 10.353, 10.342, 10.333, 10.328
+    assert all(hist[i + 1][0] < hist[i][0] + 0.002 for i in range(5)) and hist[5][0] < hist[0][0] - 0.06    # measured 10.405, 10.373, 10.353, 10.342, 10.333, 10.328 (run to run +-0.002)
     assert hist[1][1] < 0.6 and all(hist[i][1] < 0.3 for i in range(2, 6))      # measured 0.36, 0.16, 0.11, 0.09, 0.08
     assert all(torch.isfinite(p.detach().float()).all() for p in model.parameters())
 
