@@ -540,7 +540,7 @@ def test_rccl_world1_gradient_all_reduce_path():
     rank a SUM all-reduce is the identity (checked bit for bit on arena memory); the two-step training runs are compared like the other
     optimizer tests (fp32 atomics make two runs of the same step differ in the last bits, which Adam's first steps amplify to <= 2 lr)."""
     import torch.multiprocessing as mp
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()      # (not fork: a forked copy of a process with a live HIP runtime crashed in its garbage collector, one full-suite run in four)
     ret = mgr.dict()
     mp.spawn(_nccl_world1, args=(29600 + (os.getpid() % 2000), ret), nprocs=1, join=True)
     print(f"RCCL world-1: backend {ret['backend']}, world {ret['world']}, results (max |dw| vs no collectives, #collectives, bytes) {dict(ret['res'])}")

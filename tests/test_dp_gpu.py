@@ -121,7 +121,7 @@ def _worker(rank, world, port, ret, shard):
 @pytest.mark.parametrize("shard", [False, True], ids=["allreduce", "sharded_optimizer"])
 def test_two_ranks_equal_one_large_batch(shard):
     world = 2
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()      # (not fork: a forked copy of a process with a live HIP runtime crashed in its garbage collector, one full-suite run in four)
     ret = mgr.dict()
     port = 29500 + (os.getpid() % 2000) + (7 if shard else 0)
     mp.spawn(_worker, args=(world, port, ret, shard), nprocs=world, join=True)

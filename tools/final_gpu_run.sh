@@ -3,7 +3,7 @@
 # copied to profiles/ by hand)
 T=${1:-r06_a}
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/${T}_pytest.txt
+timeout 2400 python -m pytest tests -m gpu -q --tb=short -rf > gpurun_out/${T}_pytest_full.txt 2>&1; tail -6 gpurun_out/${T}_pytest_full.txt > gpurun_out/${T}_pytest.txt; grep -q failed gpurun_out/${T}_pytest.txt || rm -f gpurun_out/${T}_pytest_full.txt
 cat gpurun_out/${T}_pytest.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.txt 2>&1; tail -1 gpurun_out/${T}_smoke.txt
 timeout 900 python bench.py > gpurun_out/${T}_bench.log 2> gpurun_out/${T}_bench.err
