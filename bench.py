@@ -265,115 +265,119 @@ def main():
         out["data_parallel"]["prediction"] = pred
         out["data_parallel"]["measured_vs_predicted"] = {"exposed_comm_ms": round(comm_ms, 3), "ms_per_step": round(ms_per_step, 3)}
     if rank == 0 and world == 1 and not a.packing and not a.no_generate:
-        # the same step with the engine's default padding-free text encoder (pad-token rows are not computed; exact, see
-        # DESIGN.md): reported beside `value`, which computes them like the reference does
-        eng = model.engine()
-        eng.pack = True
-        trainer.step(batch)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
+        with _Leg(out, "padding_free", model):
+            # the same step with the engine's default padding-free text encoder (pad-token rows are not computed; exact, see
+            # DESIGN.md): reported beside `value`, which computes them like the reference does
+            eng = model.engine()
+            eng.pack = True
             trainer.step(batch)
-        torch.cuda.synchronize()
-        dtp = (time.perf_counter() - t0) / 3
-        eng.pack = False
-        out["padding_free"] = {"valid_encoder_tokens": int(sum(batch["input_lens"])), "padded_encoder_tokens": int(B * Lx),
-                               "valid_decoder_rows": int(sum(batch["output_lens"])), "padded_decoder_rows": int(B * Lo),
-                               "ms_per_step": round(dtp * 1e3, 3), "samples_per_s": round(B / dtp, 2),
-                               "note": "engine default (Engine.pack, Engine.pack_dec): the text encoder runs on the non-pad tokens only and the "
-                                       "decoder on the rows of real targets only; exact because the reference masks those rows as keys everywhere "
-                                       "and ignores their labels.  `value` above does NOT use it"}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                trainer.step(batch)
+            torch.cuda.synchronize()
+            dtp = (time.perf_counter() - t0) / 3
+            eng.pack = False
+            out["padding_free"] = {"valid_encoder_tokens": int(sum(batch["input_lens"])), "padded_encoder_tokens": int(B * Lx),
+                                   "valid_decoder_rows": int(sum(batch["output_lens"])), "padded_decoder_rows": int(B * Lo),
+                                   "ms_per_step": round(dtp * 1e3, 3), "samples_per_s": round(B / dtp, 2),
+                                   "note": "engine default (Engine.pack, Engine.pack_dec): the text encoder runs on the non-pad tokens only and the "
+                                           "decoder on the rows of real targets only; exact because the reference masks those rows as keys everywhere "
+                                           "and ignores their labels.  `value` above does NOT use it"}
     if rank == 0 and world == 1 and not a.no_generate:
-        # the same step replayed from ONE hipGraph (Trainer.step_graph: batch / dropout salt / Adam scalars read from device memory):
-        # host time per step and device time per step; `value` above is the eager path, which is faster on the device on this stack
-        gb = {k: v for k, v in batch.items() if torch.is_tensor(v)}
-        for _ in range(3):
-            trainer.step_graph(gb)
-        torch.cuda.synchronize()
-        enq, wall = [], []
-        for _ in range(5):
-            t0 = time.perf_counter(); trainer.step_graph(gb); t1 = time.perf_counter()
-            torch.cuda.synchronize(); t2 = time.perf_counter()
-            enq.append((t1 - t0) * 1e3); wall.append((t2 - t0) * 1e3)
-        eag = []
-        for _ in range(4):               # the first eager step after the replays re-creates the eager workspaces: not counted
-            t0 = time.perf_counter(); trainer.step(batch); t1 = time.perf_counter(); torch.cuda.synchronize()
-            eag.append((t1 - t0) * 1e3)
-        eag = sorted(eag[1:])
-        out["captured_step"] = {"host_enqueue_ms_per_step": round(sorted(enq)[2], 3), "ms_per_step": round(sorted(wall)[2], 3),
-                                "eager_host_call_ms_per_step": round(eag[1], 3),
-                                "note": "Trainer.step_graph: one hipGraph launch per step (~2500 kernel nodes on three streams).  eager_host_call = time inside the eager Trainer.step() on the host, which includes waiting for room in the launch queue once the host is ~1000 launches ahead of the GPU (tools/cpu_enqueue.py measures 15-23 ms of pure enqueue work)"}
+        with _Leg(out, "captured_step", model):
+            # the same step replayed from ONE hipGraph (Trainer.step_graph: batch / dropout salt / Adam scalars read from device memory):
+            # host time per step and device time per step; `value` above is the eager path, which is faster on the device on this stack
+            gb = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+            for _ in range(3):
+                trainer.step_graph(gb)
+            torch.cuda.synchronize()
+            enq, wall = [], []
+            for _ in range(5):
+                t0 = time.perf_counter(); trainer.step_graph(gb); t1 = time.perf_counter()
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                enq.append((t1 - t0) * 1e3); wall.append((t2 - t0) * 1e3)
+            eag = []
+            for _ in range(4):               # the first eager step after the replays re-creates the eager workspaces: not counted
+                t0 = time.perf_counter(); trainer.step(batch); t1 = time.perf_counter(); torch.cuda.synchronize()
+                eag.append((t1 - t0) * 1e3)
+            eag = sorted(eag[1:])
+            out["captured_step"] = {"host_enqueue_ms_per_step": round(sorted(enq)[2], 3), "ms_per_step": round(sorted(wall)[2], 3),
+                                    "eager_host_call_ms_per_step": round(eag[1], 3),
+                                    "note": "Trainer.step_graph: one hipGraph launch per step (~2500 kernel nodes on three streams).  eager_host_call = time inside the eager Trainer.step() on the host, which includes waiting for room in the launch queue once the host is ~1000 launches ahead of the GPU (tools/cpu_enqueue.py measures 15-23 ms of pure enqueue work)"}
     if rank == 0 and world == 1 and not a.no_roofline:      # N=1 only: the extra step would issue collectives other ranks do not join
-        eng = model.engine()
-        was = eng.overlap
-        eng.overlap = False                 # per-launch durations are only meaningful without concurrent kernels
-        with L.KernelTimer(by_symbol=True) as kt:
-            trainer.step(batch)
-        eng.overlap = was
-        summ = kt.summary()
-        log("roofline leg done")
-        # dominant kernel = the kernel SYMBOL with the largest summed duration (GEMM launches are tagged with the variant the
-        # library dispatched, so the name and the per-launch average line up with rocprofv3 --kernel-trace --stats)
-        tag = max(summ, key=lambda k: summ[k][1])
-        n, ms, work = summ[tag]
-        ach = work / (ms / 1e3) / 1e12
-        out["roofline"] = {"kernel": tag, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                           "effective_sclk_mhz": out["clock_power"].get("effective_sclk_mhz"), "power_w_avg": out["clock_power"].get("power_w_avg"),
-                           "launches_per_step": n, "avg_launch_us": round(ms / n * 1e3, 2),
-                           "algorithmic_gflop_per_launch": round(work / n / 1e9, 2),
-                           "note": "achieved = sum over the step's launches of this kernel of 2*M*N*K (attention: 4*B*H*Nq*Nk*64 fwd, "
-                                   "8*... bwd) / their summed HIP-event durations, measured with stream overlap disabled"}
-        # the round-5 kernel family (persistent asm-scheduled GEMM) next to the dominant symbol: its launches, time and rate in this same step
-        fam = [(k, v) for k, v in summ.items() if k.startswith("gemm_a4p_kernel")]
-        if fam:
-            fn_, fms, fwork = sum(v[0] for _, v in fam), sum(v[1] for _, v in fam), sum(v[2] for _, v in fam)
-            fach = fwork / (fms / 1e3) / 1e12
-            out["roofline"]["gemm_a4p_family"] = {"symbols": sorted(k for k, _ in fam), "launches_per_step": fn_, "ms_per_step": round(fms, 3),
-                                                  "achieved": round(fach, 1), "unit": "TFLOP/s", "frac": round(fach / PEAK_BF16_TFLOPS, 4),
-                                                  "frac_of_sustained_mfma": round(fach / 1650.0, 4),
-                                                  "note": "all instantiations of gemm_a4p_kernel in this step; sustained = 1650 TF/s, pure v_mfma on random bf16 operands "
-                                                          "on this chip (profiles/r05_mfma_power_ubench.txt)"}
-        # HBM traffic of that kernel: from the committed PMC passes (tools/pmc_traffic.sh -> profiles/*.json; rocprofv3 --pmc cannot
-        # wrap this whole script on this stack -- it crashes in torch's integer kernels), launch-weighted over the step's shapes
-        try:
-            for fn in sorted(os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles"))):
-                if fn.endswith(".json") and "pmc_traffic" in fn:
-                    pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", fn)))
-                    if pj.get("kernel") == tag:
-                        out["roofline"]["traffic"] = round(pj["traffic"])
-                        out["roofline"]["traffic_unit"] = "bytes per launch (PMC, offline: profiles/" + fn + ")"
-                        out["roofline"]["algorithmic_bytes_per_launch"] = round(pj["algorithmic"])
-                        # the PMC passes ran on the launch mix of the day they were taken: say so if this run's mix differs
-                        fl = sum(2.0 * sh["M"] * sh["N"] * sh["K"] * sh["launches_per_step"] for sh in pj.get("shapes", [])) / max(1, pj.get("launches_per_step", 1))
-                        out["roofline"]["traffic_matches_this_launch_mix"] = bool(pj.get("launches_per_step") == n and abs(fl - work / n) < 0.02 * fl)
-        except OSError:
-            pass
-        out["kernel_breakdown_note"] = ("HIP-event pairs around each launch on the launch stream; at ~2500 launches per step this leg is host-bound, so "
-                                        "short kernels carry launch gaps (see profiles/ for the rocprofv3 durations)")
-        out["kernel_breakdown_ms_per_step"] = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] / 1e3) / 1e12, 1)}
-                                               for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}
+        with _Leg(out, "roofline", model):
+            eng = model.engine()
+            was = eng.overlap
+            eng.overlap = False                 # per-launch durations are only meaningful without concurrent kernels
+            with L.KernelTimer(by_symbol=True) as kt:
+                trainer.step(batch)
+            eng.overlap = was
+            summ = kt.summary()
+            log("roofline leg done")
+            # dominant kernel = the kernel SYMBOL with the largest summed duration (GEMM launches are tagged with the variant the
+            # library dispatched, so the name and the per-launch average line up with rocprofv3 --kernel-trace --stats)
+            tag = max(summ, key=lambda k: summ[k][1])
+            n, ms, work = summ[tag]
+            ach = work / (ms / 1e3) / 1e12
+            out["roofline"] = {"kernel": tag, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "effective_sclk_mhz": out["clock_power"].get("effective_sclk_mhz"), "power_w_avg": out["clock_power"].get("power_w_avg"),
+                               "launches_per_step": n, "avg_launch_us": round(ms / n * 1e3, 2),
+                               "algorithmic_gflop_per_launch": round(work / n / 1e9, 2),
+                               "note": "achieved = sum over the step's launches of this kernel of 2*M*N*K (attention: 4*B*H*Nq*Nk*64 fwd, "
+                                       "8*... bwd) / their summed HIP-event durations, measured with stream overlap disabled"}
+            # the round-5 kernel family (persistent asm-scheduled GEMM) next to the dominant symbol: its launches, time and rate in this same step
+            fam = [(k, v) for k, v in summ.items() if k.startswith("gemm_a4p_kernel")]
+            if fam:
+                fn_, fms, fwork = sum(v[0] for _, v in fam), sum(v[1] for _, v in fam), sum(v[2] for _, v in fam)
+                fach = fwork / (fms / 1e3) / 1e12
+                out["roofline"]["gemm_a4p_family"] = {"symbols": sorted(k for k, _ in fam), "launches_per_step": fn_, "ms_per_step": round(fms, 3),
+                                                      "achieved": round(fach, 1), "unit": "TFLOP/s", "frac": round(fach / PEAK_BF16_TFLOPS, 4),
+                                                      "frac_of_sustained_mfma": round(fach / 1650.0, 4),
+                                                      "note": "all instantiations of gemm_a4p_kernel in this step; sustained = 1650 TF/s, pure v_mfma on random bf16 operands "
+                                                              "on this chip (profiles/r05_mfma_power_ubench.txt)"}
+            # HBM traffic of that kernel: from the committed PMC passes (tools/pmc_traffic.sh -> profiles/*.json; rocprofv3 --pmc cannot
+            # wrap this whole script on this stack -- it crashes in torch's integer kernels), launch-weighted over the step's shapes
+            try:
+                for fn in sorted(os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles"))):
+                    if fn.endswith(".json") and "pmc_traffic" in fn:
+                        pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", fn)))
+                        if pj.get("kernel") == tag:
+                            out["roofline"]["traffic"] = round(pj["traffic"])
+                            out["roofline"]["traffic_unit"] = "bytes per launch (PMC, offline: profiles/" + fn + ")"
+                            out["roofline"]["algorithmic_bytes_per_launch"] = round(pj["algorithmic"])
+                            # the PMC passes ran on the launch mix of the day they were taken: say so if this run's mix differs
+                            fl = sum(2.0 * sh["M"] * sh["N"] * sh["K"] * sh["launches_per_step"] for sh in pj.get("shapes", [])) / max(1, pj.get("launches_per_step", 1))
+                            out["roofline"]["traffic_matches_this_launch_mix"] = bool(pj.get("launches_per_step") == n and abs(fl - work / n) < 0.02 * fl)
+            except OSError:
+                pass
+            out["kernel_breakdown_note"] = ("HIP-event pairs around each launch on the launch stream; at ~2500 launches per step this leg is host-bound, so "
+                                            "short kernels carry launch gaps (see profiles/ for the rocprofv3 durations)")
+            out["kernel_breakdown_ms_per_step"] = {k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] / 1e3) / 1e12, 1)}
+                                                   for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}
 
     if rank == 0 and world == 1 and not a.no_generate and a.denoising == 0:
-        # S2 of SURVEY.md 8d, reported alongside: the dvc.py default two-pass step (generative + denoising pass on the cached
-        # video_dict, L~800 / Lo~301 span-corruption shapes from synth.make_batch), same optimizer recipe
-        tr2 = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=1.0)
-        b2 = {k: v.to(dev) for k, v in synth.make_batch(B, T, Lx, Lo, len(tok), 1234, 768, denoising=True).items()}
-        b2["video"] = b2["video"].to(torch.bfloat16)
-        tr2.step(b2)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            l2 = tr2.step(b2)
-        torch.cuda.synchronize()
-        dt2 = (time.perf_counter() - t0) / 3
-        out["two_pass_step"] = {"ms_per_step": round(dt2 * 1e3, 3), "samples_per_s": round(B / dt2, 2),
-                                "den_input_tokens": int(b2["den_input_ids"].shape[1]), "den_target_tokens": int(b2["den_output_ids"].shape[1]),
-                                "loss": round(float(l2["loss"].item()), 5)}
-        del tr2, b2
-        out["generate_greedy"] = generate_leg(model, tok, dev, Lx)
-        out["generate_beam4"] = beam_leg(model, tok, dev, Lx)
-        out["input_pipeline"] = input_leg(dev, B, Lx, Lo)
+        with _Leg(out, "two_pass_and_generate", model):
+            # S2 of SURVEY.md 8d, reported alongside: the dvc.py default two-pass step (generative + denoising pass on the cached
+            # video_dict, L~800 / Lo~301 span-corruption shapes from synth.make_batch), same optimizer recipe
+            tr2 = Trainer(model, lr=3e-4, clip_max_norm=1.0, generative=1.0, denoising=1.0)
+            b2 = {k: v.to(dev) for k, v in synth.make_batch(B, T, Lx, Lo, len(tok), 1234, 768, denoising=True).items()}
+            b2["video"] = b2["video"].to(torch.bfloat16)
+            tr2.step(b2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                l2 = tr2.step(b2)
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t0) / 3
+            out["two_pass_step"] = {"ms_per_step": round(dt2 * 1e3, 3), "samples_per_s": round(B / dt2, 2),
+                                    "den_input_tokens": int(b2["den_input_ids"].shape[1]), "den_target_tokens": int(b2["den_output_ids"].shape[1]),
+                                    "loss": round(float(l2["loss"].item()), 5)}
+            del tr2, b2
+            out["generate_greedy"] = generate_leg(model, tok, dev, Lx)
+            out["generate_beam4"] = beam_leg(model, tok, dev, Lx)
+            out["input_pipeline"] = input_leg(dev, B, Lx, Lo)
 
     if rank == 0 and "roofline" in out and "generate_greedy" in out:
         # the decode legs' summary inside `roofline` (the driver keeps that object whole): cached decode is HBM-bound, fractions of 8 TB/s
@@ -387,9 +391,10 @@ def main():
                                              "launches = library launches of one captured decode step (vidchapters_amd.lib.launch_count)"}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        log("cpu baseline (oracle on host cores) ...")
-        out["cpu_baseline"] = cpu_baseline(model, tok, Lx, Lo, all_cores=a.cpu_all_cores)
-        log("cpu baseline done")
+        with _Leg(out, "cpu_baseline", model):
+            log("cpu baseline (oracle on host cores) ...")
+            out["cpu_baseline"] = cpu_baseline(model, tok, Lx, Lo, all_cores=a.cpu_all_cores)
+            log("cpu baseline done")
 
     if rank == 0:
         print(json.dumps(out))
@@ -518,6 +523,30 @@ def beam_leg(model, tok, dev, Lx, B=16, new_tokens=64, num_beams=4):
             "roofline": decode_roofline(model, B, 100 + Lx, new_tokens, dt / new_tokens * 1e3, rows=B * num_beams,
                                         valid_keys=100 * B + int((ids != 0).sum())),
             "note": "encode + beam search, min_length = max length so that every run decodes all steps"}
+
+
+class _Leg:
+    """An optional leg of the line (everything after `value` has been measured): a Python-level failure inside it is recorded under
+    `leg_errors` and the line is still printed -- the headline must not depend on, say, a hipGraph capture working on this box."""
+
+    def __init__(self, out, name, model):
+        self.out, self.name, self.eng = out, name, model.engine()
+        self.pack, self.overlap = self.eng.pack, self.eng.overlap
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is None or not issubclass(et, Exception):
+            return False
+        self.eng.pack, self.eng.overlap = self.pack, self.overlap
+        self.out.setdefault("leg_errors", {})[self.name] = f"{et.__name__}: {ev}"[:500]
+        log(f"leg {self.name} FAILED: {et.__name__}: {ev}")
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        return True
 
 
 def input_leg(dev, B, Lx, Lo, frames=300):
