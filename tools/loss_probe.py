@@ -1,3 +1,6 @@
+"""Six optimizer steps of the bench workload (cfg-2, B = 32, dropout 0.1, dense) per value of the attn_order option: (loss, gradient norm) per step.
+The probe that showed the dK/dV early-exit race of round 6 (gradient norm 4e12 in step 0, loss -inf in step 2 while every parity test passed);
+V2S_LIB=<other build> compares builds.  usage: python tools/loss_probe.py 0 1 2"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import torch
