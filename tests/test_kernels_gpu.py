@@ -531,6 +531,54 @@ def test_attention_backward_full_chip_is_repeatable_and_right(Nq, Nk, use_bias):
         assert c > 0.999 and e < 4e-2
 
 
+def test_full_size_launches_are_repeatable():
+    """The step's big single-pass launches at their cfg-2 sizes (every CU busy for several rounds), three times each into NaN-filled outputs:
+    bit-identical, finite.  None of them reduces across blocks, so any difference is a race inside a block or between a block and its
+    successor on the same CU (round 6: such a race in the dK / dV attention kernel passed every small-grid parity test)."""
+    M = 32000
+    x768, x3072 = rnd(M, 768, seed=1, scale=0.5), rnd(M, 3072, seed=2, scale=0.5)
+    w_qkv, w_wi, w_wo = rnd(2304, 768, seed=3, scale=0.04), rnd(3072, 768, seed=4, scale=0.04), rnd(768, 3072, seed=5, scale=0.02)
+    res = rnd(M, 768, seed=6)
+    u = rnd(M, 3072, seed=7)                              # ReLU-mask operand of the masked dgrad
+    cases = {
+        "QKV forward (plain)": lambda c: L.gemm(x768, w_qkv, c(M, 2304), M, 2304, 768),
+        "wi forward (ReLU + dropout)": lambda c: L.gemm(x768, w_wi, c(M, 3072), M, 3072, 768, act=L.ACT_RELU, dropout_p=0.1, dropout_seed=11),
+        "wo forward (residual + dropout)": lambda c: L.gemm(x3072, w_wo, c(M, 768), M, 768, 3072, residual=res, dropout_p=0.1, dropout_seed=12),
+        "wi dgrad (plain, NN)": lambda c: L.gemm(x3072, w_wi, c(M, 768), M, 768, 3072, transB=True, ldb=768),
+        "wo dgrad (ReLU mask + dropout, NN)": lambda c: L.gemm(x768, w_wo, c(M, 3072), M, 3072, 768, transB=True, ldb=3072, dact=L.ACT_RELU, z=u,
+                                                                dropout_p=0.1, dropout_seed=13),
+    }
+    for name, launch in cases.items():
+        outs = []
+        for _ in range(3):
+            box = []
+            def c(m, n):
+                box.append(torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=DEV)); return box[0]
+            launch(c)
+            outs.append(box[0])
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs[0].float()).all(), name
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), name
+    # attention forward at the encoder's grid (bias, ragged masks, dropout): output and row statistics
+    B, H, N, W = 32, 12, 1000, 768
+    qkv = rnd(B, N, 3 * W, seed=21, scale=0.5)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    lens = torch.randint(int(0.7 * N), N + 1, (B,), generator=g).to(DEV)
+    mk = (torch.arange(N, device=DEV)[None, :] < lens[:, None]).to(torch.uint8).contiguous()
+    diag = rnd(H, 2 * N - 1, seed=22, dtype=torch.float32)
+    outs = []
+    for _ in range(3):
+        o = torch.full((B, N, W), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ml = torch.full((B, H, N, 2), float("nan"), dtype=torch.float32, device=DEV)
+        L.attn_fwd(L.attn_args(B, H, N, N, qkv[..., :W], qkv[..., W:2 * W], qkv[..., 2 * W:], o, (N * 3 * W, 3 * W), (N * 3 * W, 3 * W),
+                               (N * 3 * W, 3 * W), (N * W, W), ml=ml, bias_diag=diag, key_mask=mk, dropout_p=0.1, dropout_seed=5))
+        outs.append((o, ml))
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0][0].float()).all() and torch.isfinite(outs[0][1]).all()
+    for o, ml in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and torch.equal(ml, outs[0][1])
+
+
 @pytest.mark.parametrize("M,N,K,G,acc", [(768, 768, 512, 12, False), (136, 264, 192, 3, True), (2304, 768, 256, 16, False)])
 def test_gemm_grouped_weight_gradients(M, N, K, G, acc):
     """v2s_gemm_grouped: G weight gradients of one shape (dY^T X, fp32 out) in one launch == the single launches / fp32 torch."""
