@@ -220,7 +220,7 @@ def main():
         "config": {"workload": f"{'cfg-2' if a.model == 't5-base' else 'cfg-5'}: Vid2Seq {a.model} train step (generative pass"
                                f"{' + denoising pass' if a.denoising > 0 else ''}), per-GPU batch {B}, {T} frames x 768, "
                                f"{Lx} ASR tokens, {Lo} target tokens, dropout {a.dropout}, fp32 master weights + fused clip/Adam/renorm"
-                               f"{', encoder rows of pad tokens not computed (exact)' if a.packing else ', pad rows computed like the reference'}",
+                               f"{', encoder rows of pad tokens not computed (exact)' if a.packing else ', pad rows computed like the reference (their gradient is exactly zero: the attention backward kernels detect all-zero dO rows and skip them, bit-identical)'}",
                    "global_batch": world * B, "parallelism": f"dp{world}", "weights": "deterministic synthetic init (no checkpoints offline)"},
         "ms_per_step_hipevent_median": round(med_ms, 3), "samples_per_s_hipevent_median": round(world * B / (med_ms / 1e3), 2),
         "timing_note": f"value = steps / wall time between the two barrier+synchronize brackets (max over ranks): a {dt:.2f} s region of {a.steps} steps "
