@@ -965,6 +965,7 @@ def test_attention_backward_skips_zero_gradient_rows_exactly(Nq, Nk, use_bias, c
     zero[2, :] = True                                     # nothing to do for the whole sequence
     zero[3, 128:256] = True                               # a zero block in the middle, non-zero rows after it
     zero[3, Nq - 1] = True
+    zero[3, 32:64] = True                                 # one wave's 32 rows inside a block that has work
     sign = torch.where(torch.arange(W, device=DEV) % 3 == 0, -1.0, 1.0).to(torch.bfloat16)
     d_zero = torch.where(zero[..., None], (0.0 * sign)[None, None, :].expand(B, Nq, W), d_o).contiguous()      # +0 and -0
     d_tiny = torch.where(zero[..., None], (2.0 ** -100 * sign)[None, None, :].expand(B, Nq, W), d_o).contiguous()

@@ -53,6 +53,9 @@ constexpr int HD = 64;
 #ifndef ATTN_DKV_OCC
 #define ATTN_DKV_OCC ATTN_BWD_OCC
 #endif
+#ifndef ATTN_WAVEZ
+#define ATTN_WAVEZ 1            // 0: a dQ wave whose 32 rows have a zero dO still computes (A/B builds)
+#endif
 #ifndef ATTN_ZROWS
 #define ATTN_ZROWS 1            // 0: the backward kernels do not look for all-zero dO rows (A/B builds)
 #endif
@@ -739,6 +742,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_OCC) void attn_bwd_dq_kernel(const At
   const bool seen = __all(rows_real);
 
   // all 128 rows of the block have a zero dO: dQ = 0, no bias gradient (the row statistics above are written for the dK / dV kernel all the same)
+  const bool wave_zero = ATTN_ZROWS && ATTN_WAVEZ && __all(blk_zero);
   if (ATTN_ZROWS && block_and(blk_zero, smem, lane, wave)) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_OCC) void attn_bwd_dq_kernel(const At
     const bool any_flag = (tstate & 1) != 0, all_flag = (tstate & 2) != 0;
     const bool future = CAUSAL && (k0 > qmax + p.causal_off);
     const bool edge = CAUSAL && (k0 + 63 > qmin + p.causal_off);
-    const bool skip = (all_flag || future) && seen;
+    const bool skip = ((all_flag || future) && seen) || wave_zero;      // (wave_zero: the wave's 32 rows have dO = 0 -> dS = 0: it only helps staging the tiles)
 
     if (!skip) {
       f32x4 st[2][4], dp[2][4];
