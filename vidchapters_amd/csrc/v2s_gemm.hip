@@ -1490,6 +1490,22 @@ __global__ __launch_bounds__(512, 2) void gemm_p8d_kernel(const GemmP p) {
 #ifndef SKINNY_NT
 #define SKINNY_NT 0
 #endif
+// 1: a scheduling barrier between the load group and the MFMA group of a K iteration.  Without it hipcc interleaves them and REUSES the registers of the
+// first step for the last one (57 VGPRs used): the loads of step 3 are issued only after step 1 has arrived -- two or three dependent memory round trips
+// per launch in a kernel that is one latency chain (A/B builds: 0)
+#ifndef SKINNY_LOADS_FIRST
+#define SKINNY_LOADS_FIRST 1
+#endif
+// diagnostic build (tools/skinny_stamps.py): thread 0 of the first and of the last block stamp the shader clock (s_memtime) and the 100 MHz
+// reference clock (s_memrealtime) at the kernel's phase boundaries into the caller's workspace; never defined in the product build
+#ifndef SKINNY_STAMPS
+#define SKINNY_STAMPS 0
+#endif
+#if SKINNY_STAMPS
+#define SK_STAMP(i_) do { st_r[i_] = __builtin_amdgcn_s_memrealtime(); } while (0)       // (uniform values: they stay in SGPRs, the kernel's VGPR count and occupancy must not change)
+#else
+#define SK_STAMP(i_) do { } while (0)
+#endif
 __device__ __forceinline__ uint4 ld_stream(const bf16_t* ptr) {
 #if SKINNY_NT
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_;
@@ -1514,6 +1530,10 @@ template <int WAVES, int STEPS, int MT, int NT = 1>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) {
   constexpr int PITCH = NT == 1 ? 17 : NT * 16 + 4;
   __shared__ float part[WAVES][MT * 16][PITCH];
+#if SKINNY_STAMPS
+  unsigned long long st_r[8] = {};
+#endif
+  SK_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * (NT * 16), m0 = blockIdx.y * (MT * 16);
   const int kq = p.K / WAVES;                    // multiple of 32 * STEPS (checked by the dispatcher)
@@ -1546,6 +1566,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool rms = p.rms_eps > 0.f;
+  SK_STAMP(1);                                // arguments read, addresses formed
   float sq[MT];                               // fused RMSNorm: sum of squares of this lane's A elements, per 16-row fragment
 #pragma unroll
   for (int i = 0; i < MT; ++i) sq[i] = 0.f;
@@ -1559,6 +1580,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
 #pragma unroll
       for (int i = 0; i < MT; ++i) aq[s][i] = *reinterpret_cast<const uint4*>(ap[i] + k + s * 32);
     }
+#if SKINNY_LOADS_FIRST
+    __builtin_amdgcn_sched_barrier(0);          // every load of the iteration is issued before its first MFMA (see SKINNY_LOADS_FIRST)
+#endif
 #pragma unroll
     for (int s = 0; s < STEPS; ++s)
 #pragma unroll
@@ -1579,6 +1603,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
     }
   }
   __shared__ float rowsq[WAVES][MT * 16];
+#if SKINNY_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  SK_STAMP(2);                                // K loop done (every load arrived, MFMAs issued)
   if (rms) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -1594,7 +1622,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) part[wave][i * 16 + (lane >> 4) * 4 + q][t * 16 + (lane & 15)] = acc[i][t][q];
+  SK_STAMP(3);                                // partial tiles written to LDS
   __syncthreads();
+  SK_STAMP(4);                                // barrier passed
   for (int e = tid; e < MT * 16 * NT * 2; e += WAVES * 64) {
     const int ml = e / (NT * 2), m = m0 + ml, c = (e % (NT * 2)) * 8;
     const int gn = n0 + c;
@@ -1615,10 +1645,25 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const GemmP p) 
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= rstd;
       }
+#if SKINNY_STAMPS
+      if (e == 0) SK_STAMP(5);                // the eight partial sums added, row scale applied
+#endif
       if (res_ahead) epilogue_chunk<true>(p, v, m, gn, 0, res_chunk);
       else epilogue_chunk<false>(p, v, m, gn, 0);
     }
   }
+#if SKINNY_STAMPS
+  if (p.ws && tid == 0) {          // every block: entry and exit on the reference clock, from word 32 on
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ws) + 32 + 2 * (blockIdx.y * gridDim.x + blockIdx.x);
+    o[0] = st_r[0]; o[1] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (p.ws && tid == 0 && ((blockIdx.x == 0 && blockIdx.y == 0) || (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1))) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SK_STAMP(6);                              // output chunk stored (written back as far as vmcnt tells)
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ws) + ((blockIdx.x == 0 && blockIdx.y == 0) ? 0 : 16);
+    for (int i = 0; i < 7; ++i) o[8 + i] = st_r[i];
+  }
+#endif
 }
 
 // LM head of a cached decode step: M <= 64 rows against N ~ 32k columns -- 49 MB of weights, the largest single read of the step.
@@ -1974,6 +2019,9 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
       return V2S_OK;
     }
     p.tilesM = 1; p.tilesN = (a->N + 15) / 16; p.splitk = 1; p.kper = a->K; p.ws = nullptr;
+#if SKINNY_STAMPS
+    p.ws = (float*)a->workspace;
+#endif
     g_last_gemm = "gemm_skinny_kernel";
     // row fragments per block: one (grid.y walks them: four times the blocks, a quarter of the activation loads per wave) measured
     // faster on every decoder projection (greedy B = 64: 1.39 ms/step with four fragments per block, 1.17 with one;
@@ -1982,12 +2030,13 @@ static int gemm_impl(const v2s_gemm_args* a, void* stream, int row0, int p8_forc
     int waves = ((a->K % 256) == 0 && mode != 4) ? 8 : 4;
     // row fragments per block: the fewest (most blocks, least activation traffic per wave) that keep the grid within ~4 blocks per CU
     int mt = 1, nt = 1;
-    while (mt < 4 && (long)p.tilesN * ((a->M + 16 * mt - 1) / (16 * mt)) > 1024) mt *= 2;
+    const long cap = mode >= 20000 ? mode - 20000 : 1024;      // A/B (tools/decode_ab.py): gemm_skinny = 20000 + the largest grid taken with one row fragment per block
+    while (mt < 4 && (long)p.tilesN * ((a->M + 16 * mt - 1) / (16 * mt)) > cap) mt *= 2;
     if (a->M <= 64 && (mode == 2 || a->N >= 8192)) mt = 4;
     if (a->M > 64) { mt = 2; nt = 2; }       // beam rows: 32 x 32 blocks (4-beam step 2.26 -> 2.03 ms; profiles/r02_decode_ab_skinny_mt.txt)
     // A/B (tools/decode_ab.py): gemm_skinny = <waves><mt><nt> for M > 64, 1<waves><mt><nt> for M <= 64
     if (a->M > 64 && mode >= 100 && mode < 1000) { waves = mode / 100; mt = (mode / 10) % 10; nt = mode % 10; }
-    if (a->M <= 64 && a->N < 8192 && mode >= 1000) { waves = (mode / 100) % 10; mt = (mode / 10) % 10; nt = mode % 10; }
+    if (a->M <= 64 && a->N < 8192 && mode >= 1000 && mode < 20000) { waves = (mode / 100) % 10; mt = (mode / 10) % 10; nt = mode % 10; }
     if ((a->K % (waves * 32)) != 0) waves = 4;
     const int nsteps = a->K / waves / 32;
     p.tilesN = (a->N + 16 * nt - 1) / (16 * nt);
