@@ -50,7 +50,8 @@ const char* v2s_last_error(void);
  *   "gemm_big"      1: tile-size heuristics (default), 0: 128x128 only, 2: 256x128 8-wave only, 3: force the 4-wave 256x128x32 kernel
  *   "gemm_skinny"   1: dedicated weight-streaming kernels for cached decoding (M <= 64; M <= 512 when N < 8192; default),
  *                   0: general tiles (A/B of the block shape, tools/decode_ab.py: 2 = four row fragments per block,
- *                   4 = four waves, <waves><mt><nt> / 1<waves><mt><nt> = explicit shape for M > 64 / M <= 64)
+ *                   4 = four waves, <waves><mt><nt> / 1<waves><mt><nt> = explicit shape for M > 64 / M <= 64, 20000 + n = one row fragment per
+ *                   block only up to n blocks; none of them faster on the decode loop: profiles/r06_decode_chain_study.txt)
  *   "gemm_order"    GM > 0: grouped tile walk, GM tile rows deep, K slices tile-major (default 4: the blocks an XCD runs together share
  *                   operand slabs in its L2; +20..40 % on the split-K weight gradients), 0: row-major with adjacent K slices
  *   "gemm_split"    1: split-K slice count from the rounds x length cost model (default), 0: fixed block-count target
