@@ -7,6 +7,7 @@ from vidchapters_amd import lib as L
 dev = "cuda"
 paths = sys.argv[1:] or [L.LIB_PATH]
 N = int(os.environ.get("ATTN_N", "1000"))
+DB = int(os.environ.get("ATTN_DBIAS", "1"))          # 0: the dQ kernel without the bias-gradient accumulation and its atomics
 B, H = 32, 12
 W = H * 64
 torch.manual_seed(0)
@@ -41,7 +42,7 @@ for rep in range(3):
         res[p][0].append(t(lambda: L.attn_fwd(a)))
         for part in (1, 2):
             L.set_option("attn_bwd_part", part)
-            res[p][part].append(t(lambda: L.attn_bwd(a, d_o, (N * W, W), delta, dqkv, dqkv[..., W:], dqkv[..., 2 * W:], st, st, st, dbias_diag=ddiag, far=(-91, 91))))
+            res[p][part].append(t(lambda: L.attn_bwd(a, d_o, (N * W, W), delta, dqkv, dqkv[..., W:], dqkv[..., 2 * W:], st, st, st, dbias_diag=(ddiag if DB else None), far=((-91, 91) if DB else (0, 0)))))
         L.set_option("attn_bwd_part", 0)
 for p in paths:
     f, q, kv = (min(x) for x in res[p])

@@ -960,7 +960,10 @@ __global__ __launch_bounds__(256, ATTN_BWD_OCC) void attn_bwd_dq_kernel(const At
       }
     }
   }
-  if (want_dbias) {
+#ifndef ATTN_DBIAS_FLUSH
+#define ATTN_DBIAS_FLUSH 1      // 0: ablation build, the block's bias-gradient window is not added to global memory (results invalid)
+#endif
+  if (want_dbias && ATTN_DBIAS_FLUSH) {
     // dbw index i <-> (k - q) = i - (Q0 + 127);  global index = (k - q) + Nq - 1.  The far-bucket masses go to the
     // diagonals far_lo / far_hi themselves (same bucket): dbias_diag is meaningful after bucket reduction.
     float* dst = p.dbias_diag + (long)h * (p.Nq + p.Nk - 1);

@@ -1802,7 +1802,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   const int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (n0 < N) {
-    for (int m = mbeg + rr; m < mend; m += 32) {
+    // eight rows' loads in flight per thread (the rolled loop waited for every 16-byte load before it asked for the next one: 32 dependent round trips
+    // per block, 12 us for a 3200-row ViT tensor); the additions keep their order
+    int m = mbeg + rr;
+    for (; m + 7 * 32 < mend; m += 8 * 32) {
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(X + (long)(m + u * 32) * ldx + n0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float f[8];
+        unpack8(v[u], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += f[j];
+      }
+    }
+    for (; m < mend; m += 32) {
       float f[8];
       unpack8(*reinterpret_cast<const uint4*>(X + (long)m * ldx + n0), f);
 #pragma unroll

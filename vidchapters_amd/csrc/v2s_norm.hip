@@ -12,7 +12,17 @@
 namespace {
 
 constexpr int MAXC = 4;  // chunks of 8 columns per lane -> cols <= 2048
-constexpr int BWD_BLOCKS = 1024;
+// Grid of the backward kernels (grid-stride over rows).  Every block ends with one float atomic per column, and those are what the launch waits for at its
+// end: 1024 blocks of 4 waves ran a 32000 x 768 RMSNorm backward in 47.9 us, 2048 in 62, 384 blocks of 8 waves (as many rows in flight, a third of the
+// atomics) in 32.5 us = 6.05 TB/s of its four tensors (profiles/r06_norm_bwd_grid.txt; -DNORM_BWD_BLOCKS / -DNORM_BWD_WAVES for A/B builds)
+#ifndef NORM_BWD_BLOCKS
+#define NORM_BWD_BLOCKS 384
+#endif
+constexpr int BWD_BLOCKS = NORM_BWD_BLOCKS;
+#ifndef NORM_BWD_WAVES
+#define NORM_BWD_WAVES 8          // waves (= rows in flight) per backward block
+#endif
+constexpr int BW = NORM_BWD_WAVES;
 
 // activation I/O type: bf16 (the product path) or fp32 (option "fp32_io": debug mode that takes the bf16 rounding of the
 // activations out of the comparison with an fp32 reference -- SURVEY 8c asks for <= 1e-4 there)
@@ -105,13 +115,13 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const T* __restrict__ x, 
 }
 
 template <bool LN, int NCH, typename T = bf16_t>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(BW * 64) void norm_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                        const T* __restrict__ dy, T* __restrict__ dx,
                                                        const T* __restrict__ dx_add, float* __restrict__ dw_out,
                                                        float* __restrict__ db_out, int rows, int cols, T* __restrict__ dx_drop,
                                                        uint32_t p16, float inv_keep, uint32_t seed, const uint32_t* __restrict__ salt) {
-  __shared__ float red[4][NCH * 512];
+  __shared__ float red[BW][NCH * 512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = cols >> 3;
   float dwacc[NCH][8], dbacc[NCH][8];
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ x, 
       wv[i][4] = w1.x; wv[i][5] = w1.y; wv[i][6] = w1.z; wv[i][7] = w1.w;
     }
   }
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * BW + wave; row < rows; row += gridDim.x * BW) {
     const float rstd = rstd_in[row];
     const float mean = LN ? mean_in[row] : 0.f;
     float xh[NCH][8], g[NCH][8];
@@ -200,11 +210,16 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const T* __restrict__ x, 
     }
     __syncthreads();
     float* dst = pass ? db_out : dw_out;
-    for (int c = threadIdx.x; c < cols; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    for (int c = threadIdx.x; c < cols; c += BW * 64) {
+      float t = red[0][c];
+#pragma unroll
+      for (int w = 1; w < BW; ++w) t += red[w][c];
+      atomicAdd(dst + c, t);
+    }
   }
 }
 
-int bwd_blocks(int rows) { return (rows + 3) / 4 < BWD_BLOCKS ? (rows + 3) / 4 : BWD_BLOCKS; }
+int bwd_blocks(int rows) { return (rows + BW - 1) / BW < BWD_BLOCKS ? (rows + BW - 1) / BW : BWD_BLOCKS; }
 
 int check_shape(const char* who, int rows, int cols) {
   if (rows <= 0 || cols <= 0 || (cols % 8) != 0 || cols > 8 * 64 * MAXC) {
@@ -257,19 +272,19 @@ static int norm_bwd_launch(const char* who, const void* x, const float* w, const
   V2S_CHECK(!(dx_drop && !p16), V2S_ERR_ARG, "%s: dx_drop needs dropout_p > 0", who);
   if (v2s_opt_fp32_io()) {          // debug mode: fp32 activations in and out
     if (cols <= 1024)
-      hipLaunchKernelGGL((norm_bwd_kernel<LN, 2, float>), dim3(nb), dim3(256), 0, s, (const float*)x, w, mean, rstd, (const float*)dy, (float*)dx,
+      hipLaunchKernelGGL((norm_bwd_kernel<LN, 2, float>), dim3(nb), dim3(BW * 64), 0, s, (const float*)x, w, mean, rstd, (const float*)dy, (float*)dx,
                          (const float*)dx_add, dw, db, rows, cols, (float*)dd, p16, inv_keep, dropout_seed, v2s_seed_salt());
     else
-      hipLaunchKernelGGL((norm_bwd_kernel<LN, 4, float>), dim3(nb), dim3(256), 0, s, (const float*)x, w, mean, rstd, (const float*)dy, (float*)dx,
+      hipLaunchKernelGGL((norm_bwd_kernel<LN, 4, float>), dim3(nb), dim3(BW * 64), 0, s, (const float*)x, w, mean, rstd, (const float*)dy, (float*)dx,
                          (const float*)dx_add, dw, db, rows, cols, (float*)dd, p16, inv_keep, dropout_seed, v2s_seed_salt());
     V2S_LAUNCH_CHECK();
     return V2S_OK;
   }
   if (cols <= 1024)
-    hipLaunchKernelGGL((norm_bwd_kernel<LN, 2>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy, (bf16_t*)dx,
+    hipLaunchKernelGGL((norm_bwd_kernel<LN, 2>), dim3(nb), dim3(BW * 64), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy, (bf16_t*)dx,
                        (const bf16_t*)dx_add, dw, db, rows, cols, dd, p16, inv_keep, dropout_seed, v2s_seed_salt());
   else
-    hipLaunchKernelGGL((norm_bwd_kernel<LN, 4>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy, (bf16_t*)dx,
+    hipLaunchKernelGGL((norm_bwd_kernel<LN, 4>), dim3(nb), dim3(BW * 64), 0, s, (const bf16_t*)x, w, mean, rstd, (const bf16_t*)dy, (bf16_t*)dx,
                        (const bf16_t*)dx_add, dw, db, rows, cols, dd, p16, inv_keep, dropout_seed, v2s_seed_salt());
   V2S_LAUNCH_CHECK();
   return V2S_OK;
