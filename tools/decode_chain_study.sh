@@ -5,6 +5,7 @@
 #   4. tools/skinny_stamps.py on the SKINNY_STAMPS build: the phases inside the kernel and the entry time of every block
 #   5. tools/decode_ab.py: block-shape sweeps on the real greedy decode loop
 cd $GRAFT_REPO_ROOT
+[ -f tools/libvid2seq_hip_stamps.so ] || { echo "build tools/libvid2seq_hip_stamps.so first (tools/build_skinny_stamps.sh, in the build container)"; exit 1; }
 O=gpurun_out/decode_chain_study.txt
 {
 echo "== 1. kernel arguments (us per dependent node, replayed graph of 1000 nodes)"
